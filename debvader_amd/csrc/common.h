@@ -1,0 +1,151 @@
+// Shared declarations for the debvader_amd HIP engine (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace dv {
+
+// status codes (mirrored in include/debvader_hip.h)
+enum : int {
+  OK = 0,
+  E_INVALID = -1,
+  E_HIP = -2,
+  E_NOMEM = -3,
+  E_RCCL = -4,
+  E_STATE = -5,
+  E_NODEVICE = -6,
+};
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define DV_HIP(call)                                                     \
+  do {                                                                   \
+    hipError_t e__ = (call);                                             \
+    if (e__ != hipSuccess) return dv::hip_fail(e__, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define DV_TRY(call)            \
+  do {                          \
+    int s__ = (call);           \
+    if (s__ != dv::OK) return s__; \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// Gather-GEMM ("gconv"): Y[m, n] = sum_k A[m, k] * B[k, n]  with
+//   m  -> (stamp nb, class-grid row i, class-grid col j),   M = NB*Hc*Wc
+//   k  -> (tap t, input channel c),                        K = ntaps*Cin
+//   A[m,k] = X[nb, i*sin + dh[t], j*sin + dw[t], c]   (0 outside the image)
+//   B[k,n] = W[wt[t]][c][n]  (k-major)   or   W[wt[t]][n][c]  (n-major)
+//   output pixel = (i*sout + ph, j*sout + pw) of an [NB,Hout,Wout,Cout] tensor
+// Conv2D forward, Conv2DTranspose forward (stride-2 as 4 parity classes), their data gradients and
+// the Dense layers are all instances of this one contraction.
+// ---------------------------------------------------------------------------------------------
+struct GConvParams {
+  const float* X;
+  const float* W;
+  float* U;            // pre-activation / raw output (may be null)
+  float* A;            // post-activation output (epi 2) (may be null)
+  const float* bias;   // [Cout] or null
+  const float* alpha;  // [Hout*Wout*Cout] or null
+  int NB, Hin, Win, Cin;
+  int Hout, Wout, Cout;
+  int Hc, Wc;
+  int sin, sout, ph, pw;
+  int ntaps;
+  unsigned long long tapcode;  // 4 bits per tap: (dh+1) | (dw+1)<<2
+  unsigned long long wtcode;   // 4 bits per tap: weight tap index
+  int M, K;
+  int w_nmajor;
+  int epi;             // 0 raw, 1 +bias, 2 +bias then PReLU (alpha)
+  int cin_shift;       // log2(Cin) if power of two else -1
+};
+
+int launch_gconv(const GConvParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dW[(t, cx), cy] = sum_p Xg[p, t][cx] * dY[p][cy], split over pixel ranges into
+// partial slabs [nsplit][9*Cx][Cy] that reduce_partials() sums in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------
+struct WGradParams {
+  const float* X;     // gathered side [NB,Hx,Wx,Cx]
+  const float* Y;     // dense side    [NB,Hy,Wy,Cy]
+  float* part;        // [nsplit][rows_total][Cy]
+  int NB, Hx, Wx, Cx;
+  int Hy, Wy, Cy;
+  int Hc, Wc, sx, sy, ph, pw;
+  int ntaps;
+  unsigned long long tapcode, wtcode;
+  int P;              // NB*Hc*Wc
+  int rows_total;     // 9*Cx (slab rows; launch covers rows wt*Cx..)
+  int nsplit;
+  int pchunk;         // pixels per split (multiple of 32)
+};
+int launch_wgrad(const WGradParams& p, hipStream_t s);
+
+// out[(r/Cpad)*Creal + r%Cpad][c] = scale * sum_s part[s][r][c]   for r%Cpad < Creal
+int launch_reduce_partials(const float* part, float* out, int nsplit, long slab_elems, int ncols, int cpad,
+                           int creal, hipStream_t s);
+
+// pointwise / reduction kernels -----------------------------------------------------------------
+struct HeadParams {
+  const float* tpre;   // [NB,Hd,Hd,2*nb] head conv output before relu
+  const float* y;      // dataset labels [*,H,H,nb] (null: no loss)
+  const int* idx;      // per-stamp dataset row (null: first + b)
+  int first;
+  float* dt;           // [NB,Hd,Hd,2*nb] gradient wrt tpre (null: none)
+  float* loc;          // [NB,H,H,nb] or null
+  float* scale;        // [NB,H,H,nb] or null
+  float* part;         // [nblocks][2] partial sums (nll, squared error)
+  int NB, Hd, H, nb, crop0;
+  float sigma_floor;
+  float gscale;        // 1/(Bglobal*H*H*nb)
+};
+int launch_head(const HeadParams& p, hipStream_t s, int* nblocks_out);
+
+int launch_bn_stats(const float* x, const int* idx, int first, int NB, int HW, int C, float* part, int* nblocks,
+                    hipStream_t s);
+int launch_reduce_rows_f64(const float* part, int nrows, int ncols, float* out, float scale, hipStream_t s);
+// bnstate: [0..C) scale, [C..2C) shift, [2C..3C) mean, [3C..4C) inv_std
+int launch_bn_finalize(const float* sums, float count, int C, const float* gamma, const float* beta,
+                       float* moving_mean, float* moving_var, float eps, float momentum, int unbiased,
+                       int training, int update_moving, float* bnstate, hipStream_t s);
+int launch_bn_apply(const float* x, const int* idx, int first, int NB, int HW, int C, int Cpad, const float* bnstate,
+                    float* xn, hipStream_t s);
+int launch_bn_bwd(const float* dxn, const float* x, const int* idx, int first, int NB, int HW, int C, int Cpad,
+                  const float* bnstate, float* part, int* nblocks, hipStream_t s);
+
+int launch_prelu_fwd(const float* u, const float* alpha, float* a, long NB, int E, hipStream_t s);
+// da -> du in place; dalpha partials [nsplit][E]; dbias partials (mode by HW): see pointwise.hip
+int launch_prelu_bwd(float* da, const float* u, const float* alpha, int NB, int E, int C, int nsplit,
+                     float* dalpha_part, float* dbias_part, int* dbias_rows, hipStream_t s);
+int launch_colsum(const float* x, long rows, int C, float* part, int* nrows_part, hipStream_t s);
+
+struct SamplerParams {
+  const float* t;      // [NB, d + d(d+1)/2]
+  float* eps;          // [NB, d] (read; written first when gen != 0)
+  float* z;            // [NB, d]
+  float* kl;           // [NB]
+  float* stddev;       // [NB, d] or null
+  int NB, d;
+  float diag_shift;
+  int gen;             // 1: generate eps with Philox(seed, stream, row0 + b)
+  unsigned long long seed;
+  unsigned stream;
+  unsigned row0;
+};
+int launch_sampler_fwd(const SamplerParams& p, hipStream_t s);
+int launch_sampler_bwd(const float* t, const float* eps, const float* z, const float* dz, float* dt, int NB, int d,
+                       float diag_shift, float kls, hipStream_t s);
+
+int launch_adam(float* w, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps,
+                hipStream_t s);
+int launch_pad_w1(const float* w, float* wp, int taps, int cin, int cpad, int cout, hipStream_t s);
+int launch_fill(float* p, long n, float v, hipStream_t s);
+int launch_gather_rows(const float* src, const int* idx, int first, int NB, long row_elems, float* dst,
+                       hipStream_t s);
+
+}  // namespace dv

@@ -1,0 +1,1519 @@
+// Host runtime + C-ABI of libdebvader_hip.so (see include/debvader_hip.h).
+//
+// Replaces, for the hot path only, what Keras/TFP do under debvader's Python surface:
+//   create_model_vae            src/debvader/model/model.py:164-218   -> dv_model_create / dv_model_init
+//   net.fit train/test function src/debvader/training/train.py:27-37  -> dv_train_step / dv_eval_step
+//   net.compile(legacy Adam)    src/debvader/training/train.py:125-130,178-183 -> dv_optimizer_reset
+//   net(x) inside deblend()     src/debvader/deblend_cutout/deblender.py:18    -> dv_infer
+// One process drives one GPU; ranks are joined with RCCL (gradient / BN-statistic / loss all-reduce).
+// All activations are NHWC fp32 in HBM, weights + Adam slots live in three flat buffers with the
+// same layout so that one all-reduce and one fused Adam launch cover every trainable tensor.
+#include <rccl/rccl.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/debvader_hip.h"
+#include "common.h"
+
+namespace dv {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
+  return e == hipErrorOutOfMemory ? E_NOMEM : E_HIP;
+}
+#define DV_NCCL(call)                                                                      \
+  do {                                                                                     \
+    ncclResult_t r__ = (call);                                                             \
+    if (r__ != ncclSuccess) {                                                              \
+      dv::set_error("RCCL error %d (%s) in %s", (int)r__, ncclGetErrorString(r__), #call); \
+      return dv::E_RCCL;                                                                   \
+    }                                                                                      \
+  } while (0)
+
+// --------------------------------------------------------------------------------------------
+// architecture plan
+// --------------------------------------------------------------------------------------------
+struct Spec {
+  std::string name;
+  int64_t shape[4];
+  int ndim;
+  bool trainable;
+  size_t count;
+  size_t off;  // offset in the flat parameter buffer (floats)
+};
+
+static int same_pad_before(int n_in, int k, int s, int* n_out) {
+  int o = (n_in + s - 1) / s;
+  int tot = std::max((o - 1) * s + k - n_in, 0);
+  if (n_out) *n_out = o;
+  return tot / 2;
+}
+
+struct Arch {
+  dv_config cfg;
+  int H = 0, C = 0, d = 0, L = 0;
+  int tw = 0, dec_hidden = 0, w0 = 0, flat = 0, dec_out = 0, crop0 = 0;
+  std::vector<int> enc_sizes;
+  std::vector<Spec> specs;
+  size_t n_enc_train = 0, n_train = 0, n_total = 0;  // flat counts incl. alignment padding
+  int64_t n_enc_params = 0, n_dec_params = 0, n_trainable_params = 0;
+  int D0 = 0;
+
+  int enc_k(int j) const { return 4 + 3 * j; }
+  int enc_b(int j) const { return 5 + 3 * j; }
+  int enc_al(int j) const { return 6 + 3 * j; }
+  int enc_flat_al() const { return 4 + 6 * L; }
+  int enc_dk() const { return 5 + 6 * L; }
+  int enc_db() const { return 6 + 6 * L; }
+  int dec_k(int j) const { return D0 + 7 + 3 * j; }
+  int dec_b(int j) const { return D0 + 8 + 3 * j; }
+  int dec_al(int j) const { return D0 + 9 + 3 * j; }
+  int head_k() const { return D0 + 7 + 6 * L; }
+  int head_b() const { return D0 + 8 + 6 * L; }
+
+  // encoder conv j: input size/channels, output size/channels, stride
+  void enc_layer(int j, int* hin, int* cin, int* hout, int* cout, int* s) const {
+    int lvl = j / 2;
+    *s = (j % 2) ? 2 : 1;
+    *hin = enc_sizes[lvl];
+    *hout = (j % 2) ? enc_sizes[lvl + 1] : enc_sizes[lvl];
+    *cout = cfg.filters[lvl];
+    *cin = (j % 2) ? cfg.filters[lvl] : (lvl == 0 ? C : cfg.filters[lvl - 1]);
+  }
+  // decoder convT j (reference iterates filters in reverse, model.py:120)
+  void dec_layer(int j, int* hin, int* cin, int* hout, int* cout, int* s) const {
+    int jj = j / 2;
+    int lvl = L - 1 - jj;
+    *s = (j % 2) ? 1 : 2;
+    int size_in = w0 << jj;
+    *hin = (j % 2) ? size_in * 2 : size_in;
+    *hout = size_in * 2;
+    *cout = cfg.filters[lvl];
+    *cin = (j % 2) ? cfg.filters[lvl] : (jj == 0 ? cfg.filters[L - 1] : cfg.filters[lvl + 1]);
+  }
+
+  int build(const dv_config* c) {
+    cfg = *c;
+    H = c->height;
+    C = c->bands;
+    d = c->latent_dim;
+    L = c->n_levels;
+    if (c->height != c->width) {
+      set_error("only square stamps are supported (reference uses input_shape[0] for both axes)");
+      return E_INVALID;
+    }
+    if (L < 1 || L > DV_MAX_LEVELS || C < 1 || C > 8 || d < 1 || d > 64 || H < 4) {
+      set_error("unsupported architecture (levels=%d bands=%d latent=%d size=%d)", L, C, d, H);
+      return E_INVALID;
+    }
+    for (int i = 0; i < L; ++i) {
+      if (c->kernels[i] != 3) {
+        set_error("only 3x3 kernels are implemented (kernels[%d]=%d)", i, c->kernels[i]);
+        return E_INVALID;
+      }
+      if (c->filters[i] < 4 || (c->filters[i] & 3)) {
+        set_error("filters must be multiples of 4");
+        return E_INVALID;
+      }
+    }
+    tw = d + d * (d + 1) / 2;
+    dec_hidden = 32 + 32 * 33 / 2;  // hard-coded params_size(32), model.py:114
+    enc_sizes.assign(1, H);
+    for (int i = 0; i < L; ++i) enc_sizes.push_back((enc_sizes.back() + 1) / 2);
+    w0 = (H + (1 << L) - 1) >> L;  // ceil(H / 2^L), model.py:116
+    flat = enc_sizes[L] * enc_sizes[L] * c->filters[L - 1];
+    dec_out = w0 << L;
+    int crop = dec_out - H;
+    crop0 = crop > 0 ? crop / 2 : 0;  // model.py:140-148
+    if (crop < 0) {
+      set_error("decoder output smaller than the stamp");
+      return E_INVALID;
+    }
+    D0 = 7 + 6 * L;
+    specs.clear();
+    auto add = [&](const std::string& n, std::vector<int64_t> sh, bool tr) {
+      Spec s;
+      s.name = n;
+      s.ndim = (int)sh.size();
+      s.count = 1;
+      for (int i = 0; i < 4; ++i) s.shape[i] = i < s.ndim ? sh[i] : 1;
+      for (int i = 0; i < s.ndim; ++i) s.count *= (size_t)sh[i];
+      s.trainable = tr;
+      s.off = 0;
+      specs.push_back(s);
+    };
+    add("enc/bn/gamma", {C}, true);
+    add("enc/bn/beta", {C}, true);
+    add("enc/bn/moving_mean", {C}, false);
+    add("enc/bn/moving_variance", {C}, false);
+    for (int j = 0; j < 2 * L; ++j) {
+      int hin, cin, hout, cout, s;
+      enc_layer(j, &hin, &cin, &hout, &cout, &s);
+      char b[64];
+      snprintf(b, sizeof b, "enc/conv%d/kernel", j);
+      add(b, {3, 3, cin, cout}, true);
+      snprintf(b, sizeof b, "enc/conv%d/bias", j);
+      add(b, {cout}, true);
+      snprintf(b, sizeof b, "enc/prelu%d/alpha", j);
+      add(b, {hout, hout, cout}, true);
+    }
+    add("enc/prelu_flat/alpha", {flat}, true);
+    add("enc/dense/kernel", {flat, tw}, true);
+    add("enc/dense/bias", {tw}, true);
+    int r = w0 * w0 * c->filters[L - 1];
+    add("dec/prelu_in/alpha", {d}, true);
+    add("dec/dense0/kernel", {d, dec_hidden}, true);
+    add("dec/dense0/bias", {dec_hidden}, true);
+    add("dec/prelu_h/alpha", {dec_hidden}, true);
+    add("dec/dense1/kernel", {dec_hidden, r}, true);
+    add("dec/dense1/bias", {r}, true);
+    add("dec/prelu_r/alpha", {r}, true);
+    for (int j = 0; j < 2 * L; ++j) {
+      int hin, cin, hout, cout, s;
+      dec_layer(j, &hin, &cin, &hout, &cout, &s);
+      char b[64];
+      snprintf(b, sizeof b, "dec/convt%d/kernel", j);
+      add(b, {3, 3, cout, cin}, true);
+      snprintf(b, sizeof b, "dec/convt%d/bias", j);
+      add(b, {cout}, true);
+      snprintf(b, sizeof b, "dec/prelut%d/alpha", j);
+      add(b, {hout, hout, cout}, true);
+    }
+    add("dec/head/kernel", {3, 3, c->filters[0], 2 * C}, true);
+    add("dec/head/bias", {2 * C}, true);
+    if (tw & 3 || dec_hidden & 3 || d & 3 || (2 * C) & 3) {
+      set_error("latent_dim and 2*bands must be multiples of 4 for the vectorised kernels");
+      return E_INVALID;
+    }
+    // flat layout: [encoder trainables | decoder trainables | non-trainables], every tensor 16-byte aligned
+    size_t off = 0;
+    n_enc_params = n_dec_params = n_trainable_params = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+      for (size_t i = 0; i < specs.size(); ++i) {
+        Spec& s = specs[i];
+        bool enc = (int)i < D0;
+        int cls = s.trainable ? (enc ? 0 : 1) : 2;
+        if (cls != pass) continue;
+        s.off = off;
+        off += (s.count + 3) & ~(size_t)3;
+      }
+      if (pass == 0) n_enc_train = off;
+      if (pass == 1) n_train = off;
+    }
+    n_total = off;
+    for (size_t i = 0; i < specs.size(); ++i) {
+      ((int)i < D0 ? n_enc_params : n_dec_params) += (int64_t)specs[i].count;
+      if (specs[i].trainable) n_trainable_params += (int64_t)specs[i].count;
+    }
+    return OK;
+  }
+
+  void macs(int64_t* enc, int64_t* dec) const {
+    int64_t e = 0, dd = 0;
+    for (int j = 0; j < 2 * L; ++j) {
+      int hin, cin, hout, cout, s;
+      enc_layer(j, &hin, &cin, &hout, &cout, &s);
+      e += (int64_t)hout * hout * 9 * cin * cout;
+    }
+    e += (int64_t)flat * tw;
+    dd += (int64_t)d * dec_hidden + (int64_t)dec_hidden * w0 * w0 * cfg.filters[L - 1];
+    for (int j = 0; j < 2 * L; ++j) {
+      int hin, cin, hout, cout, s;
+      dec_layer(j, &hin, &cin, &hout, &cout, &s);
+      dd += (int64_t)hin * hin * 9 * cin * cout;  // every input pixel meets all 9 taps
+    }
+    dd += (int64_t)dec_out * dec_out * 9 * cfg.filters[0] * 2 * C;
+    *enc = e;
+    *dec = dd;
+  }
+};
+
+// --------------------------------------------------------------------------------------------
+// tap tables
+// --------------------------------------------------------------------------------------------
+struct Taps {
+  int n = 0;
+  unsigned long long tapcode = 0, wtcode = 0;
+  void add(int dh, int dw, int wt) {
+    tapcode |= (unsigned long long)(((dh + 1) & 3) | (((dw + 1) & 3) << 2)) << (4 * n);
+    wtcode |= (unsigned long long)(wt & 15) << (4 * n);
+    ++n;
+  }
+};
+// input pixel = out*s + k - pad_before
+static Taps taps_fprop(int pb) {
+  Taps t;
+  for (int kh = 0; kh < 3; ++kh)
+    for (int kw = 0; kw < 3; ++kw) t.add(kh - pb, kw - pb, kh * 3 + kw);
+  return t;
+}
+// data-gradient form: target pixel o = s*i~ + ph, source i = i~ + (ph + pb - kh)/s for kh == ph+pb (mod s)
+static Taps taps_dgrad(int s, int pb, int ph, int pw) {
+  Taps t;
+  for (int kh = 0; kh < 3; ++kh) {
+    int nh = ph + pb - kh;
+    if (((nh % s) + s) % s) continue;
+    for (int kw = 0; kw < 3; ++kw) {
+      int nw = pw + pb - kw;
+      if (((nw % s) + s) % s) continue;
+      t.add(nh / s, nw / s, kh * 3 + kw);
+    }
+  }
+  return t;
+}
+static int ilog2_exact(int v) {
+  for (int s = 0; s < 31; ++s)
+    if ((1 << s) == v) return s;
+  return -1;
+}
+
+}  // namespace dv
+
+// --------------------------------------------------------------------------------------------
+// handles
+// --------------------------------------------------------------------------------------------
+struct dv_ctx {
+  int device = 0, rank = 0, world = 1;
+  hipStream_t stream = nullptr;
+  ncclComm_t comm = nullptr;
+  float* red_dev = nullptr;  // small device buffer for host all-reduce
+};
+
+struct ProfRec {
+  int klass;
+  hipEvent_t a, b;
+};
+
+struct DataSlot {
+  float* x = nullptr;
+  float* y = nullptr;
+  int64_t n = 0;
+};
+
+struct dv_model {
+  dv_ctx* ctx = nullptr;
+  dv::Arch A;
+  int Bc = 0;
+  // flat parameter-shaped buffers
+  float *P = nullptr, *G = nullptr, *Mm = nullptr, *Vv = nullptr;
+  float* W1p = nullptr;  // first conv kernel padded to 8 input channels
+  bool enc_trainable = true, dec_trainable = true;
+  bool opt_enc = true, opt_dec = true;  // what the current optimizer updates (fixed at dv_optimizer_reset)
+  float lr = 1e-4f, b1 = 0.9f, b2 = 0.999f, aeps = 1e-7f;
+  int64_t iter = 0;
+  // activations
+  float* xn = nullptr;
+  std::vector<float*> enc_u, enc_a, dec_u, dec_a;
+  float *flat_a = nullptr, *t = nullptr, *eps = nullptr, *z = nullptr, *zstd = nullptr, *kl = nullptr;
+  float *dec_ain = nullptr, *dec_uh = nullptr, *dec_ah = nullptr, *dec_ur = nullptr, *dec_ar = nullptr;
+  float *tpre = nullptr, *loc = nullptr, *scale = nullptr;
+  float *gA = nullptr, *gB = nullptr;
+  float *ws1 = nullptr, *ws2 = nullptr, *ws3 = nullptr;
+  size_t ws1_elems = 0, ws2_elems = 0, ws3_elems = 0;
+  float *scal = nullptr, *bnstate = nullptr, *bnsums = nullptr;
+  float* stage_x = nullptr;  // host-batch staging (infer / encode)
+  int* idx_dev = nullptr;
+  DataSlot slots[2];
+  int lastB = 0;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  int64_t prof_n[3] = {0, 0, 0};
+  double prof_ms[3] = {0, 0, 0};
+  std::vector<void*> allocs;
+};
+
+namespace dv {
+
+static int dalloc(dv_model* m, float** p, size_t elems) {
+  void* q = nullptr;
+  if (elems == 0) elems = 4;
+  hipError_t e = hipMalloc(&q, elems * sizeof(float));
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+  m->allocs.push_back(q);
+  *p = (float*)q;
+  return OK;
+}
+
+struct ProfScope {
+  dv_model* m;
+  int klass;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(dv_model* mm, int k) : m(mm), klass(k) {
+    if (!m->prof_on) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!m->ev_pool.empty()) {
+        e = m->ev_pool.back();
+        m->ev_pool.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    a = get();
+    b = get();
+    (void)hipEventRecord(a, m->ctx->stream);
+  }
+  ~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, m->ctx->stream);
+    m->prof.push_back({klass, a, b});
+  }
+};
+
+static int prof_flush(dv_model* m) {
+  if (m->prof.empty()) return OK;
+  DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  for (auto& r : m->prof) {
+    float ms = 0.f;
+    DV_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    m->prof_n[r.klass] += 1;
+    m->prof_ms[r.klass] += ms;
+    m->ev_pool.push_back(r.a);
+    m->ev_pool.push_back(r.b);
+  }
+  m->prof.clear();
+  return OK;
+}
+
+// ---- layer launch helpers ---------------------------------------------------------------------
+static void fill_gconv_common(GConvParams& p, const Taps& t, int cin) {
+  p.ntaps = t.n;
+  p.tapcode = t.tapcode;
+  p.wtcode = t.wtcode;
+  p.K = t.n * cin;
+  p.cin_shift = ilog2_exact(cin);
+}
+
+// fprop-form gconv over an [NB,Hin,Hin,Cin] tensor: out[NB,Hout,Hout,Cout], in pixel = out*s + k - pb
+static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor, const float* bias, const float* alpha,
+                       float* U, float* Aout, int epi, int NB, int Hin, int Cin, int Hout, int Cout, int s, int pb,
+                       bool single_tap = false) {
+  GConvParams p;
+  memset(&p, 0, sizeof p);
+  p.X = X;
+  p.W = W;
+  p.U = U;
+  p.A = Aout;
+  p.bias = bias;
+  p.alpha = alpha;
+  p.NB = NB;
+  p.Hin = p.Win = Hin;
+  p.Cin = Cin;
+  p.Hout = p.Wout = Hout;
+  p.Cout = Cout;
+  p.Hc = p.Wc = Hout;
+  p.sin = s;
+  p.sout = 1;
+  p.ph = p.pw = 0;
+  p.M = NB * Hout * Hout;
+  p.w_nmajor = nmajor ? 1 : 0;
+  p.epi = epi;
+  Taps one;
+  one.add(0, 0, 0);
+  fill_gconv_common(p, single_tap ? one : taps_fprop(pb), Cin);
+  ProfScope ps(m, 0);
+  return launch_gconv(p, m->ctx->stream);
+}
+
+// data-gradient-form gconv: target [NB,Ht,Ht,Ct] (s*s parity classes), source [NB,Hs,Hs,Cs];
+// target pixel o satisfies o + pb = s*i + k for source pixel i.
+static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor, const float* bias, const float* alpha,
+                       float* U, float* Aout, int epi, int NB, int Hs, int Cs, int Ht, int Ct, int s, int pb) {
+  for (int ph = 0; ph < s; ++ph)
+    for (int pw = 0; pw < s; ++pw) {
+      int hc = (Ht - ph + s - 1) / s, wc = (Ht - pw + s - 1) / s;
+      if (hc <= 0 || wc <= 0) continue;
+      Taps t = taps_dgrad(s, pb, ph, pw);
+      GConvParams p;
+      memset(&p, 0, sizeof p);
+      p.X = X;
+      p.W = W;
+      p.U = U;
+      p.A = Aout;
+      p.bias = bias;
+      p.alpha = alpha;
+      p.NB = NB;
+      p.Hin = p.Win = Hs;
+      p.Cin = Cs;
+      p.Hout = p.Wout = Ht;
+      p.Cout = Ct;
+      p.Hc = hc;
+      p.Wc = wc;
+      p.sin = 1;
+      p.sout = s;
+      p.ph = ph;
+      p.pw = pw;
+      p.M = NB * hc * wc;
+      p.w_nmajor = nmajor ? 1 : 0;
+      p.epi = epi;
+      if (t.n == 0) {
+        set_error("empty parity class");
+        return E_INVALID;
+      }
+      fill_gconv_common(p, t, Cs);
+      ProfScope ps(m, 0);
+      DV_TRY(launch_gconv(p, m->ctx->stream));
+    }
+  return OK;
+}
+
+// dW = sum_p Xg[p,t][cx] * Y[p][cy]; X pixel = grid*sx + k - pb; result rows (wt,cx) x cols cy into `out`
+static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB, int sx, int pb,
+                 bool single_tap, float* out, int cpad, int creal) {
+  WGradParams p;
+  memset(&p, 0, sizeof p);
+  Taps t;
+  if (single_tap)
+    t.add(0, 0, 0);
+  else
+    t = taps_fprop(pb);
+  p.X = X;
+  p.Y = Y;
+  p.part = m->ws1;
+  p.NB = NB;
+  p.Hx = p.Wx = Hx;
+  p.Cx = Cx;
+  p.Hy = p.Wy = Hy;
+  p.Cy = Cy;
+  p.Hc = p.Wc = Hy;
+  p.sx = sx;
+  p.sy = 1;
+  p.ph = p.pw = 0;
+  p.ntaps = t.n;
+  p.tapcode = t.tapcode;
+  p.wtcode = t.wtcode;
+  p.P = NB * Hy * Hy;
+  p.rows_total = t.n * Cx;
+  long slab = (long)p.rows_total * Cy;
+  long tiles = ((p.rows_total + 127) / 128) * (long)((Cy + 127) / 128);
+  long ns = (768 + tiles - 1) / tiles;
+  ns = std::min(ns, (long)std::max(1, p.P / 256));
+  ns = std::min(ns, (long)(m->ws1_elems / (size_t)slab));
+  ns = std::max(ns, 1L);
+  if ((size_t)slab > m->ws1_elems) {
+    set_error("wgrad workspace too small");
+    return E_STATE;
+  }
+  int pchunk = (int)((p.P + ns - 1) / ns);
+  pchunk = (pchunk + 31) & ~31;
+  ns = (p.P + pchunk - 1) / pchunk;
+  p.nsplit = (int)ns;
+  p.pchunk = pchunk;
+  {
+    ProfScope ps(m, 1);
+    DV_TRY(launch_wgrad(p, m->ctx->stream));
+  }
+  ProfScope ps(m, 2);
+  return launch_reduce_partials(m->ws1, out, p.nsplit, slab, Cy, cpad, creal, m->ctx->stream);
+}
+
+// PReLU backward with optional parameter gradients
+static int prelu_bwd(dv_model* m, float* da, const float* u, int alpha_spec, int bias_spec, int NB, int E, int C,
+                     bool want_grads) {
+  const Arch& A = m->A;
+  int gx = (E + 1023) / 1024;
+  int nsplit = std::max(1, std::min(std::min(NB, 64), 1024 / std::max(gx, 1)));
+  while ((size_t)nsplit * E > m->ws2_elems && nsplit > 1) --nsplit;
+  float* dal = want_grads ? m->ws2 : nullptr;
+  float* dbp = (want_grads && bias_spec >= 0) ? m->ws3 : nullptr;
+  int rows = 0;
+  if (dbp) {
+    size_t need = (E == C) ? (size_t)nsplit * E : (size_t)nsplit * gx * C;
+    if (need > m->ws3_elems) {
+      set_error("bias-gradient workspace too small");
+      return E_STATE;
+    }
+  }
+  {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_prelu_bwd(da, u, m->P + A.specs[alpha_spec].off, NB, E, C, nsplit, dal, dbp, &rows,
+                            m->ctx->stream));
+  }
+  if (want_grads) {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_reduce_partials(m->ws2, m->G + A.specs[alpha_spec].off, nsplit, E, 1, 1, 1, m->ctx->stream));
+    if (dbp) DV_TRY(launch_reduce_rows_f64(m->ws3, rows, C, m->G + A.specs[bias_spec].off, 1.0f, m->ctx->stream));
+  }
+  return OK;
+}
+
+static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int bias_spec) {
+  int nr = 0;
+  if ((size_t)((rows + 2047) / 2048) * C > m->ws3_elems) {
+    set_error("colsum workspace too small");
+    return E_STATE;
+  }
+  ProfScope ps(m, 2);
+  DV_TRY(launch_colsum(dy, rows, C, m->ws3, &nr, m->ctx->stream));
+  return launch_reduce_rows_f64(m->ws3, nr, C, m->G + m->A.specs[bias_spec].off, 1.0f, m->ctx->stream);
+}
+
+static int refresh_w1p(dv_model* m) {
+  const Arch& A = m->A;
+  return launch_pad_w1(m->P + A.specs[A.enc_k(0)].off, m->W1p, 9, A.C, 8, A.cfg.filters[0], m->ctx->stream);
+}
+
+// ---- forward ----------------------------------------------------------------------------------
+// encoder: xsrc rows (idx / first) -> t.  training: batch statistics (+ moving update when upd_moving).
+static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, int Bg, bool training,
+                           bool upd_moving, bool keep_u) {
+  const Arch& A = m->A;
+  hipStream_t s = m->ctx->stream;
+  const int HW = A.H * A.H;
+  float* P = m->P;
+  if (training) {
+    int nblk = 0;
+    ProfScope ps(m, 2);
+    DV_TRY(launch_bn_stats(xsrc, idx, first, NB, HW, A.C, m->ws3, &nblk, s));
+    DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 16, m->bnsums, 1.0f, s));
+    if (m->ctx->world > 1) DV_NCCL(ncclAllReduce(m->bnsums, m->bnsums, 16, ncclFloat, ncclSum, m->ctx->comm, s));
+  }
+  {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_bn_finalize(m->bnsums, (float)((double)Bg * HW), A.C, P + A.specs[0].off, P + A.specs[1].off,
+                              P + A.specs[2].off, P + A.specs[3].off, A.cfg.bn_eps, A.cfg.bn_momentum,
+                              A.cfg.bn_moving_var_unbiased, training ? 1 : 0, upd_moving ? 1 : 0, m->bnstate, s));
+    DV_TRY(launch_bn_apply(xsrc, idx, first, NB, HW, A.C, 8, m->bnstate, m->xn, s));
+  }
+  const float* in = m->xn;
+  for (int j = 0; j < 2 * A.L; ++j) {
+    int hin, cin, hout, cout, st;
+    A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
+    int pb = same_pad_before(hin, 3, st, nullptr);
+    const float* W = j == 0 ? m->W1p : P + A.specs[A.enc_k(j)].off;
+    int cin_phys = j == 0 ? 8 : cin;
+    DV_TRY(gconv_fprop(m, in, W, false, P + A.specs[A.enc_b(j)].off, P + A.specs[A.enc_al(j)].off,
+                       keep_u ? m->enc_u[j] : nullptr, m->enc_a[j], 2, NB, hin, cin_phys, hout, cout, st, pb));
+    in = m->enc_a[j];
+  }
+  {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_prelu_fwd(in, P + A.specs[A.enc_flat_al()].off, m->flat_a, NB, A.flat, s));
+  }
+  return gconv_fprop(m, m->flat_a, P + A.specs[A.enc_dk()].off, false, P + A.specs[A.enc_db()].off, nullptr, m->t,
+                     nullptr, 1, NB, 1, A.flat, 1, A.tw, 1, 0, true);
+}
+
+static int decoder_forward(dv_model* m, const float* z, int NB, bool keep_u) {
+  const Arch& A = m->A;
+  hipStream_t s = m->ctx->stream;
+  float* P = m->P;
+  {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_prelu_fwd(z, P + A.specs[A.D0].off, m->dec_ain, NB, A.d, s));
+  }
+  DV_TRY(gconv_fprop(m, m->dec_ain, P + A.specs[A.D0 + 1].off, false, P + A.specs[A.D0 + 2].off,
+                     P + A.specs[A.D0 + 3].off, keep_u ? m->dec_uh : nullptr, m->dec_ah, 2, NB, 1, A.d, 1,
+                     A.dec_hidden, 1, 0, true));
+  int r = A.w0 * A.w0 * A.cfg.filters[A.L - 1];
+  DV_TRY(gconv_fprop(m, m->dec_ah, P + A.specs[A.D0 + 4].off, false, P + A.specs[A.D0 + 5].off,
+                     P + A.specs[A.D0 + 6].off, keep_u ? m->dec_ur : nullptr, m->dec_ar, 2, NB, 1, A.dec_hidden, 1, r,
+                     1, 0, true));
+  const float* in = m->dec_ar;
+  for (int j = 0; j < 2 * A.L; ++j) {
+    int hin, cin, hout, cout, st;
+    A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
+    int pb = same_pad_before(hout, 3, st, nullptr);
+    // Conv2DTranspose = data gradient of a SAME conv over the output grid; kernel (kh,kw,cout,cin) is n-major
+    DV_TRY(gconv_dgrad(m, in, P + A.specs[A.dec_k(j)].off, true, P + A.specs[A.dec_b(j)].off,
+                       P + A.specs[A.dec_al(j)].off, keep_u ? m->dec_u[j] : nullptr, m->dec_a[j], 2, NB, hin, cin,
+                       hout, cout, st, pb));
+    in = m->dec_a[j];
+  }
+  return gconv_fprop(m, in, P + A.specs[A.head_k()].off, false, P + A.specs[A.head_b()].off, nullptr, m->tpre, nullptr,
+                     1, NB, A.dec_out, A.cfg.filters[0], A.dec_out, 2 * A.C, 1, 1);
+}
+
+static int sampler_forward(dv_model* m, int NB, const float* eps_host, uint64_t seed, unsigned stream_id,
+                           unsigned row0, bool want_std) {
+  const Arch& A = m->A;
+  hipStream_t s = m->ctx->stream;
+  if (eps_host)
+    DV_HIP(hipMemcpyAsync(m->eps, eps_host, (size_t)NB * A.d * sizeof(float), hipMemcpyHostToDevice, s));
+  SamplerParams sp;
+  memset(&sp, 0, sizeof sp);
+  sp.t = m->t;
+  sp.eps = m->eps;
+  sp.z = m->z;
+  sp.kl = m->kl;
+  sp.stddev = want_std ? m->zstd : nullptr;
+  sp.NB = NB;
+  sp.d = A.d;
+  sp.diag_shift = A.cfg.diag_shift;
+  sp.gen = eps_host ? 0 : 1;
+  sp.seed = seed;
+  sp.stream = stream_id;
+  sp.row0 = row0;
+  ProfScope ps(m, 2);
+  return launch_sampler_fwd(sp, s);
+}
+
+// head: loss partials -> scal[0..2] = (nll sum, squared-error sum, kl sum); optionally d(loss)/d(tpre) into gA
+static int head_and_loss(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
+                         bool want_out) {
+  const Arch& A = m->A;
+  hipStream_t s = m->ctx->stream;
+  HeadParams hp;
+  memset(&hp, 0, sizeof hp);
+  hp.tpre = m->tpre;
+  hp.y = ysrc;
+  hp.idx = idx;
+  hp.first = first;
+  hp.dt = want_grad ? m->gA : nullptr;
+  hp.loc = want_out ? m->loc : nullptr;
+  hp.scale = want_out ? m->scale : nullptr;
+  hp.part = m->ws3;
+  hp.NB = NB;
+  hp.Hd = A.dec_out;
+  hp.H = A.H;
+  hp.nb = A.C;
+  hp.crop0 = A.crop0;
+  hp.sigma_floor = A.cfg.sigma_floor;
+  hp.gscale = (float)(1.0 / ((double)Bg * A.H * A.H * A.C));
+  int nblk = 0;
+  ProfScope ps(m, 2);
+  if ((size_t)(((long)NB * A.dec_out * A.dec_out + 255) / 256) * 2 > m->ws3_elems) {
+    set_error("head workspace too small");
+    return E_STATE;
+  }
+  DV_TRY(launch_head(hp, s, &nblk));
+  if (ysrc) {
+    DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 2, m->scal, 1.0f, s));
+    DV_TRY(launch_reduce_rows_f64(m->kl, NB, 1, m->scal + 2, 1.0f, s));
+  }
+  return OK;
+}
+
+// ---- backward ---------------------------------------------------------------------------------
+static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* idx, int first) {
+  const Arch& A = m->A;
+  hipStream_t s = m->ctx->stream;
+  float* P = m->P;
+  float* G = m->G;
+  const bool dg = m->dec_trainable;  // decoder parameter gradients wanted
+  float* cur = m->gA;                // d(tpre)
+  float* oth = m->gB;
+  const int Hd = A.dec_out, f0 = A.cfg.filters[0], C2 = 2 * A.C;
+  // head conv
+  if (dg) {
+    DV_TRY(wgrad(m, m->dec_a[2 * A.L - 1], Hd, f0, cur, Hd, C2, NB, 1, 1, false, G + A.specs[A.head_k()].off, f0, f0));
+    DV_TRY(bias_grad_colsum(m, cur, (long)NB * Hd * Hd, C2, A.head_b()));
+  }
+  DV_TRY(gconv_dgrad(m, cur, P + A.specs[A.head_k()].off, true, nullptr, nullptr, oth, nullptr, 0, NB, Hd, C2, Hd, f0,
+                     1, 1));
+  std::swap(cur, oth);
+  // decoder conv-transpose stack
+  for (int j = 2 * A.L - 1; j >= 0; --j) {
+    int hin, cin, hout, cout, st;
+    A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
+    int pb = same_pad_before(hout, 3, st, nullptr);
+    DV_TRY(prelu_bwd(m, cur, m->dec_u[j], A.dec_al(j), A.dec_b(j), NB, hout * hout * cout, cout, dg));
+    const float* xin = j == 0 ? m->dec_ar : m->dec_a[j - 1];
+    if (dg)
+      DV_TRY(wgrad(m, cur, hout, cout, xin, hin, cin, NB, st, pb, false, G + A.specs[A.dec_k(j)].off, cout, cout));
+    // d(input) = strided conv of d(pre-activation) with K[kh,kw,co,ci] (rows (tap,co), cols ci: k-major)
+    DV_TRY(gconv_fprop(m, cur, P + A.specs[A.dec_k(j)].off, false, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout,
+                       hin, cin, st, pb));
+    std::swap(cur, oth);
+  }
+  // dense trunk of the decoder
+  int r = A.w0 * A.w0 * A.cfg.filters[A.L - 1];
+  DV_TRY(prelu_bwd(m, cur, m->dec_ur, A.D0 + 6, A.D0 + 5, NB, r, r, dg));
+  if (dg) DV_TRY(wgrad(m, m->dec_ah, 1, A.dec_hidden, cur, 1, r, NB, 1, 0, true, G + A.specs[A.D0 + 4].off, 1, 1));
+  DV_TRY(gconv_fprop(m, cur, P + A.specs[A.D0 + 4].off, true, nullptr, nullptr, oth, nullptr, 0, NB, 1, r, 1,
+                     A.dec_hidden, 1, 0, true));
+  std::swap(cur, oth);
+  DV_TRY(prelu_bwd(m, cur, m->dec_uh, A.D0 + 3, A.D0 + 2, NB, A.dec_hidden, A.dec_hidden, dg));
+  if (dg) DV_TRY(wgrad(m, m->dec_ain, 1, A.d, cur, 1, A.dec_hidden, NB, 1, 0, true, G + A.specs[A.D0 + 1].off, 1, 1));
+  DV_TRY(gconv_fprop(m, cur, P + A.specs[A.D0 + 1].off, true, nullptr, nullptr, oth, nullptr, 0, NB, 1, A.dec_hidden,
+                     1, A.d, 1, 0, true));
+  std::swap(cur, oth);
+  DV_TRY(prelu_bwd(m, cur, m->z, A.D0, -1, NB, A.d, A.d, dg));
+  // sampler + KL
+  float kls = (float)((double)A.cfg.kl_multiplicity * A.cfg.kl_weight / ((double)Bg * (double)Bg));
+  {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, cur, oth, NB, A.d, A.cfg.diag_shift, kls, s));
+  }
+  std::swap(cur, oth);  // cur = d(t) [NB, tw]
+  // encoder dense
+  DV_TRY(bias_grad_colsum(m, cur, NB, A.tw, A.enc_db()));
+  DV_TRY(wgrad(m, m->flat_a, 1, A.flat, cur, 1, A.tw, NB, 1, 0, true, G + A.specs[A.enc_dk()].off, 1, 1));
+  DV_TRY(gconv_fprop(m, cur, P + A.specs[A.enc_dk()].off, true, nullptr, nullptr, oth, nullptr, 0, NB, 1, A.tw, 1,
+                     A.flat, 1, 0, true));
+  std::swap(cur, oth);
+  DV_TRY(prelu_bwd(m, cur, m->enc_a[2 * A.L - 1], A.enc_flat_al(), -1, NB, A.flat, A.flat, true));
+  for (int j = 2 * A.L - 1; j >= 0; --j) {
+    int hin, cin, hout, cout, st;
+    A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
+    int pb = same_pad_before(hin, 3, st, nullptr);
+    DV_TRY(prelu_bwd(m, cur, m->enc_u[j], A.enc_al(j), A.enc_b(j), NB, hout * hout * cout, cout, true));
+    const float* xin = j == 0 ? m->xn : m->enc_a[j - 1];
+    int cin_phys = j == 0 ? 8 : cin;
+    DV_TRY(wgrad(m, xin, hin, cin_phys, cur, hout, cout, NB, st, pb, false, G + A.specs[A.enc_k(j)].off, cin_phys,
+                 j == 0 ? A.C : cin_phys));
+    const float* W = j == 0 ? m->W1p : P + A.specs[A.enc_k(j)].off;
+    DV_TRY(gconv_dgrad(m, cur, W, true, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout, hin, cin_phys, st, pb));
+    std::swap(cur, oth);
+  }
+  // input BatchNorm: d(gamma), d(beta) (the input is data: no dX)
+  {
+    int nblk = 0;
+    ProfScope ps(m, 2);
+    DV_TRY(launch_bn_bwd(cur, xsrc, idx, first, NB, A.H * A.H, A.C, 8, m->bnstate, m->ws3, &nblk, s));
+    // partial rows are [dgamma(8) | dbeta(8)]; gamma and beta are adjacent 8-float slots of G
+    DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 16, G + A.specs[0].off, 1.0f, s));
+  }
+  return OK;
+}
+
+static int optimizer_step(dv_model* m) {
+  const Arch& A = m->A;
+  m->iter += 1;
+  double t = (double)m->iter;
+  float lr_t = (float)((double)m->lr * sqrt(1.0 - pow((double)m->b2, t)) / (1.0 - pow((double)m->b1, t)));
+  size_t beg = m->opt_enc ? 0 : A.n_enc_train;
+  size_t end = m->opt_dec ? A.n_train : A.n_enc_train;
+  if (end <= beg) return OK;
+  ProfScope ps(m, 2);
+  DV_TRY(launch_adam(m->P + beg, m->Mm + beg, m->Vv + beg, m->G + beg, (long)(end - beg), lr_t, m->b1, m->b2,
+                     m->aeps, m->ctx->stream));
+  if (m->opt_enc) DV_TRY(refresh_w1p(m));
+  return OK;
+}
+
+enum StepMode { MODE_TRAIN = 0, MODE_EVAL = 1, MODE_GRAD = 2 };
+
+static int check_step_args(dv_model* m, int slot, const int32_t* idx, int64_t first, int B) {
+  if (!m) {
+    set_error("null model");
+    return E_INVALID;
+  }
+  if (slot < 0 || slot > 1 || !m->slots[slot].x) {
+    set_error("data slot %d is empty (call dv_data_upload first)", slot);
+    return E_STATE;
+  }
+  if (B < 1 || B > m->Bc) {
+    set_error("batch %d outside [1, max_batch=%d]", B, m->Bc);
+    return E_INVALID;
+  }
+  if (!idx && (first < 0 || first + B > m->slots[slot].n)) {
+    set_error("rows [%lld, %lld) outside the %lld uploaded stamps", (long long)first, (long long)(first + B),
+              (long long)m->slots[slot].n);
+    return E_INVALID;
+  }
+  if (idx)
+    for (int i = 0; i < B; ++i)
+      if (idx[i] < 0 || idx[i] >= m->slots[slot].n) {
+        set_error("index %d out of range", idx[i]);
+        return E_INVALID;
+      }
+  return OK;
+}
+
+// enqueue one step (no host sync); scalars land in m->scal[0..2]
+static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx_host, int64_t first, int B, int Bg,
+                        const float* eps_host, uint64_t seed) {
+  const Arch& A = m->A;
+  hipStream_t s = m->ctx->stream;
+  const DataSlot& ds = m->slots[slot];
+  const int* idx = nullptr;
+  if (idx_host) {
+    DV_HIP(hipMemcpyAsync(m->idx_dev, idx_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+    idx = m->idx_dev;
+  }
+  const bool training = mode != MODE_EVAL;
+  const bool bwd = mode != MODE_EVAL;
+  m->lastB = B;
+  DV_TRY(encoder_forward(m, ds.x, idx, (int)first, B, Bg, training, mode == MODE_TRAIN, bwd));
+  // Philox stream: one counter row per (rank-local) stamp; ranks are separated through the stream id
+  DV_TRY(sampler_forward(m, B, eps_host, seed, (unsigned)m->ctx->rank, 0u, false));
+  DV_TRY(decoder_forward(m, m->z, B, bwd));
+  DV_TRY(head_and_loss(m, ds.y, idx, (int)first, B, Bg, bwd, true));
+  if (m->ctx->world > 1) DV_NCCL(ncclAllReduce(m->scal, m->scal, 4, ncclFloat, ncclSum, m->ctx->comm, s));
+  if (bwd) {
+    DV_TRY(backward(m, B, Bg, ds.x, idx, (int)first));
+    if (m->ctx->world > 1) {
+      size_t beg = (m->enc_trainable ? 0 : A.n_enc_train), end = (m->dec_trainable ? A.n_train : A.n_enc_train);
+      if (end > beg)
+        DV_NCCL(ncclAllReduce(m->G + beg, m->G + beg, end - beg, ncclFloat, ncclSum, m->ctx->comm, s));
+    }
+  }
+  if (mode == MODE_TRAIN) DV_TRY(optimizer_step(m));
+  return OK;
+}
+
+static int fetch_scalars(dv_model* m, int Bg, float* out) {
+  const Arch& A = m->A;
+  float h[4];
+  DV_HIP(hipMemcpyAsync(h, m->scal, sizeof h, hipMemcpyDeviceToHost, m->ctx->stream));
+  DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  double npix = (double)A.H * A.H * A.C;
+  double nll_mean = (double)h[0] / ((double)Bg * npix);
+  double mse = (double)h[1] / ((double)Bg * npix);
+  double kl_reg = (double)A.cfg.kl_multiplicity * A.cfg.kl_weight * (double)h[2] / ((double)Bg * (double)Bg);
+  if (out) {
+    out[DV_S_LOSS] = (float)(nll_mean + kl_reg);
+    out[DV_S_NLL_MEAN] = (float)nll_mean;
+    out[DV_S_KL_REG] = (float)kl_reg;
+    out[DV_S_MSE] = (float)mse;
+  }
+  return OK;
+}
+
+static int run_step(dv_model* m, StepMode mode, int slot, const int32_t* idx, int64_t first, int B, int Bg,
+                    const float* eps, uint64_t seed, float* out) {
+  DV_TRY(check_step_args(m, slot, idx, first, B));
+  if (Bg <= 0) Bg = B;
+  DV_HIP(hipSetDevice(m->ctx->device));
+  DV_TRY(enqueue_step(m, mode, slot, idx, first, B, Bg, eps, seed));
+  DV_TRY(fetch_scalars(m, Bg, out));
+  return prof_flush(m);
+}
+
+// host-batch forward used by dv_infer / dv_encode
+static int stage_host_batch(dv_model* m, const float* x, int nb) {
+  const Arch& A = m->A;
+  size_t bytes = (size_t)nb * A.H * A.H * A.C * sizeof(float);
+  DV_HIP(hipMemcpyAsync(m->stage_x, x, bytes, hipMemcpyHostToDevice, m->ctx->stream));
+  return OK;
+}
+
+}  // namespace dv
+
+// ============================================================================================
+// C-ABI
+// ============================================================================================
+using namespace dv;
+
+extern "C" {
+
+int dv_version(void) { return 100; }
+
+int dv_last_error(char* buf, size_t n) {
+  if (!buf || n == 0) return DV_E_INVALID;
+  strncpy(buf, g_err, n - 1);
+  buf[n - 1] = 0;
+  return DV_OK;
+}
+
+int dv_config_default(dv_config* c) {
+  if (!c) return DV_E_INVALID;
+  memset(c, 0, sizeof *c);
+  c->height = c->width = 59;
+  c->bands = 6;
+  c->latent_dim = 32;
+  c->n_levels = 4;
+  int f[4] = {32, 64, 128, 256};
+  for (int i = 0; i < 4; ++i) {
+    c->filters[i] = f[i];
+    c->kernels[i] = 3;
+  }
+  c->max_batch = 256;
+  c->kl_weight = 0.01f;
+  c->kl_multiplicity = 2;
+  c->bn_eps = 1e-3f;
+  c->bn_momentum = 0.99f;
+  c->bn_moving_var_unbiased = 1;
+  c->sigma_floor = 1e-4f;
+  c->diag_shift = 1e-5f;
+  return DV_OK;
+}
+
+int dv_arch_counts(const dv_config* cfg, int32_t* n_tensors, int64_t* n_enc, int64_t* n_dec, int64_t* n_train) {
+  if (!cfg) return DV_E_INVALID;
+  Arch a;
+  DV_TRY(a.build(cfg));
+  if (n_tensors) *n_tensors = (int32_t)a.specs.size();
+  if (n_enc) *n_enc = a.n_enc_params;
+  if (n_dec) *n_dec = a.n_dec_params;
+  if (n_train) *n_train = a.n_trainable_params;
+  return DV_OK;
+}
+
+int dv_arch_describe(const dv_config* cfg, int32_t i, char* name, size_t name_len, int64_t shape[4], int32_t* ndim,
+                     int32_t* trainable) {
+  if (!cfg) return DV_E_INVALID;
+  Arch a;
+  DV_TRY(a.build(cfg));
+  if (i < 0 || i >= (int)a.specs.size()) {
+    set_error("tensor index %d out of range", i);
+    return DV_E_INVALID;
+  }
+  const Spec& s = a.specs[i];
+  if (name && name_len) {
+    strncpy(name, s.name.c_str(), name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (shape)
+    for (int k = 0; k < 4; ++k) shape[k] = s.shape[k];
+  if (ndim) *ndim = s.ndim;
+  if (trainable) *trainable = s.trainable ? 1 : 0;
+  return DV_OK;
+}
+
+int dv_arch_macs(const dv_config* cfg, int64_t* enc, int64_t* dec) {
+  if (!cfg || !enc || !dec) return DV_E_INVALID;
+  Arch a;
+  DV_TRY(a.build(cfg));
+  a.macs(enc, dec);
+  return DV_OK;
+}
+
+int dv_device_count(int32_t* n) {
+  if (!n) return DV_E_INVALID;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *n = 0;
+    (void)hipGetLastError();
+    return DV_OK;
+  }
+  *n = c;
+  return DV_OK;
+}
+
+int dv_comm_unique_id(void* out_id) {
+  if (!out_id) return DV_E_INVALID;
+  static_assert(sizeof(ncclUniqueId) <= DV_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  DV_NCCL(ncclGetUniqueId(&id));
+  memset(out_id, 0, DV_UNIQUE_ID_BYTES);
+  memcpy(out_id, &id, sizeof id);
+  return DV_OK;
+}
+
+int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* unique_id, dv_ctx** out) {
+  if (!out || world < 1 || rank < 0 || rank >= world) {
+    set_error("bad rank/world (%d/%d)", rank, world);
+    return DV_E_INVALID;
+  }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device visible: the debvader_amd engine needs an MI355X (there is no CPU fallback)");
+    return DV_E_NODEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device %d out of range (%d visible)", device, n);
+    return DV_E_INVALID;
+  }
+  DV_HIP(hipSetDevice(device));
+  dv_ctx* c = new dv_ctx();
+  c->device = device;
+  c->rank = rank;
+  c->world = world;
+  DV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  DV_HIP(hipMalloc((void**)&c->red_dev, 4096 * sizeof(float)));
+  if (world > 1) {
+    if (!unique_id) {
+      set_error("world > 1 needs rank 0's unique id");
+      delete c;
+      return DV_E_INVALID;
+    }
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    DV_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+  }
+  *out = c;
+  return DV_OK;
+}
+
+int dv_ctx_destroy(dv_ctx* c) {
+  if (!c) return DV_OK;
+  (void)hipSetDevice(c->device);
+  if (c->comm) ncclCommDestroy(c->comm);
+  if (c->red_dev) (void)hipFree(c->red_dev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return DV_OK;
+}
+
+int dv_ctx_sync(dv_ctx* c) {
+  if (!c) return DV_E_INVALID;
+  DV_HIP(hipStreamSynchronize(c->stream));
+  return DV_OK;
+}
+
+int dv_ctx_allreduce_host(dv_ctx* c, float* buf, int32_t n) {
+  if (!c || !buf || n < 0 || n > 4096) return DV_E_INVALID;
+  if (c->world == 1 || n == 0) return DV_OK;
+  DV_HIP(hipMemcpyAsync(c->red_dev, buf, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  DV_NCCL(ncclAllReduce(c->red_dev, c->red_dev, n, ncclFloat, ncclSum, c->comm, c->stream));
+  DV_HIP(hipMemcpyAsync(buf, c->red_dev, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  DV_HIP(hipStreamSynchronize(c->stream));
+  return DV_OK;
+}
+
+int dv_model_destroy(dv_model* m) {
+  if (!m) return DV_OK;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  for (void* p : m->allocs) (void)hipFree(p);
+  for (int s = 0; s < 2; ++s) {
+    if (m->slots[s].x) (void)hipFree(m->slots[s].x);
+    if (m->slots[s].y) (void)hipFree(m->slots[s].y);
+  }
+  for (auto e : m->ev_pool) (void)hipEventDestroy(e);
+  for (auto& r : m->prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  delete m;
+  return DV_OK;
+}
+
+int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
+  if (!ctx || !cfg || !out) return DV_E_INVALID;
+  if (cfg->max_batch < 1) {
+    set_error("max_batch must be >= 1");
+    return DV_E_INVALID;
+  }
+  DV_HIP(hipSetDevice(ctx->device));
+  dv_model* m = new dv_model();
+  m->ctx = ctx;
+  int st = m->A.build(cfg);
+  if (st != OK) {
+    delete m;
+    return st;
+  }
+  const Arch& A = m->A;
+  const size_t Bc = (size_t)cfg->max_batch;
+  m->Bc = cfg->max_batch;
+  size_t max_act = 0;  // largest per-stamp activation (elements) for the gradient ping-pong buffers
+  auto track = [&](size_t e) { max_act = std::max(max_act, e); };
+  auto fail = [&](int s) {
+    dv_model_destroy(m);
+    return s;
+  };
+#define ALLOC(ptr, elems)                         \
+  do {                                            \
+    int s__ = dalloc(m, &(ptr), (size_t)(elems)); \
+    if (s__ != OK) return fail(s__);              \
+  } while (0)
+  ALLOC(m->P, A.n_total);
+  ALLOC(m->G, A.n_total);
+  ALLOC(m->Mm, A.n_total);
+  ALLOC(m->Vv, A.n_total);
+  ALLOC(m->W1p, 9 * 8 * cfg->filters[0]);
+  size_t in_e = (size_t)A.H * A.H * 8;
+  ALLOC(m->xn, Bc * in_e);
+  track(in_e);
+  ALLOC(m->stage_x, Bc * A.H * A.H * A.C);
+  m->enc_u.resize(2 * A.L);
+  m->enc_a.resize(2 * A.L);
+  m->dec_u.resize(2 * A.L);
+  m->dec_a.resize(2 * A.L);
+  for (int j = 0; j < 2 * A.L; ++j) {
+    int hin, cin, hout, cout, s;
+    A.enc_layer(j, &hin, &cin, &hout, &cout, &s);
+    size_t e = (size_t)hout * hout * cout;
+    ALLOC(m->enc_u[j], Bc * e);
+    ALLOC(m->enc_a[j], Bc * e);
+    track(e);
+  }
+  ALLOC(m->flat_a, Bc * A.flat);
+  ALLOC(m->t, Bc * A.tw);
+  track(A.tw);
+  ALLOC(m->eps, Bc * A.d);
+  ALLOC(m->z, Bc * A.d);
+  ALLOC(m->zstd, Bc * A.d);
+  ALLOC(m->kl, Bc);
+  ALLOC(m->dec_ain, Bc * A.d);
+  ALLOC(m->dec_uh, Bc * A.dec_hidden);
+  ALLOC(m->dec_ah, Bc * A.dec_hidden);
+  size_t r = (size_t)A.w0 * A.w0 * cfg->filters[A.L - 1];
+  ALLOC(m->dec_ur, Bc * r);
+  ALLOC(m->dec_ar, Bc * r);
+  track(r);
+  track(A.dec_hidden);
+  for (int j = 0; j < 2 * A.L; ++j) {
+    int hin, cin, hout, cout, s;
+    A.dec_layer(j, &hin, &cin, &hout, &cout, &s);
+    size_t e = (size_t)hout * hout * cout;
+    ALLOC(m->dec_u[j], Bc * e);
+    ALLOC(m->dec_a[j], Bc * e);
+    track(e);
+  }
+  size_t head_e = (size_t)A.dec_out * A.dec_out * 2 * A.C;
+  ALLOC(m->tpre, Bc * head_e);
+  track(head_e);
+  ALLOC(m->loc, Bc * A.H * A.H * A.C);
+  ALLOC(m->scale, Bc * A.H * A.H * A.C);
+  ALLOC(m->gA, Bc * max_act);
+  ALLOC(m->gB, Bc * max_act);
+  // workspaces: ws1 weight-gradient slabs, ws2 d(alpha) partials, ws3 small reductions
+  size_t max_w = 0;
+  for (auto& s : A.specs)
+    if (s.ndim >= 2) max_w = std::max(max_w, s.count);
+  max_w = std::max(max_w, (size_t)9 * 8 * cfg->filters[0]);
+  m->ws1_elems = std::max((size_t)16 << 20, max_w * 2);
+  ALLOC(m->ws1, m->ws1_elems);
+  m->ws2_elems = std::max((size_t)1 << 20, max_act * 16);
+  ALLOC(m->ws2, m->ws2_elems);
+  size_t head_blocks = (Bc * A.dec_out * A.dec_out + 255) / 256;
+  m->ws3_elems = std::max((size_t)1 << 20, head_blocks * 2 + 64);
+  m->ws3_elems = std::max(m->ws3_elems, (size_t)64 * std::max((size_t)A.flat, r));
+  ALLOC(m->ws3, m->ws3_elems);
+  ALLOC(m->scal, 16);
+  ALLOC(m->bnstate, 32);
+  ALLOC(m->bnsums, 16);
+  {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, Bc * sizeof(int));
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+    m->allocs.push_back(q);
+    m->idx_dev = (int*)q;
+  }
+#undef ALLOC
+  hipStream_t s = ctx->stream;
+  if (hipMemsetAsync(m->P, 0, A.n_total * sizeof(float), s) != hipSuccess ||
+      hipMemsetAsync(m->G, 0, A.n_total * sizeof(float), s) != hipSuccess ||
+      hipMemsetAsync(m->Mm, 0, A.n_total * sizeof(float), s) != hipSuccess ||
+      hipMemsetAsync(m->Vv, 0, A.n_total * sizeof(float), s) != hipSuccess ||
+      hipMemsetAsync(m->scal, 0, 16 * sizeof(float), s) != hipSuccess ||
+      hipMemsetAsync(m->bnsums, 0, 16 * sizeof(float), s) != hipSuccess)
+    return fail(E_HIP);
+  st = dv_model_init(m, 0);
+  if (st != OK) return fail(st);
+  *out = m;
+  return DV_OK;
+}
+
+// host-side Philox for the Glorot draws
+static void philox_host(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  uint32_t c[4] = {c0, c1, 0x243F6A88u, 0x85A308D3u};
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+
+int dv_model_init(dv_model* m, uint64_t seed) {
+  if (!m) return DV_E_INVALID;
+  const Arch& A = m->A;
+  DV_HIP(hipSetDevice(m->ctx->device));
+  std::vector<float> h(A.n_total, 0.f);
+  for (size_t i = 0; i < A.specs.size(); ++i) {
+    const Spec& s = A.specs[i];
+    const std::string& n = s.name;
+    auto ends = [&](const char* suf) {
+      size_t l = strlen(suf);
+      return n.size() >= l && n.compare(n.size() - l, l, suf) == 0;
+    };
+    float* dst = h.data() + s.off;
+    if (ends("/kernel")) {
+      double fan_in, fan_out;
+      if (s.ndim == 4) {
+        fan_in = (double)s.shape[0] * s.shape[1] * s.shape[2];
+        fan_out = (double)s.shape[0] * s.shape[1] * s.shape[3];
+      } else {
+        fan_in = (double)s.shape[0];
+        fan_out = (double)s.shape[1];
+      }
+      double lim = sqrt(6.0 / (fan_in + fan_out));  // Keras glorot_uniform
+      for (size_t e = 0; e < s.count; e += 4) {
+        uint32_t r[4];
+        philox_host((uint32_t)(e / 4), (uint32_t)i, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        for (int k = 0; k < 4 && e + k < s.count; ++k)
+          dst[e + k] = (float)((((double)r[k] + 0.5) / 4294967296.0 * 2.0 - 1.0) * lim);
+      }
+    } else if (ends("/gamma") || ends("/moving_variance")) {
+      for (size_t e = 0; e < s.count; ++e) dst[e] = 1.f;
+    }
+  }
+  DV_HIP(hipMemcpyAsync(m->P, h.data(), A.n_total * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+  DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  DV_TRY(refresh_w1p(m));
+  DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  return DV_OK;
+}
+
+static int tensor_io(dv_model* m, float* base, int32_t i, float* host, size_t nbytes, bool to_host) {
+  if (!m || !host) return DV_E_INVALID;
+  const Arch& A = m->A;
+  if (i < 0 || i >= (int)A.specs.size()) {
+    set_error("tensor index %d out of range", i);
+    return DV_E_INVALID;
+  }
+  const Spec& s = A.specs[i];
+  if (nbytes != s.count * sizeof(float)) {
+    set_error("tensor %s holds %zu bytes, caller passed %zu", s.name.c_str(), s.count * sizeof(float), nbytes);
+    return DV_E_INVALID;
+  }
+  DV_HIP(hipSetDevice(m->ctx->device));
+  DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  if (to_host)
+    DV_HIP(hipMemcpy(host, base + s.off, nbytes, hipMemcpyDeviceToHost));
+  else
+    DV_HIP(hipMemcpy(base + s.off, host, nbytes, hipMemcpyHostToDevice));
+  return DV_OK;
+}
+
+int dv_model_get_param(dv_model* m, int32_t i, float* host, size_t nbytes) {
+  return tensor_io(m, m ? m->P : nullptr, i, host, nbytes, true);
+}
+int dv_model_set_param(dv_model* m, int32_t i, const float* host, size_t nbytes) {
+  DV_TRY(tensor_io(m, m ? m->P : nullptr, i, const_cast<float*>(host), nbytes, false));
+  if (i == m->A.enc_k(0)) {
+    DV_TRY(refresh_w1p(m));
+    DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  }
+  return DV_OK;
+}
+int dv_model_get_grad(dv_model* m, int32_t i, float* host, size_t nbytes) {
+  return tensor_io(m, m ? m->G : nullptr, i, host, nbytes, true);
+}
+int dv_model_get_slot(dv_model* m, int32_t i, int32_t which, float* host, size_t nbytes) {
+  if (!m || which < 0 || which > 1) return DV_E_INVALID;
+  return tensor_io(m, which == 0 ? m->Mm : m->Vv, i, host, nbytes, true);
+}
+int dv_model_set_slot(dv_model* m, int32_t i, int32_t which, const float* host, size_t nbytes) {
+  if (!m || which < 0 || which > 1) return DV_E_INVALID;
+  return tensor_io(m, which == 0 ? m->Mm : m->Vv, i, const_cast<float*>(host), nbytes, false);
+}
+
+int dv_model_set_trainable(dv_model* m, int32_t enc, int32_t dec) {
+  if (!m) return DV_E_INVALID;
+  m->enc_trainable = enc != 0;
+  m->dec_trainable = dec != 0;
+  return DV_OK;
+}
+
+int dv_optimizer_reset(dv_model* m, float lr, float b1, float b2, float eps) {
+  if (!m) return DV_E_INVALID;
+  DV_HIP(hipSetDevice(m->ctx->device));
+  m->lr = lr;
+  m->b1 = b1;
+  m->b2 = b2;
+  m->aeps = eps;
+  m->iter = 0;
+  m->opt_enc = m->enc_trainable;
+  m->opt_dec = m->dec_trainable;
+  DV_HIP(hipMemsetAsync(m->Mm, 0, m->A.n_total * sizeof(float), m->ctx->stream));
+  DV_HIP(hipMemsetAsync(m->Vv, 0, m->A.n_total * sizeof(float), m->ctx->stream));
+  DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  return DV_OK;
+}
+int dv_optimizer_get_iter(dv_model* m, int64_t* it) {
+  if (!m || !it) return DV_E_INVALID;
+  *it = m->iter;
+  return DV_OK;
+}
+int dv_optimizer_set_iter(dv_model* m, int64_t it) {
+  if (!m || it < 0) return DV_E_INVALID;
+  m->iter = it;
+  return DV_OK;
+}
+
+int dv_data_free(dv_model* m, int32_t slot) {
+  if (!m || slot < 0 || slot > 1) return DV_E_INVALID;
+  DV_HIP(hipSetDevice(m->ctx->device));
+  DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  if (m->slots[slot].x) (void)hipFree(m->slots[slot].x);
+  if (m->slots[slot].y) (void)hipFree(m->slots[slot].y);
+  m->slots[slot] = DataSlot();
+  return DV_OK;
+}
+
+int dv_data_upload(dv_model* m, int32_t slot, const float* x, const float* y, int64_t n) {
+  if (!m || slot < 0 || slot > 1 || !x || !y || n < 1) {
+    set_error("dv_data_upload: bad arguments");
+    return DV_E_INVALID;
+  }
+  const Arch& A = m->A;
+  if ((double)n * A.H * A.H * A.C >= 2147483648.0 * 64) {
+    set_error("dataset too large");
+    return DV_E_INVALID;
+  }
+  DV_TRY(dv_data_free(m, slot));
+  size_t bytes = (size_t)n * A.H * A.H * A.C * sizeof(float);
+  DataSlot& d = m->slots[slot];
+  hipError_t e = hipMalloc((void**)&d.x, bytes);
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc(data x)", __FILE__, __LINE__);
+  e = hipMalloc((void**)&d.y, bytes);
+  if (e != hipSuccess) {
+    (void)hipFree(d.x);
+    d.x = nullptr;
+    return hip_fail(e, "hipMalloc(data y)", __FILE__, __LINE__);
+  }
+  d.n = n;
+  DV_HIP(hipMemcpy(d.x, x, bytes, hipMemcpyHostToDevice));
+  DV_HIP(hipMemcpy(d.y, y, bytes, hipMemcpyHostToDevice));
+  return DV_OK;
+}
+
+int dv_train_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t Bg,
+                  const float* eps, uint64_t seed, float* out) {
+  return run_step(m, MODE_TRAIN, slot, idx, first, B, Bg, eps, seed, out);
+}
+int dv_eval_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t Bg, const float* eps,
+                 uint64_t seed, float* out) {
+  return run_step(m, MODE_EVAL, slot, idx, first, B, Bg, eps, seed, out);
+}
+int dv_grad_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t Bg, const float* eps,
+                 uint64_t seed, float* out) {
+  return run_step(m, MODE_GRAD, slot, idx, first, B, Bg, eps, seed, out);
+}
+
+int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t Bg, int32_t steps, uint64_t seed,
+                   float* out) {
+  if (steps < 1) return DV_E_INVALID;
+  DV_TRY(check_step_args(m, slot, nullptr, 0, B));
+  if (Bg <= 0) Bg = B;
+  DV_HIP(hipSetDevice(m->ctx->device));
+  int64_t span = std::max<int64_t>(1, m->slots[slot].n - B + 1);
+  for (int k = 0; k < steps; ++k) {
+    int64_t start = (first + (int64_t)k * B) % span;
+    DV_TRY(enqueue_step(m, MODE_TRAIN, slot, nullptr, start, B, Bg, nullptr, seed + (uint64_t)k));
+    if (m->prof_on) DV_TRY(prof_flush(m));
+  }
+  DV_TRY(fetch_scalars(m, Bg, out));
+  return prof_flush(m);
+}
+
+int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
+             float* mu, float* zstd, float* z) {
+  if (!m || !x || N < 0) return DV_E_INVALID;
+  const Arch& A = m->A;
+  DV_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  const size_t stamp = (size_t)A.H * A.H * A.C;
+  for (int64_t o = 0; o < N; o += m->Bc) {
+    int nb = (int)std::min<int64_t>(m->Bc, N - o);
+    DV_TRY(stage_host_batch(m, x + o * stamp, nb));
+    DV_TRY(encoder_forward(m, m->stage_x, nullptr, 0, nb, nb, false, false, false));
+    DV_TRY(sampler_forward(m, nb, eps ? eps + o * A.d : nullptr, seed, (unsigned)m->ctx->rank, (unsigned)o,
+                           zstd != nullptr));
+    DV_TRY(decoder_forward(m, m->z, nb, false));
+    DV_TRY(head_and_loss(m, nullptr, nullptr, 0, nb, nb, false, true));
+    if (loc) DV_HIP(hipMemcpyAsync(loc + o * stamp, m->loc, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (scale)
+      DV_HIP(hipMemcpyAsync(scale + o * stamp, m->scale, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (mu)
+      DV_HIP(hipMemcpy2DAsync(mu + o * A.d, A.d * sizeof(float), m->t, A.tw * sizeof(float), A.d * sizeof(float), nb,
+                              hipMemcpyDeviceToHost, s));
+    if (zstd) DV_HIP(hipMemcpyAsync(zstd + o * A.d, m->zstd, (size_t)nb * A.d * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (z) DV_HIP(hipMemcpyAsync(z + o * A.d, m->z, (size_t)nb * A.d * sizeof(float), hipMemcpyDeviceToHost, s));
+    DV_HIP(hipStreamSynchronize(s));
+    m->lastB = nb;
+  }
+  return prof_flush(m);
+}
+
+int dv_encode(dv_model* m, const float* x, int64_t N, float* t) {
+  if (!m || !x || !t || N < 0) return DV_E_INVALID;
+  const Arch& A = m->A;
+  DV_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  const size_t stamp = (size_t)A.H * A.H * A.C;
+  for (int64_t o = 0; o < N; o += m->Bc) {
+    int nb = (int)std::min<int64_t>(m->Bc, N - o);
+    DV_TRY(stage_host_batch(m, x + o * stamp, nb));
+    DV_TRY(encoder_forward(m, m->stage_x, nullptr, 0, nb, nb, false, false, false));
+    DV_HIP(hipMemcpyAsync(t + o * A.tw, m->t, (size_t)nb * A.tw * sizeof(float), hipMemcpyDeviceToHost, s));
+    DV_HIP(hipStreamSynchronize(s));
+  }
+  return prof_flush(m);
+}
+
+int dv_decode(dv_model* m, const float* z, int64_t N, float* loc, float* scale) {
+  if (!m || !z || N < 0) return DV_E_INVALID;
+  const Arch& A = m->A;
+  DV_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  const size_t stamp = (size_t)A.H * A.H * A.C;
+  for (int64_t o = 0; o < N; o += m->Bc) {
+    int nb = (int)std::min<int64_t>(m->Bc, N - o);
+    DV_HIP(hipMemcpyAsync(m->z, z + o * A.d, (size_t)nb * A.d * sizeof(float), hipMemcpyHostToDevice, s));
+    DV_TRY(decoder_forward(m, m->z, nb, false));
+    DV_TRY(head_and_loss(m, nullptr, nullptr, 0, nb, nb, false, true));
+    if (loc) DV_HIP(hipMemcpyAsync(loc + o * stamp, m->loc, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (scale)
+      DV_HIP(hipMemcpyAsync(scale + o * stamp, m->scale, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
+    DV_HIP(hipStreamSynchronize(s));
+  }
+  return prof_flush(m);
+}
+
+int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t nbytes) {
+  if (!m || !name || !host) return DV_E_INVALID;
+  const Arch& A = m->A;
+  const size_t B = (size_t)m->lastB;
+  const float* src = nullptr;
+  size_t elems = 0;
+  std::string n(name);
+  if (n == "t") { src = m->t; elems = B * A.tw; }
+  else if (n == "z") { src = m->z; elems = B * A.d; }
+  else if (n == "eps") { src = m->eps; elems = B * A.d; }
+  else if (n == "kl") { src = m->kl; elems = B; }
+  else if (n == "loc") { src = m->loc; elems = B * A.H * A.H * A.C; }
+  else if (n == "scale") { src = m->scale; elems = B * A.H * A.H * A.C; }
+  else if (n == "head_pre") { src = m->tpre; elems = B * A.dec_out * A.dec_out * 2 * A.C; }
+  else if (n == "xn") { src = m->xn; elems = B * A.H * A.H * 8; }
+  else if (n.rfind("enc_u", 0) == 0 || n.rfind("enc_a", 0) == 0 || n.rfind("dec_u", 0) == 0 || n.rfind("dec_a", 0) == 0) {
+    int j = atoi(n.c_str() + 5);
+    if (j < 0 || j >= 2 * A.L) return DV_E_INVALID;
+    int hin, cin, hout, cout, s;
+    if (n[0] == 'e') A.enc_layer(j, &hin, &cin, &hout, &cout, &s); else A.dec_layer(j, &hin, &cin, &hout, &cout, &s);
+    elems = B * hout * hout * cout;
+    src = n[0] == 'e' ? (n[4] == 'u' ? m->enc_u[j] : m->enc_a[j]) : (n[4] == 'u' ? m->dec_u[j] : m->dec_a[j]);
+  } else {
+    set_error("unknown activation '%s'", name);
+    return DV_E_INVALID;
+  }
+  if (nbytes != elems * sizeof(float)) {
+    set_error("activation %s holds %zu bytes, caller passed %zu", name, elems * sizeof(float), nbytes);
+    return DV_E_INVALID;
+  }
+  DV_HIP(hipSetDevice(m->ctx->device));
+  DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  DV_HIP(hipMemcpy(host, src, nbytes, hipMemcpyDeviceToHost));
+  return DV_OK;
+}
+
+int dv_prof_enable(dv_model* m, int32_t on) {
+  if (!m) return DV_E_INVALID;
+  DV_TRY(prof_flush(m));
+  m->prof_on = on != 0;
+  return DV_OK;
+}
+int dv_prof_read(dv_model* m, int32_t klass, int64_t* launches, double* total_ms) {
+  if (!m || klass < 0 || klass > 2) return DV_E_INVALID;
+  DV_TRY(prof_flush(m));
+  if (launches) *launches = m->prof_n[klass];
+  if (total_ms) *total_ms = m->prof_ms[klass];
+  return DV_OK;
+}
+int dv_prof_reset(dv_model* m) {
+  if (!m) return DV_E_INVALID;
+  DV_TRY(prof_flush(m));
+  for (int k = 0; k < 3; ++k) {
+    m->prof_n[k] = 0;
+    m->prof_ms[k] = 0;
+  }
+  return DV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+// Gather-GEMM on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+//
+// One kernel serves Conv2D forward (reference model.py:81-91,137), Conv2DTranspose forward
+// (model.py:121-134; stride 2 is launched as four output-parity classes so that no zero-inserted
+// taps are multiplied), both data gradients, and the Dense layers (model.py:96-98,114,117).
+// See common.h for the contraction it computes.
+//
+// Tiling: 256 threads = 4 waves (64 lanes each). Workgroup tile BM x BN, K consumed in chunks of
+// 32 through double-buffered LDS with register staging (global -> VGPR -> LDS) so the next chunk's
+// gather is in flight while the current chunk is on the MFMA pipe.  A rows are stored [m][k] with a
+// 36-float stride: every lane reads its four k values with one ds_read_b128 (the MFMA k order is a
+// free permutation, so lane group g of MFMA jj takes physical k = 16q + 4g + jj for A and B alike).
+#include "common.h"
+
+namespace dv {
+
+constexpr int BK = 32;
+constexpr int LDA = BK + 4;
+
+__device__ __forceinline__ int tap_dh(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 3) - 1; }
+__device__ __forceinline__ int tap_dw(unsigned long long code, int t) { return (int)((code >> (4 * t + 2)) & 3) - 1; }
+__device__ __forceinline__ int tap_wt(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 15); }
+
+template <int BM, int BN, int WGM, int WGN, bool NMAJOR>
+__global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int AROWS = BM / 32;                 // A rows gathered per thread
+  constexpr int LDBK = BN + 4;                   // k-major B row stride
+  constexpr int A_ELEMS = BM * LDA;
+  constexpr int B_ELEMS = NMAJOR ? BN * LDA : BK * LDBK;
+  constexpr int BROWS_N = (BN + 31) / 32;        // n-major: rows per thread
+  constexpr int BQ = BN / 4;                     // k-major: float4 per k row
+  constexpr int BKR = 256 / BQ;                  // k-major: k rows covered per pass
+  constexpr int BPASS = (BK + BKR - 1) / BKR;    // k-major: passes per thread
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                              // [2][BM][LDA]
+  float* Bs = smem + 2 * A_ELEMS;                // [2][...]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / WGN) * WM;
+  const int wn0 = (wave % WGN) * WN;
+  const int l15 = lane & 15;
+  const int lg = lane >> 4;
+
+  // tile coordinates: N tiles fastest so that workgroups sharing an A panel are adjacent
+  const int ntn = (p.Cout + BN - 1) / BN;
+  const int tile = blockIdx.x;
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+
+  // ---- per-thread gather rows -----------------------------------------------------------
+  const int kq = tid & 7;
+  const int r0 = tid >> 3;
+  int rbase[AROWS], rih[AROWS], rjw[AROWS];
+  const int HcWc = p.Hc * p.Wc;
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) {
+    int m = m0 + r0 + 32 * i;
+    if (m < p.M) {
+      int nb = m / HcWc;
+      int rem = m - nb * HcWc;
+      int ii = rem / p.Wc;
+      int jj = rem - ii * p.Wc;
+      rbase[i] = nb * p.Hin * p.Win;
+      rih[i] = ii * p.sin;
+      rjw[i] = jj * p.sin;
+    } else {
+      rbase[i] = 0;
+      rih[i] = -1000000;
+      rjw[i] = 0;
+    }
+  }
+
+  f32x4 areg[AROWS];
+  f32x4 breg[NMAJOR ? BROWS_N : BPASS];
+
+  auto load_global = [&](int kc) {
+    const int kk = kc * BK + kq * 4;
+    int tap, ci;
+    if (p.cin_shift >= 0) {
+      tap = kk >> p.cin_shift;
+      ci = kk & (p.Cin - 1);
+    } else {
+      tap = kk / p.Cin;
+      ci = kk - tap * p.Cin;
+    }
+    const bool kvalid = kk < p.K;
+    const int dh = tap_dh(p.tapcode, tap), dw = tap_dw(p.tapcode, tap);
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      int ih = rih[i] + dh, iw = rjw[i] + dw;
+      bool ok = kvalid && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        size_t off = ((size_t)(rbase[i] + ih * p.Win + iw)) * p.Cin + ci;
+        v = *reinterpret_cast<const f32x4*>(p.X + off);
+      }
+      areg[i] = v;
+    }
+    if (NMAJOR) {
+      const int wt = tap_wt(p.wtcode, tap);
+#pragma unroll
+      for (int i = 0; i < BROWS_N; ++i) {
+        int n = n0 + r0 + 32 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kvalid && n < p.Cout && r0 + 32 * i < BN) {
+          size_t off = ((size_t)(wt * p.Cout + n)) * p.Cin + ci;
+          v = *reinterpret_cast<const f32x4*>(p.W + off);
+        }
+        breg[i] = v;
+      }
+    } else {
+      const int nq = tid % BQ;
+      const int kr0 = tid / BQ;
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        int kr = kr0 + BKR * i;
+        int kb = kc * BK + kr;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int n = n0 + nq * 4;
+        if (kr < BK && kb < p.K && n < p.Cout) {
+          int tb, cb;
+          if (p.cin_shift >= 0) {
+            tb = kb >> p.cin_shift;
+            cb = kb & (p.Cin - 1);
+          } else {
+            tb = kb / p.Cin;
+            cb = kb - tb * p.Cin;
+          }
+          int wt = tap_wt(p.wtcode, tb);
+          size_t off = ((size_t)(wt * p.Cin + cb)) * p.Cout + n;
+          v = *reinterpret_cast<const f32x4*>(p.W + off);
+        }
+        breg[i] = v;
+      }
+    }
+  };
+
+  auto store_lds = [&](int buf) {
+    float* a = As + buf * A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i)
+      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDA + kq * 4) = areg[i];
+    float* b = Bs + buf * B_ELEMS;
+    if (NMAJOR) {
+#pragma unroll
+      for (int i = 0; i < BROWS_N; ++i)
+        if (r0 + 32 * i < BN) *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDA + kq * 4) = breg[i];
+    } else {
+      const int nq = tid % BQ;
+      const int kr0 = tid / BQ;
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        int kr = kr0 + BKR * i;
+        if (kr < BK) *reinterpret_cast<f32x4*>(b + kr * LDBK + nq * 4) = breg[i];
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const float* a = As + buf * A_ELEMS;
+    const float* b = Bs + buf * B_ELEMS;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 af[TM];
+      f32x4 bf[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        af[tm] = *reinterpret_cast<const f32x4*>(a + (wm0 + tm * 16 + l15) * LDA + q * 16 + lg * 4);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        if (NMAJOR) {
+          bf[tn] = *reinterpret_cast<const f32x4*>(b + (wn0 + tn * 16 + l15) * LDA + q * 16 + lg * 4);
+        } else {
+          const float* bp = b + (q * 16 + lg * 4) * LDBK + wn0 + tn * 16 + l15;
+          bf[tn] = (f32x4){bp[0], bp[LDBK], bp[2 * LDBK], bp[3 * LDBK]};
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][jj], bf[tn][jj], acc[tm][tn], 0, 0, 0);
+    }
+  };
+
+  const int nchunks = (p.K + BK - 1) / BK;
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nchunks) load_global(kc + 1);
+    compute(cur);
+    if (kc + 1 < nchunks) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, per-element PReLU, scatter to the output pixel ---------------------
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm0 + tm * 16 + lg * 4 + r;
+      if (m >= p.M) continue;
+      int nb = m / HcWc;
+      int rem = m - nb * HcWc;
+      int ii = rem / p.Wc;
+      int jj = rem - ii * p.Wc;
+      int oh = ii * p.sout + p.ph, ow = jj * p.sout + p.pw;
+      size_t apix = (size_t)(oh * p.Wout + ow) * p.Cout;
+      size_t opix = ((size_t)nb * p.Hout * p.Wout) * p.Cout + apix;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn0 + tn * 16 + l15;
+        if (n >= p.Cout) continue;
+        float v = acc[tm][tn][r];
+        if (p.epi >= 1) v += p.bias[n];
+        if (p.U) p.U[opix + n] = v;
+        if (p.epi == 2) {
+          float al = p.alpha[apix + n];
+          float av = v > 0.f ? v : al * v;
+          p.A[opix + n] = av;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool NMAJOR>
+static int launch_cfg(const GConvParams& p, hipStream_t s) {
+  constexpr int A_ELEMS = BM * LDA;
+  constexpr int B_ELEMS = NMAJOR ? BN * LDA : BK * (BN + 4);
+  constexpr size_t smem = (size_t)(2 * A_ELEMS + 2 * B_ELEMS) * sizeof(float);
+  static bool attr_set = false;
+  auto kern = gconv_kernel<BM, BN, WGM, WGN, NMAJOR>;
+  if (!attr_set) {
+    DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    attr_set = true;
+  }
+  int tm = (p.M + BM - 1) / BM, tn = (p.Cout + BN - 1) / BN;
+  dim3 grid(tm * tn), block(256);
+  hipLaunchKernelGGL(kern, grid, block, smem, s, p);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+template <bool NMAJOR>
+static int dispatch(const GConvParams& p, hipStream_t s) {
+  const int N = p.Cout;
+  // pick the tile so that the grid still fills 256 CUs when M is small (deep, low-resolution layers)
+  if (N <= 16) return launch_cfg<128, 16, 4, 1, NMAJOR>(p, s);
+  if (N <= 32) return launch_cfg<128, 32, 4, 1, NMAJOR>(p, s);
+  if (N <= 64) {
+    long tiles = ((long)(p.M + 127) / 128);
+    if (tiles >= 256) return launch_cfg<128, 64, 2, 2, NMAJOR>(p, s);
+    return launch_cfg<64, 64, 2, 2, NMAJOR>(p, s);
+  }
+  long tiles128 = ((long)(p.M + 127) / 128) * ((N + 127) / 128);
+  if (tiles128 >= 256) return launch_cfg<128, 128, 2, 2, NMAJOR>(p, s);
+  long tiles64 = ((long)(p.M + 63) / 64) * ((N + 63) / 64);
+  if (tiles64 >= 192) return launch_cfg<64, 64, 2, 2, NMAJOR>(p, s);
+  return launch_cfg<32, 64, 2, 2, NMAJOR>(p, s);
+}
+
+int launch_gconv(const GConvParams& p, hipStream_t s) {
+  if (p.M <= 0) return OK;
+  if ((p.Cin & 3) || (p.Cout & 3)) {
+    set_error("gconv: Cin (%d) and Cout (%d) must be multiples of 4", p.Cin, p.Cout);
+    return E_INVALID;
+  }
+  if (p.ntaps < 1 || p.ntaps > 9 || p.K != p.ntaps * p.Cin) {
+    set_error("gconv: bad tap table (ntaps=%d K=%d Cin=%d)", p.ntaps, p.K, p.Cin);
+    return E_INVALID;
+  }
+  if ((long)p.NB * p.Hin * p.Win * p.Cin >= (1L << 31) || (long)p.NB * p.Hout * p.Wout * p.Cout >= (1L << 31)) {
+    set_error("gconv: tensor too large for 32-bit pixel indexing; lower the batch chunk");
+    return E_INVALID;
+  }
+  if (p.epi == 2 && (!p.alpha || !p.A)) {
+    set_error("gconv: PReLU epilogue needs alpha and A");
+    return E_INVALID;
+  }
+  return p.w_nmajor ? dispatch<true>(p, s) : dispatch<false>(p, s);
+}
+
+}  // namespace dv

@@ -1,0 +1,633 @@
+// Bandwidth-bound kernels of the conv-VAE step: input BatchNorm (reference model.py:79), per-element PReLU
+// (model.py:84,92,95,113,115,118,128,135), the MultivariateNormalTriL sampler with its Monte-Carlo KL term
+// (model.py:43-58,207-214), the relu + crop + Normal NLL head (model.py:137-159, metrics.py:16-26) and the
+// legacy-Adam update (train.py:125-130).  All are written for 64-lane wavefronts: reductions go through
+// __shfl_down across the full wave, then LDS across the 4 waves of a block, then a per-block partial that a
+// final double-precision pass sums in a fixed order (bit-reproducible, no float atomics).
+#include "common.h"
+
+namespace dv {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// sums `v` over the 256-thread block; result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* sh /*>=4 floats*/) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic column reduction of a small partial matrix in double precision: out[c] = scale * sum_r part[r][c]
+__global__ __launch_bounds__(256) void reduce_rows_f64_kernel(const float* __restrict__ part, int nrows, int ncols,
+                                                              float* __restrict__ out, float scale) {
+  __shared__ double sh[256];
+  const int c = blockIdx.x;
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += 256) acc += (double)part[(long)r * ncols + c];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = (float)(sh[0] * (double)scale);
+}
+
+int launch_reduce_rows_f64(const float* part, int nrows, int ncols, float* out, float scale, hipStream_t s) {
+  if (ncols <= 0) return OK;
+  hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(ncols), dim3(256), 0, s, part, nrows, ncols, out, scale);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm over the band axis
+constexpr int BN_MAXC = 8;
+constexpr int BN_PIX_PER_BLOCK = 4096;
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                       int first, int NB, int HW, int C, float* __restrict__ part) {
+  __shared__ float sh[4];
+  const long total = (long)NB * HW;
+  const long p0 = (long)blockIdx.x * BN_PIX_PER_BLOCK;
+  float s[BN_MAXC], ss[BN_MAXC];
+#pragma unroll
+  for (int c = 0; c < BN_MAXC; ++c) s[c] = ss[c] = 0.f;
+  for (long pp = p0 + threadIdx.x; pp < min(total, p0 + BN_PIX_PER_BLOCK); pp += 256) {
+    int b = (int)(pp / HW);
+    int pix = (int)(pp - (long)b * HW);
+    long row = idx ? idx[b] : first + b;
+    const float* px = x + (row * HW + pix) * C;
+#pragma unroll
+    for (int c = 0; c < BN_MAXC; ++c)
+      if (c < C) {
+        float v = px[c];
+        s[c] += v;
+        ss[c] += v * v;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < BN_MAXC; ++c) {
+    float a = block_sum(s[c], sh);
+    float b = block_sum(ss[c], sh);
+    if (threadIdx.x == 0) {
+      part[blockIdx.x * 2 * BN_MAXC + c] = a;
+      part[blockIdx.x * 2 * BN_MAXC + BN_MAXC + c] = b;
+    }
+  }
+}
+
+int launch_bn_stats(const float* x, const int* idx, int first, int NB, int HW, int C, float* part, int* nblocks,
+                    hipStream_t s) {
+  if (C > BN_MAXC) {
+    set_error("bn: at most %d bands supported", BN_MAXC);
+    return E_INVALID;
+  }
+  long total = (long)NB * HW;
+  int nb = (int)((total + BN_PIX_PER_BLOCK - 1) / BN_PIX_PER_BLOCK);
+  *nblocks = nb;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, s, x, idx, first, NB, HW, C, part);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// sums: [0..8) sum x, [8..16) sum x^2 (already reduced over blocks and ranks); count = global N*H*W
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ mmean,
+                                   float* __restrict__ mvar, float eps, float momentum, int unbiased, int training,
+                                   int update_moving, float* __restrict__ st) {
+  int c = threadIdx.x;
+  if (c >= BN_MAXC) return;
+  float mean = 0.f, var = 1.f, scale = 0.f, shift = 0.f, inv = 0.f;
+  if (c < C) {
+    if (training) {
+      double m = (double)sums[c] / (double)count;
+      double v = (double)sums[BN_MAXC + c] / (double)count - m * m;
+      if (v < 0) v = 0;
+      mean = (float)m;
+      var = (float)v;
+      if (update_moving) {
+        float vu = unbiased ? (float)(v * ((double)count / ((double)count - 1.0))) : var;
+        mmean[c] = mmean[c] * momentum + mean * (1.f - momentum);
+        mvar[c] = mvar[c] * momentum + vu * (1.f - momentum);
+      }
+    } else {
+      mean = mmean[c];
+      var = mvar[c];
+    }
+    inv = 1.0f / sqrtf(var + eps);
+    scale = gamma[c] * inv;
+    shift = beta[c] - mean * scale;
+  }
+  st[c] = scale;
+  st[BN_MAXC + c] = shift;
+  st[2 * BN_MAXC + c] = mean;
+  st[3 * BN_MAXC + c] = inv;
+}
+
+int launch_bn_finalize(const float* sums, float count, int C, const float* gamma, const float* beta,
+                       float* moving_mean, float* moving_var, float eps, float momentum, int unbiased, int training,
+                       int update_moving, float* bnstate, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, sums, count, C, gamma, beta, moving_mean,
+                     moving_var, eps, momentum, unbiased, training, update_moving, bnstate);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                       int first, int NB, int HW, int C, const float* __restrict__ st,
+                                                       float* __restrict__ xn) {
+  long pp = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pp >= (long)NB * HW) return;
+  int b = (int)(pp / HW);
+  int pix = (int)(pp - (long)b * HW);
+  long row = idx ? idx[b] : first + b;
+  const float* px = x + (row * HW + pix) * C;
+  float o[BN_MAXC];
+#pragma unroll
+  for (int c = 0; c < BN_MAXC; ++c) o[c] = (c < C) ? px[c] * st[c] + st[BN_MAXC + c] : 0.f;
+  f32x4* dst = reinterpret_cast<f32x4*>(xn + pp * BN_MAXC);
+  dst[0] = (f32x4){o[0], o[1], o[2], o[3]};
+  dst[1] = (f32x4){o[4], o[5], o[6], o[7]};
+}
+
+int launch_bn_apply(const float* x, const int* idx, int first, int NB, int HW, int C, int Cpad, const float* bnstate,
+                    float* xn, hipStream_t s) {
+  if (Cpad != BN_MAXC || C > BN_MAXC) {
+    set_error("bn_apply: Cpad must be %d", BN_MAXC);
+    return E_INVALID;
+  }
+  long total = (long)NB * HW;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, idx, first, NB, HW, C,
+                     bnstate, xn);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// d(gamma)_c = sum dxn_c * xhat_c ; d(beta)_c = sum dxn_c   -> part[block][16]
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ x,
+                                                     const int* __restrict__ idx, int first, int NB, int HW, int C,
+                                                     const float* __restrict__ st, float* __restrict__ part) {
+  __shared__ float sh[4];
+  const long total = (long)NB * HW;
+  const long p0 = (long)blockIdx.x * BN_PIX_PER_BLOCK;
+  float dg[BN_MAXC], db[BN_MAXC];
+#pragma unroll
+  for (int c = 0; c < BN_MAXC; ++c) dg[c] = db[c] = 0.f;
+  for (long pp = p0 + threadIdx.x; pp < min(total, p0 + BN_PIX_PER_BLOCK); pp += 256) {
+    int b = (int)(pp / HW);
+    int pix = (int)(pp - (long)b * HW);
+    long row = idx ? idx[b] : first + b;
+    const float* px = x + (row * HW + pix) * C;
+    const f32x4* g = reinterpret_cast<const f32x4*>(dxn + pp * BN_MAXC);
+    f32x4 g0 = g[0], g1 = g[1];
+    float gv[BN_MAXC] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+    for (int c = 0; c < BN_MAXC; ++c)
+      if (c < C) {
+        float xh = (px[c] - st[2 * BN_MAXC + c]) * st[3 * BN_MAXC + c];
+        dg[c] += gv[c] * xh;
+        db[c] += gv[c];
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < BN_MAXC; ++c) {
+    float a = block_sum(dg[c], sh);
+    float b = block_sum(db[c], sh);
+    if (threadIdx.x == 0) {
+      part[blockIdx.x * 2 * BN_MAXC + c] = a;
+      part[blockIdx.x * 2 * BN_MAXC + BN_MAXC + c] = b;
+    }
+  }
+}
+
+int launch_bn_bwd(const float* dxn, const float* x, const int* idx, int first, int NB, int HW, int C, int Cpad,
+                  const float* bnstate, float* part, int* nblocks, hipStream_t s) {
+  if (Cpad != BN_MAXC || C > BN_MAXC) return E_INVALID;
+  long total = (long)NB * HW;
+  int nb = (int)((total + BN_PIX_PER_BLOCK - 1) / BN_PIX_PER_BLOCK);
+  *nblocks = nb;
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3(nb), dim3(256), 0, s, dxn, x, idx, first, NB, HW, C, bnstate, part);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PReLU
+__global__ __launch_bounds__(256) void prelu_fwd_kernel(const float* __restrict__ u, const float* __restrict__ alpha,
+                                                        float* __restrict__ a, long total4, int E4) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  int e = (int)(i % E4);
+  f32x4 uv = reinterpret_cast<const f32x4*>(u)[i];
+  f32x4 al = reinterpret_cast<const f32x4*>(alpha)[e];
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = uv[k] > 0.f ? uv[k] : al[k] * uv[k];
+  reinterpret_cast<f32x4*>(a)[i] = o;
+}
+
+int launch_prelu_fwd(const float* u, const float* alpha, float* a, long NB, int E, hipStream_t s) {
+  if (E & 3) {
+    set_error("prelu: E must be a multiple of 4");
+    return E_INVALID;
+  }
+  long total4 = NB * (E / 4);
+  if (total4 == 0) return OK;
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, u, alpha, a, total4,
+                     E / 4);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// du = da * (u>0 ? 1 : alpha) in place; d(alpha)[e] = sum_n da*min(u,0); d(bias)[c] = sum_{n,hw} du.
+// grid (ceil(E/1024), nsplit): thread owns 4 consecutive elements e, loops over its slice of the batch.
+// dbias_mode 0: none; 1: E == C (dense), partial [nsplit][E]; 2: 1024 % C == 0, partial [nsplit*gridDim.x][C]
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(float* __restrict__ da, const float* __restrict__ u,
+                                                        const float* __restrict__ alpha, int NB, int E, int C,
+                                                        int nper, float* __restrict__ dalpha_part,
+                                                        float* __restrict__ dbias_part, int dbias_mode) {
+  __shared__ f32x4 shv[256];
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int split = blockIdx.y;
+  const bool act = e < E;
+  f32x4 dal = {0.f, 0.f, 0.f, 0.f}, dbs = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+    const f32x4 al = *reinterpret_cast<const f32x4*>(alpha + e);
+    const int nbeg = split * nper, nend = min(NB, nbeg + nper);
+    for (int n = nbeg; n < nend; ++n) {
+      const size_t off = (size_t)n * E + e;
+      f32x4 g = *reinterpret_cast<const f32x4*>(da + off);
+      f32x4 uv = *reinterpret_cast<const f32x4*>(u + off);
+      f32x4 d;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bool pos = uv[k] > 0.f;
+        d[k] = pos ? g[k] : g[k] * al[k];
+        dal[k] += pos ? 0.f : g[k] * uv[k];
+        dbs[k] += d[k];
+      }
+      *reinterpret_cast<f32x4*>(da + off) = d;
+    }
+    if (dalpha_part) *reinterpret_cast<f32x4*>(dalpha_part + (size_t)split * E + e) = dal;
+    if (dbias_mode == 1) *reinterpret_cast<f32x4*>(dbias_part + (size_t)split * E + e) = dbs;
+  }
+  if (dbias_mode == 2) {
+    shv[threadIdx.x] = dbs;
+    __syncthreads();
+    const int cq = C / 4;
+    if ((int)threadIdx.x < cq) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int t = threadIdx.x; t < 256; t += cq) acc += shv[t];
+      size_t row = (size_t)split * gridDim.x + blockIdx.x;
+      *reinterpret_cast<f32x4*>(dbias_part + row * C + threadIdx.x * 4) = acc;
+    }
+  }
+}
+
+int launch_prelu_bwd(float* da, const float* u, const float* alpha, int NB, int E, int C, int nsplit,
+                     float* dalpha_part, float* dbias_part, int* dbias_rows, hipStream_t s) {
+  if ((E & 3) || nsplit < 1) return E_INVALID;
+  int mode = 0;
+  int gx = (E + 1023) / 1024;
+  if (dbias_part) {
+    if (E == C) {
+      mode = 1;
+      *dbias_rows = nsplit;
+    } else if (C <= 1024 && (1024 % C) == 0) {
+      mode = 2;
+      *dbias_rows = nsplit * gx;
+    } else {
+      set_error("prelu_bwd: unsupported channel count %d for the fused bias gradient", C);
+      return E_INVALID;
+    }
+  }
+  int nper = (NB + nsplit - 1) / nsplit;
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(gx, nsplit), dim3(256), 0, s, da, u, alpha, NB, E, C, nper, dalpha_part,
+                     dbias_part, mode);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// column sums of x[rows][C] (C multiple of 4, C/4 <= 256) -> part[block][C]
+constexpr int COLSUM_ROWS = 2048;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long rows, int C,
+                                                     float* __restrict__ part) {
+  __shared__ f32x4 shv[256];
+  const int cq = C / 4;
+  const int rpb = 256 / cq;
+  const int t = threadIdx.x;
+  const int q = t % cq, rr = t / cq;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const long r0 = (long)blockIdx.x * COLSUM_ROWS;
+  const long r1 = min(rows, r0 + COLSUM_ROWS);
+  if (rr < rpb)
+    for (long r = r0 + rr; r < r1; r += rpb) acc += *reinterpret_cast<const f32x4*>(x + r * C + q * 4);
+  shv[t] = acc;
+  __syncthreads();
+  if (t < cq) {
+    f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < rpb; ++k) tot += shv[k * cq + t];
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + t * 4) = tot;
+  }
+}
+
+int launch_colsum(const float* x, long rows, int C, float* part, int* nrows_part, hipStream_t s) {
+  if ((C & 3) || C / 4 > 256) {
+    set_error("colsum: unsupported C=%d", C);
+    return E_INVALID;
+  }
+  int nb = (int)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
+  *nrows_part = nb;
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, s, x, rows, C, part);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// relu + crop + Normal(loc, floor + scale) head: loss partial sums, outputs and d(loss)/d(tpre)
+constexpr int HEAD_MAXNB = 8;
+__global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
+  __shared__ float sh[4];
+  const long total = (long)p.NB * p.Hd * p.Hd;
+  const long pp = (long)blockIdx.x * 256 + threadIdx.x;
+  float nll = 0.f, se = 0.f;
+  if (pp < total) {
+    const int HdHd = p.Hd * p.Hd;
+    const int b = (int)(pp / HdHd);
+    const int rem = (int)(pp - (long)b * HdHd);
+    const int oh = rem / p.Hd, ow = rem - oh * p.Hd;
+    const int h = oh - p.crop0, w = ow - p.crop0;
+    const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.H;
+    const int nb2 = 2 * p.nb;
+    const float* tp = p.tpre + pp * nb2;
+    float* dtp = p.dt ? p.dt + pp * nb2 : nullptr;
+    if (!in) {
+      if (dtp)
+        for (int c = 0; c < nb2; ++c) dtp[c] = 0.f;
+    } else {
+      const long opix = ((long)b * p.H + h) * p.H + w;
+      const float* yp = nullptr;
+      if (p.y) {
+        long row = p.idx ? p.idx[b] : p.first + b;
+        yp = p.y + ((row * p.H + h) * p.H + w) * p.nb;
+      }
+#pragma unroll
+      for (int c = 0; c < HEAD_MAXNB; ++c) {
+        if (c >= p.nb) break;
+        const float tl = tp[c], ts = tp[p.nb + c];
+        const float loc = fmaxf(tl, 0.f);
+        const float sig = p.sigma_floor + fmaxf(ts, 0.f);
+        if (p.loc) p.loc[opix * p.nb + c] = loc;
+        if (p.scale) p.scale[opix * p.nb + c] = sig;
+        if (yp) {
+          const float inv = 1.0f / sig;
+          const float d = yp[c] - loc;
+          const float r = d * inv;
+          nll += 0.5f * r * r + logf(sig) + 0.91893853320467274178f;
+          se += d * d;
+          if (dtp) {
+            dtp[c] = tl > 0.f ? -(r * inv) * p.gscale : 0.f;
+            dtp[p.nb + c] = ts > 0.f ? (inv - r * r * inv) * p.gscale : 0.f;
+          }
+        }
+      }
+    }
+  }
+  float a = block_sum(nll, sh);
+  float b = block_sum(se, sh);
+  if (threadIdx.x == 0 && p.part) {
+    p.part[blockIdx.x * 2] = a;
+    p.part[blockIdx.x * 2 + 1] = b;
+  }
+}
+
+int launch_head(const HeadParams& p, hipStream_t s, int* nblocks_out) {
+  if (p.nb > HEAD_MAXNB) {
+    set_error("head: at most %d bands", HEAD_MAXNB);
+    return E_INVALID;
+  }
+  long total = (long)p.NB * p.Hd * p.Hd;
+  int nb = (int)((total + 255) / 256);
+  if (nblocks_out) *nblocks_out = nb;
+  if (nb == 0) return OK;
+  hipLaunchKernelGGL(head_kernel, dim3(nb), dim3(256), 0, s, p);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MultivariateNormalTriL sampler + MC KL; one 64-lane wave per stamp, lane i owns row i of L.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__device__ __forceinline__ int tril_src(int d, int i, int j) {
+  // position inside t[d:] that tfp.math.fill_triangular puts at L[i][j] (j <= i)
+  const int m = d * (d + 1) / 2;
+  const int q = i * d + j;
+  return q < m - d ? d + q : d * d - 1 - q;
+}
+
+__global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= p.NB) return;
+  const int d = p.d;
+  const int tw = d + d * (d + 1) / 2;
+  const float* t = p.t + (size_t)b * tw;
+  float e = 0.f;
+  if (lane < d) {
+    if (p.gen) {
+      unsigned r[4];
+      philox4x32_10(p.row0 + b, lane >> 2, p.stream, 0u, (unsigned)p.seed, (unsigned)(p.seed >> 32), r);
+      const int a = lane & 3;
+      const float u1 = ((float)r[a & ~1] + 1.0f) * 2.3283064365386963e-10f;
+      const float u2 = ((float)r[(a & ~1) + 1] + 1.0f) * 2.3283064365386963e-10f;
+      // (r+1)*2^-32 in fp32 can round to exactly 1.0 -> log(1)=0, still finite
+      const float rad = sqrtf(-2.0f * logf(fminf(u1, 1.0f)));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      e = (a & 1) ? rad * sn : rad * cs;
+      p.eps[(size_t)b * d + lane] = e;
+    } else {
+      e = p.eps[(size_t)b * d + lane];
+    }
+  }
+  float z = 0.f, logd = 0.f, l2 = 0.f;
+  if (lane < d) z = t[lane];
+  for (int j = 0; j < d; ++j) {
+    const float ej = __shfl(e, j, 64);
+    if (lane < d && j <= lane) {
+      float l = t[d + tril_src(d, lane, j)];
+      if (j == lane) {
+        l = softplus_f(l) + p.diag_shift;
+        logd = logf(l);
+      }
+      z += l * ej;
+      l2 += l * l;
+    }
+  }
+  float k = (lane < d) ? (0.5f * z * z - 0.5f * e * e - logd) : 0.f;
+  k = wave_sum(k);
+  if (lane < d) {
+    p.z[(size_t)b * d + lane] = z;
+    if (p.stddev) p.stddev[(size_t)b * d + lane] = sqrtf(l2);
+  }
+  if (lane == 0) p.kl[b] = k;
+}
+
+int launch_sampler_fwd(const SamplerParams& p, hipStream_t s) {
+  if (p.d > 64 || p.d < 1) {
+    set_error("sampler: latent_dim must be in [1,64]");
+    return E_INVALID;
+  }
+  if (p.NB == 0) return OK;
+  hipLaunchKernelGGL(sampler_fwd_kernel, dim3((p.NB + 3) / 4), dim3(256), 0, s, p);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+__global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restrict__ t, const float* __restrict__ eps,
+                                                          const float* __restrict__ z, const float* __restrict__ dz,
+                                                          float* __restrict__ dt, int NB, int d, float diag_shift,
+                                                          float kls) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= NB) return;
+  const int tw = d + d * (d + 1) / 2;
+  const float* tb = t + (size_t)b * tw;
+  float* dtb = dt + (size_t)b * tw;
+  float e = 0.f, g = 0.f;
+  if (lane < d) {
+    e = eps[(size_t)b * d + lane];
+    g = dz[(size_t)b * d + lane] + kls * z[(size_t)b * d + lane];
+    dtb[lane] = g;
+  }
+  for (int j = 0; j < d; ++j) {
+    const float ej = __shfl(e, j, 64);
+    if (lane < d && j <= lane) {
+      const int src = d + tril_src(d, lane, j);
+      float v = g * ej;
+      if (j == lane) {
+        const float raw = tb[src];
+        const float l = softplus_f(raw) + diag_shift;
+        const float sg = 1.0f / (1.0f + expf(-raw));
+        v = (v - kls / l) * sg;
+      }
+      dtb[src] = v;
+    }
+  }
+}
+
+int launch_sampler_bwd(const float* t, const float* eps, const float* z, const float* dz, float* dt, int NB, int d,
+                       float diag_shift, float kls, hipStream_t s) {
+  if (NB == 0) return OK;
+  hipLaunchKernelGGL(sampler_bwd_kernel, dim3((NB + 3) / 4), dim3(256), 0, s, t, eps, z, dz, dt, NB, d, diag_shift,
+                     kls);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.optimizers.legacy.Adam (reference train.py:126): m += (g-m)(1-b1); v += (g^2-v)(1-b2); w -= lr_t m/(sqrt(v)+eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ g, long n4, float lr_t, float b1,
+                                                   float b2, float eps) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 gw = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mw = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vw = reinterpret_cast<f32x4*>(v)[i];
+    f32x4 ww = reinterpret_cast<f32x4*>(w)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mw[k] += (gw[k] - mw[k]) * (1.f - b1);
+      vw[k] += (gw[k] * gw[k] - vw[k]) * (1.f - b2);
+      ww[k] -= lr_t * mw[k] / (sqrtf(vw[k]) + eps);
+    }
+    reinterpret_cast<f32x4*>(m)[i] = mw;
+    reinterpret_cast<f32x4*>(v)[i] = vw;
+    reinterpret_cast<f32x4*>(w)[i] = ww;
+  }
+}
+
+int launch_adam(float* w, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps,
+                hipStream_t s) {
+  if (n & 3) return E_INVALID;
+  long n4 = n / 4;
+  if (n4 == 0) return OK;
+  int blocks = (int)min((n4 + 255) / 256, (long)2048);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, w, m, v, g, n4, lr_t, b1, b2, eps);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+__global__ void pad_w1_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int cin, int cpad,
+                              int cout) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int total = taps * cpad * cout;
+  if (i >= total) return;
+  int co = i % cout;
+  int c = (i / cout) % cpad;
+  int t = i / (cout * cpad);
+  wp[i] = c < cin ? w[(t * cin + c) * cout + co] : 0.f;
+}
+
+int launch_pad_w1(const float* w, float* wp, int taps, int cin, int cpad, int cout, hipStream_t s) {
+  int total = taps * cpad * cout;
+  hipLaunchKernelGGL(pad_w1_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, wp, taps, cin, cpad, cout);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+__global__ void fill_kernel(float* p, long n, float v) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
+}
+int launch_fill(float* p, long n, float v, hipStream_t s) {
+  if (n <= 0) return OK;
+  int blocks = (int)min((n + 255) / 256, (long)2048);
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, n, v);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int first, int NB,
+                                   long row_elems, float* __restrict__ dst) {
+  long total = (long)NB * row_elems;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int b = (int)(i / row_elems);
+    long e = i - (long)b * row_elems;
+    long row = idx ? idx[b] : first + b;
+    dst[i] = src[row * row_elems + e];
+  }
+}
+int launch_gather_rows(const float* src, const int* idx, int first, int NB, long row_elems, float* dst,
+                       hipStream_t s) {
+  long total = (long)NB * row_elems;
+  if (total <= 0) return OK;
+  int blocks = (int)min((total + 255) / 256, (long)4096);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, s, src, idx, first, NB, row_elems, dst);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+}  // namespace dv

@@ -1,0 +1,214 @@
+// Weight-gradient contraction on the fp32 matrix cores, split over pixel ranges.
+//
+// dW[(t, cx), cy] = sum over class-grid pixels p=(nb,i,j) of  X[nb, i*sx+dh[t], j*sx+dw[t], cx] * Y[nb, i*sy+ph, j*sy+pw, cy]
+// covers d(kernel) of Conv2D (X = layer input, Y = d(pre-activation); reference model.py:81-91,137),
+// of Conv2DTranspose (X = d(pre-activation) of the layer output, Y = layer input; model.py:121-134) and
+// of Dense (one tap, 1x1 grid; model.py:96-98,114,117).  The reduction dimension (pixels) is the long one,
+// so every workgroup owns one (row tile, column tile) of dW for a contiguous pixel range and writes
+// a partial slab; reduce_partials() sums the slabs in a fixed order, which keeps results bit-reproducible.
+#include "common.h"
+
+namespace dv {
+
+constexpr int BKP = 32;  // pixels per LDS stage
+
+__device__ __forceinline__ int wtap_dh(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 3) - 1; }
+__device__ __forceinline__ int wtap_dw(unsigned long long code, int t) { return (int)((code >> (4 * t + 2)) & 3) - 1; }
+__device__ __forceinline__ int wtap_wt(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 15); }
+
+template <int BMW, int BNW, int WGM, int WGN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int WM = BMW / WGM, WN = BNW / WGN;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int LDAW = BMW + 4, LDBW = BNW + 4;
+  constexpr int AQ = (BMW + 31) / 32, BQ = (BNW + 31) / 32;
+  constexpr int A_ELEMS = BKP * LDAW, B_ELEMS = BKP * LDBW;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  const int rows_launch = p.ntaps * p.Cx;
+  const int ntn = (p.Cy + BNW - 1) / BNW;
+  const int m0 = (blockIdx.x / ntn) * BMW;
+  const int n0 = (blockIdx.x % ntn) * BNW;
+  const int split = blockIdx.y;
+  const int pstart = split * p.pchunk;
+  const int pend = min(p.P, pstart + p.pchunk);
+
+  const int ps = tid >> 3, q = tid & 7;
+  int adh[AQ], adw[AQ], acx[AQ];
+  bool aok[AQ];
+#pragma unroll
+  for (int i = 0; i < AQ; ++i) {
+    int rl = 4 * (q + 8 * i);
+    int r = m0 + rl;
+    aok[i] = (rl < BMW) && (r < rows_launch);
+    int t = aok[i] ? r / p.Cx : 0;
+    acx[i] = r - t * p.Cx;
+    adh[i] = wtap_dh(p.tapcode, t);
+    adw[i] = wtap_dw(p.tapcode, t);
+  }
+  const int HcWc = p.Hc * p.Wc;
+
+  f32x4 areg[AQ], breg[BQ];
+  auto load_global = [&](int kc) {
+    const int pp = pstart + kc * BKP + ps;
+    const bool pv = pp < pend;
+    int nb = 0, ii = 0, jj = 0;
+    if (pv) {
+      nb = pp / HcWc;
+      int rem = pp - nb * HcWc;
+      ii = rem / p.Wc;
+      jj = rem - ii * p.Wc;
+    }
+#pragma unroll
+    for (int i = 0; i < AQ; ++i) {
+      int ih = ii * p.sx + adh[i], iw = jj * p.sx + adw[i];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pv && aok[i] && (unsigned)ih < (unsigned)p.Hx && (unsigned)iw < (unsigned)p.Wx) {
+        size_t off = ((size_t)((nb * p.Hx + ih) * p.Wx + iw)) * p.Cx + acx[i];
+        v = *reinterpret_cast<const f32x4*>(p.X + off);
+      }
+      areg[i] = v;
+    }
+    const size_t ypix = (size_t)((nb * p.Hy + ii * p.sy + p.ph) * p.Wy + jj * p.sy + p.pw) * p.Cy;
+#pragma unroll
+    for (int i = 0; i < BQ; ++i) {
+      int cl = 4 * (q + 8 * i);
+      int c = n0 + cl;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pv && cl < BNW && c < p.Cy) v = *reinterpret_cast<const f32x4*>(p.Y + ypix + c);
+      breg[i] = v;
+    }
+  };
+  auto store_lds = [&](int buf) {
+    float* a = As + buf * A_ELEMS + ps * LDAW;
+    float* b = Bs + buf * B_ELEMS + ps * LDBW;
+#pragma unroll
+    for (int i = 0; i < AQ; ++i)
+      if (4 * (q + 8 * i) < BMW) *reinterpret_cast<f32x4*>(a + 4 * (q + 8 * i)) = areg[i];
+#pragma unroll
+    for (int i = 0; i < BQ; ++i)
+      if (4 * (q + 8 * i) < BNW) *reinterpret_cast<f32x4*>(b + 4 * (q + 8 * i)) = breg[i];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const float* a = As + buf * A_ELEMS;
+    const float* b = Bs + buf * B_ELEMS;
+#pragma unroll
+    for (int s = 0; s < BKP / 4; ++s) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) af[tm] = a[(4 * s + lg) * LDAW + wm0 + tm * 16 + l15];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bf[tn] = b[(4 * s + lg) * LDBW + wn0 + tn * 16 + l15];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+    }
+  };
+
+  const int npix = max(pend - pstart, 0);
+  const int nchunks = (npix + BKP - 1) / BKP;
+  if (nchunks > 0) {
+    load_global(0);
+    store_lds(0);
+  }
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nchunks) load_global(kc + 1);
+    compute(cur);
+    if (kc + 1 < nchunks) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* slab = p.part + (size_t)split * p.rows_total * p.Cy;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int rl = m0 + wm0 + tm * 16 + lg * 4 + r;
+      if (rl >= rows_launch) continue;
+      int t = rl / p.Cx;
+      int cx = rl - t * p.Cx;
+      size_t grow = (size_t)(wtap_wt(p.wtcode, t) * p.Cx + cx) * p.Cy;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        int c = n0 + wn0 + tn * 16 + l15;
+        if (c < p.Cy) slab[grow + c] = acc[tm][tn][r];
+      }
+    }
+  }
+}
+
+template <int BMW, int BNW, int WGM, int WGN>
+static int launch_w(const WGradParams& p, hipStream_t s) {
+  constexpr size_t smem = (size_t)(2 * BKP * (BMW + 4) + 2 * BKP * (BNW + 4)) * sizeof(float);
+  auto kern = wgrad_kernel<BMW, BNW, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    attr_set = true;
+  }
+  int rows = p.ntaps * p.Cx;
+  dim3 grid(((rows + BMW - 1) / BMW) * ((p.Cy + BNW - 1) / BNW), p.nsplit), block(256);
+  hipLaunchKernelGGL(kern, grid, block, smem, s, p);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+int launch_wgrad(const WGradParams& p, hipStream_t s) {
+  if (p.P <= 0) return OK;
+  if ((p.Cx & 3) || (p.Cy & 3) || (p.pchunk % BKP) || p.nsplit < 1 || (long)p.nsplit * p.pchunk < p.P) {
+    set_error("wgrad: bad parameters (Cx=%d Cy=%d pchunk=%d nsplit=%d P=%d)", p.Cx, p.Cy, p.pchunk, p.nsplit, p.P);
+    return E_INVALID;
+  }
+  const int rows = p.ntaps * p.Cx;
+  if (p.Cy <= 16) return launch_w<128, 16, 4, 1>(p, s);
+  if (p.Cy <= 32) return rows <= 32 ? launch_w<32, 32, 2, 2>(p, s) : launch_w<64, 32, 4, 1>(p, s);
+  if (p.Cy <= 64) return rows <= 64 ? launch_w<64, 64, 2, 2>(p, s) : launch_w<128, 64, 2, 2>(p, s);
+  return rows <= 64 ? launch_w<64, 128, 2, 2>(p, s) : launch_w<128, 128, 2, 2>(p, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int nsplit, long slab, int ncols, int cpad, int creal) {
+  long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= slab) return;
+  long r = e / ncols;
+  int c = (int)(e - r * ncols);
+  int ci = (int)(r % cpad);
+  if (ci >= creal) return;
+  float acc = 0.f;
+  for (int s = 0; s < nsplit; ++s) acc += part[(long)s * slab + e];
+  long ro = (r / cpad) * creal + ci;
+  out[ro * ncols + c] = acc;
+}
+
+int launch_reduce_partials(const float* part, float* out, int nsplit, long slab_elems, int ncols, int cpad, int creal,
+                           hipStream_t s) {
+  if (slab_elems <= 0) return OK;
+  long blocks = (slab_elems + 255) / 256;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, s, part, out, nsplit, slab_elems,
+                     ncols, cpad, creal);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+}  // namespace dv

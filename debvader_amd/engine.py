@@ -1,0 +1,310 @@
+"""Thin numpy-level wrapper over the C-ABI (one Context per process/GPU, one Engine per network).
+
+This is the only module that touches ctypes pointers; the Keras-like objects in debvader_amd.model
+sit on top of it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import DvConfig, check, lib
+
+
+def make_config(input_shape=(59, 59, 6), latent_dim=32, filters=(32, 64, 128, 256), kernels=(3, 3, 3, 3),
+                max_batch=256, **overrides) -> DvConfig:
+    cfg = DvConfig()
+    check(lib.dv_config_default(C.byref(cfg)))
+    if len(filters) != len(kernels):
+        raise ValueError("filters and kernels must have the same length")
+    if len(filters) > _lib.DV_MAX_LEVELS:
+        raise ValueError(f"at most {_lib.DV_MAX_LEVELS} levels")
+    cfg.height, cfg.width, cfg.bands = int(input_shape[0]), int(input_shape[1]), int(input_shape[2])
+    cfg.latent_dim = int(latent_dim)
+    cfg.n_levels = len(filters)
+    for i in range(_lib.DV_MAX_LEVELS):
+        cfg.filters[i] = int(filters[i]) if i < len(filters) else 0
+        cfg.kernels[i] = int(kernels[i]) if i < len(kernels) else 0
+    cfg.max_batch = int(max_batch)
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown config field {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+def arch_specs(cfg: DvConfig) -> List[Tuple[str, Tuple[int, ...], bool]]:
+    """(name, shape, trainable) of every tensor in TF-checkpoint order. Host only."""
+    n = C.c_int32()
+    check(lib.dv_arch_counts(C.byref(cfg), C.byref(n), None, None, None))
+    out = []
+    for i in range(n.value):
+        name = C.create_string_buffer(128)
+        shape = (C.c_int64 * 4)()
+        nd, tr = C.c_int32(), C.c_int32()
+        check(lib.dv_arch_describe(C.byref(cfg), i, name, 128, shape, C.byref(nd), C.byref(tr)))
+        out.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value)), bool(tr.value)))
+    return out
+
+
+def arch_counts(cfg: DvConfig) -> Dict[str, int]:
+    n = C.c_int32()
+    e, d, t = C.c_int64(), C.c_int64(), C.c_int64()
+    check(lib.dv_arch_counts(C.byref(cfg), C.byref(n), C.byref(e), C.byref(d), C.byref(t)))
+    return dict(tensors=n.value, encoder=e.value, decoder=d.value, trainable=t.value)
+
+
+def arch_macs(cfg: DvConfig) -> Tuple[int, int]:
+    e, d = C.c_int64(), C.c_int64()
+    check(lib.dv_arch_macs(C.byref(cfg), C.byref(e), C.byref(d)))
+    return e.value, d.value
+
+
+def device_count() -> int:
+    n = C.c_int32()
+    check(lib.dv_device_count(C.byref(n)))
+    return n.value
+
+
+def _fp(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32c(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+class Context:
+    """One per process: selects the GPU, owns the HIP stream and the RCCL communicator."""
+
+    def __init__(self, device: int = 0, rank: int = 0, world: int = 1, unique_id: Optional[bytes] = None):
+        self._h = C.c_void_p()
+        self.rank, self.world, self.device = rank, world, device
+        idbuf = None
+        if world > 1:
+            if unique_id is None or len(unique_id) != _lib.DV_UNIQUE_ID_BYTES:
+                raise ValueError("world > 1 needs rank 0's unique id (Context.unique_id())")
+            idbuf = C.create_string_buffer(unique_id, _lib.DV_UNIQUE_ID_BYTES)
+        check(lib.dv_ctx_create(device, rank, world, idbuf, C.byref(self._h)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(_lib.DV_UNIQUE_ID_BYTES)
+        check(lib.dv_comm_unique_id(buf))
+        return buf.raw
+
+    def sync(self):
+        check(lib.dv_ctx_sync(self._h))
+
+    def allreduce(self, values: Sequence[float]) -> np.ndarray:
+        a = np.ascontiguousarray(values, dtype=np.float32)
+        check(lib.dv_ctx_allreduce_host(self._h, _fp(a), a.size))
+        return a
+
+    def close(self):
+        if self._h:
+            lib.dv_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0, 0, 1, None)
+    return _default_ctx
+
+
+def set_default_context(ctx: Optional[Context]):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+class Engine:
+    """Weights, Adam state, workspaces and step functions of one conv-VAE on one GPU."""
+
+    def __init__(self, cfg: DvConfig, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib.dv_model_create(self.ctx._h, C.byref(cfg), C.byref(self._h)))
+        self.specs = arch_specs(cfg)
+        self.index = {n: i for i, (n, _, _) in enumerate(self.specs)}
+        self.latent = cfg.latent_dim
+        self.tw = self.latent + self.latent * (self.latent + 1) // 2
+        self.stamp_shape = (cfg.height, cfg.width, cfg.bands)
+        self.max_batch = cfg.max_batch
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            lib.dv_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters -------------------------------------------------------------------------
+    def init(self, seed: int = 0):
+        check(lib.dv_model_init(self._h, seed))
+
+    def _tensor(self, fn, i, *extra) -> np.ndarray:
+        name, shape, _ = self.specs[i]
+        a = np.empty(shape, dtype=np.float32)
+        check(fn(self._h, i, *extra, _fp(a), a.nbytes))
+        return a
+
+    def get_param(self, key) -> np.ndarray:
+        return self._tensor(lib.dv_model_get_param, self._idx(key))
+
+    def get_grad(self, key) -> np.ndarray:
+        return self._tensor(lib.dv_model_get_grad, self._idx(key))
+
+    def get_slot(self, key, which: int) -> np.ndarray:
+        return self._tensor(lib.dv_model_get_slot, self._idx(key), which)
+
+    def set_param(self, key, value):
+        i = self._idx(key)
+        a = _f32c(value, self.specs[i][1])
+        check(lib.dv_model_set_param(self._h, i, _fp(a), a.nbytes))
+
+    def set_slot(self, key, which: int, value):
+        i = self._idx(key)
+        a = _f32c(value, self.specs[i][1])
+        check(lib.dv_model_set_slot(self._h, i, which, _fp(a), a.nbytes))
+
+    def _idx(self, key) -> int:
+        return key if isinstance(key, int) else self.index[key]
+
+    def get_params(self) -> Dict[str, np.ndarray]:
+        return {n: self.get_param(i) for i, (n, _, _) in enumerate(self.specs)}
+
+    def set_params(self, params: Dict[str, np.ndarray]):
+        for n, v in params.items():
+            self.set_param(n, v)
+
+    def set_trainable(self, encoder: bool, decoder: bool):
+        check(lib.dv_model_set_trainable(self._h, int(encoder), int(decoder)))
+
+    def optimizer_reset(self, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-7):
+        check(lib.dv_optimizer_reset(self._h, lr, beta1, beta2, eps))
+
+    @property
+    def iterations(self) -> int:
+        it = C.c_int64()
+        check(lib.dv_optimizer_get_iter(self._h, C.byref(it)))
+        return it.value
+
+    @iterations.setter
+    def iterations(self, v: int):
+        check(lib.dv_optimizer_set_iter(self._h, int(v)))
+
+    # -- data -------------------------------------------------------------------------------
+    def upload(self, slot: int, x, y):
+        x = _f32c(x)
+        y = _f32c(y)
+        if x.shape != y.shape or x.shape[1:] != self.stamp_shape:
+            raise ValueError(f"expected x, y of shape (N,{self.stamp_shape}), got {x.shape} and {y.shape}")
+        check(lib.dv_data_upload(self._h, slot, _fp(x), _fp(y), x.shape[0]))
+        return x.shape[0]
+
+    def free_data(self, slot: int):
+        check(lib.dv_data_free(self._h, slot))
+
+    # -- steps ------------------------------------------------------------------------------
+    def _step(self, fn, slot, idx, first, B, global_batch, eps, seed) -> Dict[str, float]:
+        out = np.zeros(_lib.DV_N_SCALARS, dtype=np.float32)
+        ip = None
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            B = idx.size
+            ip = idx.ctypes.data_as(C.POINTER(C.c_int32))
+        if eps is not None:
+            eps = _f32c(eps, (B, self.latent))
+        check(fn(self._h, slot, ip, int(first), int(B), int(global_batch or 0), _fp(eps), int(seed), _fp(out)))
+        return {k: float(out[i]) for i, k in enumerate(_lib.SCALAR_NAMES)}
+
+    def train_step(self, slot=0, idx=None, first=0, B=None, global_batch=None, eps=None, seed=0):
+        return self._step(lib.dv_train_step, slot, idx, first, B, global_batch, eps, seed)
+
+    def eval_step(self, slot=1, idx=None, first=0, B=None, global_batch=None, eps=None, seed=0):
+        return self._step(lib.dv_eval_step, slot, idx, first, B, global_batch, eps, seed)
+
+    def grad_step(self, slot=0, idx=None, first=0, B=None, global_batch=None, eps=None, seed=0):
+        return self._step(lib.dv_grad_step, slot, idx, first, B, global_batch, eps, seed)
+
+    def train_steps(self, slot, first, B, steps, global_batch=None, seed=0) -> Dict[str, float]:
+        out = np.zeros(_lib.DV_N_SCALARS, dtype=np.float32)
+        check(lib.dv_train_steps(self._h, slot, int(first), int(B), int(global_batch or 0), int(steps), int(seed),
+                                 _fp(out)))
+        return {k: float(out[i]) for i, k in enumerate(_lib.SCALAR_NAMES)}
+
+    # -- inference --------------------------------------------------------------------------
+    def infer(self, x, eps=None, seed=0, want=("loc", "scale")) -> Dict[str, np.ndarray]:
+        x = _f32c(x)
+        if x.ndim != 4 or x.shape[1:] != self.stamp_shape:
+            raise ValueError(f"expected images of shape (N,{self.stamp_shape}), got {x.shape}")
+        N = x.shape[0]
+        bufs = {}
+        for k in ("loc", "scale"):
+            bufs[k] = np.empty((N,) + self.stamp_shape, np.float32) if k in want else None
+        for k in ("mu", "zstd", "z"):
+            bufs[k] = np.empty((N, self.latent), np.float32) if k in want else None
+        if eps is not None:
+            eps = _f32c(eps, (N, self.latent))
+        check(lib.dv_infer(self._h, _fp(x), N, _fp(eps), int(seed), _fp(bufs["loc"]), _fp(bufs["scale"]),
+                           _fp(bufs["mu"]), _fp(bufs["zstd"]), _fp(bufs["z"])))
+        return {k: v for k, v in bufs.items() if v is not None}
+
+    def encode(self, x) -> np.ndarray:
+        x = _f32c(x)
+        if x.ndim != 4 or x.shape[1:] != self.stamp_shape:
+            raise ValueError(f"expected images of shape (N,{self.stamp_shape}), got {x.shape}")
+        t = np.empty((x.shape[0], self.tw), np.float32)
+        check(lib.dv_encode(self._h, _fp(x), x.shape[0], _fp(t)))
+        return t
+
+    def decode(self, z) -> Tuple[np.ndarray, np.ndarray]:
+        z = _f32c(z)
+        if z.ndim != 2 or z.shape[1] != self.latent:
+            raise ValueError(f"expected latents of shape (N,{self.latent}), got {z.shape}")
+        loc = np.empty((z.shape[0],) + self.stamp_shape, np.float32)
+        scale = np.empty_like(loc)
+        check(lib.dv_decode(self._h, _fp(z), z.shape[0], _fp(loc), _fp(scale)))
+        return loc, scale
+
+    # -- introspection ----------------------------------------------------------------------
+    def activation(self, name: str, shape) -> np.ndarray:
+        a = np.empty(shape, np.float32)
+        check(lib.dv_model_get_activation(self._h, name.encode(), _fp(a), a.nbytes))
+        return a
+
+    def prof_enable(self, on: bool):
+        check(lib.dv_prof_enable(self._h, int(on)))
+
+    def prof_reset(self):
+        check(lib.dv_prof_reset(self._h))
+
+    def prof_read(self, klass: int) -> Tuple[int, float]:
+        n, ms = C.c_int64(), C.c_double()
+        check(lib.dv_prof_read(self._h, klass, C.byref(n), C.byref(ms)))
+        return n.value, ms.value

@@ -1,0 +1,143 @@
+/* debvader_hip.h — C-ABI of libdebvader_hip.so, the MI355X (gfx950) engine behind debvader's
+ * create_model_vae / train_* / deblend() call surface.
+ *
+ * The reference (astrodeepnet/debvader) has no FFI for this path: its boundary is the Python call
+ * surface that bottoms out in Keras/TFP (`net.fit`, `net(x)`, `net.compile`, `net.load_weights`).
+ * Each entry point below names the reference call it replaces (paths relative to the reference repo).
+ * The Python shim in debvader_amd/ binds these with ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions: every call returns an int status (0 = DV_OK, <0 = DV_E_*); dv_last_error() holds the
+ * message of the last failure on the calling thread.  Nothing throws or exits across this boundary.
+ * The caller owns every host buffer (C-contiguous float32 / int32); the library owns all device memory.
+ * A dv_model is not thread-safe.  One process drives one GPU; ranks are joined through RCCL.
+ */
+#ifndef DEBVADER_HIP_H
+#define DEBVADER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DV_OK 0
+#define DV_E_INVALID (-1)
+#define DV_E_HIP (-2)
+#define DV_E_NOMEM (-3)
+#define DV_E_RCCL (-4)
+#define DV_E_STATE (-5)
+#define DV_E_NODEVICE (-6)
+
+#define DV_MAX_LEVELS 8
+#define DV_UNIQUE_ID_BYTES 128
+
+typedef struct dv_ctx dv_ctx;
+typedef struct dv_model dv_model;
+
+/* Architecture + numerics of create_model_vae(input_shape, latent_dim, filters, kernels)
+ * (src/debvader/model/model.py:164-218; fixed values used by train_deblender: training/train.py:104-107). */
+typedef struct dv_config {
+  int32_t height, width, bands;      /* input_shape (59,59,6) */
+  int32_t latent_dim;                /* 32 */
+  int32_t n_levels;                  /* len(filters) */
+  int32_t filters[DV_MAX_LEVELS];    /* [32,64,128,256] */
+  int32_t kernels[DV_MAX_LEVELS];    /* [3,3,3,3] (only 3 is implemented) */
+  int32_t max_batch;                 /* stamps per device step (workspace capacity) */
+  float kl_weight;                   /* KLDivergenceRegularizer weight, model.py:213 (0.01) */
+  int32_t kl_multiplicity;           /* times Keras adds the activity loss (2) */
+  float bn_eps, bn_momentum;         /* Keras BatchNormalization defaults, model.py:79 (1e-3, 0.99) */
+  int32_t bn_moving_var_unbiased;    /* fused-BN moving variance uses the Bessel-corrected batch variance (1) */
+  float sigma_floor;                 /* model.py:156 (1e-4) */
+  float diag_shift;                  /* model.py:49 (1e-5) */
+} dv_config;
+
+/* scalars written by the step functions */
+enum { DV_S_LOSS = 0, DV_S_NLL_MEAN = 1, DV_S_KL_REG = 2, DV_S_MSE = 3, DV_N_SCALARS = 4 };
+
+int dv_version(void);
+int dv_last_error(char* buf, size_t n);
+int dv_config_default(dv_config* cfg);
+
+/* ---- architecture queries: host only, no GPU needed (replace net.summary(), train.py:118) ---- */
+int dv_arch_counts(const dv_config* cfg, int32_t* n_tensors, int64_t* n_encoder, int64_t* n_decoder,
+                   int64_t* n_trainable);
+int dv_arch_describe(const dv_config* cfg, int32_t i, char* name, size_t name_len, int64_t shape[4], int32_t* ndim,
+                     int32_t* trainable);
+/* forward multiply-accumulates per stamp (padding taps counted), for roofline accounting */
+int dv_arch_macs(const dv_config* cfg, int64_t* encoder_macs, int64_t* decoder_macs);
+
+/* ---- context: one per process / GPU -------------------------------------------------------- */
+int dv_device_count(int32_t* n);
+int dv_comm_unique_id(void* out_id /* DV_UNIQUE_ID_BYTES */);
+/* world == 1: id may be NULL.  world > 1: every rank passes rank 0's id (exchanged by the host). */
+int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* unique_id, dv_ctx** out);
+int dv_ctx_destroy(dv_ctx* ctx);
+int dv_ctx_sync(dv_ctx* ctx);
+/* sum `n` floats over ranks in place (host buffer); used by the host loop for History scalars */
+int dv_ctx_allreduce_host(dv_ctx* ctx, float* buf, int32_t n);
+
+/* ---- model --------------------------------------------------------------------------------- */
+/* replaces create_model_vae (model.py:164); weights start at Keras defaults (Glorot-uniform kernels,
+ * zero biases/alphas, BN gamma=1): dv_model_init draws them from the engine's own Philox stream */
+int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out);
+int dv_model_destroy(dv_model* m);
+int dv_model_init(dv_model* m, uint64_t seed);
+/* tensor i in TF-checkpoint order (dv_arch_describe): replaces net.get_weights / net.load_weights (model.py:266) */
+int dv_model_get_param(dv_model* m, int32_t i, float* host, size_t nbytes);
+int dv_model_set_param(dv_model* m, int32_t i, const float* host, size_t nbytes);
+int dv_model_get_grad(dv_model* m, int32_t i, float* host, size_t nbytes);
+/* optimizer slots of tensor i (which = 0: m, 1: v); replaces the checkpoint's .OPTIMIZER_SLOT entries */
+int dv_model_get_slot(dv_model* m, int32_t i, int32_t which, float* host, size_t nbytes);
+int dv_model_set_slot(dv_model* m, int32_t i, int32_t which, const float* host, size_t nbytes);
+/* decoder.trainable = False (train.py:175, model.py:252) takes effect at the next optimizer reset */
+int dv_model_set_trainable(dv_model* m, int32_t encoder_trainable, int32_t decoder_trainable);
+/* net.compile(optimizer=legacy.Adam(lr)) (train.py:125-130,178-183): fresh slots, iteration 0 */
+int dv_optimizer_reset(dv_model* m, float lr, float beta1, float beta2, float eps);
+int dv_optimizer_get_iter(dv_model* m, int64_t* iter);
+int dv_optimizer_set_iter(dv_model* m, int64_t iter);
+
+/* ---- data resident in HBM ------------------------------------------------------------------ */
+/* slot 0/1 (train / validation): copies n stamps x[n,H,W,C], y[n,H,W,C] to the device once per fit() */
+int dv_data_upload(dv_model* m, int32_t slot, const float* x, const float* y, int64_t n);
+int dv_data_free(dv_model* m, int32_t slot);
+
+/* ---- steps: replace one Keras train_function / test_function call inside net.fit (train.py:27-37) ---- */
+/* Batch = rows idx[0..B) of `slot` (idx == NULL: rows first..first+B).  eps == NULL: the engine draws
+ * eps ~ N(0,I) from Philox(seed); else eps[B,latent] is used (parity tests).  global_batch = sum of B over ranks
+ * (0: B).  out[DV_N_SCALARS] are the GLOBAL loss, nll mean, kl regulariser and mse-vs-mean. */
+int dv_train_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t global_batch,
+                  const float* eps, uint64_t seed, float* out);
+/* forward + losses in inference mode (moving BN statistics), no update: Keras validation step */
+int dv_eval_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t global_batch,
+                 const float* eps, uint64_t seed, float* out);
+/* gradients only (training-mode forward + backward, no Adam, no moving-stat update): parity tests */
+int dv_grad_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t global_batch,
+                 const float* eps, uint64_t seed, float* out);
+/* queue K back-to-back training steps on consecutive batches of `slot` without host round trips
+ * (bench.py timed region); scalars of the last step are returned */
+int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t global_batch, int32_t steps,
+                   uint64_t seed, float* out);
+
+/* ---- inference: replaces net(x) in deblend() (deblend_cutout/deblender.py:18,24) ----------- */
+/* x[N,H,W,C] host.  Outputs (any may be NULL): loc/scale [N,H,W,C] = distribution mean / stddev;
+ * mu [N,latent], zstd [N,latent] = z.mean()/z.stddev(); z [N,latent] = the sample fed to the decoder. */
+int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
+             float* mu, float* zstd, float* z);
+/* encoder(x) -> t[N, latent + latent(latent+1)/2]  (model.py:61-100) */
+int dv_encode(dv_model* m, const float* x, int64_t N, float* t);
+/* decoder(z) -> loc, scale  (model.py:103-161) */
+int dv_decode(dv_model* m, const float* z, int64_t N, float* loc, float* scale);
+
+/* ---- introspection for tests and bench ----------------------------------------------------- */
+/* copy a named activation of the last step to host: "t","z","kl","eps","loc","scale","head_pre" */
+int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t nbytes);
+/* HIP-event timing of kernel classes on the engine stream: class 0 gconv, 1 wgrad, 2 everything else */
+int dv_prof_enable(dv_model* m, int32_t on);
+int dv_prof_read(dv_model* m, int32_t klass, int64_t* launches, double* total_ms);
+int dv_prof_reset(dv_model* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEBVADER_HIP_H */
