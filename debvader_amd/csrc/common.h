@@ -108,7 +108,9 @@ int launch_head(const HeadParams& p, hipStream_t s, int* nblocks_out);
 
 int launch_bn_stats(const float* x, const int* idx, int first, int NB, int HW, int C, float* part, int* nblocks,
                     hipStream_t s);
-int launch_reduce_rows_f64(const float* part, int nrows, int ncols, float* out, float scale, hipStream_t s);
+// out[c] = scale * sum_r part[r*ld + c] for c < ncols (ld = row stride, 0: ncols)
+int launch_reduce_rows_f64(const float* part, int nrows, int ncols, float* out, float scale, hipStream_t s,
+                           int ld = 0);
 // bnstate: [0..C) scale, [C..2C) shift, [2C..3C) mean, [3C..4C) inv_std
 int launch_bn_finalize(const float* sums, float count, int C, const float* gamma, const float* beta,
                        float* moving_mean, float* moving_var, float eps, float momentum, int unbiased,

@@ -504,6 +504,7 @@ static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, in
   long tiles = ((p.rows_total + 127) / 128) * (long)((Cy + 127) / 128);
   long ns = (768 + tiles - 1) / tiles;
   ns = std::min(ns, (long)std::max(1, p.P / 256));
+  ns = std::min(ns, 256L);
   ns = std::min(ns, (long)(m->ws1_elems / (size_t)slab));
   ns = std::max(ns, 1L);
   if ((size_t)slab > m->ws1_elems) {
@@ -528,7 +529,7 @@ static int prelu_bwd(dv_model* m, float* da, const float* u, int alpha_spec, int
                      bool want_grads) {
   const Arch& A = m->A;
   int gx = (E + 1023) / 1024;
-  int nsplit = std::max(1, std::min(std::min(NB, 64), 1024 / std::max(gx, 1)));
+  int nsplit = std::max(1, std::min(std::min(NB, 32), 1024 / std::max(gx, 1)));
   while ((size_t)nsplit * E > m->ws2_elems && nsplit > 1) --nsplit;
   float* dal = want_grads ? m->ws2 : nullptr;
   float* dbp = (want_grads && bias_spec >= 0) ? m->ws3 : nullptr;
@@ -547,7 +548,7 @@ static int prelu_bwd(dv_model* m, float* da, const float* u, int alpha_spec, int
   }
   if (want_grads) {
     ProfScope ps(m, 2);
-    DV_TRY(launch_reduce_partials(m->ws2, m->G + A.specs[alpha_spec].off, nsplit, E, 1, 1, 1, m->ctx->stream));
+    DV_TRY(launch_reduce_partials(m->ws2, m->G + A.specs[alpha_spec].off, nsplit, E, 4, 1, 1, m->ctx->stream));
     if (dbp) DV_TRY(launch_reduce_rows_f64(m->ws3, rows, C, m->G + A.specs[bias_spec].off, 1.0f, m->ctx->stream));
   }
   return OK;
@@ -777,8 +778,9 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     int nblk = 0;
     ProfScope ps(m, 2);
     DV_TRY(launch_bn_bwd(cur, xsrc, idx, first, NB, A.H * A.H, A.C, 8, m->bnstate, m->ws3, &nblk, s));
-    // partial rows are [dgamma(8) | dbeta(8)]; gamma and beta are adjacent 8-float slots of G
-    DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 16, G + A.specs[0].off, 1.0f, s));
+    // partial rows are [dgamma(8) | dbeta(8)]
+    DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, A.C, G + A.specs[0].off, 1.0f, s, 16));
+    DV_TRY(launch_reduce_rows_f64(m->ws3 + 8, nblk, A.C, G + A.specs[1].off, 1.0f, s, 16));
   }
   return OK;
 }

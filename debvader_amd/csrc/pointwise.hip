@@ -25,12 +25,12 @@ __device__ __forceinline__ float block_sum(float v, float* sh /*>=4 floats*/) {
 
 // ------------------------------------------------------------------------------------------------
 // generic column reduction of a small partial matrix in double precision: out[c] = scale * sum_r part[r][c]
-__global__ __launch_bounds__(256) void reduce_rows_f64_kernel(const float* __restrict__ part, int nrows, int ncols,
+__global__ __launch_bounds__(256) void reduce_rows_f64_kernel(const float* __restrict__ part, int nrows, int ld,
                                                               float* __restrict__ out, float scale) {
   __shared__ double sh[256];
   const int c = blockIdx.x;
   double acc = 0.0;
-  for (int r = threadIdx.x; r < nrows; r += 256) acc += (double)part[(long)r * ncols + c];
+  for (int r = threadIdx.x; r < nrows; r += 256) acc += (double)part[(long)r * ld + c];
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -40,9 +40,10 @@ __global__ __launch_bounds__(256) void reduce_rows_f64_kernel(const float* __res
   if (threadIdx.x == 0) out[c] = (float)(sh[0] * (double)scale);
 }
 
-int launch_reduce_rows_f64(const float* part, int nrows, int ncols, float* out, float scale, hipStream_t s) {
+int launch_reduce_rows_f64(const float* part, int nrows, int ncols, float* out, float scale, hipStream_t s, int ld) {
   if (ncols <= 0) return OK;
-  hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(ncols), dim3(256), 0, s, part, nrows, ncols, out, scale);
+  if (ld <= 0) ld = ncols;
+  hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(ncols), dim3(256), 0, s, part, nrows, ld, out, scale);
   DV_HIP(hipGetLastError());
   return OK;
 }

@@ -187,26 +187,63 @@ int launch_wgrad(const WGradParams& p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// out[(r/cpad)*creal + r%cpad][c] = sum_s part[s][r][c]; 4 consecutive columns per thread, splits summed in
+// a fixed order with 4 independent accumulators so the loads of different slabs overlap.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              int nsplit, long slab, int ncols, int cpad, int creal) {
-  long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= slab) return;
-  long r = e / ncols;
-  int c = (int)(e - r * ncols);
-  int ci = (int)(r % cpad);
+                                                              int nsplit, int slab4, int ncols4, int cpad, int creal) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= slab4) return;
+  const int r = e / ncols4;
+  const int c4 = e - r * ncols4;
+  const int ci = r % cpad;
   if (ci >= creal) return;
-  float acc = 0.f;
-  for (int s = 0; s < nsplit; ++s) acc += part[(long)s * slab + e];
-  long ro = (r / cpad) * creal + ci;
-  out[ro * ncols + c] = acc;
+  const f32x4* p = reinterpret_cast<const f32x4*>(part) + e;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    a0 += p[(size_t)(s + 0) * slab4];
+    a1 += p[(size_t)(s + 1) * slab4];
+    a2 += p[(size_t)(s + 2) * slab4];
+    a3 += p[(size_t)(s + 3) * slab4];
+  }
+  for (; s < nsplit; ++s) a0 += p[(size_t)s * slab4];
+  const int ro = (r / cpad) * creal + ci;
+  reinterpret_cast<f32x4*>(out)[(size_t)ro * ncols4 + c4] = (a0 + a1) + (a2 + a3);
+}
+
+// scalar variant for column counts that are not a multiple of 4 (d(alpha) slabs use ncols = 1)
+__global__ __launch_bounds__(256) void reduce_partials_scalar_kernel(const float* __restrict__ part,
+                                                                     float* __restrict__ out, int nsplit, int slab) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= slab) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    a0 += part[(size_t)(s + 0) * slab + e];
+    a1 += part[(size_t)(s + 1) * slab + e];
+    a2 += part[(size_t)(s + 2) * slab + e];
+    a3 += part[(size_t)(s + 3) * slab + e];
+  }
+  for (; s < nsplit; ++s) a0 += part[(size_t)s * slab + e];
+  out[e] = (a0 + a1) + (a2 + a3);
 }
 
 int launch_reduce_partials(const float* part, float* out, int nsplit, long slab_elems, int ncols, int cpad, int creal,
                            hipStream_t s) {
   if (slab_elems <= 0) return OK;
-  long blocks = (slab_elems + 255) / 256;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, s, part, out, nsplit, slab_elems,
-                     ncols, cpad, creal);
+  if (slab_elems >= (1L << 31)) return E_INVALID;
+  if ((ncols & 3) == 0 && (slab_elems & 3) == 0) {
+    int slab4 = (int)(slab_elems / 4);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((slab4 + 255) / 256), dim3(256), 0, s, part, out, nsplit, slab4,
+                       ncols / 4, cpad, creal);
+  } else {
+    if (cpad != creal) {
+      set_error("reduce_partials: row compaction needs ncols %% 4 == 0");
+      return E_INVALID;
+    }
+    hipLaunchKernelGGL(reduce_partials_scalar_kernel, dim3((unsigned)((slab_elems + 255) / 256)), dim3(256), 0, s, part,
+                       out, nsplit, (int)slab_elems);
+  }
   DV_HIP(hipGetLastError());
   return OK;
 }

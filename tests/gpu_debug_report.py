@@ -41,5 +41,6 @@ def report(arch, B, seed, data=None):
 if __name__ == "__main__":
     print("small arch B=5"); report(small_arch(), 5, 0)
     if len(sys.argv) > 1:
-        x, y = vo.synthetic_stamps(4, seed=5)
+        from debvader_amd.data import synthetic_stamps
+        x, y = synthetic_stamps(4, seed=5)
         print("full arch B=4"); report(vo.Arch(), 4, 2, (x, y))

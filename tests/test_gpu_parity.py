@@ -81,10 +81,18 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True):
             worst = (name, e)
         assert e <= 1e-3, (name, e)
 
-    # one full training step: Adam update + BN moving statistics
+    # one full training step: Adam update + BN moving statistics.  The first Adam step moves every weight by
+    # ~lr*sign(g), so weights whose gradient is at rounding level may legitimately differ by 2*lr from the
+    # oracle's update; the update itself is therefore checked against the oracle's Adam fed with the
+    # engine's own gradients (the step recomputes them bit-identically), and against the oracle's
+    # gradients only where those are resolved (|g| > 1e-2 max|g|).
+    gg = {name: eng.get_grad(name).astype(np.float64) for name in g}
     st = vo.AdamState()
     p2 = {k: v.copy() for k, v in p.items()}
-    vo.adam_step(st, p2, g)
+    vo.adam_step(st, p2, gg)
+    st3 = vo.AdamState()
+    p3 = {k: v.copy() for k, v in p.items()}
+    vo.adam_step(st3, p3, g)
     vo.bn_moving_update(arch, p2, c)
     out2 = eng.train_step(0, first=0, B=B, eps=eps)
     assert abs(out2["loss"] - ref["loss"]) <= 1e-4 * abs(ref["loss"])
@@ -93,7 +101,12 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True):
             np.testing.assert_array_equal(eng.get_param(name), p[name].astype(np.float32))   # frozen decoder
             continue
         got = eng.get_param(name)
-        assert np.abs(got - p2[name]).max() <= 2e-6, (name, np.abs(got - p2[name]).max())
+        assert np.abs(got - p2[name]).max() <= 1e-6, (name, np.abs(got - p2[name]).max())
+        if name in g:
+            res = np.abs(g[name]) > 1e-2 * np.abs(g[name]).max()
+            assert np.abs(got - p3[name])[res].max() <= 1e-6, name
+            np.testing.assert_allclose(eng.get_slot(name, 0), st.m[name], rtol=5e-5, atol=1e-30)  # fp32 (1-beta) as in TF
+            np.testing.assert_allclose(eng.get_slot(name, 1), st.v[name], rtol=5e-5, atol=1e-30)
     assert eng.iterations == 1
     eng.close()
     return worst
@@ -109,8 +122,9 @@ def test_small_arch_parity_ragged_batch_and_frozen_decoder():
 
 
 def test_full_arch_parity_b4():
-    rng = np.random.default_rng(3)
-    x, y = vo.synthetic_stamps(4, seed=5)
+    from debvader_amd.data import synthetic_stamps
+
+    x, y = synthetic_stamps(4, seed=5)
     _run_parity(vo.Arch(), B=4, seed=2, data=(x, y))
 
 
