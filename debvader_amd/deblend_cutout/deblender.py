@@ -1,0 +1,26 @@
+"""Batched inference entry point (reference: src/debvader/deblend_cutout/deblender.py:6-24)."""
+import numpy as np
+
+from debvader_amd.distributions import Normal
+from debvader_amd.normalize.normalize import denormalize_non_linear, normalize_non_linear
+
+
+def deblend(net, images, normalise=False):
+    """Deblend stamps with the network.
+
+    parameters:
+        net: network returned by create_model_vae / load_deblender
+        images: array (N, size, size, bands), any float dtype (cast to float32 as the reference does)
+        normalise: apply tanh(arcsinh(.)) to the inputs and undo it on the predicted mean.
+            The reference's normalise=True branch cannot run (it applies numpy arctanh to a
+            distribution object, deblender.py:20-24); the evident intent is implemented instead.
+    returns (mean ndarray (N,size,size,bands), distribution)
+    """
+    images = np.asarray(images)
+    if normalise:
+        images = normalize_non_linear(images)
+    out = net(images.astype(np.float32))          # one stochastic forward pass, BN in inference mode
+    if normalise:
+        mean = denormalize_non_linear(np.clip(out.mean().numpy(), -1 + 1e-7, 1 - 1e-7))
+        return mean, Normal(mean, out.stddev().numpy())
+    return out.mean().numpy(), out

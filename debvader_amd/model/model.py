@@ -1,0 +1,395 @@
+"""create_model_vae / load_deblender on the MI355X engine.
+
+Drop-in for src/debvader/model/model.py:61-271 of the reference: same function names, argument
+meaning and return tuples, with Keras-like objects whose arithmetic runs in libdebvader_hip.so.
+The four returned models share one set of weights, as the Keras sub-models do.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from debvader_amd import engine as E
+from debvader_amd.distributions import MultivariateNormalTriL, Normal, Tensor
+from debvader_amd.training.metrics import vae_loss
+
+
+class Adam:
+    """Stand-in for tf.optimizers.legacy.Adam(learning_rate=...) (train.py:126); defaults as in TF."""
+
+    def __init__(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
+
+
+class History:
+    def __init__(self):
+        self.history: Dict[str, List[float]] = {}
+        self.epoch: List[int] = []
+
+
+def _optimizer_hparams(opt):
+    if opt is None:
+        return 1e-4, 0.9, 0.999, 1e-7
+    if isinstance(opt, str):
+        if opt.lower() != "adam":
+            raise ValueError("only Adam is implemented (the reference compiles with legacy Adam, train.py:126)")
+        return 1e-3, 0.9, 0.999, 1e-7
+    get = lambda n, d: float(getattr(opt, n, d)) if not callable(getattr(opt, n, d)) else d
+    return get("learning_rate", 1e-3), get("beta_1", 0.9), get("beta_2", 0.999), get("epsilon", 1e-7)
+
+
+class _SubModel:
+    """encoder / decoder handle: carries the Keras `trainable` flag (train.py:175, model.py:252)."""
+
+    def __init__(self, core: "_Core", which: str):
+        self._core, self._which, self.trainable = core, which, True
+
+    def count_params(self):
+        c = E.arch_counts(self._core.cfg)
+        return c["encoder"] if self._which == "encoder" else c["decoder"]
+
+
+class _Core:
+    """State shared by net / encoder / decoder / z."""
+
+    def __init__(self, input_shape, latent_dim, filters, kernels, max_batch, ctx, **cfg_over):
+        self.input_shape = tuple(int(v) for v in input_shape)
+        self.latent_dim = int(latent_dim)
+        self.cfg = E.make_config(self.input_shape, latent_dim, tuple(filters), tuple(kernels),
+                                 max_batch=max_batch, **cfg_over)
+        self.engine = E.Engine(self.cfg, ctx)
+        self.ctx = self.engine.ctx
+        self.seed_counter = int.from_bytes(os.urandom(4), "little")
+        self.compiled = False
+
+    def next_seed(self):
+        self.seed_counter += 1
+        return self.seed_counter
+
+
+class Encoder(_SubModel):
+    """Model(input, Dense(params_size)) of create_encoder (model.py:61-100)."""
+
+    def __call__(self, x, training=False):
+        return Tensor(self._core.engine.encode(np.asarray(x, dtype=np.float32)))
+
+    predict = __call__
+
+
+class Decoder(_SubModel):
+    """Model(z, Normal) of create_decoder (model.py:103-161)."""
+
+    def __call__(self, z, training=False):
+        z = np.asarray(z.numpy() if hasattr(z, "numpy") else z, dtype=np.float32)
+        loc, scale = self._core.engine.decode(z)
+        return Normal(loc, scale)
+
+
+class LatentModel:
+    """Model(x, MultivariateNormalTriL) — the 4th return value of create_model_vae (model.py:218)."""
+
+    def __init__(self, core):
+        self._core = core
+
+    def __call__(self, x, training=False):
+        t = self._core.engine.encode(np.asarray(x, dtype=np.float32))
+        return MultivariateNormalTriL(t, self._core.latent_dim, self._core.cfg.diag_shift)
+
+
+class VAENet:
+    """`net` of create_model_vae: compile / fit / __call__ / summary / load_weights / losses."""
+
+    def __init__(self, core: _Core, encoder: Encoder, decoder: Decoder):
+        self._core, self.encoder, self.decoder = core, encoder, decoder
+        self.losses: List[float] = []
+        self.metrics_names: List[str] = ["loss"]
+        self._metrics: List = []
+        self.stop_training = False
+        self.history = None
+
+    # -- Keras surface -----------------------------------------------------------------------
+    def compile(self, optimizer=None, loss=None, metrics=None, **kwargs):
+        """net.compile(optimizer=legacy.Adam(1e-4), loss=vae_loss, metrics=["mse", kl_metric], ...)
+        (train.py:125-130,178-183; model.py:255-259).  Fresh Adam slots; honours `trainable` flags."""
+        if loss is not None and loss is not vae_loss and getattr(loss, "__name__", "") != "vae_loss":
+            raise NotImplementedError("the engine fuses the reference's vae_loss (Normal NLL); other losses are "
+                                      "not implemented")
+        lr, b1, b2, eps = _optimizer_hparams(optimizer)
+        eng = self._core.engine
+        eng.set_trainable(bool(self.encoder.trainable), bool(self.decoder.trainable))
+        eng.optimizer_reset(lr, b1, b2, eps)
+        self._metrics = list(metrics or [])
+        self._core.compiled = True
+
+    def summary(self, print_fn=print):
+        cfg = self._core.cfg
+        c = E.arch_counts(cfg)
+        specs = self._core.engine.specs
+        enc_tr = sum(int(np.prod(s)) for n, s, t in specs if t and n.startswith("enc/")) if self.encoder.trainable else 0
+        dec_tr = sum(int(np.prod(s)) for n, s, t in specs if t and n.startswith("dec/")) if self.decoder.trainable else 0
+        total = c["encoder"] + c["decoder"]
+        print_fn('Model: "model"')
+        print_fn(f" input                    (None, {cfg.height}, {cfg.width}, {cfg.bands})")
+        print_fn(f" encoder (Functional)     (None, {self._core.engine.tw})          {c['encoder']}")
+        print_fn(f" multivariate_normal_tri_l ((None, {cfg.latent_dim}), (None, {cfg.latent_dim}))   0")
+        print_fn(f" decoder (Functional)     (None, {cfg.height}, {cfg.width}, {cfg.bands})   {c['decoder']}")
+        print_fn(f"Total params: {total}")
+        print_fn(f"Trainable params: {enc_tr + dec_tr}")
+        print_fn(f"Non-trainable params: {total - enc_tr - dec_tr}")
+
+    def count_params(self):
+        c = E.arch_counts(self._core.cfg)
+        return c["encoder"] + c["decoder"]
+
+    def __call__(self, x, training=False):
+        """net(x): one stochastic forward pass in inference mode (deblender.py:18)."""
+        x = np.asarray(x.numpy() if hasattr(x, "numpy") else x, dtype=np.float32)
+        r = self._core.engine.infer(x, seed=self._core.next_seed(), want=("loc", "scale"))
+        return Normal(r["loc"], r["scale"])
+
+    def predict(self, x, batch_size=None, verbose=0):
+        return self(x).sample().numpy()
+
+    # -- weights -----------------------------------------------------------------------------
+    def get_weights(self):
+        return [self._core.engine.get_param(i) for i in range(len(self._core.engine.specs))]
+
+    def set_weights(self, weights):
+        for i, w in enumerate(weights):
+            self._core.engine.set_param(i, w)
+
+    def save_weights(self, filepath, overwrite=True, save_format=None):
+        """Writes <filepath>.npz (parameters, Adam slots, iteration) and a `checkpoint` index file next to
+        it, mirroring what ModelCheckpoint(save_weights_only=True) leaves on disk (train.py:54-71).
+        TF tensor-bundle output is not implemented yet."""
+        eng = self._core.engine
+        path = filepath if filepath.endswith(".npz") else filepath + ".npz"
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        blob = {"__iter__": np.array(eng.iterations, dtype=np.int64)}
+        for i, (name, _, tr) in enumerate(eng.specs):
+            blob["p/" + name] = eng.get_param(i)
+            if tr:
+                blob["m/" + name] = eng.get_slot(i, 0)
+                blob["v/" + name] = eng.get_slot(i, 1)
+        np.savez(path, **blob)
+        with open(os.path.join(os.path.dirname(os.path.abspath(path)), "checkpoint"), "w") as f:
+            f.write(f'model_checkpoint_path: "{os.path.basename(path)}"\n')
+
+    def load_weights(self, filepath):
+        """Loads a checkpoint written by save_weights.  TF tensor-bundle checkpoints (the reference's
+        data/weights/<survey>/*.ckpt.index) are not readable yet."""
+        if filepath is None:
+            raise FileNotFoundError("no checkpoint found (latest_checkpoint returned None)")
+        path = filepath if filepath.endswith(".npz") else filepath + ".npz"
+        if not os.path.exists(path):
+            if os.path.exists(filepath + ".index"):
+                raise NotImplementedError("TensorFlow tensor-bundle checkpoints are not supported yet; "
+                                          "convert to the engine's .npz format")
+            raise FileNotFoundError(path)
+        eng = self._core.engine
+        with np.load(path) as z:
+            for i, (name, shape, tr) in enumerate(eng.specs):
+                eng.set_param(i, z["p/" + name])
+                if tr and ("m/" + name) in z:
+                    eng.set_slot(i, 0, z["m/" + name])
+                    eng.set_slot(i, 1, z["v/" + name])
+            if "__iter__" in z:
+                eng.iterations = int(z["__iter__"])
+        return self
+
+    # -- training ----------------------------------------------------------------------------
+    def _metric_values(self, scal):
+        out = {"loss": scal["loss"]}
+        for mt in self._metrics:
+            if isinstance(mt, str):
+                if mt in ("mse", "mean_squared_error"):
+                    out["mse"] = scal["mse"]
+                else:
+                    raise NotImplementedError(f"metric {mt!r} is not implemented")
+            elif callable(mt):
+                out[getattr(mt, "__name__", "metric")] = float(mt(None, None))
+        return out
+
+    def _set_losses(self, scal):
+        # net.losses: one activity-regulariser scalar per application; their sum is kl_metric
+        k = max(1, int(self._core.cfg.kl_multiplicity))
+        self.losses = [scal["kl_reg"] / k] * k
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, shuffle=True,
+            validation_data=None, validation_steps=None, initial_epoch=0, **kwargs):
+        """Keras Model.fit for in-memory arrays (train.py:27-37): per-epoch shuffle, last partial batch used,
+        validation in inference mode, returns History with loss / mse / <metric fn names> / val_*.
+        With several ranks (debvader_amd.parallel) `batch_size` is the GLOBAL batch; each rank runs its
+        contiguous slice of every batch and gradients are all-reduced inside the engine."""
+        if not self._core.compiled:
+            raise RuntimeError("You must compile your model before training/testing. Use `model.compile(...)`.")
+        core, eng = self._core, self._core.engine
+        x = np.asarray(x, dtype=np.float32)
+        y = np.asarray(y, dtype=np.float32)
+        n = x.shape[0]
+        batch_size = int(batch_size or 32)
+        rank, world = core.ctx.rank, core.ctx.world
+        from debvader_amd.parallel import shard_range
+
+        if shard_range(batch_size, 0, world)[1] > eng.max_batch:
+            raise ValueError(f"batch_size {batch_size} over {world} rank(s) exceeds the engine's max_batch "
+                             f"{eng.max_batch}; pass max_batch= to create_model_vae")
+        eng.upload(0, x, y)
+        nv = 0
+        if validation_data is not None:
+            xv = np.asarray(validation_data[0], dtype=np.float32)
+            yv = np.asarray(validation_data[1], dtype=np.float32)
+            nv = xv.shape[0]
+            eng.upload(1, xv, yv)
+        hist = History()
+        cbs = list(callbacks or [])
+        for cb in cbs:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+        rng = np.random.default_rng(kwargs.get("shuffle_seed", 0x5EED))   # identical on every rank
+        self.stop_training = False
+        for epoch in range(initial_epoch, epochs):
+            t0 = time.time()
+            order = rng.permutation(n) if shuffle else np.arange(n)
+            sums: Dict[str, float] = {}
+            seen = 0
+            for b0 in range(0, n, batch_size):
+                gidx = order[b0:b0 + batch_size]
+                lo, hi = shard_range(len(gidx), rank, world)
+                if hi <= lo:
+                    raise ValueError("a rank received an empty shard; use batch sizes >= number of ranks")
+                scal = eng.train_step(0, idx=gidx[lo:hi].astype(np.int32), global_batch=len(gidx),
+                                      seed=core.next_seed())
+                self._set_losses(scal)
+                for k, v in self._metric_values(scal).items():
+                    sums[k] = sums.get(k, 0.0) + v * len(gidx)
+                seen += len(gidx)
+            logs = {k: v / seen for k, v in sums.items()}
+            if nv:
+                steps = validation_steps if validation_steps else -(-nv // batch_size)
+                vs: Dict[str, float] = {}
+                vseen = 0
+                for s in range(int(steps)):
+                    b0 = s * batch_size
+                    if b0 >= nv:
+                        break
+                    gb = min(batch_size, nv - b0)
+                    lo, hi = shard_range(gb, rank, world)
+                    scal = eng.eval_step(1, first=b0 + lo, B=hi - lo, global_batch=gb, seed=core.next_seed())
+                    self._set_losses(scal)
+                    for k, v in self._metric_values(scal).items():
+                        vs[k] = vs.get(k, 0.0) + v * gb
+                    vseen += gb
+                if vseen:
+                    logs.update({"val_" + k: v / vseen for k, v in vs.items()})
+            hist.epoch.append(epoch)
+            for k, v in logs.items():
+                hist.history.setdefault(k, []).append(float(v))
+            if verbose and rank == 0:
+                msg = " - ".join(f"{k}: {v:.4f}" for k, v in logs.items())
+                print(f"Epoch {epoch + 1}/{epochs} - {time.time() - t0:.1f}s - {msg}")
+            for cb in cbs:
+                if hasattr(cb, "on_epoch_end"):
+                    cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        self.history = hist
+        return hist
+
+    def evaluate(self, x, y, batch_size=32, verbose=0):
+        eng, core = self._core.engine, self._core
+        n = eng.upload(1, x, y)
+        tot: Dict[str, float] = {}
+        for b0 in range(0, n, batch_size):
+            gb = min(batch_size, n - b0)
+            scal = eng.eval_step(1, first=b0, B=gb, seed=core.next_seed())
+            self._set_losses(scal)
+            for k, v in self._metric_values(scal).items():
+                tot[k] = tot.get(k, 0.0) + v * gb
+        return {k: v / n for k, v in tot.items()}
+
+
+def _build(input_shape, latent_dim, filters, kernels, for_onnx, max_batch, ctx, cfg_over):
+    if for_onnx:
+        raise NotImplementedError("for_onnx=True builds a TF graph for tf2onnx export (model.py:151-152,203-204); "
+                                  "ONNX export is outside this engine's scope")
+    core = _Core(input_shape, latent_dim, filters, kernels, max_batch, ctx, **cfg_over)
+    enc, dec = Encoder(core, "encoder"), Decoder(core, "decoder")
+    if core.cfg.height != int(np.ceil(core.cfg.height / 2 ** len(filters))) * 2 ** len(filters):
+        print("in cropping")                                  # model.py:142
+    return core, enc, dec
+
+
+def create_encoder(input_shape, latent_dim, filters, kernels, conv_activation=None, dense_activation=None,
+                   max_batch=256, ctx=None, **cfg_over):
+    """Encoder-only model (model.py:61-100).  Activations are ignored, as in the reference."""
+    core, enc, _ = _build(input_shape, latent_dim, filters, kernels, False, max_batch, ctx, cfg_over)
+    return enc
+
+
+def create_decoder(input_shape, latent_dim, filters, kernels, conv_activation=None, dense_activation=None,
+                   for_onnx=False, max_batch=256, ctx=None, **cfg_over):
+    """Decoder-only model (model.py:103-161)."""
+    core, _, dec = _build(input_shape, latent_dim, filters, kernels, for_onnx, max_batch, ctx, cfg_over)
+    return dec
+
+
+def create_model_vae(input_shape, latent_dim, filters, kernels, conv_activation=None, dense_activation=None,
+                     for_onnx=False, max_batch=256, ctx=None, **cfg_over):
+    """Create the VAE model (model.py:164-218).
+
+    parameters:
+        input_shape: shape of input tensor
+        latent_dim: size of the latent space
+        filters: filters used for the convolutional layers
+        kernels: kernels used for the convolutional layers
+        conv_activation, dense_activation: accepted and ignored (the reference passes None down, model.py:187-197)
+        max_batch: per-GPU stamps per step the engine allocates workspaces for (engine-specific)
+        ctx: debvader_amd.engine.Context (GPU / rank); default: GPU 0, single rank
+    returns (net, encoder, decoder, z)
+    """
+    core, enc, dec = _build(input_shape, latent_dim, filters, kernels, for_onnx, max_batch, ctx, cfg_over)
+    net = VAENet(core, enc, dec)
+    return net, enc, dec, LatentModel(core)
+
+
+def latest_checkpoint(directory):
+    """tf.train.latest_checkpoint for the engine's checkpoints: reads `<dir>/checkpoint`."""
+    f = os.path.join(directory, "checkpoint")
+    if not os.path.exists(f):
+        return None
+    with open(f) as fh:
+        for line in fh:
+            if line.startswith("model_checkpoint_path:"):
+                return os.path.join(directory, line.split(":", 1)[1].strip().strip('"'))
+    return None
+
+
+def weights_dir(survey):
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "weights", str(survey))
+
+
+def load_deblender(survey, input_shape, latent_dim, filters, kernels, return_encoder_decoder_z=False,
+                   for_onnx=False, max_batch=256, ctx=None):
+    """load weights trained for a particular dataset (model.py:221-271).
+
+    The reference ships only `dc2`, and its tensor shard is missing from the repository
+    (.MISSING_LARGE_BLOBS); this function loads checkpoints written by this engine under
+    debvader_amd/data/weights/<survey>/ (see VAENet.save_weights).
+    """
+    net, encoder, decoder, z = create_model_vae(input_shape, latent_dim, filters, kernels, for_onnx=for_onnx,
+                                                max_batch=max_batch, ctx=ctx)
+    decoder.trainable = False                                       # model.py:252
+    net.compile(optimizer=Adam(learning_rate=1e-4), loss=vae_loss)   # model.py:255-259
+    loading_path = weights_dir(survey)
+    print(loading_path)
+    latest = latest_checkpoint(loading_path)
+    if latest is None:
+        raise FileNotFoundError(f"no checkpoint under {loading_path}")
+    net.load_weights(latest)
+    if return_encoder_decoder_z:
+        return net, encoder, decoder, z
+    return net

@@ -1,0 +1,149 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/debvader_hip.h declares,
+architecture queries (host-only entry points) agree with the reference's structural pins, host helpers."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "debvader_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dv_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from debvader_amd import _lib
+
+    names = _declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in include/debvader_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in debvader_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.lib.dv_version() >= 100
+
+
+def test_config_struct_matches_header_defaults():
+    from debvader_amd import _lib
+    from debvader_amd.engine import make_config
+
+    cfg = make_config()
+    assert (cfg.height, cfg.width, cfg.bands, cfg.latent_dim, cfg.n_levels) == (59, 59, 6, 32, 4)
+    assert list(cfg.filters)[:4] == [32, 64, 128, 256] and list(cfg.kernels)[:4] == [3, 3, 3, 3]
+    assert abs(cfg.kl_weight - 0.01) < 1e-9 and cfg.kl_multiplicity == 2
+    assert abs(cfg.bn_eps - 1e-3) < 1e-9 and abs(cfg.sigma_floor - 1e-4) < 1e-10 and abs(cfg.diag_shift - 1e-5) < 1e-11
+    assert C.sizeof(_lib.DvConfig) == 4 * (5 + 8 + 8 + 1 + 7)
+
+
+def test_arch_queries_match_reference_summary_and_oracle():
+    from debvader_amd import engine as E
+    from oracle import vae_oracle as vo
+
+    cfg = E.make_config()
+    c = E.arch_counts(cfg)
+    # notebooks/deblender_to_onnx.ipynb:158,225,229-231
+    assert c == dict(tensors=64, encoder=3_741_224, decoder=4_577_228, trainable=8_318_440)
+    assert E.arch_specs(cfg) == vo.Arch().param_specs()
+    enc, dec = E.arch_macs(cfg)
+    assert (enc, dec) == (95_824_064, 233_522_688)
+    small = E.make_config((13, 13, 4), 8, (8, 16), (3, 3))
+    assert E.arch_specs(small) == vo.Arch((13, 13, 4), 8, (8, 16), (3, 3)).param_specs()
+
+
+def test_bad_architectures_are_rejected_with_a_message():
+    from debvader_amd import engine as E
+    from debvader_amd._lib import DvError
+
+    with pytest.raises(DvError, match="3x3"):
+        E.arch_counts(E.make_config(kernels=(3, 5, 3, 3)))
+    with pytest.raises(DvError, match="square"):
+        E.arch_counts(E.make_config(input_shape=(59, 60, 6)))
+    with pytest.raises(ValueError):
+        E.make_config(filters=(32, 64), kernels=(3,))
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from debvader_amd import engine as E
+    from debvader_amd._lib import DvError
+
+    if E.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(DvError, match="no HIP device"):
+        E.Context()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "debvader_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert "oracle" not in src.replace("PARITY", ""), f"{f} mentions the oracle"
+                assert "import torch" not in src, f"{f} imports torch"
+
+
+def test_shard_ranges_and_normalisers():
+    from debvader_amd.parallel import loss_normalisers, shard_range, shard_sizes
+
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_sizes(2048, 8) == [256] * 8
+    assert shard_sizes(5, 8) == [1, 1, 1, 1, 1, 0, 0, 0]
+    for n in (0, 1, 7, 1000003):
+        for w in (1, 2, 3, 8):
+            rs = [shard_range(n, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+    with pytest.raises(ValueError):
+        shard_range(4, 4, 4)
+    a, b = loss_normalisers(2048, 59 * 59 * 6, 0.01, 2)
+    assert abs(a - 1 / (2048 * 20886)) < 1e-18 and abs(b - 0.02 / 2048 ** 2) < 1e-18
+
+
+def test_distribution_wrappers_against_oracle():
+    from debvader_amd.distributions import MultivariateNormalTriL, Normal, fill_triangular
+    from oracle import vae_oracle as vo
+
+    np.testing.assert_array_equal(fill_triangular(np.arange(1.0, 7.0)), [[4, 0, 0], [6, 5, 0], [3, 2, 1]])
+    rng = np.random.default_rng(0)
+    arch = vo.Arch(latent_dim=8)
+    t = rng.normal(size=(5, arch.params_size))
+    eps = rng.normal(size=(5, 8))
+    mu, L, _, z, _ = vo.sampler_forward(arch, t, eps)
+    mvn = MultivariateNormalTriL(t, 8)
+    np.testing.assert_allclose(mvn.mean(), mu, rtol=1e-6)
+    np.testing.assert_allclose(mvn.scale_tril, L, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mvn.stddev(), np.sqrt((L ** 2).sum(-1)), rtol=1e-5)
+    assert mvn.sample(100).shape == (100, 5, 8) and hasattr(mvn.mean(), "numpy")
+    loc, scale = rng.normal(size=(2, 3, 3, 2)), np.abs(rng.normal(size=(2, 3, 3, 2))) + 1e-4
+    y = rng.normal(size=(2, 3, 3, 2))
+    n = Normal(loc, scale)
+    np.testing.assert_allclose(-n.log_prob(y), vo.normal_nll(y, loc, scale), rtol=2e-5, atol=1e-5)
+    assert n.sample(7).shape == (7, 2, 3, 3, 2)
+    s = n.sample(4000, seed=1)
+    assert np.abs(s.mean(0) - loc).max() < 0.2 * scale.max() + 0.05
+
+
+def test_metrics_and_normalise_helpers():
+    from debvader_amd.distributions import Normal
+    from debvader_amd.normalize.normalize import denormalize_non_linear, normalize_non_linear
+    from debvader_amd.training.metrics import mse, vae_loss
+
+    a, b = np.arange(6.0).reshape(2, 3), np.ones((2, 3))
+    assert mse(a, b) == np.mean((a - b) ** 2)
+    x = np.linspace(-3, 14, 50)
+    np.testing.assert_allclose(denormalize_non_linear(normalize_non_linear(x)), x, rtol=1e-6)
+    n = Normal(np.zeros((1, 2)), np.ones((1, 2)))
+    np.testing.assert_allclose(vae_loss(np.zeros((1, 2)), n), 0.5 * np.log(2 * np.pi), rtol=1e-6)
+
+
+def test_synthetic_stamps_are_deterministic_and_in_range():
+    from debvader_amd.data import synthetic_stamps
+
+    x, y = synthetic_stamps(8, seed=0)
+    x2, _ = synthetic_stamps(8, seed=0)
+    np.testing.assert_array_equal(x, x2)
+    assert x.shape == (8, 59, 59, 6) and x.dtype == np.float32 and y.min() >= 0 and x.max() < 60

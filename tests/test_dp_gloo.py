@@ -1,0 +1,83 @@
+"""World-size-2 data-parallel semantics on CPU (gloo): the host-side plumbing the N>1 bench uses
+(rank-0 id broadcast, contiguous shards, global-batch normalisers) and the rule the engine's RCCL
+all-reduce implements — per-shard gradients computed with GLOBAL normalisers SUM to the full-batch
+gradient.  The arithmetic here is the fp64 oracle (this is a test of the sharding contract, not of HIP)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist          # noqa: E402
+import torch.multiprocessing as mp        # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from debvader_amd.parallel import shard_range
+        from oracle import vae_oracle as vo
+
+        # (1) id exchange plumbing: rank 0's 128 bytes reach every rank unchanged
+        payload = [bytes(range(128)) if rank == 0 else None]
+        dist.broadcast_object_list(payload, src=0)
+        assert payload[0] == bytes(range(128))
+
+        # (2) sharded step == full-batch step
+        arch = vo.Arch(input_shape=(11, 11, 2), latent_dim=8, filters=(4, 8), kernels=(3, 3))
+        rng = np.random.default_rng(0)                      # identical data on every rank
+        Bg = 5                                              # odd: shards of 3 and 2
+        p = vo.init_params(arch, seed=1, perturb=0.05)
+        x = rng.normal(size=(Bg, 11, 11, 2))
+        y = np.abs(rng.normal(size=(Bg, 11, 11, 2)))
+        eps = rng.normal(size=(Bg, 8))
+        lo, hi = shard_range(Bg, rank, world)
+        # global BN statistics: all-reduce of [sum x, sum x^2] per band, as the engine does
+        s = torch.tensor(np.concatenate([x[lo:hi].sum((0, 1, 2)), (x[lo:hi] ** 2).sum((0, 1, 2))]))
+        dist.all_reduce(s)
+        cnt = Bg * 11 * 11
+        mean = s[:2].numpy() / cnt
+        var = s[2:].numpy() / cnt - mean ** 2
+        ps = dict(p)
+        ps["enc/bn/moving_mean"], ps["enc/bn/moving_variance"] = mean, var
+        c = vo.forward(arch, ps, x[lo:hi], eps[lo:hi], training=False)      # shard forward with global stats
+        part = vo.losses(arch, c, y[lo:hi], global_batch=Bg)
+        g = vo.backward(arch, ps, c, y[lo:hi], global_batch=Bg)
+        loss = torch.tensor([part["loss"]])
+        dist.all_reduce(loss)
+        flat = torch.tensor(np.concatenate([g[k].ravel() for k in sorted(g)]))
+        dist.all_reduce(flat)                                                # what ncclAllReduce(sum) does
+        if rank == 0:
+            cf = vo.forward(arch, p, x, eps, training=True)
+            full = vo.losses(arch, cf, y)
+            gf = vo.backward(arch, p, cf, y)
+            ref = np.concatenate([gf[k].ravel() for k in sorted(gf) if k in g])
+            # BN gamma/beta gradients pass through batch statistics only via data -> identical too
+            q.put((abs(loss.item() - full["loss"]) / abs(full["loss"]),
+                   float(np.abs(flat.numpy() - ref).max() / np.abs(ref).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step_equals_full_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    loss_rel, grad_rel = q.get(timeout=5)
+    assert loss_rel < 1e-12 and grad_rel < 1e-10

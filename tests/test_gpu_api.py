@@ -1,0 +1,145 @@
+"""GPU tests of the drop-in Python surface (create_model_vae / train_deblender / deblend) and of
+size-independent properties at the BASELINE batch size (256 stamps of 59x59x6)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ARCH = dict(input_shape=(59, 59, 6), latent_dim=32, filters=[32, 64, 128, 256], kernels=[3, 3, 3, 3])
+
+
+def _data(n, seed):
+    from debvader_amd.data import synthetic_stamps
+
+    return synthetic_stamps(n, seed=seed)
+
+
+def test_fit_history_and_deblend_like_the_training_notebook(tmp_path, capsys):
+    from debvader_amd.deblend_cutout.deblender import deblend
+    from debvader_amd.model import model
+    from debvader_amd.training.metrics import vae_loss
+
+    net, encoder, decoder, z = model.create_model_vae(**ARCH, max_batch=8)
+    assert "in cropping" in capsys.readouterr().out            # model.py:142 prints it for 59-px stamps
+    with pytest.raises(RuntimeError):
+        net.fit(np.zeros((1, 59, 59, 6)), np.zeros((1, 59, 59, 6)))
+
+    def kl_metric(y_true, y_pred):
+        return sum(net.losses)
+
+    net.compile(optimizer=model.Adam(learning_rate=1e-4), loss=vae_loss, metrics=["mse", kl_metric],
+                experimental_run_tf_function=False)
+    x, y = _data(12, 1)
+    xv, yv = _data(5, 2)
+    hist = net.fit(x, y, epochs=2, batch_size=5, verbose=0, shuffle=True, validation_data=(xv, yv),
+                   validation_steps=1)
+    assert sorted(hist.history) == ["kl_metric", "loss", "mse", "val_kl_metric", "val_loss", "val_mse"]
+    assert all(len(v) == 2 and np.isfinite(v).all() for v in hist.history.values())
+    assert net._core.engine.iterations == 2 * 3                 # 12 stamps / batch 5 -> 3 steps (last partial batch used)
+    assert len(net.losses) == 2 and abs(sum(net.losses) - hist.history["val_kl_metric"][-1]) < 1e-6
+
+    mean, dist = deblend(net, x[:3].astype(np.float64))
+    assert mean.shape == (3, 59, 59, 6) and mean.dtype == np.float32
+    assert dist.stddev().numpy().min() >= 1e-4 * (1 - 1e-6)
+    assert dist.sample(4).shape == (4, 3, 59, 59, 6) and dist.log_prob(y[:3]).shape == (3, 59, 59, 6)
+    # epistemic-uncertainty usage (field_deblender.py:303-313): repeated decodes of one stamp must vary
+    rep, _ = deblend(net, np.repeat(x[:1], 16, axis=0))
+    assert np.std(rep, axis=0).max() > 0
+    # sub-models share the weights
+    t = encoder(x[:2])
+    assert t.numpy().shape == (2, 560)
+    q = z(x[:2])
+    np.testing.assert_allclose(q.mean().numpy(), t[:, :32], rtol=0, atol=0)
+    assert q.stddev().numpy().shape == (2, 32) and (q.stddev().numpy() > 0).all()
+    d = decoder(q.mean())
+    assert d.mean().numpy().shape == (2, 59, 59, 6)
+    # normalise=True: evident intent of deblender.py:14-22
+    mn, _ = deblend(net, x[:2], normalise=True)
+    assert np.isfinite(mn).all()
+
+    # checkpoint round trip (ModelCheckpoint(save_weights_only=True) semantics)
+    before = net.get_weights()
+    net.save_weights(str(tmp_path / "w" / "weights_noisy_v4.ckpt"))
+    net.fit(x, y, epochs=1, batch_size=6, verbose=0)
+    assert any(np.abs(a - b).max() > 0 for a, b in zip(before, net.get_weights()))
+    net.load_weights(model.latest_checkpoint(str(tmp_path / "w")))
+    for a, b in zip(before, net.get_weights()):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_train_deblender_two_stages_freezes_decoder(monkeypatch, tmp_path):
+    from debvader_amd.model import model
+    from debvader_amd.training import train
+
+    monkeypatch.setattr(model, "weights_dir", lambda survey: str(tmp_path / str(survey)))
+    x, y = _data(5, 3)
+    xv, yv = _data(5, 4)
+    captured = {}
+    orig = train.train_network
+
+    def spy(net, *a, **k):
+        captured.setdefault("dec", []).append(net._core.engine.get_param("dec/convt3/kernel"))
+        captured.setdefault("enc", []).append(net._core.engine.get_param("enc/conv3/kernel"))
+        return orig(net, *a, **k)
+
+    monkeypatch.setattr(train, "train_network", spy)
+    hv, hd, net = train.train_deblender("dc2_test", None, 2, (x, y), (xv, yv), (x, y), (xv, yv), nb_of_bands=6,
+                                        batch_size=5, with_callbacks=True, verbose=2)
+    assert set(hv.history) == {"loss", "mse", "kl_metric", "val_loss", "val_mse", "val_kl_metric"}
+    eng = net._core.engine
+    dec_after, enc_after = eng.get_param("dec/convt3/kernel"), eng.get_param("enc/conv3/kernel")
+    assert np.abs(captured["dec"][1] - captured["dec"][0]).max() > 0        # stage 1 trains the decoder
+    np.testing.assert_array_equal(dec_after, captured["dec"][1])            # stage 2 leaves it untouched
+    assert np.abs(enc_after - captured["enc"][1]).max() > 0                 # ... and trains the encoder
+    assert eng.iterations == 2                                              # fresh Adam after re-compile (train.py:178)
+    assert (tmp_path / "dc2_test" / "vae" / "val_loss" / "checkpoint").exists()
+    with pytest.raises(ValueError):
+        train.train_deblender("s", None, 1, (x[..., :5], y[..., :5]), (xv, yv), (x, y), (xv, yv), nb_of_bands=6)
+
+
+def test_full_batch_determinism_and_permutation_invariance():
+    """BASELINE configs[1] size (B=256): same inputs twice -> bit-identical update; permuting the stamps
+    (and their eps) changes only the summation order."""
+    from debvader_amd import engine as E
+
+    B = 256
+    x, y = _data(B, 7)
+    eps = np.random.default_rng(1).normal(size=(B, 32)).astype(np.float32)
+    res = []
+    for perm in (np.arange(B), np.arange(B), np.random.default_rng(2).permutation(B)):
+        eng = E.Engine(E.make_config(max_batch=B))
+        eng.init(seed=5)
+        eng.optimizer_reset(1e-4)
+        eng.upload(0, x[perm], y[perm])
+        out = eng.grad_step(0, first=0, B=B, eps=eps[perm])
+        res.append((out, eng.get_grad("dec/convt5/kernel"), eng.get_grad("enc/conv0/kernel"),
+                    eng.get_grad("enc/prelu2/alpha"), eng.get_grad("enc/dense/bias")))
+        eng.close()
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        np.testing.assert_array_equal(a, b)
+    assert np.isfinite(res[0][0]["loss"])
+    assert abs(res[0][0]["loss"] - res[2][0]["loss"]) <= 1e-5 * abs(res[0][0]["loss"])
+    for a, b in zip(res[0][1:], res[2][1:]):
+        assert np.abs(a - b).max() <= 1e-3 * np.abs(a).max()
+
+
+def test_train_steps_queue_matches_stepwise():
+    from debvader_amd import engine as E
+
+    x, y = _data(16, 9)
+    outs = []
+    for mode in ("queue", "step"):
+        eng = E.Engine(E.make_config(max_batch=8))
+        eng.init(seed=3)
+        eng.optimizer_reset(1e-4)
+        eng.upload(0, x, y)
+        if mode == "queue":
+            o = eng.train_steps(0, 0, 8, 3, seed=10)
+        else:
+            for k in range(3):
+                o = eng.train_step(0, first=(k * 8) % 9, B=8, seed=10 + k)
+        outs.append((o, eng.get_param("dec/head/kernel")))
+        eng.close()
+    assert outs[0][0] == outs[1][0]
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
