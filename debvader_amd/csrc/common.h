@@ -62,9 +62,36 @@ struct GConvParams {
   int w_nmajor;
   int epi;             // 0 raw, 1 +bias, 2 +bias then PReLU (alpha)
   int cin_shift;       // log2(Cin) if power of two else -1
+  int dbg;             // 0 normal; >0 timing ablations (wrong results), see gconv.hip
 };
 
 int launch_gconv(const GConvParams& p, hipStream_t s);
+void debug_set_gconv_tile(int code);  // -1: automatic; code = tile + 100*ablation
+int debug_mfma_peak(float* out, int blocks, int iters, hipStream_t s);
+
+// Second-generation gather-GEMM (gconv2.hip): same contraction, Cin % 32 == 0, all output-parity classes of
+// one layer in a single launch.
+struct GClass2 {
+  int Hc, Wc, M, ph, pw, ntaps, tile0;
+  unsigned long long tapcode, wtcode;
+};
+struct GConv2Params {
+  const float* X;
+  const float* W;
+  float* U;
+  float* A;
+  const float* bias;
+  const float* alpha;
+  int NB, Hin, Win, Cin;
+  int Hout, Wout, Cout;
+  int sin, sout;
+  int nclass;
+  GClass2 cls[4];
+  int w_nmajor;
+  int epi;
+};
+int launch_gconv2(const GConv2Params& p, hipStream_t s);
+void debug_set_gconv2_tile(int code);
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[(t, cx), cy] = sum_p Xg[p, t][cx] * dY[p][cy], split over pixel ranges into

@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
 
   f32x4 areg[AROWS];
   f32x4 breg[NMAJOR ? BROWS_N : BPASS];
+  unsigned amask = 0, bmask = 0;   // which staged vectors are real data (the rest are stored as zeros)
 
+  // Loads are issued unconditionally from a clamped (always valid) address and masked when they are written
+  // to LDS: a branch around a load makes hipcc wait vmcnt(0) right behind it, which would serialise the gather
+  // with the MFMA work it is meant to overlap.
   auto load_global = [&](int kc) {
     const int kk = kc * BK + kq * 4;
     int tap, ci;
@@ -91,28 +95,25 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
     }
     const bool kvalid = kk < p.K;
     const int dh = tap_dh(p.tapcode, tap), dw = tap_dw(p.tapcode, tap);
+    amask = 0;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       int ih = rih[i] + dh, iw = rjw[i] + dw;
       bool ok = kvalid && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        size_t off = ((size_t)(rbase[i] + ih * p.Win + iw)) * p.Cin + ci;
-        v = *reinterpret_cast<const f32x4*>(p.X + off);
-      }
-      areg[i] = v;
+      size_t off = ok ? ((size_t)(rbase[i] + ih * p.Win + iw)) * p.Cin + ci : 0;
+      areg[i] = *reinterpret_cast<const f32x4*>(p.X + off);
+      amask |= (ok ? 1u : 0u) << i;
     }
+    bmask = 0;
     if (NMAJOR) {
       const int wt = tap_wt(p.wtcode, tap);
 #pragma unroll
       for (int i = 0; i < BROWS_N; ++i) {
         int n = n0 + r0 + 32 * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kvalid && n < p.Cout && r0 + 32 * i < BN) {
-          size_t off = ((size_t)(wt * p.Cout + n)) * p.Cin + ci;
-          v = *reinterpret_cast<const f32x4*>(p.W + off);
-        }
-        breg[i] = v;
+        bool ok = kvalid && n < p.Cout && r0 + 32 * i < BN;
+        size_t off = ok ? ((size_t)(wt * p.Cout + n)) * p.Cin + ci : 0;
+        breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+        bmask |= (ok ? 1u : 0u) << i;
       }
     } else {
       const int nq = tid % BQ;
@@ -121,43 +122,43 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
       for (int i = 0; i < BPASS; ++i) {
         int kr = kr0 + BKR * i;
         int kb = kc * BK + kr;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         int n = n0 + nq * 4;
-        if (kr < BK && kb < p.K && n < p.Cout) {
-          int tb, cb;
-          if (p.cin_shift >= 0) {
-            tb = kb >> p.cin_shift;
-            cb = kb & (p.Cin - 1);
-          } else {
-            tb = kb / p.Cin;
-            cb = kb - tb * p.Cin;
-          }
-          int wt = tap_wt(p.wtcode, tb);
-          size_t off = ((size_t)(wt * p.Cin + cb)) * p.Cout + n;
-          v = *reinterpret_cast<const f32x4*>(p.W + off);
+        bool ok = kr < BK && kb < p.K && n < p.Cout;
+        int tb, cb;
+        if (p.cin_shift >= 0) {
+          tb = kb >> p.cin_shift;
+          cb = kb & (p.Cin - 1);
+        } else {
+          tb = kb / p.Cin;
+          cb = kb - tb * p.Cin;
         }
-        breg[i] = v;
+        int wt = tap_wt(p.wtcode, ok ? tb : 0);
+        size_t off = ok ? ((size_t)(wt * p.Cin + cb)) * p.Cout + n : 0;
+        breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+        bmask |= (ok ? 1u : 0u) << i;
       }
     }
   };
 
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto store_lds = [&](int buf) {
     float* a = As + buf * A_ELEMS;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i)
-      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDA + kq * 4) = areg[i];
+      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDA + kq * 4) = ((amask >> i) & 1u) ? areg[i] : zero4;
     float* b = Bs + buf * B_ELEMS;
     if (NMAJOR) {
 #pragma unroll
       for (int i = 0; i < BROWS_N; ++i)
-        if (r0 + 32 * i < BN) *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDA + kq * 4) = breg[i];
+        if (r0 + 32 * i < BN)
+          *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDA + kq * 4) = ((bmask >> i) & 1u) ? breg[i] : zero4;
     } else {
       const int nq = tid % BQ;
       const int kr0 = tid / BQ;
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
         int kr = kr0 + BKR * i;
-        if (kr < BK) *reinterpret_cast<f32x4*>(b + kr * LDBK + nq * 4) = breg[i];
+        if (kr < BK) *reinterpret_cast<f32x4*>(b + kr * LDBK + nq * 4) = ((bmask >> i) & 1u) ? breg[i] : zero4;
       }
     }
   };
@@ -201,12 +202,29 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
   load_global(0);
   store_lds(0);
   __syncthreads();
-  for (int kc = 0; kc < nchunks; ++kc) {
-    const int cur = kc & 1;
-    if (kc + 1 < nchunks) load_global(kc + 1);
-    compute(cur);
-    if (kc + 1 < nchunks) store_lds(cur ^ 1);
-    __syncthreads();
+  if (p.dbg == 0) {
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const int cur = kc & 1;
+      if (kc + 1 < nchunks) load_global(kc + 1);
+      compute(cur);
+      if (kc + 1 < nchunks) store_lds(cur ^ 1);
+      __syncthreads();
+    }
+  } else if (p.dbg == 1) {  // ablation: MFMA + LDS reads only (timing aid, results are wrong)
+    for (int kc = 0; kc < nchunks; ++kc) compute(kc & 1);
+  } else if (p.dbg == 2) {  // ablation: no global loads, keep LDS stores + barrier
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const int cur = kc & 1;
+      compute(cur);
+      if (kc + 1 < nchunks) store_lds(cur ^ 1);
+      __syncthreads();
+    }
+  } else {                  // ablation: global loads + MFMA, no LDS store / barrier
+    for (int kc = 0; kc < nchunks; ++kc) {
+      if (kc + 1 < nchunks) load_global(kc + 1);
+      compute(kc & 1);
+      asm volatile("" ::"v"(areg[0]), "v"(breg[0]));
+    }
   }
 
   // ---- epilogue: bias, per-element PReLU, scatter to the output pixel ---------------------
@@ -259,9 +277,47 @@ static int launch_cfg(const GConvParams& p, hipStream_t s) {
   return OK;
 }
 
+static int g_tile_override = -1;
+static int g_dbg = 0;
+void debug_set_gconv_tile(int code) {
+  g_tile_override = code < 0 ? -1 : code % 100;
+  g_dbg = code < 0 ? 0 : code / 100;
+}
+
+// pure MFMA issue-rate probe: 16 independent accumulators per wave, no memory traffic in the loop
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  f32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float a = threadIdx.x * 0.001f, b = blockIdx.x * 0.002f + 1.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    a += 1e-6f;
+  }
+  f32x4 t = acc[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) t += acc[i];
+  out[blockIdx.x * 256 + threadIdx.x] = t[0] + t[1] + t[2] + t[3];
+}
+int debug_mfma_peak(float* out, int blocks, int iters, hipStream_t s) {
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, out, iters);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
 template <bool NMAJOR>
 static int dispatch(const GConvParams& p, hipStream_t s) {
   const int N = p.Cout;
+  switch (g_tile_override) {
+    case 0: return launch_cfg<128, 128, 2, 2, NMAJOR>(p, s);
+    case 1: return launch_cfg<128, 64, 2, 2, NMAJOR>(p, s);
+    case 2: return launch_cfg<64, 64, 2, 2, NMAJOR>(p, s);
+    case 3: return launch_cfg<128, 32, 4, 1, NMAJOR>(p, s);
+    case 4: return launch_cfg<32, 64, 2, 2, NMAJOR>(p, s);
+    case 5: return launch_cfg<128, 16, 4, 1, NMAJOR>(p, s);
+    default: break;
+  }
   // pick the tile so that the grid still fills 256 CUs when M is small (deep, low-resolution layers)
   if (N <= 16) return launch_cfg<128, 16, 4, 1, NMAJOR>(p, s);
   if (N <= 32) return launch_cfg<128, 32, 4, 1, NMAJOR>(p, s);
@@ -295,7 +351,9 @@ int launch_gconv(const GConvParams& p, hipStream_t s) {
     set_error("gconv: PReLU epilogue needs alpha and A");
     return E_INVALID;
   }
-  return p.w_nmajor ? dispatch<true>(p, s) : dispatch<false>(p, s);
+  GConvParams q = p;
+  q.dbg = g_dbg;
+  return q.w_nmajor ? dispatch<true>(q, s) : dispatch<false>(q, s);
 }
 
 }  // namespace dv

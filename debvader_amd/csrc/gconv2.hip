@@ -1,0 +1,351 @@
+// Gather-GEMM, second generation: the main-loop kernel for every layer whose input channel count is a
+// multiple of 32 (all but the first conv, the head's data gradient and the 560-wide dense operands).
+//
+// Same contraction as gconv.hip (see common.h); what changes is everything around the MFMAs:
+//  * one launch covers all output-parity classes of a stride-2 Conv2DTranspose / conv data gradient
+//    (blockIdx -> class, heaviest class first), instead of four launches with four tails;
+//  * a K chunk of 32 is one (tap, 32-channel slab), so the tap is wave-uniform: per-row gather state is a
+//    32-bit element offset plus a 9-bit tap-validity mask computed ONCE per workgroup (LDS row table), and the
+//    per-chunk address work is one add per row;
+//  * A (and n-major B) tiles sit in LDS as [row][32] with the 16-byte quad index XOR-swizzled by (row>>1)&7:
+//    no padding, and the ds_read_b128 fragment reads of v_mfma_f32_16x16x4_f32 are bank-conflict free;
+//  * the epilogue goes through a per-wave LDS staging tile so that bias / PReLU / stores run on float4 rows
+//    (256-byte contiguous segments per output pixel) instead of 64-byte column fragments.
+#include "common.h"
+
+namespace dv {
+
+namespace {
+constexpr int BK2 = 32;
+
+__device__ __forceinline__ int t_dh(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 3) - 1; }
+__device__ __forceinline__ int t_dw(unsigned long long code, int t) { return (int)((code >> (4 * t + 2)) & 3) - 1; }
+__device__ __forceinline__ int t_wt(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 15); }
+}  // namespace
+
+template <int BM, int BN, int WGM, int WGN, bool NMAJOR>
+__global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int AROWS = BM / 32;
+  constexpr int LDBK = BN + 4;
+  constexpr int A_ELEMS = BM * BK2;
+  constexpr int B_ELEMS = NMAJOR ? BN * BK2 : BK2 * LDBK;
+  constexpr int BROWS_N = (BN + 31) / 32;
+  constexpr int BQ = BN / 4;
+  constexpr int BKR = 256 / BQ;
+  constexpr int BPASS = (BK2 + BKR - 1) / BKR;
+  constexpr int LDC = WN + 4;                    // staging row stride (floats)
+  constexpr int STG_ROWS = 32;                   // rows staged per pass and wave (2 MFMA row blocks)
+  static_assert(4 * STG_ROWS * LDC <= 2 * A_ELEMS + 2 * B_ELEMS, "staging must fit in the operand buffers");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_ELEMS;
+  int* s_in = reinterpret_cast<int*>(smem + 2 * A_ELEMS + 2 * B_ELEMS);  // [BM] gather base (elements)
+  int* s_mask = s_in + BM;                                                // [BM] tap validity bits
+  int* s_out = s_mask + BM;                                               // [BM] output pixel offset (elements) or -1
+  int* s_al = s_out + BM;                                                 // [BM] alpha pixel offset
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  // ---- which class / tile ---------------------------------------------------------------------
+  int c = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (k < p.nclass && (int)blockIdx.x >= p.cls[k].tile0) c = k;
+  const GClass2 cl = p.cls[c];
+  const int ntn = (p.Cout + BN - 1) / BN;
+  const int t = blockIdx.x - cl.tile0;
+  const int m0 = (t / ntn) * BM;
+  const int n0 = (t % ntn) * BN;
+
+  // ---- row table (one division pair per ROW of the tile, not per thread and chunk) -------------
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int in_off = 0, mask = 0, out_off = -1, al_off = 0;
+    if (m < cl.M) {
+      const int HcWc = cl.Hc * cl.Wc;
+      const int nb = m / HcWc;
+      const int rem = m - nb * HcWc;
+      const int ii = rem / cl.Wc;
+      const int jj = rem - ii * cl.Wc;
+      const int ih0 = ii * p.sin, iw0 = jj * p.sin;
+      in_off = ((nb * p.Hin + ih0) * p.Win + iw0) * p.Cin;
+      for (int tp = 0; tp < cl.ntaps; ++tp) {
+        const int ih = ih0 + t_dh(cl.tapcode, tp), iw = iw0 + t_dw(cl.tapcode, tp);
+        if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) mask |= 1 << tp;
+      }
+      const int oh = ii * p.sout + cl.ph, ow = jj * p.sout + cl.pw;
+      al_off = (oh * p.Wout + ow) * p.Cout;
+      out_off = nb * p.Hout * p.Wout * p.Cout + al_off;
+    }
+    s_in[tid] = in_off;
+    s_mask[tid] = mask;
+    s_out[tid] = out_off;
+    s_al[tid] = al_off;
+  }
+  __syncthreads();
+
+  const int kq = tid & 7, r0 = tid >> 3;
+  int rin[AROWS], rmask[AROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) {
+    rin[i] = s_in[r0 + 32 * i] + kq * 4;
+    rmask[i] = s_mask[r0 + 32 * i];
+  }
+  // weight addressing: thread-constant part
+  int wthr[NMAJOR ? BROWS_N : BPASS];
+  unsigned wok = 0;
+  if (NMAJOR) {
+#pragma unroll
+    for (int i = 0; i < BROWS_N; ++i) {
+      const int n = n0 + r0 + 32 * i;
+      const bool ok = n < p.Cout && r0 + 32 * i < BN;
+      wthr[i] = ok ? n * p.Cin + kq * 4 : 0;
+      wok |= (ok ? 1u : 0u) << i;
+    }
+  } else {
+    const int nq = tid % BQ, kr0 = tid / BQ;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int kr = kr0 + BKR * i;
+      const int n = n0 + nq * 4;
+      const bool ok = kr < BK2 && n < p.Cout;
+      wthr[i] = ok ? kr * p.Cout + n : 0;
+      wok |= (ok ? 1u : 0u) << i;
+    }
+  }
+
+  f32x4 areg[AROWS];
+  f32x4 breg[NMAJOR ? BROWS_N : BPASS];
+  unsigned amask = 0;
+  const int cpt = p.Cin / BK2;                    // chunks per tap
+  int tap = 0, cc = 0;                            // chunk -> (tap, channel slab), advanced incrementally
+
+  auto load_global = [&]() {                      // loads chunk (tap, cc), then advances
+    const int dh = t_dh(cl.tapcode, tap), dw = t_dw(cl.tapcode, tap);
+    const int wt = t_wt(cl.wtcode, tap);
+    const int tapoff = (dh * p.Win + dw) * p.Cin + cc * BK2;
+    amask = 0;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const bool ok = (rmask[i] >> tap) & 1;
+      const unsigned off = ok ? (unsigned)(rin[i] + tapoff) : 0u;
+      areg[i] = *reinterpret_cast<const f32x4*>(p.X + off);
+      amask |= (ok ? 1u : 0u) << i;
+    }
+    if (NMAJOR) {
+      const int wbase = wt * p.Cout * p.Cin + cc * BK2;
+#pragma unroll
+      for (int i = 0; i < BROWS_N; ++i) {
+        const unsigned off = ((wok >> i) & 1u) ? (unsigned)(wbase + wthr[i]) : 0u;
+        breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+      }
+    } else {
+      const int wbase = (wt * p.Cin + cc * BK2) * p.Cout;
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const unsigned off = ((wok >> i) & 1u) ? (unsigned)(wbase + wthr[i]) : 0u;
+        breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+      }
+    }
+    if (++cc == cpt) {
+      cc = 0;
+      ++tap;
+    }
+  };
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int sw_w = (r0 >> 1) & 7;                 // swizzle of the rows this thread writes (r0 + 32 i: same value)
+  auto store_lds = [&](int buf) {
+    float* a = As + buf * A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i)
+      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * BK2 + ((kq ^ sw_w) << 2)) = ((amask >> i) & 1u) ? areg[i] : zero4;
+    float* b = Bs + buf * B_ELEMS;
+    if (NMAJOR) {
+#pragma unroll
+      for (int i = 0; i < BROWS_N; ++i)
+        if (r0 + 32 * i < BN)
+          *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * BK2 + ((kq ^ sw_w) << 2)) = ((wok >> i) & 1u) ? breg[i] : zero4;
+    } else {
+      const int nq = tid % BQ, kr0 = tid / BQ;
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const int kr = kr0 + BKR * i;
+        if (kr < BK2) *reinterpret_cast<f32x4*>(b + kr * LDBK + nq * 4) = ((wok >> i) & 1u) ? breg[i] : zero4;
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = zero4;
+
+  const int sw_r = l15 >> 1;                      // swizzle of the fragment rows this lane reads
+  auto compute = [&](int buf) {
+    const float* a = As + buf * A_ELEMS;
+    const float* b = Bs + buf * B_ELEMS;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int quad = ((q * 4 + lg) ^ sw_r) << 2;
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        af[tm] = *reinterpret_cast<const f32x4*>(a + (wm0 + tm * 16 + l15) * BK2 + quad);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        if (NMAJOR) {
+          bf[tn] = *reinterpret_cast<const f32x4*>(b + (wn0 + tn * 16 + l15) * BK2 + quad);
+        } else {
+          const float* bp = b + (q * 16 + lg * 4) * LDBK + wn0 + tn * 16 + l15;
+          bf[tn] = (f32x4){bp[0], bp[LDBK], bp[2 * LDBK], bp[3 * LDBK]};
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][jj], bf[tn][jj], acc[tm][tn], 0, 0, 0);
+    }
+  };
+
+  const int nchunks = cl.ntaps * cpt;
+  load_global();
+  store_lds(0);
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nchunks) load_global();
+    compute(cur);
+    if (kc + 1 < nchunks) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> per-wave LDS staging -> float4 rows --------------------------
+  float* stg = smem + wave * (STG_ROWS * LDC);    // operand buffers are free after the last barrier
+  constexpr int F4_PER_ROW = WN / 4;
+  constexpr int ROWS_PER_IT = 64 / F4_PER_ROW;
+  constexpr int TM_PER_PASS = STG_ROWS / 16;
+#pragma unroll
+  for (int pass = 0; pass < (TM + TM_PER_PASS - 1) / TM_PER_PASS; ++pass) {
+#pragma unroll
+    for (int tl = 0; tl < TM_PER_PASS; ++tl) {
+      const int tm = pass * TM_PER_PASS + tl;
+      if (tm < TM) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stg[(tl * 16 + lg * 4 + r) * LDC + tn * 16 + l15] = acc[tm][tn][r];
+      }
+    }
+    // wave-private region: only this wave's own LDS writes have to land before it reads them back
+    __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    const int f4 = lane % F4_PER_ROW;
+    const int col = n0 + wn0 + f4 * 4;
+#pragma unroll
+    for (int rr = lane / F4_PER_ROW; rr < STG_ROWS; rr += ROWS_PER_IT) {
+      const int tm = pass * TM_PER_PASS + rr / 16;
+      if (tm >= TM) break;
+      const int row = wm0 + tm * 16 + (rr & 15);  // row inside the workgroup tile
+      const int ooff = s_out[row];
+      if (ooff < 0 || col >= p.Cout) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * LDC + f4 * 4);
+      if (p.epi >= 1) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+      if (p.U) *reinterpret_cast<f32x4*>(p.U + (unsigned)ooff + col) = v;
+      if (p.epi == 2) {
+        const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + (unsigned)s_al[row] + col);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = v[k] > 0.f ? v[k] : al[k] * v[k];
+        *reinterpret_cast<f32x4*>(p.A + (unsigned)ooff + col) = o;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool NMAJOR>
+static int launch2_cfg(GConv2Params p, hipStream_t s) {
+  constexpr int A_ELEMS = BM * BK2;
+  constexpr int B_ELEMS = NMAJOR ? BN * BK2 : BK2 * (BN + 4);
+  constexpr size_t smem = (size_t)(2 * A_ELEMS + 2 * B_ELEMS) * sizeof(float) + 4 * BM * sizeof(int);
+  static bool attr_set = false;
+  auto kern = gconv2_kernel<BM, BN, WGM, WGN, NMAJOR>;
+  if (!attr_set) {
+    DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    attr_set = true;
+  }
+  const int ntn = (p.Cout + BN - 1) / BN;
+  int tiles = 0;
+  for (int c = 0; c < p.nclass; ++c) {
+    p.cls[c].tile0 = tiles;
+    tiles += ((p.cls[c].M + BM - 1) / BM) * ntn;
+  }
+  if (tiles == 0) return OK;
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, s, p);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+static int g2_tile_override = -1;
+void debug_set_gconv2_tile(int code) { g2_tile_override = code; }
+
+template <bool NMAJOR>
+static int dispatch2(const GConv2Params& p, hipStream_t s) {
+  const int N = p.Cout;
+  long Mtot = 0;
+  for (int c = 0; c < p.nclass; ++c) Mtot += p.cls[c].M;
+  switch (g2_tile_override) {
+    case 0: return launch2_cfg<128, 128, 2, 2, NMAJOR>(p, s);
+    case 1: return launch2_cfg<128, 64, 2, 2, NMAJOR>(p, s);
+    case 2: return launch2_cfg<64, 64, 2, 2, NMAJOR>(p, s);
+    case 3: return launch2_cfg<128, 32, 4, 1, NMAJOR>(p, s);
+    case 4: return launch2_cfg<64, 128, 2, 2, NMAJOR>(p, s);
+    case 5: return launch2_cfg<128, 16, 4, 1, NMAJOR>(p, s);
+    default: break;
+  }
+  if (N <= 16) return launch2_cfg<128, 16, 4, 1, NMAJOR>(p, s);
+  if (N <= 32) return launch2_cfg<128, 32, 4, 1, NMAJOR>(p, s);
+  if (N <= 64) {
+    if ((Mtot + 127) / 128 >= 512) return launch2_cfg<128, 64, 2, 2, NMAJOR>(p, s);
+    return launch2_cfg<64, 64, 2, 2, NMAJOR>(p, s);
+  }
+  // aim for at least two resident workgroups per CU before growing the tile; parity-class launches have
+  // short K loops (1-4 taps), so they want twice as many, smaller tiles (measured per layer, tools/layer_bench.py)
+  const long want = p.nclass > 1 ? 1024 : 512;
+  const long t128 = ((Mtot + 127) / 128) * ((N + 127) / 128);
+  if (t128 >= want) return launch2_cfg<128, 128, 2, 2, NMAJOR>(p, s);
+  const long t12864 = ((Mtot + 127) / 128) * ((N + 63) / 64);
+  if (t12864 >= want) return launch2_cfg<128, 64, 2, 2, NMAJOR>(p, s);
+  return launch2_cfg<64, 64, 2, 2, NMAJOR>(p, s);
+}
+
+int launch_gconv2(const GConv2Params& p, hipStream_t s) {
+  if (p.nclass < 1 || p.nclass > 4 || (p.Cin % BK2) || (p.Cout & 3)) {
+    set_error("gconv2: unsupported shape (Cin=%d Cout=%d nclass=%d)", p.Cin, p.Cout, p.nclass);
+    return E_INVALID;
+  }
+  if ((long)p.NB * p.Hin * p.Win * p.Cin >= (1L << 30) || (long)p.NB * p.Hout * p.Wout * p.Cout >= (1L << 30) ||
+      (long)9 * p.Cin * p.Cout >= (1L << 30)) {
+    set_error("gconv2: tensor too large for 32-bit byte offsets; lower max_batch");
+    return E_INVALID;
+  }
+  if (p.epi == 2 && (!p.alpha || !p.A)) {
+    set_error("gconv2: PReLU epilogue needs alpha and A");
+    return E_INVALID;
+  }
+  return p.w_nmajor ? dispatch2<true>(p, s) : dispatch2<false>(p, s);
+}
+
+}  // namespace dv

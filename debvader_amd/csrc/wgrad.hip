@@ -57,6 +57,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
   const int HcWc = p.Hc * p.Wc;
 
   f32x4 areg[AQ], breg[BQ];
+  unsigned amask = 0, bmask = 0;
+  // unconditional loads from clamped addresses, masked at the LDS store (see gconv.hip)
   auto load_global = [&](int kc) {
     const int pp = pstart + kc * BKP + ps;
     const bool pv = pp < pend;
@@ -67,35 +69,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
       ii = rem / p.Wc;
       jj = rem - ii * p.Wc;
     }
+    amask = 0;
 #pragma unroll
     for (int i = 0; i < AQ; ++i) {
       int ih = ii * p.sx + adh[i], iw = jj * p.sx + adw[i];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pv && aok[i] && (unsigned)ih < (unsigned)p.Hx && (unsigned)iw < (unsigned)p.Wx) {
-        size_t off = ((size_t)((nb * p.Hx + ih) * p.Wx + iw)) * p.Cx + acx[i];
-        v = *reinterpret_cast<const f32x4*>(p.X + off);
-      }
-      areg[i] = v;
+      bool ok = pv && aok[i] && (unsigned)ih < (unsigned)p.Hx && (unsigned)iw < (unsigned)p.Wx;
+      size_t off = ok ? ((size_t)((nb * p.Hx + ih) * p.Wx + iw)) * p.Cx + acx[i] : 0;
+      areg[i] = *reinterpret_cast<const f32x4*>(p.X + off);
+      amask |= (ok ? 1u : 0u) << i;
     }
     const size_t ypix = (size_t)((nb * p.Hy + ii * p.sy + p.ph) * p.Wy + jj * p.sy + p.pw) * p.Cy;
+    bmask = 0;
 #pragma unroll
     for (int i = 0; i < BQ; ++i) {
       int cl = 4 * (q + 8 * i);
       int c = n0 + cl;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pv && cl < BNW && c < p.Cy) v = *reinterpret_cast<const f32x4*>(p.Y + ypix + c);
-      breg[i] = v;
+      bool ok = pv && cl < BNW && c < p.Cy;
+      breg[i] = *reinterpret_cast<const f32x4*>(p.Y + (ok ? ypix + c : 0));
+      bmask |= (ok ? 1u : 0u) << i;
     }
   };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto store_lds = [&](int buf) {
     float* a = As + buf * A_ELEMS + ps * LDAW;
     float* b = Bs + buf * B_ELEMS + ps * LDBW;
 #pragma unroll
     for (int i = 0; i < AQ; ++i)
-      if (4 * (q + 8 * i) < BMW) *reinterpret_cast<f32x4*>(a + 4 * (q + 8 * i)) = areg[i];
+      if (4 * (q + 8 * i) < BMW) *reinterpret_cast<f32x4*>(a + 4 * (q + 8 * i)) = ((amask >> i) & 1u) ? areg[i] : zero4;
 #pragma unroll
     for (int i = 0; i < BQ; ++i)
-      if (4 * (q + 8 * i) < BNW) *reinterpret_cast<f32x4*>(b + 4 * (q + 8 * i)) = breg[i];
+      if (4 * (q + 8 * i) < BNW) *reinterpret_cast<f32x4*>(b + 4 * (q + 8 * i)) = ((bmask >> i) & 1u) ? breg[i] : zero4;
   };
 
   f32x4 acc[TM][TN];

@@ -137,6 +137,16 @@ int dv_prof_enable(dv_model* m, int32_t on);
 int dv_prof_read(dv_model* m, int32_t klass, int64_t* launches, double* total_ms);
 int dv_prof_reset(dv_model* m);
 
+/* kernel micro-benchmarks on random data (tuning aid; average ms per call over `iters`).
+ * gconv: source [NB,Hs,Hs,Cs] -> target [NB,Ht,Ht,Ct]; dgrad_form selects the parity-class form; tile -1 = automatic */
+int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, int32_t Ct, int32_t stride,
+                   int32_t pad_before, int32_t dgrad_form, int32_t nmajor, int32_t epi, int32_t single_tap,
+                   int32_t tile, int32_t iters, float* ms_out);
+/* issue-rate probe of v_mfma_f32_16x16x4_f32 (no memory traffic): measured TFLOP/s */
+int dv_debug_mfma_peak(dv_ctx* ctx, int32_t blocks, int32_t iters, float* tflops);
+int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, int32_t Cy, int32_t sx,
+                   int32_t pad_before, int32_t single_tap, int32_t iters, float* ms_out);
+
 #ifdef __cplusplus
 }
 #endif
