@@ -67,7 +67,7 @@ struct GConvParams {
 
 int launch_gconv(const GConvParams& p, hipStream_t s);
 void debug_set_gconv_tile(int code);  // -1: automatic; code = tile + 100*ablation
-int debug_mfma_peak(float* out, int blocks, int iters, hipStream_t s);
+int debug_mfma_peak(float* out, int blocks, int iters, int nacc, int randomize, hipStream_t s);
 
 // Second-generation gather-GEMM (gconv2.hip): same contraction, Cin % 32 == 0, all output-parity classes of
 // one layer in a single launch.
@@ -89,7 +89,10 @@ struct GConv2Params {
   GClass2 cls[4];
   int w_nmajor;
   int epi;
+  int ksplit;          // >1: grid.y K slices, raw partial slabs [ksplit][M][N] written to U
 };
+int launch_splitk_finish(const float* slabs, int ksplit, long total, int N, const float* bias, const float* alpha,
+                         long alpha_per_stamp, float* U, float* A, hipStream_t s);
 int launch_gconv2(const GConv2Params& p, hipStream_t s);
 void debug_set_gconv2_tile(int code);
 
@@ -112,6 +115,22 @@ struct WGradParams {
   int pchunk;         // pixels per split (multiple of 32)
 };
 int launch_wgrad(const WGradParams& p, hipStream_t s);
+
+// Strip form for the high-resolution few-channel layers (wgrad_strip.hip)
+struct WStripParams {
+  const float* X;
+  const float* Y;
+  float* part;
+  size_t part_capacity;   // floats available in `part`
+  int NB, Hx, Wx, Hy, Wy;
+  int pb;
+  const float* zero;      // >= 16 bytes of zeros in device memory (source of out-of-image LDS-DMA pieces)
+  int R, XR, xs_floats, ys_floats, strips_per_stamp, nstrips, strips_per_wg;   // filled by the launcher
+  int dbg;                // timing ablations (wrong results), bit flags: 1 no refill DMA, 2 no MFMA, 4 phase stamps, 8 MFMA only
+};
+void debug_set_strip(int v);
+bool wgrad_strip_supported(int Cx, int Cy, int sx, int ntaps);
+int launch_wgrad_strip(const WStripParams& p, int Cx, int Cy, int sx, hipStream_t s, int* nsplit_out);
 
 // out[(r/Cpad)*Creal + r%Cpad][c] = scale * sum_s part[s][r][c]   for r%Cpad < Creal
 int launch_reduce_partials(const float* part, float* out, int nsplit, long slab_elems, int ncols, int cpad,

@@ -325,6 +325,7 @@ struct dv_model {
   size_t ws1_elems = 0, ws2_elems = 0, ws3_elems = 0;
   float *scal = nullptr, *bnstate = nullptr, *bnsums = nullptr;
   float* stage_x = nullptr;  // host-batch staging (infer / encode)
+  float* zero_page = nullptr;  // 256 B of zeros (LDS-DMA source for out-of-image pieces)
   int* idx_dev = nullptr;
   DataSlot slots[2];
   int lastB = 0;
@@ -438,6 +439,26 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     q.cls[0].Hc = q.cls[0].Wc = Hout; q.cls[0].M = NB * Hout * Hout; q.cls[0].ph = q.cls[0].pw = 0;
     q.cls[0].ntaps = tp.n; q.cls[0].tapcode = tp.tapcode; q.cls[0].wtcode = tp.wtcode;
     q.w_nmajor = nmajor ? 1 : 0; q.epi = epi;
+    // dense-shaped contractions (few output tiles, long K): slice K over blockIdx.y into ws1 slabs
+    const long MN = (long)NB * Hout * Hout * Cout;
+    const long tiles64 = ((q.cls[0].M + 63) / 64) * (long)((Cout + 63) / 64);
+    const int nchunks = tp.n * (Cin / 32);
+    if (single_tap && tiles64 < 256 && nchunks >= 32 && m->ws1) {
+      int ks = (int)std::min<long>(std::min<long>(16, nchunks / 8), (long)(m->ws1_elems / (size_t)MN));
+      if (ks > 1) {
+        q.ksplit = ks;
+        q.U = m->ws1;
+        q.A = nullptr;
+        q.epi = 0;
+        {
+          ProfScope ps(m, 0);
+          DV_TRY(launch_gconv2(q, m->ctx->stream));
+        }
+        ProfScope ps(m, 2);
+        return launch_splitk_finish(m->ws1, ks, MN, Cout, epi >= 1 ? bias : nullptr, epi == 2 ? alpha : nullptr,
+                                    (long)Hout * Hout * Cout, U, epi == 2 ? Aout : nullptr, m->ctx->stream);
+      }
+    }
     ProfScope ps(m, 0);
     return launch_gconv2(q, m->ctx->stream);
   }
@@ -520,6 +541,20 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
 // dW = sum_p Xg[p,t][cx] * Y[p][cy]; X pixel = grid*sx + k - pb; result rows (wt,cx) x cols cy into `out`
 static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB, int sx, int pb,
                  bool single_tap, float* out, int cpad, int creal) {
+  if (!single_tap && !g_force_v1 && cpad == creal && wgrad_strip_supported(Cx, Cy, sx, 9)) {
+    WStripParams sp;
+    memset(&sp, 0, sizeof sp);
+    sp.X = X; sp.Y = Y; sp.part = m->ws1; sp.part_capacity = m->ws1_elems;
+    sp.NB = NB; sp.Hx = sp.Wx = Hx; sp.Hy = sp.Wy = Hy; sp.pb = pb;
+    sp.zero = m->zero_page;
+    int ns = 0;
+    {
+      ProfScope ps(m, 1);
+      DV_TRY(launch_wgrad_strip(sp, Cx, Cy, sx, m->ctx->stream, &ns));
+    }
+    ProfScope ps(m, 2);
+    return launch_reduce_partials(m->ws1, out, ns, (long)9 * Cx * Cy, Cy, cpad, creal, m->ctx->stream);
+  }
   WGradParams p;
   memset(&p, 0, sizeof p);
   Taps t;
@@ -1209,7 +1244,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   for (auto& s : A.specs)
     if (s.ndim >= 2) max_w = std::max(max_w, s.count);
   max_w = std::max(max_w, (size_t)9 * 8 * cfg->filters[0]);
-  m->ws1_elems = std::max((size_t)16 << 20, max_w * 2);
+  m->ws1_elems = std::max((size_t)32 << 20, max_w * 2);
   ALLOC(m->ws1, m->ws1_elems);
   m->ws2_elems = std::max((size_t)1 << 20, max_act * 16);
   ALLOC(m->ws2, m->ws2_elems);
@@ -1218,6 +1253,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   m->ws3_elems = std::max(m->ws3_elems, (size_t)64 * std::max((size_t)A.flat, r));
   ALLOC(m->ws3, m->ws3_elems);
   ALLOC(m->scal, 16);
+  ALLOC(m->zero_page, 64);
   ALLOC(m->bnstate, 32);
   ALLOC(m->bnsums, 16);
   {
@@ -1234,6 +1270,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
       hipMemsetAsync(m->Mm, 0, A.n_total * sizeof(float), s) != hipSuccess ||
       hipMemsetAsync(m->Vv, 0, A.n_total * sizeof(float), s) != hipSuccess ||
       hipMemsetAsync(m->scal, 0, 16 * sizeof(float), s) != hipSuccess ||
+      hipMemsetAsync(m->zero_page, 0, 64 * sizeof(float), s) != hipSuccess ||
       hipMemsetAsync(m->bnsums, 0, 16 * sizeof(float), s) != hipSuccess)
     return fail(E_HIP);
   st = dv_model_init(m, 0);
@@ -1569,6 +1606,8 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   float* bias = W + 9 * (size_t)Cs * Ct;     // reuse the tail as bias / alpha
   float* Y2 = nullptr;
   DV_HIP(hipMalloc((void**)&Y2, ny * sizeof(float)));
+  m.ws1_elems = (size_t)16 << 20;
+  DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
   g_force_v1 = tile >= 1000;
   if (g_force_v1) debug_set_gconv_tile(tile - 1000 == 99 ? -1 : tile - 1000); else debug_set_gconv2_tile(tile);
   hipEvent_t a, b;
@@ -1591,27 +1630,32 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   float ms = 0;
   DV_HIP(hipEventElapsedTime(&ms, a, b));
   *ms_out = ms / iters;
-  (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(Y2);
+  (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(Y2); (void)hipFree(m.ws1);
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   return st;
 }
 
-int dv_debug_mfma_peak(dv_ctx* ctx, int32_t blocks, int32_t iters, float* tflops) {
-  if (!ctx || !tflops) return DV_E_INVALID;
+int dv_debug_mfma_peak(dv_ctx* ctx, int32_t blocks, int32_t iters, int32_t nacc, int32_t randomize, float* out3) {
+  if (!ctx || !out3) return DV_E_INVALID;
   DV_HIP(hipSetDevice(ctx->device));
   float* out;
-  DV_HIP(hipMalloc((void**)&out, (size_t)blocks * 256 * sizeof(float)));
+  DV_HIP(hipMalloc((void**)&out, ((size_t)blocks * 256 + 16) * sizeof(float)));
   hipEvent_t a, b;
   DV_HIP(hipEventCreate(&a));
   DV_HIP(hipEventCreate(&b));
-  DV_TRY(debug_mfma_peak(out, blocks, iters, ctx->stream));
+  if (nacc != 36) nacc = 16;
+  DV_TRY(debug_mfma_peak(out, blocks, iters, nacc, randomize, ctx->stream));
   DV_HIP(hipEventRecord(a, ctx->stream));
-  DV_TRY(debug_mfma_peak(out, blocks, iters, ctx->stream));
+  DV_TRY(debug_mfma_peak(out, blocks, iters, nacc, randomize, ctx->stream));
   DV_HIP(hipEventRecord(b, ctx->stream));
   DV_HIP(hipEventSynchronize(b));
   float ms = 0;
   DV_HIP(hipEventElapsedTime(&ms, a, b));
-  *tflops = (float)((double)blocks * 4 * iters * 16 * 2048.0 / (ms * 1e-3) / 1e12);
+  float h[2];
+  DV_HIP(hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost));
+  out3[0] = (float)((double)blocks * 4 * iters * nacc * 2048.0 / (ms * 1e-3) / 1e12);   // TFLOP/s
+  out3[1] = h[1] > 0 ? h[0] / h[1] * 100.0f : 0.f;                                       // in-kernel clock, MHz
+  out3[2] = h[0] / ((float)iters * nacc);                                                // cycles per MFMA
   (void)hipFree(out);
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   return DV_OK;
@@ -1627,20 +1671,33 @@ int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, 
   DV_TRY(debug_buffers(ctx, nx, ny, nw, &X, &Yb, &out));
   m.ws1_elems = (size_t)16 << 20;
   DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
+  DV_HIP(hipMalloc((void**)&m.zero_page, 256));
+  DV_HIP(hipMemset(m.zero_page, 0, 256));
   hipEvent_t a, b;
   DV_HIP(hipEventCreate(&a));
   DV_HIP(hipEventCreate(&b));
   int st = OK;
+  DV_HIP(hipEventRecord(a, ctx->stream));
   for (int it = -2; it < iters && st == OK; ++it) {
     if (it == 0) DV_HIP(hipEventRecord(a, ctx->stream));
-    st = wgrad(&m, X, Hx, Cx, Yb, Hy, Cy, NB, sx, pb, single_tap != 0, out, Cx, Cx);
+    g_force_v1 = (single_tap & 2) != 0;
+    debug_set_strip(single_tap >> 2);
+    st = wgrad(&m, X, Hx, Cx, Yb, Hy, Cy, NB, sx, pb, (single_tap & 1) != 0, out, Cx, Cx);
+    g_force_v1 = false;
+    debug_set_strip(0);
   }
   DV_HIP(hipEventRecord(b, ctx->stream));
   DV_HIP(hipEventSynchronize(b));
   float ms = 0;
   DV_HIP(hipEventElapsedTime(&ms, a, b));
   *ms_out = ms / iters;
-  (void)hipFree(X); (void)hipFree(Yb); (void)hipFree(out); (void)hipFree(m.ws1);
+  if ((single_tap >> 2) == 4) {
+    float h[16];
+    DV_HIP(hipMemcpy(h, m.ws1 + m.ws1_elems - 64, sizeof h, hipMemcpyDeviceToHost));
+    for (int w = 0; w < 4; ++w)
+      fprintf(stderr, "  wave %d: barrier %.0f  dma-issue %.0f  compute %.0f cycles over %.0f strips\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
+  }
+  (void)hipFree(X); (void)hipFree(Yb); (void)hipFree(out); (void)hipFree(m.ws1); (void)hipFree(m.zero_page);
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   return st;
 }

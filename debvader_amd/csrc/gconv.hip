@@ -284,24 +284,43 @@ void debug_set_gconv_tile(int code) {
   g_dbg = code < 0 ? 0 : code / 100;
 }
 
-// pure MFMA issue-rate probe: 16 independent accumulators per wave, no memory traffic in the loop
-__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
-  f32x4 acc[16];
+// pure MFMA issue-rate probe: NACC independent accumulators per wave, no memory traffic in the loop; operands
+// either trivial or pseudo-random (data-dependent power -> clock).  Writes shader cycles (s_memtime) and
+// 100 MHz ticks (s_memrealtime) of block 0 so the in-kernel clock can be derived.
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, int randomize) {
+  f32x4 acc[NACC];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float a = threadIdx.x * 0.001f, b = blockIdx.x * 0.002f + 1.f;
+  for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float a[4], b[4];
+  unsigned st = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st = st * 1664525u + 1013904223u;
+    a[i] = randomize ? ((st >> 8) * (1.0f / 8388608.0f) - 1.0f) : 0.001f * threadIdx.x;
+    st = st * 1664525u + 1013904223u;
+    b[i] = randomize ? ((st >> 8) * (1.0f / 8388608.0f) - 1.0f) : 1.0f;
+  }
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
-    a += 1e-6f;
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
   }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   f32x4 t = acc[0];
 #pragma unroll
-  for (int i = 1; i < 16; ++i) t += acc[i];
-  out[blockIdx.x * 256 + threadIdx.x] = t[0] + t[1] + t[2] + t[3];
+  for (int i = 1; i < NACC; ++i) t += acc[i];
+  out[16 + blockIdx.x * 256 + threadIdx.x] = t[0] + t[1] + t[2] + t[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = (float)(t1 - t0);
+    out[1] = (float)(r1 - r0);
+  }
 }
-int debug_mfma_peak(float* out, int blocks, int iters, hipStream_t s) {
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, out, iters);
+int debug_mfma_peak(float* out, int blocks, int iters, int nacc, int randomize, hipStream_t s) {
+  if (nacc == 36)
+    hipLaunchKernelGGL(mfma_peak_kernel<36>, dim3(blocks), dim3(256), 0, s, out, iters, randomize);
+  else
+    hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(256), 0, s, out, iters, randomize);
   DV_HIP(hipGetLastError());
   return OK;
 }

@@ -218,9 +218,22 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     }
   };
 
-  const int nchunks = cl.ntaps * cpt;
-  load_global();
-  store_lds(0);
+  // split-K (dense layers with few output tiles): blockIdx.y owns a contiguous range of chunks and writes a raw
+  // partial tile into slab blockIdx.y of U; splitk_finish_kernel sums the slabs in order and applies the epilogue
+  int nchunks = cl.ntaps * cpt;
+  float* Uout = p.U;
+  if (p.ksplit > 1) {
+    const int cps = (nchunks + p.ksplit - 1) / p.ksplit;
+    const int kbeg = blockIdx.y * cps;
+    nchunks = max(0, min(nchunks, kbeg + cps) - kbeg);
+    tap = kbeg / cpt;
+    cc = kbeg - tap * cpt;
+    Uout += (size_t)blockIdx.y * p.NB * p.Hout * p.Wout * p.Cout;
+  }
+  if (nchunks > 0) {
+    load_global();
+    store_lds(0);
+  }
   __syncthreads();
   for (int kc = 0; kc < nchunks; ++kc) {
     const int cur = kc & 1;
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
       if (ooff < 0 || col >= p.Cout) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * LDC + f4 * 4);
       if (p.epi >= 1) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-      if (p.U) *reinterpret_cast<f32x4*>(p.U + (unsigned)ooff + col) = v;
+      if (Uout) *reinterpret_cast<f32x4*>(Uout + (unsigned)ooff + col) = v;
       if (p.epi == 2) {
         const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + (unsigned)s_al[row] + col);
         f32x4 o;
@@ -293,7 +306,7 @@ static int launch2_cfg(GConv2Params p, hipStream_t s) {
     tiles += ((p.cls[c].M + BM - 1) / BM) * ntn;
   }
   if (tiles == 0) return OK;
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, s, p);
+  hipLaunchKernelGGL(kern, dim3(tiles, p.ksplit > 1 ? p.ksplit : 1), dim3(256), smem, s, p);
   DV_HIP(hipGetLastError());
   return OK;
 }
@@ -331,6 +344,37 @@ static int dispatch2(const GConv2Params& p, hipStream_t s) {
   return launch2_cfg<64, 64, 2, 2, NMAJOR>(p, s);
 }
 
+// out = sum_k slab[k] (+bias) -> U ; PReLU(alpha) -> A.  total4 = M*N/4 float4 elements, N4 = N/4.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs, int ksplit, int total4,
+                                                            int N4, const float* __restrict__ bias,
+                                                            const float* __restrict__ alpha, int alpha4_per_stamp,
+                                                            float* __restrict__ U, float* __restrict__ A) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total4) return;
+  const f32x4* sp = reinterpret_cast<const f32x4*>(slabs) + e;
+  f32x4 v = sp[0];
+  for (int k = 1; k < ksplit; ++k) v += sp[(size_t)k * total4];
+  if (bias) v += reinterpret_cast<const f32x4*>(bias)[e % N4];
+  if (U) reinterpret_cast<f32x4*>(U)[e] = v;
+  if (A) {
+    const f32x4 al = reinterpret_cast<const f32x4*>(alpha)[e % alpha4_per_stamp];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = v[k] > 0.f ? v[k] : al[k] * v[k];
+    reinterpret_cast<f32x4*>(A)[e] = o;
+  }
+}
+
+int launch_splitk_finish(const float* slabs, int ksplit, long total, int N, const float* bias, const float* alpha,
+                         long alpha_per_stamp, float* U, float* A, hipStream_t s) {
+  if ((total & 3) || (N & 3) || total / 4 >= (1L << 31)) return E_INVALID;
+  int total4 = (int)(total / 4);
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((total4 + 255) / 256), dim3(256), 0, s, slabs, ksplit, total4, N / 4,
+                     bias, alpha, (int)(alpha_per_stamp / 4), U, A);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
 int launch_gconv2(const GConv2Params& p, hipStream_t s) {
   if (p.nclass < 1 || p.nclass > 4 || (p.Cin % BK2) || (p.Cout & 3)) {
     set_error("gconv2: unsupported shape (Cin=%d Cout=%d nclass=%d)", p.Cin, p.Cout, p.nclass);
@@ -343,6 +387,10 @@ int launch_gconv2(const GConv2Params& p, hipStream_t s) {
   }
   if (p.epi == 2 && (!p.alpha || !p.A)) {
     set_error("gconv2: PReLU epilogue needs alpha and A");
+    return E_INVALID;
+  }
+  if (p.ksplit > 1 && (p.nclass != 1 || p.epi != 0)) {
+    set_error("gconv2: split-K launches write raw partial slabs (one class, epi 0)");
     return E_INVALID;
   }
   return p.w_nmajor ? dispatch2<true>(p, s) : dispatch2<false>(p, s);

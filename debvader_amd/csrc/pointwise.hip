@@ -410,6 +410,84 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
   }
 }
 
+// 6-band specialisation (the reference's only exercised band count): 3 x 16-byte loads/stores per pixel for the
+// 12-channel head tensors, 8-byte accesses for the 6-channel label / output rows.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void head6_kernel(const HeadParams p) {
+  __shared__ float sh[4];
+  const long total = (long)p.NB * p.Hd * p.Hd;
+  const long pp = (long)blockIdx.x * 256 + threadIdx.x;
+  float nll = 0.f, se = 0.f;
+  if (pp < total) {
+    const int HdHd = p.Hd * p.Hd;
+    const int b = (int)(pp / HdHd);
+    const int rem = (int)(pp - (long)b * HdHd);
+    const int oh = rem / p.Hd, ow = rem - oh * p.Hd;
+    const int h = oh - p.crop0, w = ow - p.crop0;
+    const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.H;
+    f32x4* dtp = p.dt ? reinterpret_cast<f32x4*>(p.dt + pp * 12) : nullptr;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    if (!in) {
+      if (dtp) {
+        dtp[0] = z4;
+        dtp[1] = z4;
+        dtp[2] = z4;
+      }
+    } else {
+      const f32x4* tp = reinterpret_cast<const f32x4*>(p.tpre + pp * 12);
+      const f32x4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+      const float t[12] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3]};
+      const long opix = ((long)b * p.H + h) * p.H + w;
+      float yv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (p.y) {
+        long row = p.idx ? p.idx[b] : p.first + b;
+        const f32x2* yp = reinterpret_cast<const f32x2*>(p.y + ((row * p.H + h) * p.H + w) * 6);
+        const f32x2 y0 = yp[0], y1 = yp[1], y2 = yp[2];
+        yv[0] = y0[0]; yv[1] = y0[1]; yv[2] = y1[0]; yv[3] = y1[1]; yv[4] = y2[0]; yv[5] = y2[1];
+      }
+      float loc[6], sig[6], d[12];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        loc[c] = fmaxf(t[c], 0.f);
+        sig[c] = p.sigma_floor + fmaxf(t[6 + c], 0.f);
+        d[c] = d[6 + c] = 0.f;
+        if (p.y) {
+          const float inv = 1.0f / sig[c];
+          const float df = yv[c] - loc[c];
+          const float r = df * inv;
+          nll += 0.5f * r * r + logf(sig[c]) + 0.91893853320467274178f;
+          se += df * df;
+          d[c] = t[c] > 0.f ? -(r * inv) * p.gscale : 0.f;
+          d[6 + c] = t[6 + c] > 0.f ? (inv - r * r * inv) * p.gscale : 0.f;
+        }
+      }
+      if (dtp) {
+        dtp[0] = (f32x4){d[0], d[1], d[2], d[3]};
+        dtp[1] = (f32x4){d[4], d[5], d[6], d[7]};
+        dtp[2] = (f32x4){d[8], d[9], d[10], d[11]};
+      }
+      if (p.loc) {
+        f32x2* lp = reinterpret_cast<f32x2*>(p.loc + opix * 6);
+        lp[0] = (f32x2){loc[0], loc[1]};
+        lp[1] = (f32x2){loc[2], loc[3]};
+        lp[2] = (f32x2){loc[4], loc[5]};
+      }
+      if (p.scale) {
+        f32x2* sp = reinterpret_cast<f32x2*>(p.scale + opix * 6);
+        sp[0] = (f32x2){sig[0], sig[1]};
+        sp[1] = (f32x2){sig[2], sig[3]};
+        sp[2] = (f32x2){sig[4], sig[5]};
+      }
+    }
+  }
+  float a = block_sum(nll, sh);
+  float b2 = block_sum(se, sh);
+  if (threadIdx.x == 0 && p.part) {
+    p.part[blockIdx.x * 2] = a;
+    p.part[blockIdx.x * 2 + 1] = b2;
+  }
+}
+
 int launch_head(const HeadParams& p, hipStream_t s, int* nblocks_out) {
   if (p.nb > HEAD_MAXNB) {
     set_error("head: at most %d bands", HEAD_MAXNB);
@@ -419,7 +497,10 @@ int launch_head(const HeadParams& p, hipStream_t s, int* nblocks_out) {
   int nb = (int)((total + 255) / 256);
   if (nblocks_out) *nblocks_out = nb;
   if (nb == 0) return OK;
-  hipLaunchKernelGGL(head_kernel, dim3(nb), dim3(256), 0, s, p);
+  if (p.nb == 6)
+    hipLaunchKernelGGL(head6_kernel, dim3(nb), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(head_kernel, dim3(nb), dim3(256), 0, s, p);
   DV_HIP(hipGetLastError());
   return OK;
 }

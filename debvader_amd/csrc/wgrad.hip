@@ -214,6 +214,39 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   reinterpret_cast<f32x4*>(out)[(size_t)ro * ncols4 + c4] = (a0 + a1) + (a2 + a3);
 }
 
+// small slabs with many splits: a block owns 16 float4 columns and 16 split lanes (each sums every 16th slab
+// with 4 loads in flight), then the 16 partial sums are added in a fixed order through LDS.
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ part,
+                                                                   float* __restrict__ out, int nsplit, int slab4,
+                                                                   int ncols4, int cpad, int creal) {
+  __shared__ f32x4 sh[16][17];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + cl;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  if (e < slab4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + e;
+    int s = sl;
+    for (; s + 48 < nsplit; s += 64) {
+      a0 += p[(size_t)(s + 0) * slab4];
+      a1 += p[(size_t)(s + 16) * slab4];
+      a2 += p[(size_t)(s + 32) * slab4];
+      a3 += p[(size_t)(s + 48) * slab4];
+    }
+    for (; s < nsplit; s += 16) a0 += p[(size_t)s * slab4];
+  }
+  sh[sl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && e < slab4) {
+    f32x4 v = sh[0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v += sh[k][cl];
+    const int r = e / ncols4;
+    const int c4 = e - r * ncols4;
+    const int ci = r % cpad;
+    if (ci < creal) reinterpret_cast<f32x4*>(out)[(size_t)((r / cpad) * creal + ci) * ncols4 + c4] = v;
+  }
+}
+
 // scalar variant for column counts that are not a multiple of 4 (d(alpha) slabs use ncols = 1)
 __global__ __launch_bounds__(256) void reduce_partials_scalar_kernel(const float* __restrict__ part,
                                                                      float* __restrict__ out, int nsplit, int slab) {
@@ -237,8 +270,12 @@ int launch_reduce_partials(const float* part, float* out, int nsplit, long slab_
   if (slab_elems >= (1L << 31)) return E_INVALID;
   if ((ncols & 3) == 0 && (slab_elems & 3) == 0) {
     int slab4 = (int)(slab_elems / 4);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((slab4 + 255) / 256), dim3(256), 0, s, part, out, nsplit, slab4,
-                       ncols / 4, cpad, creal);
+    if (nsplit >= 32 && slab4 <= 65536)
+      hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((slab4 + 15) / 16), dim3(256), 0, s, part, out, nsplit,
+                         slab4, ncols / 4, cpad, creal);
+    else
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((slab4 + 255) / 256), dim3(256), 0, s, part, out, nsplit,
+                         slab4, ncols / 4, cpad, creal);
   } else {
     if (cpad != creal) {
       set_error("reduce_partials: row compaction needs ncols %% 4 == 0");

@@ -66,12 +66,12 @@ for tile in tiles:
         tw = tf = 0
         for i, (hi, ci, ho, co, s, pb) in enumerate(enc):
             fl = flops_conv(ho, ci if i else 6, co)
-            ms = wgrad(hi, ci, ho, co, s, pb); print(f"enc conv{i} wgrad: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF"); tw += ms; tf += fl
+            ms = wgrad(hi, ci, ho, co, s, pb); ms1 = wgrad(hi, ci, ho, co, s, pb, single=2); print(f"enc conv{i} wgrad: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF   (v1 {ms1*1e3:8.1f} us)"); tw += ms; tf += fl
         for i, (hi, ci, ho, co, s, pb) in enumerate(dec):
             fl = 2.0 * B * hi * hi * 9 * ci * co
-            ms = wgrad(ho, co, hi, ci, s, pb); print(f"dec convt{i} wgrad: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF"); tw += ms; tf += fl
+            ms = wgrad(ho, co, hi, ci, s, pb); ms1 = wgrad(ho, co, hi, ci, s, pb, single=2); print(f"dec convt{i} wgrad: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF   (v1 {ms1*1e3:8.1f} us)"); tw += ms; tf += fl
         fl = flops_conv(64, 32, 12)
-        ms = wgrad(64, 32, 64, 12, 1, 1); print(f"head wgrad: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF"); tw += ms; tf += fl
+        ms = wgrad(64, 32, 64, 12, 1, 1); ms1 = wgrad(64, 32, 64, 12, 1, 1, single=2); print(f"head wgrad: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF   (v1 {ms1*1e3:8.1f} us)"); tw += ms; tf += fl
         for (k, n) in ((4096, 560), (32, 560), (560, 4096)):
             fl = 2.0 * B * k * n
             ms = wgrad(1, k, 1, n, 1, 0, single=1); print(f"dense {k}->{n} wgrad: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF"); tw += ms; tf += fl
