@@ -1608,6 +1608,12 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   DV_HIP(hipMalloc((void**)&Y2, ny * sizeof(float)));
   m.ws1_elems = (size_t)16 << 20;
   DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
+  const bool stamps = tile >= 500 && tile < 1000;
+  if (stamps) {
+    tile -= 500;
+    if (tile == 99) tile = -1;
+    debug_set_gconv2_dbg(1, m.ws1 + m.ws1_elems - 64);
+  }
   g_force_v1 = tile >= 1000;
   if (g_force_v1) debug_set_gconv_tile(tile - 1000 == 99 ? -1 : tile - 1000); else debug_set_gconv2_tile(tile);
   hipEvent_t a, b;
@@ -1626,7 +1632,14 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   DV_HIP(hipEventSynchronize(b));
   debug_set_gconv_tile(-1);
   debug_set_gconv2_tile(-1);
+  debug_set_gconv2_dbg(0, nullptr);
   g_force_v1 = false;
+  if (stamps) {
+    float h[32];
+    DV_HIP(hipMemcpy(h, m.ws1 + m.ws1_elems - 64, sizeof h, hipMemcpyDeviceToHost));
+    for (int w = 0; w < 4; ++w)
+      fprintf(stderr, "  wave %d: load-issue %.0f  compute %.0f  wait+store %.0f  barrier %.0f cycles over %.0f chunks\n", w, h[8 * w], h[8 * w + 1], h[8 * w + 2], h[8 * w + 3], h[8 * w + 4]);
+  }
   float ms = 0;
   DV_HIP(hipEventElapsedTime(&ms, a, b));
   *ms_out = ms / iters;

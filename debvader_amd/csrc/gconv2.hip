@@ -235,12 +235,33 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     store_lds(0);
   }
   __syncthreads();
-  for (int kc = 0; kc < nchunks; ++kc) {
-    const int cur = kc & 1;
-    if (kc + 1 < nchunks) load_global();
-    compute(cur);
-    if (kc + 1 < nchunks) store_lds(cur ^ 1);
-    __syncthreads();
+  if (p.dbg == 0) {
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const int cur = kc & 1;
+      if (kc + 1 < nchunks) load_global();
+      compute(cur);
+      if (kc + 1 < nchunks) store_lds(cur ^ 1);
+      __syncthreads();
+    }
+  } else {  // timing build path: same loop with s_memtime stamps per phase (block 5 reports)
+    unsigned long long tl = 0, tc = 0, ts = 0, tb = 0, t0 = __builtin_amdgcn_s_memtime(), t1;
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const int cur = kc & 1;
+      if (kc + 1 < nchunks) load_global();
+      t1 = __builtin_amdgcn_s_memtime(); tl += t1 - t0; t0 = t1;
+      compute(cur);
+      asm volatile("" ::"v"(acc[0][0]), "v"(acc[TM - 1][TN - 1]));
+      t1 = __builtin_amdgcn_s_memtime(); tc += t1 - t0; t0 = t1;
+      if (kc + 1 < nchunks) store_lds(cur ^ 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      t1 = __builtin_amdgcn_s_memtime(); ts += t1 - t0; t0 = t1;
+      __syncthreads();
+      t1 = __builtin_amdgcn_s_memtime(); tb += t1 - t0; t0 = t1;
+    }
+    if (blockIdx.x == 5 && lane == 0 && p.dbg_out) {
+      float* d = p.dbg_out + wave * 8;
+      d[0] = (float)tl; d[1] = (float)tc; d[2] = (float)ts; d[3] = (float)tb; d[4] = (float)nchunks;
+    }
   }
 
   // ---- epilogue: accumulators -> per-wave LDS staging -> float4 rows --------------------------
@@ -375,7 +396,17 @@ int launch_splitk_finish(const float* slabs, int ksplit, long total, int N, cons
   return OK;
 }
 
-int launch_gconv2(const GConv2Params& p, hipStream_t s) {
+static int g2_dbg = 0;
+static float* g2_dbg_out = nullptr;
+void debug_set_gconv2_dbg(int v, float* out) {
+  g2_dbg = v;
+  g2_dbg_out = out;
+}
+
+int launch_gconv2(const GConv2Params& p0, hipStream_t s) {
+  GConv2Params p = p0;
+  p.dbg = g2_dbg;
+  p.dbg_out = g2_dbg_out;
   if (p.nclass < 1 || p.nclass > 4 || (p.Cin % BK2) || (p.Cout & 3)) {
     set_error("gconv2: unsupported shape (Cin=%d Cout=%d nclass=%d)", p.Cin, p.Cout, p.nclass);
     return E_INVALID;

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int WM = BMW / WGM, WN = BNW / WGN;
   constexpr int TM = WM / 16, TN = WN / 16;
-  constexpr int LDAW = BMW + 4, LDBW = BNW + 4;
+  constexpr int LDAW = BMW + 16, LDBW = BNW + 16;   // lane groups lg, lg+1 land 16 banks apart: conflict-free b32 reads
   constexpr int AQ = (BMW + 31) / 32, BQ = (BNW + 31) / 32;
   constexpr int A_ELEMS = BKP * LDAW, B_ELEMS = BKP * LDBW;
 
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
 
 template <int BMW, int BNW, int WGM, int WGN>
 static int launch_w(const WGradParams& p, hipStream_t s) {
-  constexpr size_t smem = (size_t)(2 * BKP * (BMW + 4) + 2 * BKP * (BNW + 4)) * sizeof(float);
+  constexpr size_t smem = (size_t)(2 * BKP * (BMW + 16) + 2 * BKP * (BNW + 16)) * sizeof(float);
   auto kern = wgrad_kernel<BMW, BNW, WGM, WGN>;
   static bool attr_set = false;
   if (!attr_set) {
