@@ -92,8 +92,10 @@ struct GConv2Params {
   int ksplit;          // >1: grid.y K slices, raw partial slabs [ksplit][M][N] written to U
   int dbg;             // timing build: phase stamps
   float* dbg_out;
+  int prio;            // s_setprio level of the load-issue / LDS-store phases
 };
 void debug_set_gconv2_dbg(int v, float* out);
+void debug_set_gconv2_prio(int v);
 int launch_splitk_finish(const float* slabs, int ksplit, long total, int N, const float* bias, const float* alpha,
                          long alpha_per_stamp, float* U, float* A, hipStream_t s);
 int launch_gconv2(const GConv2Params& p, hipStream_t s);

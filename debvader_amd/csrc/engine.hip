@@ -288,6 +288,10 @@ static int ilog2_exact(int v) {
 struct dv_ctx {
   int device = 0, rank = 0, world = 1;
   hipStream_t stream = nullptr;
+  hipStream_t comm_stream = nullptr;   // gradient all-reduce runs here, overlapped with the encoder backward
+  hipStream_t aux_stream = nullptr;    // weight-gradient kernels run here, beside the data-gradient chain
+  hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_buf[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_dec = nullptr, ev_enc = nullptr, ev_comm = nullptr;
   ncclComm_t comm = nullptr;
   float* red_dev = nullptr;  // small device buffer for host all-reduce
 };
@@ -320,7 +324,11 @@ struct dv_model {
   float *flat_a = nullptr, *t = nullptr, *eps = nullptr, *z = nullptr, *zstd = nullptr, *kl = nullptr;
   float *dec_ain = nullptr, *dec_uh = nullptr, *dec_ah = nullptr, *dec_ur = nullptr, *dec_ar = nullptr;
   float *tpre = nullptr, *loc = nullptr, *scale = nullptr;
-  float *gA = nullptr, *gB = nullptr;
+  float *gA = nullptr, *gB = nullptr, *gC = nullptr;
+  float* ws4 = nullptr;  // split-K slabs of the dense layers (ws1 belongs to the weight-gradient stream)
+  size_t ws4_elems = 0;
+  hipStream_t wstream = nullptr;  // stream the weight-gradient kernels are queued on (aux or main)
+  bool overlap_wgrad = true;
   float *ws1 = nullptr, *ws2 = nullptr, *ws3 = nullptr;
   size_t ws1_elems = 0, ws2_elems = 0, ws3_elems = 0;
   float *scal = nullptr, *bnstate = nullptr, *bnsums = nullptr;
@@ -353,8 +361,9 @@ static int dalloc(dv_model* m, float** p, size_t elems) {
 struct ProfScope {
   dv_model* m;
   int klass;
+  hipStream_t st;
   hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(dv_model* mm, int k) : m(mm), klass(k) {
+  ProfScope(dv_model* mm, int k, hipStream_t s = nullptr) : m(mm), klass(k), st(s ? s : mm->ctx->stream) {
     if (!m->prof_on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -368,11 +377,11 @@ struct ProfScope {
     };
     a = get();
     b = get();
-    (void)hipEventRecord(a, m->ctx->stream);
+    (void)hipEventRecord(a, st);
   }
   ~ProfScope() {
     if (!a) return;
-    (void)hipEventRecord(b, m->ctx->stream);
+    (void)hipEventRecord(b, st);
     m->prof.push_back({klass, a, b});
   }
 };
@@ -443,11 +452,11 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     const long MN = (long)NB * Hout * Hout * Cout;
     const long tiles64 = ((q.cls[0].M + 63) / 64) * (long)((Cout + 63) / 64);
     const int nchunks = tp.n * (Cin / 32);
-    if (single_tap && tiles64 < 256 && nchunks >= 32 && m->ws1) {
-      int ks = (int)std::min<long>(std::min<long>(16, nchunks / 8), (long)(m->ws1_elems / (size_t)MN));
+    if (single_tap && tiles64 < 256 && nchunks >= 32 && m->ws4) {
+      int ks = (int)std::min<long>(std::min<long>(16, nchunks / 8), (long)(m->ws4_elems / (size_t)MN));
       if (ks > 1) {
         q.ksplit = ks;
-        q.U = m->ws1;
+        q.U = m->ws4;
         q.A = nullptr;
         q.epi = 0;
         {
@@ -455,7 +464,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
           DV_TRY(launch_gconv2(q, m->ctx->stream));
         }
         ProfScope ps(m, 2);
-        return launch_splitk_finish(m->ws1, ks, MN, Cout, epi >= 1 ? bias : nullptr, epi == 2 ? alpha : nullptr,
+        return launch_splitk_finish(m->ws4, ks, MN, Cout, epi >= 1 ? bias : nullptr, epi == 2 ? alpha : nullptr,
                                     (long)Hout * Hout * Cout, U, epi == 2 ? Aout : nullptr, m->ctx->stream);
       }
     }
@@ -539,8 +548,23 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
 }
 
 // dW = sum_p Xg[p,t][cx] * Y[p][cy]; X pixel = grid*sx + k - pb; result rows (wt,cx) x cols cy into `out`
+static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB,
+                      int sx, int pb, bool single_tap, float* out, int cpad, int creal);
+
+// Weight gradients are queued on m->wstream.  When that is the aux stream, the call first makes it wait for
+// everything the main stream has produced so far (the operand d(pre-activation) is final at this point).
 static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB, int sx, int pb,
                  bool single_tap, float* out, int cpad, int creal) {
+  hipStream_t ws = m->wstream ? m->wstream : m->ctx->stream;
+  if (ws != m->ctx->stream) {
+    DV_HIP(hipEventRecord(m->ctx->ev_ready, m->ctx->stream));
+    DV_HIP(hipStreamWaitEvent(ws, m->ctx->ev_ready, 0));
+  }
+  return wgrad_impl(m, ws, X, Hx, Cx, Y, Hy, Cy, NB, sx, pb, single_tap, out, cpad, creal);
+}
+
+static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB,
+                      int sx, int pb, bool single_tap, float* out, int cpad, int creal) {
   if (!single_tap && !g_force_v1 && cpad == creal && wgrad_strip_supported(Cx, Cy, sx, 9)) {
     WStripParams sp;
     memset(&sp, 0, sizeof sp);
@@ -549,11 +573,11 @@ static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, in
     sp.zero = m->zero_page;
     int ns = 0;
     {
-      ProfScope ps(m, 1);
-      DV_TRY(launch_wgrad_strip(sp, Cx, Cy, sx, m->ctx->stream, &ns));
+      ProfScope ps(m, 1, ws);
+      DV_TRY(launch_wgrad_strip(sp, Cx, Cy, sx, ws, &ns));
     }
-    ProfScope ps(m, 2);
-    return launch_reduce_partials(m->ws1, out, ns, (long)9 * Cx * Cy, Cy, cpad, creal, m->ctx->stream);
+    ProfScope ps(m, 2, ws);
+    return launch_reduce_partials(m->ws1, out, ns, (long)9 * Cx * Cy, Cy, cpad, creal, ws);
   }
   WGradParams p;
   memset(&p, 0, sizeof p);
@@ -596,11 +620,11 @@ static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, in
   p.nsplit = (int)ns;
   p.pchunk = pchunk;
   {
-    ProfScope ps(m, 1);
-    DV_TRY(launch_wgrad(p, m->ctx->stream));
+    ProfScope ps(m, 1, ws);
+    DV_TRY(launch_wgrad(p, ws));
   }
-  ProfScope ps(m, 2);
-  return launch_reduce_partials(m->ws1, out, p.nsplit, slab, Cy, cpad, creal, m->ctx->stream);
+  ProfScope ps(m, 2, ws);
+  return launch_reduce_partials(m->ws1, out, p.nsplit, slab, Cy, cpad, creal, ws);
 }
 
 // PReLU backward with optional parameter gradients
@@ -787,17 +811,54 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   float* P = m->P;
   float* G = m->G;
   const bool dg = m->dec_trainable;  // decoder parameter gradients wanted
-  float* cur = m->gA;                // d(tpre)
-  float* oth = m->gB;
+  // The activation gradient walks down the chain through three rotating buffers.  Weight-gradient kernels run
+  // on the aux stream beside the data-gradient chain; a buffer is only overwritten after the weight-gradient
+  // launch that read it has been waited for (ev_buf), which with three buffers is two layers later.
+  dv_ctx* cx = m->ctx;
+  const bool ovl = m->overlap_wgrad && !m->prof_on && cx->aux_stream != nullptr;
+  m->wstream = ovl ? cx->aux_stream : s;
+  float* bufs[3] = {m->gA, m->gB, m->gC};
+  bool pend[3] = {false, false, false};
+  int ci = 0;                        // bufs[0] holds d(tpre)
+  float* cur = bufs[0];
+  float* oth = nullptr;
+  auto next_out = [&]() -> int {     // pick the output buffer of the next data-gradient launch
+    const int o = (ci + 1) % 3;
+    if (pend[o]) {
+      if (hipStreamWaitEvent(s, cx->ev_buf[o], 0) != hipSuccess) return -1;
+      pend[o] = false;
+    }
+    oth = bufs[o];
+    return o;
+  };
+  auto wgrad_read = [&]() -> int {   // the weight-gradient launch just queued reads bufs[ci]
+    if (!ovl) return OK;
+    if (hipEventRecord(cx->ev_buf[ci], cx->aux_stream) != hipSuccess) return E_HIP;
+    pend[ci] = true;
+    return OK;
+  };
+  auto advance = [&]() {             // the data gradient just written becomes the current one
+    ci = (ci + 1) % 3;
+    cur = bufs[ci];
+  };
+#define DV_NEXT_OUT()                                  \
+  do {                                                 \
+    if (next_out() < 0) {                              \
+      set_error("hipStreamWaitEvent failed");          \
+      return E_HIP;                                    \
+    }                                                  \
+  } while (0)
   const int Hd = A.dec_out, f0 = A.cfg.filters[0], C2 = 2 * A.C;
   // head conv
   if (dg) {
     DV_TRY(wgrad(m, m->dec_a[2 * A.L - 1], Hd, f0, cur, Hd, C2, NB, 1, 1, false, G + A.specs[A.head_k()].off, f0, f0));
+    DV_TRY(wgrad_read());
     DV_TRY(bias_grad_colsum(m, cur, (long)NB * Hd * Hd, C2, A.head_b()));
   }
+  DV_NEXT_OUT();
   DV_TRY(gconv_dgrad(m, cur, P + A.specs[A.head_k()].off, true, nullptr, nullptr, oth, nullptr, 0, NB, Hd, C2, Hd, f0,
                      1, 1));
-  std::swap(cur, oth);
+  advance();
   // decoder conv-transpose stack
   for (int j = 2 * A.L - 1; j >= 0; --j) {
     int hin, cin, hout, cout, st;
@@ -805,39 +866,64 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     int pb = same_pad_before(hout, 3, st, nullptr);
     DV_TRY(prelu_bwd(m, cur, m->dec_u[j], A.dec_al(j), A.dec_b(j), NB, hout * hout * cout, cout, dg));
     const float* xin = j == 0 ? m->dec_ar : m->dec_a[j - 1];
-    if (dg)
+    if (dg) {
       DV_TRY(wgrad(m, cur, hout, cout, xin, hin, cin, NB, st, pb, false, G + A.specs[A.dec_k(j)].off, cout, cout));
+      DV_TRY(wgrad_read());
+    }
     // d(input) = strided conv of d(pre-activation) with K[kh,kw,co,ci] (rows (tap,co), cols ci: k-major)
+    DV_NEXT_OUT();
     DV_TRY(gconv_fprop(m, cur, P + A.specs[A.dec_k(j)].off, false, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout,
                        hin, cin, st, pb));
-    std::swap(cur, oth);
+    advance();
   }
   // dense trunk of the decoder
   int r = A.w0 * A.w0 * A.cfg.filters[A.L - 1];
   DV_TRY(prelu_bwd(m, cur, m->dec_ur, A.D0 + 6, A.D0 + 5, NB, r, r, dg));
-  if (dg) DV_TRY(wgrad(m, m->dec_ah, 1, A.dec_hidden, cur, 1, r, NB, 1, 0, true, G + A.specs[A.D0 + 4].off, 1, 1));
+  if (dg) {
+    DV_TRY(wgrad(m, m->dec_ah, 1, A.dec_hidden, cur, 1, r, NB, 1, 0, true, G + A.specs[A.D0 + 4].off, 1, 1));
+    DV_TRY(wgrad_read());
+  }
+  DV_NEXT_OUT();
   DV_TRY(gconv_fprop(m, cur, P + A.specs[A.D0 + 4].off, true, nullptr, nullptr, oth, nullptr, 0, NB, 1, r, 1,
                      A.dec_hidden, 1, 0, true));
-  std::swap(cur, oth);
+  advance();
   DV_TRY(prelu_bwd(m, cur, m->dec_uh, A.D0 + 3, A.D0 + 2, NB, A.dec_hidden, A.dec_hidden, dg));
-  if (dg) DV_TRY(wgrad(m, m->dec_ain, 1, A.d, cur, 1, A.dec_hidden, NB, 1, 0, true, G + A.specs[A.D0 + 1].off, 1, 1));
+  if (dg) {
+    DV_TRY(wgrad(m, m->dec_ain, 1, A.d, cur, 1, A.dec_hidden, NB, 1, 0, true, G + A.specs[A.D0 + 1].off, 1, 1));
+    DV_TRY(wgrad_read());
+  }
+  DV_NEXT_OUT();
   DV_TRY(gconv_fprop(m, cur, P + A.specs[A.D0 + 1].off, true, nullptr, nullptr, oth, nullptr, 0, NB, 1, A.dec_hidden,
                      1, A.d, 1, 0, true));
-  std::swap(cur, oth);
+  advance();
   DV_TRY(prelu_bwd(m, cur, m->z, A.D0, -1, NB, A.d, A.d, dg));
+  // every decoder gradient is final here: all-reduce that bucket on the comm stream while the encoder backward runs
+  if (m->ctx->world > 1 && dg && A.n_train > A.n_enc_train) {
+    DV_HIP(hipEventRecord(m->ctx->ev_dec, s));
+    DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, m->ctx->ev_dec, 0));
+    if (ovl) {                                       // ... and the decoder weight gradients on the aux stream
+      DV_HIP(hipEventRecord(cx->ev_join, cx->aux_stream));
+      DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, cx->ev_join, 0));
+    }
+    DV_NCCL(ncclAllReduce(G + A.n_enc_train, G + A.n_enc_train, A.n_train - A.n_enc_train, ncclFloat, ncclSum,
+                          m->ctx->comm, m->ctx->comm_stream));
+  }
   // sampler + KL
   float kls = (float)((double)A.cfg.kl_multiplicity * A.cfg.kl_weight / ((double)Bg * (double)Bg));
   {
     ProfScope ps(m, 2);
+    DV_NEXT_OUT();
     DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, cur, oth, NB, A.d, A.cfg.diag_shift, kls, s));
   }
-  std::swap(cur, oth);  // cur = d(t) [NB, tw]
+  advance();  // cur = d(t) [NB, tw]
   // encoder dense
   DV_TRY(bias_grad_colsum(m, cur, NB, A.tw, A.enc_db()));
   DV_TRY(wgrad(m, m->flat_a, 1, A.flat, cur, 1, A.tw, NB, 1, 0, true, G + A.specs[A.enc_dk()].off, 1, 1));
+  DV_TRY(wgrad_read());
+  DV_NEXT_OUT();
   DV_TRY(gconv_fprop(m, cur, P + A.specs[A.enc_dk()].off, true, nullptr, nullptr, oth, nullptr, 0, NB, 1, A.tw, 1,
                      A.flat, 1, 0, true));
-  std::swap(cur, oth);
+  advance();
   DV_TRY(prelu_bwd(m, cur, m->enc_a[2 * A.L - 1], A.enc_flat_al(), -1, NB, A.flat, A.flat, true));
   for (int j = 2 * A.L - 1; j >= 0; --j) {
     int hin, cin, hout, cout, st;
@@ -848,9 +934,11 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     int cin_phys = j == 0 ? 8 : cin;
     DV_TRY(wgrad(m, xin, hin, cin_phys, cur, hout, cout, NB, st, pb, false, G + A.specs[A.enc_k(j)].off, cin_phys,
                  j == 0 ? A.C : cin_phys));
+    DV_TRY(wgrad_read());
     const float* W = j == 0 ? m->W1p : P + A.specs[A.enc_k(j)].off;
+    DV_NEXT_OUT();
     DV_TRY(gconv_dgrad(m, cur, W, true, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout, hin, cin_phys, st, pb));
-    std::swap(cur, oth);
+    advance();
   }
   // input BatchNorm: d(gamma), d(beta) (the input is data: no dX)
   {
@@ -861,6 +949,12 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, A.C, G + A.specs[0].off, 1.0f, s, 16));
     DV_TRY(launch_reduce_rows_f64(m->ws3 + 8, nblk, A.C, G + A.specs[1].off, 1.0f, s, 16));
   }
+  if (ovl) {                                         // join: every weight gradient is final past this point
+    DV_HIP(hipEventRecord(cx->ev_join, cx->aux_stream));
+    DV_HIP(hipStreamWaitEvent(s, cx->ev_join, 0));
+  }
+  m->wstream = s;
+#undef DV_NEXT_OUT
   return OK;
 }
 
@@ -931,9 +1025,13 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   if (bwd) {
     DV_TRY(backward(m, B, Bg, ds.x, idx, (int)first));
     if (m->ctx->world > 1) {
-      size_t beg = (m->enc_trainable ? 0 : A.n_enc_train), end = (m->dec_trainable ? A.n_train : A.n_enc_train);
-      if (end > beg)
-        DV_NCCL(ncclAllReduce(m->G + beg, m->G + beg, end - beg, ncclFloat, ncclSum, m->ctx->comm, s));
+      // encoder bucket (the decoder bucket was queued inside backward()); the optimizer waits for both
+      DV_HIP(hipEventRecord(m->ctx->ev_enc, s));
+      DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, m->ctx->ev_enc, 0));
+      if (A.n_enc_train > 0)
+        DV_NCCL(ncclAllReduce(m->G, m->G, A.n_enc_train, ncclFloat, ncclSum, m->ctx->comm, m->ctx->comm_stream));
+      DV_HIP(hipEventRecord(m->ctx->ev_comm, m->ctx->comm_stream));
+      DV_HIP(hipStreamWaitEvent(s, m->ctx->ev_comm, 0));
     }
   }
   if (mode == MODE_TRAIN) DV_TRY(optimizer_step(m));
@@ -1101,6 +1199,14 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
   c->rank = rank;
   c->world = world;
   DV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  DV_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  DV_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_buf[i], hipEventDisableTiming));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_dec, hipEventDisableTiming));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_enc, hipEventDisableTiming));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
   DV_HIP(hipMalloc((void**)&c->red_dev, 4096 * sizeof(float)));
   if (world > 1) {
     if (!unique_id) {
@@ -1121,6 +1227,15 @@ int dv_ctx_destroy(dv_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->red_dev) (void)hipFree(c->red_dev);
+  if (c->ev_dec) (void)hipEventDestroy(c->ev_dec);
+  if (c->ev_enc) (void)hipEventDestroy(c->ev_enc);
+  if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  for (int i = 0; i < 3; ++i)
+    if (c->ev_buf[i]) (void)hipEventDestroy(c->ev_buf[i]);
+  if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return DV_OK;
@@ -1239,6 +1354,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   ALLOC(m->scale, Bc * A.H * A.H * A.C);
   ALLOC(m->gA, Bc * max_act);
   ALLOC(m->gB, Bc * max_act);
+  ALLOC(m->gC, Bc * max_act);
   // workspaces: ws1 weight-gradient slabs, ws2 d(alpha) partials, ws3 small reductions
   size_t max_w = 0;
   for (auto& s : A.specs)
@@ -1246,6 +1362,9 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   max_w = std::max(max_w, (size_t)9 * 8 * cfg->filters[0]);
   m->ws1_elems = std::max((size_t)32 << 20, max_w * 2);
   ALLOC(m->ws1, m->ws1_elems);
+  m->ws4_elems = (size_t)16 * Bc * std::max((size_t)A.flat, (size_t)A.tw);
+  ALLOC(m->ws4, m->ws4_elems);
+  m->wstream = ctx->stream;
   m->ws2_elems = std::max((size_t)1 << 20, max_act * 16);
   ALLOC(m->ws2, m->ws2_elems);
   size_t head_blocks = (Bc * A.dec_out * A.dec_out + 255) / 256;
@@ -1608,6 +1727,11 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   DV_HIP(hipMalloc((void**)&Y2, ny * sizeof(float)));
   m.ws1_elems = (size_t)16 << 20;
   DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
+  if (tile >= 2000) {
+    debug_set_gconv2_prio(1);
+    tile -= 2000;
+    if (tile == 99) tile = -1;
+  }
   const bool stamps = tile >= 500 && tile < 1000;
   if (stamps) {
     tile -= 500;
@@ -1633,6 +1757,7 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   debug_set_gconv_tile(-1);
   debug_set_gconv2_tile(-1);
   debug_set_gconv2_dbg(0, nullptr);
+  debug_set_gconv2_prio(0);
   g_force_v1 = false;
   if (stamps) {
     float h[32];

@@ -238,9 +238,16 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
   if (p.dbg == 0) {
     for (int kc = 0; kc < nchunks; ++kc) {
       const int cur = kc & 1;
+      // the gather's address arithmetic competes with the co-resident workgroup's MFMA stream for VALU issue
+      // slots; at default priority it trails behind it for thousands of cycles.  Raise it for the short
+      // issue phases so the loads (and later the LDS stores) go out early, MFMA phases run at priority 0.
+      if (p.prio) __builtin_amdgcn_s_setprio(2);
       if (kc + 1 < nchunks) load_global();
+      __builtin_amdgcn_s_setprio(0);
       compute(cur);
+      if (p.prio) __builtin_amdgcn_s_setprio(2);
       if (kc + 1 < nchunks) store_lds(cur ^ 1);
+      __builtin_amdgcn_s_setprio(0);
       __syncthreads();
     }
   } else {  // timing build path: same loop with s_memtime stamps per phase (block 5 reports)
@@ -396,6 +403,8 @@ int launch_splitk_finish(const float* slabs, int ksplit, long total, int N, cons
   return OK;
 }
 
+static int g2_prio = 0;
+void debug_set_gconv2_prio(int v) { g2_prio = v; }
 static int g2_dbg = 0;
 static float* g2_dbg_out = nullptr;
 void debug_set_gconv2_dbg(int v, float* out) {
@@ -407,6 +416,7 @@ int launch_gconv2(const GConv2Params& p0, hipStream_t s) {
   GConv2Params p = p0;
   p.dbg = g2_dbg;
   p.dbg_out = g2_dbg_out;
+  p.prio = g2_prio;
   if (p.nclass < 1 || p.nclass > 4 || (p.Cin % BK2) || (p.Cout & 3)) {
     set_error("gconv2: unsupported shape (Cin=%d Cout=%d nclass=%d)", p.Cin, p.Cout, p.nclass);
     return E_INVALID;
