@@ -141,12 +141,21 @@ def main():
             "gconv_kernel": (2.0 * fwd_flops * B, ms_g / args.steps, n_g // args.steps),
             "wgrad_kernel": (1.0 * fwd_flops * B, ms_w / args.steps, n_w // args.steps),
         }
+        traffic = None
+        try:    # HBM bytes per step of the family from the committed PMC passes (profiles/r01_pmc_traffic.json)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)["per_step_bytes"]
+            traffic = {"gconv_kernel": pmc["gconv2_kernel"]["hbm_bytes"],
+                       "wgrad_kernel": pmc["wgrad_kernel+wgrad_strip_kernel"]["hbm_bytes"]}
+        except Exception:
+            traffic = None
         dom = max(cls, key=lambda k: cls[k][1])
         fl, ms, nl = cls[dom]
         achieved = fl / (ms * 1e-3) / 1e12
         roofline = {
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": (traffic or {}).get(dom),
             "launch": f"one training step's launches of the {dom} family ({nl} launches, batch {B})",
             "flops_per_step": fl, "ms_per_step_in_kernel": ms,
             "classes_ms_per_step": {"gconv": ms_g / args.steps, "wgrad": ms_w / args.steps,

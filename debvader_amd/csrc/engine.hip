@@ -1727,7 +1727,11 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   DV_HIP(hipMalloc((void**)&Y2, ny * sizeof(float)));
   m.ws1_elems = (size_t)16 << 20;
   DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
-  if (tile >= 2000) {
+  if (tile >= 3000) {
+    debug_set_gconv2_prio(2);
+    tile -= 3000;
+    if (tile == 99) tile = -1;
+  } else if (tile >= 2000) {
     debug_set_gconv2_prio(1);
     tile -= 2000;
     if (tile == 99) tile = -1;

@@ -53,13 +53,21 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
   const int l15 = lane & 15, lg = lane >> 4;
 
   // ---- which class / tile ---------------------------------------------------------------------
+  // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Neighbouring tiles share input
+  // rows (3x3 halo, the N tiles of one M panel), so give every XCD a contiguous range of tiles: block b of
+  // XCD group b%8 takes tile (b%8)*ceil + b/8 (bijective form for grids that are not a multiple of 8).
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  }
   int c = 0;
 #pragma unroll
   for (int k = 1; k < 4; ++k)
-    if (k < p.nclass && (int)blockIdx.x >= p.cls[k].tile0) c = k;
+    if (k < p.nclass && bid >= p.cls[k].tile0) c = k;
   const GClass2 cl = p.cls[c];
   const int ntn = (p.Cout + BN - 1) / BN;
-  const int t = blockIdx.x - cl.tile0;
+  const int t = bid - cl.tile0;
   const int m0 = (t / ntn) * BM;
   const int n0 = (t % ntn) * BN;
 
@@ -222,6 +230,12 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
   // partial tile into slab blockIdx.y of U; splitk_finish_kernel sums the slabs in order and applies the epilogue
   int nchunks = cl.ntaps * cpt;
   float* Uout = p.U;
+  if (p.prio >= 2) {
+    // stagger experiment: the second resident workgroup of a CU (odd hardware wave slot) starts half a chunk late so
+    // that its memory phases fall under the partner's MFMA phases instead of running in lockstep with them
+    const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));   // HW_REG_HW_ID.wave_id
+    if (hwid & 1) __builtin_amdgcn_s_sleep(40);
+  }
   if (p.ksplit > 1) {
     const int cps = (nchunks + p.ksplit - 1) / p.ksplit;
     const int kbeg = blockIdx.y * cps;
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
       __syncthreads();
       t1 = __builtin_amdgcn_s_memtime(); tb += t1 - t0; t0 = t1;
     }
-    if (blockIdx.x == 5 && lane == 0 && p.dbg_out) {
+    if (bid == 5 && lane == 0 && p.dbg_out) {
       float* d = p.dbg_out + wave * 8;
       d[0] = (float)tl; d[1] = (float)tc; d[2] = (float)ts; d[3] = (float)tb; d[4] = (float)nchunks;
     }
@@ -354,6 +368,8 @@ static int dispatch2(const GConv2Params& p, hipStream_t s) {
     case 3: return launch2_cfg<128, 32, 4, 1, NMAJOR>(p, s);
     case 4: return launch2_cfg<64, 128, 2, 2, NMAJOR>(p, s);
     case 5: return launch2_cfg<128, 16, 4, 1, NMAJOR>(p, s);
+    case 6: return launch2_cfg<256, 32, 4, 1, NMAJOR>(p, s);
+    case 7: return launch2_cfg<256, 16, 4, 1, NMAJOR>(p, s);
     default: break;
   }
   if (N <= 16) return launch2_cfg<128, 16, 4, 1, NMAJOR>(p, s);
