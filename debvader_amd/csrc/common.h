@@ -196,7 +196,10 @@ int launch_sampler_bwd(const float* t, const float* eps, const float* z, const f
 
 int launch_adam(float* w, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps,
                 hipStream_t s);
-int launch_pad_w1(const float* w, float* wp, int taps, int cin, int cpad, int cout, hipStream_t s);
+int launch_pad_w1(const float* w, const float* gamma, const float* beta, float* wp, int taps, int cin, int cpad,
+                  int cout, hipStream_t s);
+int launch_bn_conv0_grads(const float* G, const float* w, const float* gamma, const float* beta, float* dW,
+                          float* dgamma, float* dbeta, int taps, int cin, int cpad, int cout, hipStream_t s);
 int launch_fill(float* p, long n, float v, hipStream_t s);
 int launch_gather_rows(const float* src, const int* idx, int first, int NB, long row_elems, float* dst,
                        hipStream_t s);

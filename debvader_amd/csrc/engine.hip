@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -115,7 +116,7 @@ struct Arch {
       set_error("only square stamps are supported (reference uses input_shape[0] for both axes)");
       return E_INVALID;
     }
-    if (L < 1 || L > DV_MAX_LEVELS || C < 1 || C > 8 || d < 1 || d > 64 || H < 4) {
+    if (L < 1 || L > DV_MAX_LEVELS || C < 1 || C > 7 || d < 1 || d > 64 || H < 4) {
       set_error("unsupported architecture (levels=%d bands=%d latent=%d size=%d)", L, C, d, H);
       return E_INVALID;
     }
@@ -313,7 +314,8 @@ struct dv_model {
   int Bc = 0;
   // flat parameter-shaped buffers
   float *P = nullptr, *G = nullptr, *Mm = nullptr, *Vv = nullptr;
-  float* W1p = nullptr;  // first conv kernel padded to 8 input channels
+  float* W1p = nullptr;  // first conv kernel with the input BatchNorm folded in, 8 input channels
+  float* G0s = nullptr;  // gradient w.r.t. W1p (scratch)
   bool enc_trainable = true, dec_trainable = true;
   bool opt_enc = true, opt_dec = true;  // what the current optimizer updates (fixed at dv_optimizer_reset)
   float lr = 1e-4f, b1 = 0.9f, b2 = 0.999f, aeps = 1e-7f;
@@ -326,9 +328,12 @@ struct dv_model {
   float *tpre = nullptr, *loc = nullptr, *scale = nullptr;
   float *gA = nullptr, *gB = nullptr, *gC = nullptr;
   float* ws4 = nullptr;  // split-K slabs of the dense layers (ws1 belongs to the weight-gradient stream)
+  float* arena = nullptr;  // per-step bump arena for d(alpha)/d(bias) partials reduced on the aux stream
+  size_t arena_elems = 0, arena_off = 0;
   size_t ws4_elems = 0;
   hipStream_t wstream = nullptr;  // stream the weight-gradient kernels are queued on (aux or main)
   bool overlap_wgrad = true;
+  bool arena_reduce = true;   // queue d(alpha)/d(bias) reductions on the aux stream (tuning toggles: DV_NO_OVERLAP, DV_NO_ARENA)
   float *ws1 = nullptr, *ws2 = nullptr, *ws3 = nullptr;
   size_t ws1_elems = 0, ws2_elems = 0, ws3_elems = 0;
   float *scal = nullptr, *bnstate = nullptr, *bnsums = nullptr;
@@ -627,32 +632,62 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   return launch_reduce_partials(m->ws1, out, p.nsplit, slab, Cy, cpad, creal, ws);
 }
 
-// PReLU backward with optional parameter gradients
+// PReLU backward with optional parameter gradients.  du is needed by the next launches of the main stream; the
+// reductions that turn the d(alpha) / d(bias) partials into gradients are not, so (when the aux stream is in use)
+// they are queued there, reading partials from a per-step bump arena that no later main-stream kernel overwrites.
 static int prelu_bwd(dv_model* m, float* da, const float* u, int alpha_spec, int bias_spec, int NB, int E, int C,
                      bool want_grads) {
   const Arch& A = m->A;
+  hipStream_t s = m->ctx->stream;
+  hipStream_t rs = (m->arena_reduce && m->wstream && m->wstream != s) ? m->wstream : s;   // where the reductions go
   int gx = (E + 1023) / 1024;
   int nsplit = std::max(1, std::min(std::min(NB, 32), 1024 / std::max(gx, 1)));
-  while ((size_t)nsplit * E > m->ws2_elems && nsplit > 1) --nsplit;
-  float* dal = want_grads ? m->ws2 : nullptr;
-  float* dbp = (want_grads && bias_spec >= 0) ? m->ws3 : nullptr;
-  int rows = 0;
-  if (dbp) {
-    size_t need = (E == C) ? (size_t)nsplit * E : (size_t)nsplit * gx * C;
-    if (need > m->ws3_elems) {
-      set_error("bias-gradient workspace too small");
-      return E_STATE;
+  float *dal = nullptr, *dbp = nullptr;
+  if (want_grads) {
+    const bool arena = rs != s;
+    size_t cap2 = arena ? m->arena_elems - m->arena_off : m->ws2_elems;
+    size_t need3 = bias_spec >= 0 ? ((E == C) ? (size_t)nsplit * E : (size_t)nsplit * gx * C) : 0;
+    need3 = (need3 + 3) & ~(size_t)3;
+    while ((size_t)nsplit * E + need3 > cap2 && nsplit > 1) {
+      --nsplit;
+      need3 = bias_spec >= 0 ? ((E == C) ? (size_t)nsplit * E : (size_t)nsplit * gx * C) : 0;
+      need3 = (need3 + 3) & ~(size_t)3;
+    }
+    if (arena) {
+      if ((size_t)nsplit * E + need3 > cap2) {
+        set_error("gradient-partial arena exhausted");
+        return E_STATE;
+      }
+      dal = m->arena + m->arena_off;
+      m->arena_off += (size_t)nsplit * E;
+      if (bias_spec >= 0) {
+        dbp = m->arena + m->arena_off;
+        m->arena_off += need3;
+      }
+    } else {
+      dal = m->ws2;
+      if (bias_spec >= 0) {
+        if (need3 > m->ws3_elems) {
+          set_error("bias-gradient workspace too small");
+          return E_STATE;
+        }
+        dbp = m->ws3;
+      }
     }
   }
+  int rows = 0;
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_prelu_bwd(da, u, m->P + A.specs[alpha_spec].off, NB, E, C, nsplit, dal, dbp, &rows,
-                            m->ctx->stream));
+    DV_TRY(launch_prelu_bwd(da, u, m->P + A.specs[alpha_spec].off, NB, E, C, nsplit, dal, dbp, &rows, s));
   }
   if (want_grads) {
-    ProfScope ps(m, 2);
-    DV_TRY(launch_reduce_partials(m->ws2, m->G + A.specs[alpha_spec].off, nsplit, E, 4, 1, 1, m->ctx->stream));
-    if (dbp) DV_TRY(launch_reduce_rows_f64(m->ws3, rows, C, m->G + A.specs[bias_spec].off, 1.0f, m->ctx->stream));
+    if (rs != s) {
+      DV_HIP(hipEventRecord(m->ctx->ev_ready, s));
+      DV_HIP(hipStreamWaitEvent(rs, m->ctx->ev_ready, 0));
+    }
+    ProfScope ps(m, 2, rs);
+    DV_TRY(launch_reduce_partials(dal, m->G + A.specs[alpha_spec].off, nsplit, E, 4, 1, 1, rs));
+    if (dbp) DV_TRY(launch_reduce_rows_f64(dbp, rows, C, m->G + A.specs[bias_spec].off, 1.0f, rs));
   }
   return OK;
 }
@@ -670,7 +705,8 @@ static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int 
 
 static int refresh_w1p(dv_model* m) {
   const Arch& A = m->A;
-  return launch_pad_w1(m->P + A.specs[A.enc_k(0)].off, m->W1p, 9, A.C, 8, A.cfg.filters[0], m->ctx->stream);
+  return launch_pad_w1(m->P + A.specs[A.enc_k(0)].off, m->P + A.specs[0].off, m->P + A.specs[1].off, m->W1p, 9, A.C, 8,
+                       A.cfg.filters[0], m->ctx->stream);
 }
 
 // ---- forward ----------------------------------------------------------------------------------
@@ -817,6 +853,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   dv_ctx* cx = m->ctx;
   const bool ovl = m->overlap_wgrad && !m->prof_on && cx->aux_stream != nullptr;
   m->wstream = ovl ? cx->aux_stream : s;
+  m->arena_off = 0;
   float* bufs[3] = {m->gA, m->gB, m->gC};
   bool pend[3] = {false, false, false};
   int ci = 0;                        // bufs[0] holds d(tpre)
@@ -932,22 +969,25 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     DV_TRY(prelu_bwd(m, cur, m->enc_u[j], A.enc_al(j), A.enc_b(j), NB, hout * hout * cout, cout, true));
     const float* xin = j == 0 ? m->xn : m->enc_a[j - 1];
     int cin_phys = j == 0 ? 8 : cin;
+    if (j == 0) {
+      // first conv + input BatchNorm: the gradient w.r.t. the folded 8-channel kernel gives d(kernel), d(gamma) and
+      // d(beta) directly (bn_conv0_grads_kernel), so this layer needs no data-gradient pass at all
+      hipStream_t ws = m->wstream ? m->wstream : s;
+      DV_TRY(wgrad(m, xin, hin, 8, cur, hout, cout, NB, st, pb, false, m->G0s, 8, 8));
+      ProfScope ps(m, 2, ws);
+      DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
+                                   G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, 9, A.C, 8,
+                                   cout, ws));
+      DV_TRY(wgrad_read());
+      break;
+    }
     DV_TRY(wgrad(m, xin, hin, cin_phys, cur, hout, cout, NB, st, pb, false, G + A.specs[A.enc_k(j)].off, cin_phys,
-                 j == 0 ? A.C : cin_phys));
+                 cin_phys));
     DV_TRY(wgrad_read());
-    const float* W = j == 0 ? m->W1p : P + A.specs[A.enc_k(j)].off;
+    const float* W = P + A.specs[A.enc_k(j)].off;
     DV_NEXT_OUT();
     DV_TRY(gconv_dgrad(m, cur, W, true, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout, hin, cin_phys, st, pb));
     advance();
-  }
-  // input BatchNorm: d(gamma), d(beta) (the input is data: no dX)
-  {
-    int nblk = 0;
-    ProfScope ps(m, 2);
-    DV_TRY(launch_bn_bwd(cur, xsrc, idx, first, NB, A.H * A.H, A.C, 8, m->bnstate, m->ws3, &nblk, s));
-    // partial rows are [dgamma(8) | dbeta(8)]
-    DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, A.C, G + A.specs[0].off, 1.0f, s, 16));
-    DV_TRY(launch_reduce_rows_f64(m->ws3 + 8, nblk, A.C, G + A.specs[1].off, 1.0f, s, 16));
   }
   if (ovl) {                                         // join: every weight gradient is final past this point
     DV_HIP(hipEventRecord(cx->ev_join, cx->aux_stream));
@@ -1308,6 +1348,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   ALLOC(m->Mm, A.n_total);
   ALLOC(m->Vv, A.n_total);
   ALLOC(m->W1p, 9 * 8 * cfg->filters[0]);
+  ALLOC(m->G0s, 9 * 8 * cfg->filters[0]);
   size_t in_e = (size_t)A.H * A.H * 8;
   ALLOC(m->xn, Bc * in_e);
   track(in_e);
@@ -1365,6 +1406,13 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   m->ws4_elems = (size_t)16 * Bc * std::max((size_t)A.flat, (size_t)A.tw);
   ALLOC(m->ws4, m->ws4_elems);
   m->wstream = ctx->stream;
+  if (getenv("DV_NO_OVERLAP")) m->overlap_wgrad = false;
+  if (getenv("DV_NO_ARENA")) m->arena_reduce = false;
+  m->arena_elems = 0;
+  for (auto& sp : A.specs)
+    if (sp.name.size() > 6 && sp.name.compare(sp.name.size() - 6, 6, "/alpha") == 0)
+      m->arena_elems += (size_t)33 * ((sp.count + 3) & ~(size_t)3) + 65536;
+  ALLOC(m->arena, m->arena_elems);
   m->ws2_elems = std::max((size_t)1 << 20, max_act * 16);
   ALLOC(m->ws2, m->ws2_elems);
   size_t head_blocks = (Bc * A.dec_out * A.dec_out + 255) / 256;
@@ -1478,7 +1526,7 @@ int dv_model_get_param(dv_model* m, int32_t i, float* host, size_t nbytes) {
 }
 int dv_model_set_param(dv_model* m, int32_t i, const float* host, size_t nbytes) {
   DV_TRY(tensor_io(m, m ? m->P : nullptr, i, const_cast<float*>(host), nbytes, false));
-  if (i == m->A.enc_k(0)) {
+  if (i == m->A.enc_k(0) || i == 0 || i == 1) {
     DV_TRY(refresh_w1p(m));
     DV_HIP(hipStreamSynchronize(m->ctx->stream));
   }

@@ -151,9 +151,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   int pix = (int)(pp - (long)b * HW);
   long row = idx ? idx[b] : first + b;
   const float* px = x + (row * HW + pix) * C;
+  // channels [0,C): xhat = (x - mean) * inv_std; channel C: 1 (carries beta through the folded first conv, see
+  // fold_bn_w1_kernel); remaining pad channels: 0.  gamma/beta live in the folded weights, not here.
   float o[BN_MAXC];
 #pragma unroll
-  for (int c = 0; c < BN_MAXC; ++c) o[c] = (c < C) ? px[c] * st[c] + st[BN_MAXC + c] : 0.f;
+  for (int c = 0; c < BN_MAXC; ++c)
+    o[c] = (c < C) ? (px[c] - st[2 * BN_MAXC + c]) * st[3 * BN_MAXC + c] : (c == C ? 1.f : 0.f);
   f32x4* dst = reinterpret_cast<f32x4*>(xn + pp * BN_MAXC);
   dst[0] = (f32x4){o[0], o[1], o[2], o[3]};
   dst[1] = (f32x4){o[4], o[5], o[6], o[7]};
@@ -161,8 +164,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 int launch_bn_apply(const float* x, const int* idx, int first, int NB, int HW, int C, int Cpad, const float* bnstate,
                     float* xn, hipStream_t s) {
-  if (Cpad != BN_MAXC || C > BN_MAXC) {
-    set_error("bn_apply: Cpad must be %d", BN_MAXC);
+  if (Cpad != BN_MAXC || C >= BN_MAXC) {
+    set_error("bn_apply: needs Cpad == %d and at most %d bands (one pad channel carries the BN shift)", BN_MAXC,
+              BN_MAXC - 1);
     return E_INVALID;
   }
   long total = (long)NB * HW;
@@ -663,20 +667,85 @@ int launch_adam(float* w, float* m, float* v, const float* g, long n, float lr_t
   return OK;
 }
 
-__global__ void pad_w1_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int cin, int cpad,
-                              int cout) {
+// First conv with the input BatchNorm folded in (reference model.py:79-83): conv(gamma*xhat + beta) over the
+// zero-padded image equals conv'(xhat8) with
+//   wp[t][c][co] = w[t][c][co] * gamma[c]  (c < cin),   wp[t][cin][co] = sum_c w[t][c][co] * beta[c],   0 beyond,
+// where channel `cin` of xhat8 is 1 inside the image.  The weight gradient w.r.t. wp (G) then yields every
+// gradient of the layer pair without a data-gradient pass: see bn_conv0_grads_kernel.
+__global__ void fold_bn_w1_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float* __restrict__ wp, int taps, int cin, int cpad,
+                                  int cout) {
   int i = blockIdx.x * 256 + threadIdx.x;
   int total = taps * cpad * cout;
   if (i >= total) return;
   int co = i % cout;
   int c = (i / cout) % cpad;
   int t = i / (cout * cpad);
-  wp[i] = c < cin ? w[(t * cin + c) * cout + co] : 0.f;
+  float v = 0.f;
+  if (c < cin) {
+    v = w[(t * cin + c) * cout + co] * gamma[c];
+  } else if (c == cin) {
+    for (int k = 0; k < cin; ++k) v += w[(t * cin + k) * cout + co] * beta[k];
+  }
+  wp[i] = v;
 }
 
-int launch_pad_w1(const float* w, float* wp, int taps, int cin, int cpad, int cout, hipStream_t s) {
+int launch_pad_w1(const float* w, const float* gamma, const float* beta, float* wp, int taps, int cin, int cpad,
+                  int cout, hipStream_t s) {
+  if (cin >= cpad) return E_INVALID;
   int total = taps * cpad * cout;
-  hipLaunchKernelGGL(pad_w1_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, wp, taps, cin, cpad, cout);
+  hipLaunchKernelGGL(fold_bn_w1_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, gamma, beta, wp, taps, cin,
+                     cpad, cout);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// G[t][c8][co] = d(loss)/d(wp).  dW[t][c][co] = gamma[c] G[t][c][co] + beta[c] G[t][cin][co];
+// d(gamma)[c] = sum_{t,co} w[t][c][co] G[t][c][co];  d(beta)[c] = sum_{t,co} w[t][c][co] G[t][cin][co].   One block.
+__global__ __launch_bounds__(256) void bn_conv0_grads_kernel(const float* __restrict__ G, const float* __restrict__ w,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ dW,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int taps, int cin, int cpad, int cout) {
+  __shared__ double sg[BN_MAXC][256], sb[BN_MAXC][256];
+  double ag[BN_MAXC], ab[BN_MAXC];
+#pragma unroll
+  for (int c = 0; c < BN_MAXC; ++c) ag[c] = ab[c] = 0.0;
+  const int total = taps * cin * cout;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int co = i % cout;
+    const int c = (i / cout) % cin;
+    const int t = i / (cout * cin);
+    const float g = G[(t * cpad + c) * cout + co];
+    const float g1 = G[(t * cpad + cin) * cout + co];
+    const float wv = w[i];
+    dW[i] = gamma[c] * g + beta[c] * g1;
+#pragma unroll
+    for (int k = 0; k < BN_MAXC; ++k)
+      if (k == c) {
+        ag[k] += (double)wv * g;
+        ab[k] += (double)wv * g1;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < BN_MAXC; ++c) {
+    sg[c][threadIdx.x] = ag[c];
+    sb[c][threadIdx.x] = ab[c];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * cin) {
+    const int c = threadIdx.x % cin;
+    const bool isb = (int)threadIdx.x >= cin;
+    double acc = 0.0;
+    for (int k = 0; k < 256; ++k) acc += isb ? sb[c][k] : sg[c][k];
+    (isb ? dbeta : dgamma)[c] = (float)acc;
+  }
+}
+
+int launch_bn_conv0_grads(const float* G, const float* w, const float* gamma, const float* beta, float* dW,
+                          float* dgamma, float* dbeta, int taps, int cin, int cpad, int cout, hipStream_t s) {
+  hipLaunchKernelGGL(bn_conv0_grads_kernel, dim3(1), dim3(256), 0, s, G, w, gamma, beta, dW, dgamma, dbeta, taps, cin,
+                     cpad, cout);
   DV_HIP(hipGetLastError());
   return OK;
 }
