@@ -152,6 +152,7 @@ struct HeadParams {
   float* scale;        // [NB,H,H,nb] or null
   float* part;         // [nblocks][2] partial sums (nll, squared error)
   int NB, Hd, H, nb, crop0;
+  int ld;              // channels per pixel row of tpre / dt (2*nb, or padded to 16)
   float sigma_floor;
   float gscale;        // 1/(Bglobal*H*H*nb)
 };
@@ -201,6 +202,8 @@ int launch_pad_w1(const float* w, const float* gamma, const float* beta, float* 
 int launch_bn_conv0_grads(const float* G, const float* w, const float* gamma, const float* beta, float* dW,
                           float* dgamma, float* dbeta, int taps, int cin, int cpad, int cout, hipStream_t s);
 int launch_fill(float* p, long n, float v, hipStream_t s);
+int launch_pad_cols(const float* src, float* dst, int rows, int nsrc, int ndst, hipStream_t s);
+int launch_take_cols(const float* src, float* dst, int rows, int nsrc, int ndst, hipStream_t s);
 int launch_gather_rows(const float* src, const int* idx, int first, int NB, long row_elems, float* dst,
                        hipStream_t s);
 

@@ -67,6 +67,7 @@ struct Arch {
   dv_config cfg;
   int H = 0, C = 0, d = 0, L = 0;
   int tw = 0, dec_hidden = 0, w0 = 0, flat = 0, dec_out = 0, crop0 = 0;
+  int C2p = 0;  // head output channels as stored: 2*bands padded to a multiple of 16
   std::vector<int> enc_sizes;
   std::vector<Spec> specs;
   size_t n_enc_train = 0, n_train = 0, n_total = 0;  // flat counts incl. alignment padding
@@ -144,6 +145,7 @@ struct Arch {
       return E_INVALID;
     }
     D0 = 7 + 6 * L;
+    C2p = ((2 * C + 15) / 16) * 16;
     specs.clear();
     auto add = [&](const std::string& n, std::vector<int64_t> sh, bool tr) {
       Spec s;
@@ -316,6 +318,7 @@ struct dv_model {
   float *P = nullptr, *G = nullptr, *Mm = nullptr, *Vv = nullptr;
   float* W1p = nullptr;  // first conv kernel with the input BatchNorm folded in, 8 input channels
   float* G0s = nullptr;  // gradient w.r.t. W1p (scratch)
+  float *Whp = nullptr, *bhp = nullptr, *Ghs = nullptr;  // head kernel/bias padded to C2p output channels, grad scratch
   bool enc_trainable = true, dec_trainable = true;
   bool opt_enc = true, opt_dec = true;  // what the current optimizer updates (fixed at dv_optimizer_reset)
   float lr = 1e-4f, b1 = 0.9f, b2 = 0.999f, aeps = 1e-7f;
@@ -444,7 +447,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
   Taps one;
   one.add(0, 0, 0);
   const Taps tp = single_tap ? one : taps_fprop(pb);
-  if (Cin % 32 == 0 && !g_force_v1) {
+  if ((Cin % 32 == 0 || ((Cin == 8 || Cin == 16) && Cout <= 32 && !single_tap)) && !g_force_v1) {
     GConv2Params q;
     memset(&q, 0, sizeof q);
     q.X = X; q.W = W; q.U = U; q.A = Aout; q.bias = bias; q.alpha = alpha;
@@ -485,7 +488,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
 // target pixel o satisfies o + pb = s*i + k for source pixel i.
 static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor, const float* bias, const float* alpha,
                        float* U, float* Aout, int epi, int NB, int Hs, int Cs, int Ht, int Ct, int s, int pb) {
-  if (Cs % 32 == 0 && s <= 2 && !g_force_v1) {
+  if ((Cs % 32 == 0 || ((Cs == 8 || Cs == 16) && Ct <= 32)) && s <= 2 && !g_force_v1) {
     GConv2Params q;
     memset(&q, 0, sizeof q);
     q.X = X; q.W = W; q.U = U; q.A = Aout; q.bias = bias; q.alpha = alpha;
@@ -692,7 +695,7 @@ static int prelu_bwd(dv_model* m, float* da, const float* u, int alpha_spec, int
   return OK;
 }
 
-static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int bias_spec) {
+static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int ncols_out, int bias_spec) {
   int nr = 0;
   if ((size_t)((rows + 2047) / 2048) * C > m->ws3_elems) {
     set_error("colsum workspace too small");
@@ -700,7 +703,13 @@ static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int 
   }
   ProfScope ps(m, 2);
   DV_TRY(launch_colsum(dy, rows, C, m->ws3, &nr, m->ctx->stream));
-  return launch_reduce_rows_f64(m->ws3, nr, C, m->G + m->A.specs[bias_spec].off, 1.0f, m->ctx->stream);
+  return launch_reduce_rows_f64(m->ws3, nr, ncols_out, m->G + m->A.specs[bias_spec].off, 1.0f, m->ctx->stream, C);
+}
+
+static int refresh_head_pad(dv_model* m) {
+  const Arch& A = m->A;
+  DV_TRY(launch_pad_cols(m->P + A.specs[A.head_k()].off, m->Whp, 9 * A.cfg.filters[0], 2 * A.C, A.C2p, m->ctx->stream));
+  return launch_pad_cols(m->P + A.specs[A.head_b()].off, m->bhp, 1, 2 * A.C, A.C2p, m->ctx->stream);
 }
 
 static int refresh_w1p(dv_model* m) {
@@ -776,8 +785,8 @@ static int decoder_forward(dv_model* m, const float* z, int NB, bool keep_u) {
                        hout, cout, st, pb));
     in = m->dec_a[j];
   }
-  return gconv_fprop(m, in, P + A.specs[A.head_k()].off, false, P + A.specs[A.head_b()].off, nullptr, m->tpre, nullptr,
-                     1, NB, A.dec_out, A.cfg.filters[0], A.dec_out, 2 * A.C, 1, 1);
+  return gconv_fprop(m, in, m->Whp, false, m->bhp, nullptr, m->tpre, nullptr, 1, NB, A.dec_out, A.cfg.filters[0],
+                     A.dec_out, A.C2p, 1, 1);
 }
 
 static int sampler_forward(dv_model* m, int NB, const float* eps_host, uint64_t seed, unsigned stream_id,
@@ -824,6 +833,7 @@ static int head_and_loss(dv_model* m, const float* ysrc, const int* idx, int fir
   hp.H = A.H;
   hp.nb = A.C;
   hp.crop0 = A.crop0;
+  hp.ld = A.C2p;
   hp.sigma_floor = A.cfg.sigma_floor;
   hp.gscale = (float)(1.0 / ((double)Bg * A.H * A.H * A.C));
   int nblk = 0;
@@ -885,16 +895,20 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
       return E_HIP;                                    \
     }                                                  \
   } while (0)
-  const int Hd = A.dec_out, f0 = A.cfg.filters[0], C2 = 2 * A.C;
-  // head conv
+  const int Hd = A.dec_out, f0 = A.cfg.filters[0], C2 = 2 * A.C, C2p = A.C2p;
+  // head conv (stored with C2p output channels; the pad channels carry zeros)
   if (dg) {
-    DV_TRY(wgrad(m, m->dec_a[2 * A.L - 1], Hd, f0, cur, Hd, C2, NB, 1, 1, false, G + A.specs[A.head_k()].off, f0, f0));
+    hipStream_t ws = m->wstream ? m->wstream : s;
+    DV_TRY(wgrad(m, m->dec_a[2 * A.L - 1], Hd, f0, cur, Hd, C2p, NB, 1, 1, false, m->Ghs, f0, f0));
+    {
+      ProfScope ps(m, 2, ws);
+      DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, C2p, C2, ws));
+    }
     DV_TRY(wgrad_read());
-    DV_TRY(bias_grad_colsum(m, cur, (long)NB * Hd * Hd, C2, A.head_b()));
+    DV_TRY(bias_grad_colsum(m, cur, (long)NB * Hd * Hd, C2p, C2, A.head_b()));
   }
   DV_NEXT_OUT();
-  DV_TRY(gconv_dgrad(m, cur, P + A.specs[A.head_k()].off, true, nullptr, nullptr, oth, nullptr, 0, NB, Hd, C2, Hd, f0,
-                     1, 1));
+  DV_TRY(gconv_dgrad(m, cur, m->Whp, true, nullptr, nullptr, oth, nullptr, 0, NB, Hd, C2p, Hd, f0, 1, 1));
   advance();
   // decoder conv-transpose stack
   for (int j = 2 * A.L - 1; j >= 0; --j) {
@@ -954,7 +968,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   }
   advance();  // cur = d(t) [NB, tw]
   // encoder dense
-  DV_TRY(bias_grad_colsum(m, cur, NB, A.tw, A.enc_db()));
+  DV_TRY(bias_grad_colsum(m, cur, NB, A.tw, A.tw, A.enc_db()));
   DV_TRY(wgrad(m, m->flat_a, 1, A.flat, cur, 1, A.tw, NB, 1, 0, true, G + A.specs[A.enc_dk()].off, 1, 1));
   DV_TRY(wgrad_read());
   DV_NEXT_OUT();
@@ -1010,6 +1024,7 @@ static int optimizer_step(dv_model* m) {
   DV_TRY(launch_adam(m->P + beg, m->Mm + beg, m->Vv + beg, m->G + beg, (long)(end - beg), lr_t, m->b1, m->b2,
                      m->aeps, m->ctx->stream));
   if (m->opt_enc) DV_TRY(refresh_w1p(m));
+  if (m->opt_dec) DV_TRY(refresh_head_pad(m));
   return OK;
 }
 
@@ -1349,6 +1364,9 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   ALLOC(m->Vv, A.n_total);
   ALLOC(m->W1p, 9 * 8 * cfg->filters[0]);
   ALLOC(m->G0s, 9 * 8 * cfg->filters[0]);
+  ALLOC(m->Whp, 9 * cfg->filters[0] * A.C2p);
+  ALLOC(m->Ghs, 9 * cfg->filters[0] * A.C2p);
+  ALLOC(m->bhp, A.C2p);
   size_t in_e = (size_t)A.H * A.H * 8;
   ALLOC(m->xn, Bc * in_e);
   track(in_e);
@@ -1388,7 +1406,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
     ALLOC(m->dec_a[j], Bc * e);
     track(e);
   }
-  size_t head_e = (size_t)A.dec_out * A.dec_out * 2 * A.C;
+  size_t head_e = (size_t)A.dec_out * A.dec_out * A.C2p;
   ALLOC(m->tpre, Bc * head_e);
   track(head_e);
   ALLOC(m->loc, Bc * A.H * A.H * A.C);
@@ -1496,6 +1514,7 @@ int dv_model_init(dv_model* m, uint64_t seed) {
   DV_HIP(hipMemcpyAsync(m->P, h.data(), A.n_total * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
   DV_HIP(hipStreamSynchronize(m->ctx->stream));
   DV_TRY(refresh_w1p(m));
+  DV_TRY(refresh_head_pad(m));
   DV_HIP(hipStreamSynchronize(m->ctx->stream));
   return DV_OK;
 }
@@ -1526,6 +1545,10 @@ int dv_model_get_param(dv_model* m, int32_t i, float* host, size_t nbytes) {
 }
 int dv_model_set_param(dv_model* m, int32_t i, const float* host, size_t nbytes) {
   DV_TRY(tensor_io(m, m ? m->P : nullptr, i, const_cast<float*>(host), nbytes, false));
+  if (i == m->A.head_k() || i == m->A.head_b()) {
+    DV_TRY(refresh_head_pad(m));
+    DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  }
   if (i == m->A.enc_k(0) || i == 0 || i == 1) {
     DV_TRY(refresh_w1p(m));
     DV_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -1720,7 +1743,18 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
   else if (n == "kl") { src = m->kl; elems = B; }
   else if (n == "loc") { src = m->loc; elems = B * A.H * A.H * A.C; }
   else if (n == "scale") { src = m->scale; elems = B * A.H * A.H * A.C; }
-  else if (n == "head_pre") { src = m->tpre; elems = B * A.dec_out * A.dec_out * 2 * A.C; }
+  else if (n == "head_pre") {
+    elems = B * A.dec_out * A.dec_out * 2 * A.C;
+    if (nbytes != elems * sizeof(float)) {
+      set_error("activation head_pre holds %zu bytes, caller passed %zu", elems * sizeof(float), nbytes);
+      return DV_E_INVALID;
+    }
+    DV_HIP(hipSetDevice(m->ctx->device));
+    DV_HIP(hipStreamSynchronize(m->ctx->stream));
+    DV_HIP(hipMemcpy2D(host, 2 * A.C * sizeof(float), m->tpre, A.C2p * sizeof(float), 2 * A.C * sizeof(float),
+                       B * A.dec_out * A.dec_out, hipMemcpyDeviceToHost));
+    return DV_OK;
+  }
   else if (n == "xn") { src = m->xn; elems = B * A.H * A.H * 8; }
   else if (n.rfind("enc_u", 0) == 0 || n.rfind("enc_a", 0) == 0 || n.rfind("dec_u", 0) == 0 || n.rfind("dec_a", 0) == 0) {
     int j = atoi(n.c_str() + 5);

@@ -23,7 +23,8 @@ __device__ __forceinline__ int t_dw(unsigned long long code, int t) { return (in
 __device__ __forceinline__ int t_wt(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 15); }
 }  // namespace
 
-template <int BM, int BN, int WGM, int WGN, bool NMAJOR>
+// SUB = taps per 32-wide K chunk: 1 for Cin % 32 == 0, 2 for Cin == 16, 4 for Cin == 8 (tap then varies per lane)
+template <int BM, int BN, int WGM, int WGN, bool NMAJOR, int SUB = 1>
 __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -38,6 +39,8 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
   constexpr int BPASS = (BK2 + BKR - 1) / BKR;
   constexpr int LDC = WN + 4;                    // staging row stride (floats)
   constexpr int STG_ROWS = 32;                   // rows staged per pass and wave (2 MFMA row blocks)
+  constexpr int CINS = BK2 / SUB;                // channels per tap inside a chunk (SUB > 1: equals Cin)
+  constexpr int QPT = 8 / SUB;                   // 16-byte quads per tap inside a chunk
   static_assert(4 * STG_ROWS * LDC <= 2 * A_ELEMS + 2 * B_ELEMS, "staging must fit in the operand buffers");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
   int rin[AROWS], rmask[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
-    rin[i] = s_in[r0 + 32 * i] + kq * 4;
+    rin[i] = s_in[r0 + 32 * i] + (SUB == 1 ? kq : kq % QPT) * 4;
     rmask[i] = s_mask[r0 + 32 * i];
   }
   // weight addressing: thread-constant part
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     for (int i = 0; i < BROWS_N; ++i) {
       const int n = n0 + r0 + 32 * i;
       const bool ok = n < p.Cout && r0 + 32 * i < BN;
-      wthr[i] = ok ? n * p.Cin + kq * 4 : 0;
+      wthr[i] = ok ? n * p.Cin + (SUB == 1 ? kq : kq % QPT) * 4 : 0;
       wok |= (ok ? 1u : 0u) << i;
     }
   } else {
@@ -123,47 +126,87 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
       const int kr = kr0 + BKR * i;
       const int n = n0 + nq * 4;
       const bool ok = kr < BK2 && n < p.Cout;
-      wthr[i] = ok ? kr * p.Cout + n : 0;
+      wthr[i] = ok ? (SUB == 1 ? kr : kr % CINS) * p.Cout + n : 0;
       wok |= (ok ? 1u : 0u) << i;
     }
   }
 
   f32x4 areg[AROWS];
   f32x4 breg[NMAJOR ? BROWS_N : BPASS];
-  unsigned amask = 0;
-  const int cpt = p.Cin / BK2;                    // chunks per tap
+  unsigned amask = 0, bmaskv = 0xffffffffu;
+  const int cpt = SUB == 1 ? p.Cin / BK2 : 1;     // chunks per tap
   int tap = 0, cc = 0;                            // chunk -> (tap, channel slab), advanced incrementally
 
   auto load_global = [&]() {                      // loads chunk (tap, cc), then advances
-    const int dh = t_dh(cl.tapcode, tap), dw = t_dw(cl.tapcode, tap);
-    const int wt = t_wt(cl.wtcode, tap);
-    const int tapoff = (dh * p.Win + dw) * p.Cin + cc * BK2;
-    amask = 0;
+    if constexpr (SUB == 1) {
+      const int dh = t_dh(cl.tapcode, tap), dw = t_dw(cl.tapcode, tap);
+      const int wt = t_wt(cl.wtcode, tap);
+      const int tapoff = (dh * p.Win + dw) * p.Cin + cc * BK2;
+      amask = 0;
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-      const bool ok = (rmask[i] >> tap) & 1;
-      const unsigned off = ok ? (unsigned)(rin[i] + tapoff) : 0u;
-      areg[i] = *reinterpret_cast<const f32x4*>(p.X + off);
-      amask |= (ok ? 1u : 0u) << i;
-    }
-    if (NMAJOR) {
-      const int wbase = wt * p.Cout * p.Cin + cc * BK2;
+      for (int i = 0; i < AROWS; ++i) {
+        const bool ok = (rmask[i] >> tap) & 1;
+        const unsigned off = ok ? (unsigned)(rin[i] + tapoff) : 0u;
+        areg[i] = *reinterpret_cast<const f32x4*>(p.X + off);
+        amask |= (ok ? 1u : 0u) << i;
+      }
+      if (NMAJOR) {
+        const int wbase = wt * p.Cout * p.Cin + cc * BK2;
 #pragma unroll
-      for (int i = 0; i < BROWS_N; ++i) {
-        const unsigned off = ((wok >> i) & 1u) ? (unsigned)(wbase + wthr[i]) : 0u;
-        breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+        for (int i = 0; i < BROWS_N; ++i) {
+          const unsigned off = ((wok >> i) & 1u) ? (unsigned)(wbase + wthr[i]) : 0u;
+          breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+        }
+      } else {
+        const int wbase = (wt * p.Cin + cc * BK2) * p.Cout;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+          const unsigned off = ((wok >> i) & 1u) ? (unsigned)(wbase + wthr[i]) : 0u;
+          breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+        }
+      }
+      if (++cc == cpt) {
+        cc = 0;
+        ++tap;
       }
     } else {
-      const int wbase = (wt * p.Cin + cc * BK2) * p.Cout;
+      // several taps share one chunk: this lane's quad belongs to tap (tap + kq / QPT); taps past the table read 0
+      const int mytap = tap + kq / QPT;
+      const int tcl = min(mytap, 8);
+      const int dh = t_dh(cl.tapcode, tcl), dw = t_dw(cl.tapcode, tcl);
+      const int tapoff = (dh * p.Win + dw) * p.Cin;
+      amask = 0;
 #pragma unroll
-      for (int i = 0; i < BPASS; ++i) {
-        const unsigned off = ((wok >> i) & 1u) ? (unsigned)(wbase + wthr[i]) : 0u;
-        breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+      for (int i = 0; i < AROWS; ++i) {
+        const bool ok = mytap < cl.ntaps && ((rmask[i] >> tcl) & 1);
+        const unsigned off = ok ? (unsigned)(rin[i] + tapoff) : 0u;
+        areg[i] = *reinterpret_cast<const f32x4*>(p.X + off);
+        amask |= (ok ? 1u : 0u) << i;
       }
-    }
-    if (++cc == cpt) {
-      cc = 0;
-      ++tap;
+      bmaskv = 0;
+      if (NMAJOR) {
+        const int wt = t_wt(cl.wtcode, tcl);
+#pragma unroll
+        for (int i = 0; i < BROWS_N; ++i) {
+          const bool ok = ((wok >> i) & 1u) && mytap < cl.ntaps;
+          const unsigned off = ok ? (unsigned)(wt * p.Cout * p.Cin + wthr[i]) : 0u;
+          breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+          bmaskv |= (ok ? 1u : 0u) << i;
+        }
+      } else {
+        const int kr0b = tid / BQ;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+          const int kr = kr0b + BKR * i;
+          const int btap = tap + kr / CINS;
+          const int bcl = min(btap, 8);
+          const bool ok = ((wok >> i) & 1u) && btap < cl.ntaps;
+          const unsigned off = ok ? (unsigned)(t_wt(cl.wtcode, bcl) * p.Cin * p.Cout + wthr[i]) : 0u;
+          breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+          bmaskv |= (ok ? 1u : 0u) << i;
+        }
+      }
+      tap += SUB;
     }
   };
 
@@ -179,13 +222,13 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
 #pragma unroll
       for (int i = 0; i < BROWS_N; ++i)
         if (r0 + 32 * i < BN)
-          *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * BK2 + ((kq ^ sw_w) << 2)) = ((wok >> i) & 1u) ? breg[i] : zero4;
+          *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * BK2 + ((kq ^ sw_w) << 2)) = (((wok & bmaskv) >> i) & 1u) ? breg[i] : zero4;
     } else {
       const int nq = tid % BQ, kr0 = tid / BQ;
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
         const int kr = kr0 + BKR * i;
-        if (kr < BK2) *reinterpret_cast<f32x4*>(b + kr * LDBK + nq * 4) = ((wok >> i) & 1u) ? breg[i] : zero4;
+        if (kr < BK2) *reinterpret_cast<f32x4*>(b + kr * LDBK + nq * 4) = (((wok & bmaskv) >> i) & 1u) ? breg[i] : zero4;
       }
     }
   };
@@ -228,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
 
   // split-K (dense layers with few output tiles): blockIdx.y owns a contiguous range of chunks and writes a raw
   // partial tile into slab blockIdx.y of U; splitk_finish_kernel sums the slabs in order and applies the epilogue
-  int nchunks = cl.ntaps * cpt;
+  int nchunks = SUB == 1 ? cl.ntaps * cpt : (cl.ntaps + SUB - 1) / SUB;
   float* Uout = p.U;
   if (p.prio >= 2) {
     // stagger experiment: the second resident workgroup of a CU (odd hardware wave slot) starts half a chunk late so
@@ -329,13 +372,13 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool NMAJOR>
+template <int BM, int BN, int WGM, int WGN, bool NMAJOR, int SUB = 1>
 static int launch2_cfg(GConv2Params p, hipStream_t s) {
   constexpr int A_ELEMS = BM * BK2;
   constexpr int B_ELEMS = NMAJOR ? BN * BK2 : BK2 * (BN + 4);
   constexpr size_t smem = (size_t)(2 * A_ELEMS + 2 * B_ELEMS) * sizeof(float) + 4 * BM * sizeof(int);
   static bool attr_set = false;
-  auto kern = gconv2_kernel<BM, BN, WGM, WGN, NMAJOR>;
+  auto kern = gconv2_kernel<BM, BN, WGM, WGN, NMAJOR, SUB>;
   if (!attr_set) {
     DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
@@ -359,6 +402,8 @@ void debug_set_gconv2_tile(int code) { g2_tile_override = code; }
 template <bool NMAJOR>
 static int dispatch2(const GConv2Params& p, hipStream_t s) {
   const int N = p.Cout;
+  if (p.Cin == 8) return N <= 16 ? launch2_cfg<128, 16, 4, 1, NMAJOR, 4>(p, s) : launch2_cfg<128, 32, 4, 1, NMAJOR, 4>(p, s);
+  if (p.Cin == 16) return N <= 16 ? launch2_cfg<128, 16, 4, 1, NMAJOR, 2>(p, s) : launch2_cfg<128, 32, 4, 1, NMAJOR, 2>(p, s);
   long Mtot = 0;
   for (int c = 0; c < p.nclass; ++c) Mtot += p.cls[c].M;
   switch (g2_tile_override) {
@@ -433,7 +478,8 @@ int launch_gconv2(const GConv2Params& p0, hipStream_t s) {
   p.dbg = g2_dbg;
   p.dbg_out = g2_dbg_out;
   p.prio = g2_prio;
-  if (p.nclass < 1 || p.nclass > 4 || (p.Cin % BK2) || (p.Cout & 3)) {
+  const bool small_cin = (p.Cin == 8 || p.Cin == 16) && p.Cout <= 32 && p.ksplit <= 1;
+  if (p.nclass < 1 || p.nclass > 4 || ((p.Cin % BK2) && !small_cin) || (p.Cout & 3)) {
     set_error("gconv2: unsupported shape (Cin=%d Cout=%d nclass=%d)", p.Cin, p.Cout, p.nclass);
     return E_INVALID;
   }

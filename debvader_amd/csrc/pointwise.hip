@@ -371,12 +371,13 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
     const int oh = rem / p.Hd, ow = rem - oh * p.Hd;
     const int h = oh - p.crop0, w = ow - p.crop0;
     const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.H;
-    const int nb2 = 2 * p.nb;
-    const float* tp = p.tpre + pp * nb2;
-    float* dtp = p.dt ? p.dt + pp * nb2 : nullptr;
+    const float* tp = p.tpre + pp * p.ld;
+    float* dtp = p.dt ? p.dt + pp * p.ld : nullptr;
+    if (dtp)
+      for (int c = 2 * p.nb; c < p.ld; ++c) dtp[c] = 0.f;
     if (!in) {
       if (dtp)
-        for (int c = 0; c < nb2; ++c) dtp[c] = 0.f;
+        for (int c = 0; c < 2 * p.nb; ++c) dtp[c] = 0.f;
     } else {
       const long opix = ((long)b * p.H + h) * p.H + w;
       const float* yp = nullptr;
@@ -429,8 +430,9 @@ __global__ __launch_bounds__(256) void head6_kernel(const HeadParams p) {
     const int oh = rem / p.Hd, ow = rem - oh * p.Hd;
     const int h = oh - p.crop0, w = ow - p.crop0;
     const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.H;
-    f32x4* dtp = p.dt ? reinterpret_cast<f32x4*>(p.dt + pp * 12) : nullptr;
+    f32x4* dtp = p.dt ? reinterpret_cast<f32x4*>(p.dt + pp * p.ld) : nullptr;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    if (dtp && p.ld == 16) dtp[3] = z4;                 // pad channels 12..15 of the 16-wide rows
     if (!in) {
       if (dtp) {
         dtp[0] = z4;
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void head6_kernel(const HeadParams p) {
         dtp[2] = z4;
       }
     } else {
-      const f32x4* tp = reinterpret_cast<const f32x4*>(p.tpre + pp * 12);
+      const f32x4* tp = reinterpret_cast<const f32x4*>(p.tpre + pp * p.ld);
       const f32x4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
       const float t[12] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3]};
       const long opix = ((long)b * p.H + h) * p.H + w;
@@ -501,7 +503,11 @@ int launch_head(const HeadParams& p, hipStream_t s, int* nblocks_out) {
   int nb = (int)((total + 255) / 256);
   if (nblocks_out) *nblocks_out = nb;
   if (nb == 0) return OK;
-  if (p.nb == 6)
+  if (p.ld < 2 * p.nb || (p.ld & 3)) {
+    set_error("head: bad row stride");
+    return E_INVALID;
+  }
+  if (p.nb == 6 && (p.ld == 12 || p.ld == 16))
     hipLaunchKernelGGL(head6_kernel, dim3(nb), dim3(256), 0, s, p);
   else
     hipLaunchKernelGGL(head_kernel, dim3(nb), dim3(256), 0, s, p);
@@ -746,6 +752,33 @@ int launch_bn_conv0_grads(const float* G, const float* w, const float* gamma, co
                           float* dgamma, float* dbeta, int taps, int cin, int cpad, int cout, hipStream_t s) {
   hipLaunchKernelGGL(bn_conv0_grads_kernel, dim3(1), dim3(256), 0, s, G, w, gamma, beta, dW, dgamma, dbeta, taps, cin,
                      cpad, cout);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// head conv kernel/bias padded from 2*bands to a multiple of 16 output channels (zeros), so that its output and the
+// loss gradient are 16-channel rows the 32-wide-K gather-GEMM can consume
+__global__ void pad_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int nsrc, int ndst) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * ndst) return;
+  int r = i / ndst, c = i - r * ndst;
+  dst[i] = c < nsrc ? src[r * nsrc + c] : 0.f;
+}
+int launch_pad_cols(const float* src, float* dst, int rows, int nsrc, int ndst, hipStream_t s) {
+  int total = rows * ndst;
+  hipLaunchKernelGGL(pad_cols_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, rows, nsrc, ndst);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+__global__ void take_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int nsrc, int ndst) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * ndst) return;
+  int r = i / ndst, c = i - r * ndst;
+  dst[i] = src[r * nsrc + c];
+}
+int launch_take_cols(const float* src, float* dst, int rows, int nsrc, int ndst, hipStream_t s) {
+  int total = rows * ndst;
+  hipLaunchKernelGGL(take_cols_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, rows, nsrc, ndst);
   DV_HIP(hipGetLastError());
   return OK;
 }
