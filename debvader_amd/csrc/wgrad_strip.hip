@@ -242,6 +242,169 @@ __global__ __launch_bounds__(256, 1) void wgrad_strip_kernel(const WStripParams 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// First-layer variant: Cx = 8 (6 bands + the BN "ones" channel + 1 pad), Cy = 32, stride 1.  dW rows are
+// (tap, cx) = 72 -> five 16-row MFMA blocks, each spanning two taps (lanes 0-7 / 8-15); tap 9 does not exist and
+// contributes zeros.  Four waves split the pixels of a strip; the partial tiles are summed through LDS.
+__global__ __launch_bounds__(256, 1) void wgrad_strip8_kernel(const WStripParams p) {
+  constexpr int CX = 8, CY = 32, CX4 = 2, CY4 = 8, WKS = 4, MB = 5, NBK = 2;
+  constexpr int MAXGX = 8, MAXGY = 12;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int XC = p.Wy + 2;
+  const int buf_floats = p.xs_floats + p.ys_floats;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  f32x4 acc[MB][NBK];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int strip_px = p.R * p.Wy;
+  const int ksteps = (strip_px + 3) / 4;
+  const int kpw = (ksteps + WKS - 1) / WKS;
+  const int ks0 = wk * kpw, ks1 = min(ksteps, ks0 + kpw);
+
+  // per-lane tap offsets of the five row blocks (floats inside the patch), -1: no such tap
+  int toff[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int tap = 2 * mb + (l15 >> 3);
+    toff[mb] = tap < 9 ? ((tap / 3) * XC + (tap % 3)) * CX + (l15 & 7) : -1;
+  }
+
+  const int xtot = p.XR * XC * CX4;
+  const int ngx = (xtot + 63) / 64, ngy = (strip_px * CY4 + 63) / 64;
+  int xrel[MAXGX], xrow[MAXGX];
+#pragma unroll
+  for (int k = 0; k < MAXGX; ++k) {
+    const int e = 64 * (wave + 4 * k) + lane;
+    const int px = e / CX4, c4 = e - px * CX4;
+    const int xr = px / XC, xc = px - xr * XC;
+    const int gc = xc - p.pb;
+    const bool ok = e < xtot && (unsigned)gc < (unsigned)p.Wx;
+    xrel[k] = (xr * p.Wx + gc) * CX + c4 * 4;
+    xrow[k] = ok ? xr : -100000;
+  }
+  auto issue_dma = [&](int sidx, int buf) {
+    const int n = sidx / p.strips_per_stamp;
+    const int i0 = (sidx - n * p.strips_per_stamp) * p.R;
+    const int gr0 = i0 - p.pb;
+    const int xbase = (n * p.Hx + gr0) * p.Wx * CX;
+    float* xs = smem + buf * buf_floats;
+    float* ys = xs + p.xs_floats;
+#pragma unroll
+    for (int k = 0; k < MAXGX; ++k) {
+      const int g = wave + 4 * k;
+      if (g < ngx) {
+        const bool ok = (unsigned)(gr0 + xrow[k]) < (unsigned)p.Hx;
+        const float* src = ok ? p.X + (unsigned)(xbase + xrel[k]) : p.zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + g * 256), 16, 0, 0);
+      }
+    }
+    const unsigned ybase = (unsigned)((n * p.Hy + i0) * p.Wy) * CY;
+    const int yvalid4 = min(p.R, p.Hy - i0) * p.Wy * CY4;
+#pragma unroll
+    for (int k = 0; k < MAXGY; ++k) {
+      const int g = wave + 4 * k;
+      if (g < ngy) {
+        const int e = 64 * g + lane;
+        const float* src = e < yvalid4 ? p.Y + ybase + (unsigned)(e * 4) : p.zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + g * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  const int s_begin = blockIdx.x * p.strips_per_wg;
+  const int s_end = min(p.nstrips, s_begin + p.strips_per_wg);
+  if (s_begin < s_end) issue_dma(s_begin, 0);
+  int buf = 0;
+  for (int sidx = s_begin; sidx < s_end; ++sidx) {
+    __syncthreads();
+    if (sidx + 1 < s_end) issue_dma(sidx + 1, buf ^ 1);
+    const float* Xs = smem + buf * buf_floats;
+    const float* Ys = Xs + p.xs_floats;
+    int q = 4 * ks0 + lg;
+    int pr = q / p.Wy, pj = q - pr * p.Wy;
+    for (int ks = ks0; ks < ks1; ++ks) {
+      const bool qv = q < strip_px;
+      const int base = qv ? (pr * XC + pj) * CX : 0;
+      const float msk = qv ? 1.f : 0.f;
+      float bf[NBK], af[MB];
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) bf[nb] = Ys[(qv ? q : 0) * CY + nb * 16 + l15] * msk;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) af[mb] = Xs[base + max(toff[mb], 0)] * (toff[mb] >= 0 ? 1.f : 0.f);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bf[nb], acc[mb][nb], 0, 0, 0);
+      q += 4;
+      pj += 4;
+      const int wrap = pj >= p.Wy ? 1 : 0;
+      pj -= wrap ? p.Wy : 0;
+      pr += wrap;
+    }
+    buf ^= 1;
+  }
+  __syncthreads();
+  // sum the four pixel-split copies through LDS: T[wk][80][32]
+  float* T = smem;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(wk * 80 + mb * 16 + lg * 4 + r) * CY + nb * 16 + l15] = acc[mb][nb][r];
+  __syncthreads();
+  float* slab = p.part + (size_t)blockIdx.x * (9 * CX) * CY;
+  for (int e = tid; e < 72 * CY; e += 256) {
+    float v = T[e];
+#pragma unroll
+    for (int k = 1; k < WKS; ++k) v += T[k * 80 * CY + e];
+    slab[e] = v;
+  }
+}
+
+static int launch_strip8(WStripParams p, hipStream_t s, int* nsplit_out) {
+  const int XC = p.Wy + 2;
+  auto xfl = [&](int r) { return (((size_t)(r + 2) * XC * 2 + 63) / 64) * 256; };
+  auto yfl = [&](int r) { return (((size_t)r * p.Wy * 8 + 63) / 64) * 256; };
+  auto fits = [&](int r) {
+    return 2 * (xfl(r) + yfl(r)) * sizeof(float) <= 128 * 1024 && xfl(r) / 256 <= 4 * 8 && yfl(r) / 256 <= 4 * 12;
+  };
+  if (p.Wy < 4 || !fits(1)) {
+    set_error("wgrad_strip8: unsupported image width");
+    return E_INVALID;
+  }
+  int R = 1;
+  while (R < p.Hy && R < 8 && fits(R + 1)) ++R;
+  p.R = R;
+  p.XR = R + 2;
+  p.xs_floats = (int)xfl(R);
+  p.ys_floats = (int)yfl(R);
+  p.strips_per_stamp = (p.Hy + R - 1) / R;
+  p.nstrips = p.NB * p.strips_per_stamp;
+  int wgs = std::min(p.nstrips, 256);
+  wgs = std::max(1, std::min(wgs, (int)(p.part_capacity / ((size_t)72 * 32))));
+  p.strips_per_wg = (p.nstrips + wgs - 1) / wgs;
+  wgs = (p.nstrips + p.strips_per_wg - 1) / p.strips_per_wg;
+  const size_t smem = std::max((size_t)2 * (p.xs_floats + p.ys_floats), (size_t)4 * 80 * 32) * sizeof(float);
+  static size_t attr = 0;
+  if (smem > attr) {
+    DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_strip8_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = smem;
+  }
+  hipLaunchKernelGGL(wgrad_strip8_kernel, dim3(wgs), dim3(256), smem, s, p);
+  DV_HIP(hipGetLastError());
+  *nsplit_out = wgs;
+  return OK;
+}
+
 template <int CX, int CY, int SX, int WMS, int WNS, int WKS>
 static int launch_strip_cfg(WStripParams p, hipStream_t s, int* nsplit_out) {
   constexpr int CX4 = CX / 4, CY4 = CY / 4;
@@ -290,6 +453,7 @@ static int launch_strip_cfg(WStripParams p, hipStream_t s, int* nsplit_out) {
 
 bool wgrad_strip_supported(int Cx, int Cy, int sx, int ntaps) {
   if (ntaps != 9 || (sx != 1 && sx != 2)) return false;
+  if (Cx == 8 && Cy == 32 && sx == 1) return true;
   return (Cx == 32 && (Cy == 32 || Cy == 64 || Cy == 12 || Cy == 16)) || (Cx == 64 && Cy == 64);
 }
 
@@ -299,6 +463,13 @@ void debug_set_strip(int v) { g_strip_dbg = v; }
 int launch_wgrad_strip(const WStripParams& p0, int Cx, int Cy, int sx, hipStream_t s, int* nsplit_out) {
   WStripParams p = p0;
   p.dbg = g_strip_dbg;
+  if (Cx == 8 && Cy == 32 && sx == 1) {
+    if (p.pb != 1 || p.Hx != p.Hy) {
+      set_error("wgrad_strip8: expects a stride-1 SAME 3x3 layer");
+      return E_INVALID;
+    }
+    return launch_strip8(p, s, nsplit_out);
+  }
   if ((long)p.NB * p.Hx * p.Wx * Cx >= (1L << 30) || (long)p.NB * p.Hy * p.Wy * Cy >= (1L << 30)) {
     set_error("wgrad_strip: tensor too large for 32-bit offsets");
     return E_INVALID;
