@@ -294,7 +294,7 @@ struct dv_ctx {
   hipStream_t comm_stream = nullptr;   // gradient all-reduce runs here, overlapped with the encoder backward
   hipStream_t aux_stream = nullptr;    // weight-gradient kernels run here, beside the data-gradient chain
   hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_buf[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_dec = nullptr, ev_enc = nullptr, ev_comm = nullptr;
+  hipEvent_t ev_dec = nullptr, ev_enc = nullptr, ev_comm = nullptr, ev_small = nullptr, ev_small2 = nullptr;
   ncclComm_t comm = nullptr;
   float* red_dev = nullptr;  // small device buffer for host all-reduce
 };
@@ -410,6 +410,18 @@ static int prof_flush(dv_model* m) {
 }
 
 static bool g_force_v1 = false;  // tuning aid: route everything through the first-generation kernel
+
+// Every collective of a context is issued on ONE stream (comm_stream), the usual single-stream-per-communicator
+// pattern; the main stream hands data over and takes it back through events.
+static int allreduce_small(dv_ctx* c, float* buf, size_t n) {
+  if (!c->comm) return OK;
+  DV_HIP(hipEventRecord(c->ev_small, c->stream));
+  DV_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_small, 0));
+  DV_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, c->comm, c->comm_stream));
+  DV_HIP(hipEventRecord(c->ev_small2, c->comm_stream));
+  DV_HIP(hipStreamWaitEvent(c->stream, c->ev_small2, 0));
+  return OK;
+}
 
 // ---- layer launch helpers ---------------------------------------------------------------------
 static void fill_gconv_common(GConvParams& p, const Taps& t, int cin) {
@@ -697,7 +709,7 @@ static int prelu_bwd(dv_model* m, float* da, const float* u, int alpha_spec, int
 
 static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int ncols_out, int bias_spec) {
   int nr = 0;
-  if ((size_t)((rows + 2047) / 2048) * C > m->ws3_elems) {
+  if ((size_t)(std::max<long>((rows + 2047) / 2048, 64) + 1) * C > m->ws3_elems) {
     set_error("colsum workspace too small");
     return E_STATE;
   }
@@ -731,7 +743,7 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
     ProfScope ps(m, 2);
     DV_TRY(launch_bn_stats(xsrc, idx, first, NB, HW, A.C, m->ws3, &nblk, s));
     DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 16, m->bnsums, 1.0f, s));
-    if (m->ctx->world > 1) DV_NCCL(ncclAllReduce(m->bnsums, m->bnsums, 16, ncclFloat, ncclSum, m->ctx->comm, s));
+    DV_TRY(allreduce_small(m->ctx, m->bnsums, 16));
   }
   {
     ProfScope ps(m, 2);
@@ -949,7 +961,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   advance();
   DV_TRY(prelu_bwd(m, cur, m->z, A.D0, -1, NB, A.d, A.d, dg));
   // every decoder gradient is final here: all-reduce that bucket on the comm stream while the encoder backward runs
-  if (m->ctx->world > 1 && dg && A.n_train > A.n_enc_train) {
+  if (m->ctx->comm && dg && A.n_train > A.n_enc_train) {
     DV_HIP(hipEventRecord(m->ctx->ev_dec, s));
     DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, m->ctx->ev_dec, 0));
     if (ovl) {                                       // ... and the decoder weight gradients on the aux stream
@@ -1076,10 +1088,10 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   DV_TRY(sampler_forward(m, B, eps_host, seed, (unsigned)m->ctx->rank, 0u, false));
   DV_TRY(decoder_forward(m, m->z, B, bwd));
   DV_TRY(head_and_loss(m, ds.y, idx, (int)first, B, Bg, bwd, true));
-  if (m->ctx->world > 1) DV_NCCL(ncclAllReduce(m->scal, m->scal, 4, ncclFloat, ncclSum, m->ctx->comm, s));
+  DV_TRY(allreduce_small(m->ctx, m->scal, 4));
   if (bwd) {
     DV_TRY(backward(m, B, Bg, ds.x, idx, (int)first));
-    if (m->ctx->world > 1) {
+    if (m->ctx->comm) {
       // encoder bucket (the decoder bucket was queued inside backward()); the optimizer waits for both
       DV_HIP(hipEventRecord(m->ctx->ev_enc, s));
       DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, m->ctx->ev_enc, 0));
@@ -1262,7 +1274,16 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
   DV_HIP(hipEventCreateWithFlags(&c->ev_dec, hipEventDisableTiming));
   DV_HIP(hipEventCreateWithFlags(&c->ev_enc, hipEventDisableTiming));
   DV_HIP(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_small, hipEventDisableTiming));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_small2, hipEventDisableTiming));
   DV_HIP(hipMalloc((void**)&c->red_dev, 4096 * sizeof(float)));
+  if (world == 1 && getenv("DV_FORCE_COMM")) {
+    // test hook: a one-rank communicator, so that the collective code paths (streams, events, in-place all-reduces)
+    // run on a single-GPU box; results must equal the communicator-free path bit for bit
+    ncclUniqueId id;
+    DV_NCCL(ncclGetUniqueId(&id));
+    DV_NCCL(ncclCommInitRank(&c->comm, 1, id, 0));
+  }
   if (world > 1) {
     if (!unique_id) {
       set_error("world > 1 needs rank 0's unique id");
@@ -1285,6 +1306,8 @@ int dv_ctx_destroy(dv_ctx* c) {
   if (c->ev_dec) (void)hipEventDestroy(c->ev_dec);
   if (c->ev_enc) (void)hipEventDestroy(c->ev_enc);
   if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+  if (c->ev_small) (void)hipEventDestroy(c->ev_small);
+  if (c->ev_small2) (void)hipEventDestroy(c->ev_small2);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < 3; ++i)
@@ -1304,9 +1327,9 @@ int dv_ctx_sync(dv_ctx* c) {
 
 int dv_ctx_allreduce_host(dv_ctx* c, float* buf, int32_t n) {
   if (!c || !buf || n < 0 || n > 4096) return DV_E_INVALID;
-  if (c->world == 1 || n == 0) return DV_OK;
+  if (!c->comm || n == 0) return DV_OK;
   DV_HIP(hipMemcpyAsync(c->red_dev, buf, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  DV_NCCL(ncclAllReduce(c->red_dev, c->red_dev, n, ncclFloat, ncclSum, c->comm, c->stream));
+  DV_TRY(allreduce_small(c, c->red_dev, (size_t)n));
   DV_HIP(hipMemcpyAsync(buf, c->red_dev, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   DV_HIP(hipStreamSynchronize(c->stream));
   return DV_OK;

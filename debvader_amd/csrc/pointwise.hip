@@ -4,6 +4,8 @@
 // legacy-Adam update (train.py:125-130).  All are written for 64-lane wavefronts: reductions go through
 // __shfl_down across the full wave, then LDS across the 4 waves of a block, then a per-block partial that a
 // final double-precision pass sums in a fixed order (bit-reproducible, no float atomics).
+#include <algorithm>
+
 #include "common.h"
 
 namespace dv {
@@ -324,15 +326,15 @@ int launch_prelu_bwd(float* da, const float* u, const float* alpha, int NB, int 
 // column sums of x[rows][C] (C multiple of 4, C/4 <= 256) -> part[block][C]
 constexpr int COLSUM_ROWS = 2048;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long rows, int C,
-                                                     float* __restrict__ part) {
+                                                     float* __restrict__ part, int rows_per_block) {
   __shared__ f32x4 shv[256];
   const int cq = C / 4;
   const int rpb = 256 / cq;
   const int t = threadIdx.x;
   const int q = t % cq, rr = t / cq;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const long r0 = (long)blockIdx.x * COLSUM_ROWS;
-  const long r1 = min(rows, r0 + COLSUM_ROWS);
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(rows, r0 + rows_per_block);
   if (rr < rpb)
     for (long r = r0 + rr; r < r1; r += rpb) acc += *reinterpret_cast<const f32x4*>(x + r * C + q * 4);
   shv[t] = acc;
@@ -349,9 +351,11 @@ int launch_colsum(const float* x, long rows, int C, float* part, int* nrows_part
     set_error("colsum: unsupported C=%d", C);
     return E_INVALID;
   }
-  int nb = (int)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
+  // at least ~64 blocks for short matrices (the 256 x 560 encoder-dense bias gradient used to run in one block)
+  int rpb = (int)std::min<long>(COLSUM_ROWS, std::max<long>(4, (rows + 63) / 64));
+  int nb = (int)((rows + rpb - 1) / rpb);
   *nrows_part = nb;
-  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, s, x, rows, C, part);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, s, x, rows, C, part, rpb);
   DV_HIP(hipGetLastError());
   return OK;
 }

@@ -143,3 +143,37 @@ def test_train_steps_queue_matches_stepwise():
         eng.close()
     assert outs[0][0] == outs[1][0]
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+def test_collective_code_path_with_one_rank_communicator():
+    """DV_FORCE_COMM builds a 1-rank RCCL communicator so the multi-GPU code path (comm stream, events, in-place
+    all-reduces of BN sums / loss sums / both gradient buckets) executes on this single-GPU box; it must not
+    change a single bit of the update."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from debvader_amd import engine as E
+from debvader_amd.data import synthetic_stamps
+x, y = synthetic_stamps(16, seed=3)
+eng = E.Engine(E.make_config(max_batch=8))
+eng.init(seed=4); eng.optimizer_reset(1e-4); eng.upload(0, x, y)
+out = eng.train_steps(0, 0, 8, 3, seed=7)
+w = eng.get_param("dec/convt5/kernel"); v = eng.get_param("enc/conv0/kernel")
+print(repr(out["loss"]), float(np.abs(w).sum()), float(np.abs(v).sum()), float(eng.ctx.allreduce([1.5, 2.5]).sum()))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for force in ("", "1"):
+        env = dict(os.environ)
+        env.pop("DV_FORCE_COMM", None)
+        if force:
+            env["DV_FORCE_COMM"] = "1"
+        r = subprocess.run([sys.executable, "-c", code % root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1], outs
+    assert outs[0].endswith(" 4.0")
