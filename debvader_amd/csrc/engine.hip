@@ -591,13 +591,17 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
     sp.X = X; sp.Y = Y; sp.part = m->ws1; sp.part_capacity = m->ws1_elems;
     sp.NB = NB; sp.Hx = sp.Wx = Hx; sp.Hy = sp.Wy = Hy; sp.pb = pb;
     sp.zero = m->zero_page;
-    int ns = 0;
+    int ns = 0, st;
     {
       ProfScope ps(m, 1, ws);
-      DV_TRY(launch_wgrad_strip(sp, Cx, Cy, sx, ws, &ns));
+      st = launch_wgrad_strip(sp, Cx, Cy, sx, ws, &ns);
     }
-    ProfScope ps(m, 2, ws);
-    return launch_reduce_partials(m->ws1, out, ns, (long)9 * Cx * Cy, Cy, cpad, creal, ws);
+    if (st < 0) return st;
+    if (st == 0) {
+      ProfScope ps(m, 2, ws);
+      return launch_reduce_partials(m->ws1, out, ns, (long)9 * Cx * Cy, Cy, cpad, creal, ws);
+    }
+    // st > 0: the strip form does not fit this geometry (very wide rows): use the tiled kernel below
   }
   WGradParams p;
   memset(&p, 0, sizeof p);
@@ -625,7 +629,8 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   p.rows_total = t.n * Cx;
   long slab = (long)p.rows_total * Cy;
   long tiles = ((p.rows_total + 127) / 128) * (long)((Cy + 127) / 128);
-  long ns = (768 + tiles - 1) / tiles;
+  static const long target = getenv("DV_WGRAD_TARGET") ? atol(getenv("DV_WGRAD_TARGET")) : 768;
+  long ns = (target + tiles - 1) / tiles;
   ns = std::min(ns, (long)std::max(1, p.P / 256));
   ns = std::min(ns, 256L);
   ns = std::min(ns, (long)(m->ws1_elems / (size_t)slab));

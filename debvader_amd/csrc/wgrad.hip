@@ -6,6 +6,8 @@
 // of Dense (one tap, 1x1 grid; model.py:96-98,114,117).  The reduction dimension (pixels) is the long one,
 // so every workgroup owns one (row tile, column tile) of dW for a contiguous pixel range and writes
 // a partial slab; reduce_partials() sums the slabs in a fixed order, which keeps results bit-reproducible.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dv {
@@ -183,6 +185,10 @@ int launch_wgrad(const WGradParams& p, hipStream_t s) {
     return E_INVALID;
   }
   const int rows = p.ntaps * p.Cx;
+  static const int force = getenv("DV_WGRAD_TILE") ? atoi(getenv("DV_WGRAD_TILE")) : 0;
+  if (force == 1 && p.Cy >= 128) return launch_w<64, 128, 2, 2>(p, s);
+  if (force == 2 && p.Cy >= 64) return launch_w<128, 64, 2, 2>(p, s);
+  if (force == 3 && p.Cy >= 64) return launch_w<64, 64, 2, 2>(p, s);
   if (p.Cy <= 16) return launch_w<128, 16, 4, 1>(p, s);
   if (p.Cy <= 32) return rows <= 32 ? launch_w<32, 32, 2, 2>(p, s) : launch_w<64, 32, 4, 1>(p, s);
   if (p.Cy <= 64) return rows <= 64 ? launch_w<64, 64, 2, 2>(p, s) : launch_w<128, 64, 2, 2>(p, s);

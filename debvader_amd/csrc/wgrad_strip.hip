@@ -376,10 +376,7 @@ static int launch_strip8(WStripParams p, hipStream_t s, int* nsplit_out) {
   auto fits = [&](int r) {
     return 2 * (xfl(r) + yfl(r)) * sizeof(float) <= 128 * 1024 && xfl(r) / 256 <= 4 * 8 && yfl(r) / 256 <= 4 * 12;
   };
-  if (p.Wy < 4 || !fits(1)) {
-    set_error("wgrad_strip8: unsupported image width");
-    return E_INVALID;
-  }
+  if (p.Wy < 4 || !fits(1)) return 1;   // fall back to wgrad_kernel
   int R = 1;
   while (R < p.Hy && R < 8 && fits(R + 1)) ++R;
   p.R = R;
@@ -415,14 +412,7 @@ static int launch_strip_cfg(WStripParams p, hipStream_t s, int* nsplit_out) {
     return 2 * (xfl(r) + yfl(r)) * sizeof(float) <= 128 * 1024 && xfl(r) / 256 <= 4 * 12 && yfl(r) / 256 <= 4 * 8;
   };
   int R = 1;
-  if (p.Wy < 4) {
-    set_error("wgrad_strip: rows narrower than 4 pixels are not supported");
-    return E_INVALID;
-  }
-  if (!fits(1)) {
-    set_error("wgrad_strip: image row too wide for the LDS strip buffers");
-    return E_INVALID;
-  }
+  if (p.Wy < 4 || !fits(1)) return 1;   // geometry does not fit the strip buffers: caller falls back to wgrad_kernel
   while (R < p.Hy && R < 8 && fits(R + 1)) ++R;
   p.R = R;
   p.XR = (R - 1) * SX + 3;
@@ -464,10 +454,7 @@ int launch_wgrad_strip(const WStripParams& p0, int Cx, int Cy, int sx, hipStream
   WStripParams p = p0;
   p.dbg = g_strip_dbg;
   if (Cx == 8 && Cy == 32 && sx == 1) {
-    if (p.pb != 1 || p.Hx != p.Hy) {
-      set_error("wgrad_strip8: expects a stride-1 SAME 3x3 layer");
-      return E_INVALID;
-    }
+    if (p.pb != 1 || p.Hx != p.Hy) return 1;
     return launch_strip8(p, s, nsplit_out);
   }
   if ((long)p.NB * p.Hx * p.Wx * Cx >= (1L << 30) || (long)p.NB * p.Hy * p.Wy * Cy >= (1L << 30)) {

@@ -128,6 +128,14 @@ def test_full_arch_parity_b4():
     _run_parity(vo.Arch(), B=4, seed=2, data=(x, y))
 
 
+def test_deeper_128px_arch_parity():
+    # BASELINE configs[3] shape: 128x128x6 stamps, 6 levels (filters as in SURVEY 8(d)): exercises 512-channel
+    # layers, no crop (128 = 2^7), wide rows (strip kernels must fit or fall back)
+    arch = vo.Arch(input_shape=(128, 128, 6), latent_dim=32, filters=(32, 64, 128, 256, 512, 512), kernels=(3,) * 6)
+    assert arch.crop == (0, 0) and arch.flat == 2 * 2 * 512
+    _run_parity(arch, B=2, seed=21)
+
+
 def test_inference_matches_oracle_and_is_stochastic():
     arch = small_arch()
     p, x, y, eps = _case(arch, 6, seed=9)
