@@ -90,6 +90,11 @@ struct GConv2Params {
   int w_nmajor;
   int epi;
   int ksplit;          // >1: grid.y K slices, raw partial slabs [ksplit][M][N] written to U
+  int batch_major;     // tiles walk (pixel, stamp) instead of (stamp, pixel)
+  const float* Uin;    // epi 3: pre-activation of the layer whose output gradient this launch produces
+  float* dal_part;     // epi 3: d(alpha) partial slots [slots][alpha_elems] (may be null: no parameter gradients)
+  float* db_part;      // epi 3: d(bias) partial rows [m tiles * WGM][Cout] (may be null)
+  long alpha_elems;    // Hout*Wout*Cout
   int dbg;             // timing build: phase stamps
   float* dbg_out;
   int prio;            // s_setprio level of the load-issue / LDS-store phases
@@ -99,6 +104,8 @@ void debug_set_gconv2_prio(int v);
 int launch_splitk_finish(const float* slabs, int ksplit, long total, int N, const float* bias, const float* alpha,
                          long alpha_per_stamp, float* U, float* A, hipStream_t s);
 int launch_gconv2(const GConv2Params& p, hipStream_t s);
+// tile geometry the dispatcher will pick (for sizing the epi-3 partial buffers): BM rows, WGM waves along M
+void gconv2_tile_geometry(const GConv2Params& p, int* bm, int* wgm, long* mtiles);
 void debug_set_gconv2_tile(int code);
 
 // ---------------------------------------------------------------------------------------------

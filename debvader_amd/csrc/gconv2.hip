@@ -80,8 +80,10 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     int in_off = 0, mask = 0, out_off = -1, al_off = 0;
     if (m < cl.M) {
       const int HcWc = cl.Hc * cl.Wc;
-      const int nb = m / HcWc;
-      const int rem = m - nb * HcWc;
+      // row-major tiles walk (stamp, pixel); batch-major tiles walk (pixel, stamp): all rows of a tile then share
+      // one output pixel, which lets the epilogue reduce d(alpha) / d(bias) over the stamps of the tile
+      const int nb = p.batch_major ? m % p.NB : m / HcWc;
+      const int rem = p.batch_major ? m / p.NB : m - nb * HcWc;
       const int ii = rem / cl.Wc;
       const int jj = rem - ii * cl.Wc;
       const int ih0 = ii * p.sin, iw0 = jj * p.sin;
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
   constexpr int F4_PER_ROW = WN / 4;
   constexpr int ROWS_PER_IT = 64 / F4_PER_ROW;
   constexpr int TM_PER_PASS = STG_ROWS / 16;
+  f32x4 pdal = {0.f, 0.f, 0.f, 0.f}, pdb = {0.f, 0.f, 0.f, 0.f};   // epi 3: this lane's partial sums over its rows
 #pragma unroll
   for (int pass = 0; pass < (TM + TM_PER_PASS - 1) / TM_PER_PASS; ++pass) {
 #pragma unroll
@@ -358,6 +361,22 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
       const int ooff = s_out[row];
       if (ooff < 0 || col >= p.Cout) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * LDC + f4 * 4);
+      if (p.epi == 3) {
+        // fused PReLU backward of the layer that produced this tensor: v is d(activation); write
+        // d(pre-activation) = v * (u > 0 ? 1 : alpha) and accumulate the parameter-gradient partials
+        const f32x4 uu = *reinterpret_cast<const f32x4*>(p.Uin + (unsigned)ooff + col);
+        const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + (unsigned)s_al[row] + col);
+        f32x4 d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool pos = uu[k] > 0.f;
+          d[k] = pos ? v[k] : v[k] * al[k];
+          pdal[k] += pos ? 0.f : v[k] * uu[k];
+          pdb[k] += d[k];
+        }
+        *reinterpret_cast<f32x4*>(Uout + (unsigned)ooff + col) = d;
+        continue;
+      }
       if (p.epi >= 1) v += *reinterpret_cast<const f32x4*>(p.bias + col);
       if (Uout) *reinterpret_cast<f32x4*>(Uout + (unsigned)ooff + col) = v;
       if (p.epi == 2) {
@@ -369,6 +388,27 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (p.epi == 3 && p.dal_part) {
+    // lanes with the same column quad (lane % F4_PER_ROW) hold partial sums over different rows: butterfly them.
+    // Every row of the tile is the same output pixel (batch-major tiles), so the sums are that pixel's
+    // d(alpha) / d(bias) contributions of this wave's stamps; slots are summed later in a fixed order.
+#pragma unroll
+    for (int o = F4_PER_ROW; o < 64; o <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pdal[k] += __shfl_xor(pdal[k], o, 64);
+        pdb[k] += __shfl_xor(pdb[k], o, 64);
+      }
+    }
+    const int colq = n0 + wn0 + (lane % F4_PER_ROW) * 4;
+    if (lane < F4_PER_ROW && colq < p.Cout && m0 < cl.M) {
+      const int wmi = wave / WGN;
+      const int slot = ((m0 % p.NB) / BM) * WGM + wmi;
+      *reinterpret_cast<f32x4*>(p.dal_part + (size_t)slot * p.alpha_elems + (unsigned)s_al[0] + colq) = pdal;
+      if (p.db_part)
+        *reinterpret_cast<f32x4*>(p.db_part + ((size_t)(bid / ntn) * WGM + wmi) * p.Cout + colq) = pdb;
+    }
   }
 }
 
@@ -399,14 +439,44 @@ static int launch2_cfg(GConv2Params p, hipStream_t s) {
 static int g2_tile_override = -1;
 void debug_set_gconv2_tile(int code) { g2_tile_override = code; }
 
-template <bool NMAJOR>
-static int dispatch2(const GConv2Params& p, hipStream_t s) {
+// tile choice (code -> BM x BN, waves along M): 0 128x128 (2), 1 128x64 (2), 2 64x64 (2), 3 128x32 (4), 4 64x128 (2),
+// 5 128x16 (4), 6 256x32 (4), 7 256x16 (4)
+static int choose_tile(const GConv2Params& p) {
   const int N = p.Cout;
-  if (p.Cin == 8) return N <= 16 ? launch2_cfg<128, 16, 4, 1, NMAJOR, 4>(p, s) : launch2_cfg<128, 32, 4, 1, NMAJOR, 4>(p, s);
-  if (p.Cin == 16) return N <= 16 ? launch2_cfg<128, 16, 4, 1, NMAJOR, 2>(p, s) : launch2_cfg<128, 32, 4, 1, NMAJOR, 2>(p, s);
+  if (p.Cin == 8 || p.Cin == 16) return N <= 16 ? 5 : 3;
+  if (g2_tile_override >= 0 && g2_tile_override <= 7) return g2_tile_override;
   long Mtot = 0;
   for (int c = 0; c < p.nclass; ++c) Mtot += p.cls[c].M;
-  switch (g2_tile_override) {
+  if (N <= 16) return 5;
+  if (N <= 32) return 3;
+  if (N <= 64) return (Mtot + 127) / 128 >= 512 ? 1 : 2;
+  // aim for at least two resident workgroups per CU before growing the tile; parity-class launches have
+  // short K loops (1-4 taps), so they want twice as many, smaller tiles (measured per layer, tools/layer_bench.py)
+  const long want = p.nclass > 1 ? 1024 : 512;
+  const long t128 = ((Mtot + 127) / 128) * ((N + 127) / 128);
+  if (t128 >= want) return 0;
+  const long t12864 = ((Mtot + 127) / 128) * ((N + 63) / 64);
+  if (t12864 >= want) return 1;
+  return 2;
+}
+
+void gconv2_tile_geometry(const GConv2Params& p, int* bm, int* wgm, long* mtiles) {
+  static const int BMs[8] = {128, 128, 64, 128, 64, 128, 256, 256};
+  static const int WGMs[8] = {2, 2, 2, 4, 2, 4, 4, 4};
+  const int t = choose_tile(p);
+  *bm = BMs[t];
+  *wgm = WGMs[t];
+  long mt = 0;
+  for (int c = 0; c < p.nclass; ++c) mt += (p.cls[c].M + BMs[t] - 1) / BMs[t];
+  *mtiles = mt;
+}
+
+template <bool NMAJOR>
+static int dispatch2(const GConv2Params& p, hipStream_t s) {
+  const int t = choose_tile(p);
+  if (p.Cin == 8) return t == 5 ? launch2_cfg<128, 16, 4, 1, NMAJOR, 4>(p, s) : launch2_cfg<128, 32, 4, 1, NMAJOR, 4>(p, s);
+  if (p.Cin == 16) return t == 5 ? launch2_cfg<128, 16, 4, 1, NMAJOR, 2>(p, s) : launch2_cfg<128, 32, 4, 1, NMAJOR, 2>(p, s);
+  switch (t) {
     case 0: return launch2_cfg<128, 128, 2, 2, NMAJOR>(p, s);
     case 1: return launch2_cfg<128, 64, 2, 2, NMAJOR>(p, s);
     case 2: return launch2_cfg<64, 64, 2, 2, NMAJOR>(p, s);
@@ -414,23 +484,8 @@ static int dispatch2(const GConv2Params& p, hipStream_t s) {
     case 4: return launch2_cfg<64, 128, 2, 2, NMAJOR>(p, s);
     case 5: return launch2_cfg<128, 16, 4, 1, NMAJOR>(p, s);
     case 6: return launch2_cfg<256, 32, 4, 1, NMAJOR>(p, s);
-    case 7: return launch2_cfg<256, 16, 4, 1, NMAJOR>(p, s);
-    default: break;
+    default: return launch2_cfg<256, 16, 4, 1, NMAJOR>(p, s);
   }
-  if (N <= 16) return launch2_cfg<128, 16, 4, 1, NMAJOR>(p, s);
-  if (N <= 32) return launch2_cfg<128, 32, 4, 1, NMAJOR>(p, s);
-  if (N <= 64) {
-    if ((Mtot + 127) / 128 >= 512) return launch2_cfg<128, 64, 2, 2, NMAJOR>(p, s);
-    return launch2_cfg<64, 64, 2, 2, NMAJOR>(p, s);
-  }
-  // aim for at least two resident workgroups per CU before growing the tile; parity-class launches have
-  // short K loops (1-4 taps), so they want twice as many, smaller tiles (measured per layer, tools/layer_bench.py)
-  const long want = p.nclass > 1 ? 1024 : 512;
-  const long t128 = ((Mtot + 127) / 128) * ((N + 127) / 128);
-  if (t128 >= want) return launch2_cfg<128, 128, 2, 2, NMAJOR>(p, s);
-  const long t12864 = ((Mtot + 127) / 128) * ((N + 63) / 64);
-  if (t12864 >= want) return launch2_cfg<128, 64, 2, 2, NMAJOR>(p, s);
-  return launch2_cfg<64, 64, 2, 2, NMAJOR>(p, s);
 }
 
 // out = sum_k slab[k] (+bias) -> U ; PReLU(alpha) -> A.  total4 = M*N/4 float4 elements, N4 = N/4.
@@ -490,6 +545,10 @@ int launch_gconv2(const GConv2Params& p0, hipStream_t s) {
   }
   if (p.epi == 2 && (!p.alpha || !p.A)) {
     set_error("gconv2: PReLU epilogue needs alpha and A");
+    return E_INVALID;
+  }
+  if (p.epi == 3 && (!p.batch_major || !p.Uin || !p.alpha || !p.U || p.ksplit > 1)) {
+    set_error("gconv2: the fused PReLU-backward epilogue needs batch-major tiles, u, alpha and an output");
     return E_INVALID;
   }
   if (p.ksplit > 1 && (p.nclass != 1 || p.epi != 0)) {
