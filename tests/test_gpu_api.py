@@ -167,13 +167,18 @@ print(repr(out["loss"]), float(np.abs(w).sum()), float(np.abs(v).sum()), float(e
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for force in ("", "1"):
+    for force in ("", "1", "fuse"):
         env = dict(os.environ)
         env.pop("DV_FORCE_COMM", None)
-        if force:
+        env.pop("DV_FUSE_PRELU_BWD", None)
+        if force == "1":
             env["DV_FORCE_COMM"] = "1"
+        if force == "fuse":      # opt-in fused PReLU-backward epilogue: same math, different summation order
+            env["DV_FUSE_PRELU_BWD"] = "1"
         r = subprocess.run([sys.executable, "-c", code % root], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1], outs
     assert outs[0].endswith(" 4.0")
+    a, b = [float(v) for v in outs[0].split()], [float(v) for v in outs[2].split()]
+    assert all(abs(x - y) <= 1e-4 * abs(x) for x, y in zip(a, b)), (outs[0], outs[2])
