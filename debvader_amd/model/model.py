@@ -164,7 +164,7 @@ class VAENet:
     def save_weights(self, filepath, overwrite=True, save_format=None):
         """Writes <filepath>.npz (parameters, Adam slots, iteration) and a `checkpoint` index file next to
         it, mirroring what ModelCheckpoint(save_weights_only=True) leaves on disk (train.py:54-71).
-        TF tensor-bundle output is not implemented yet (SURVEY 8(f) next #1)."""
+        Writing TF tensor-bundles is not implemented (a loadable Keras checkpoint also needs the object graph)."""
         eng = self._core.engine
         path = filepath if filepath.endswith(".npz") else filepath + ".npz"
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
@@ -179,15 +179,18 @@ class VAENet:
             f.write(f'model_checkpoint_path: "{os.path.basename(path)}"\n')
 
     def load_weights(self, filepath):
-        """Loads a checkpoint written by save_weights.  TF tensor-bundle checkpoints (the reference's
-        data/weights/<survey>/*.ckpt.index) are not readable yet (SURVEY 8(f) next #1)."""
+        """Loads a checkpoint written by save_weights (.npz) or a TensorFlow tensor-bundle checkpoint written by
+        the reference (`<prefix>.index` + `.data-*` shards; debvader_amd/model/tf_checkpoint.py)."""
         if filepath is None:
             raise FileNotFoundError("no checkpoint found (latest_checkpoint returned None)")
         path = filepath if filepath.endswith(".npz") else filepath + ".npz"
         if not os.path.exists(path):
             if os.path.exists(filepath + ".index"):
-                raise NotImplementedError("TensorFlow tensor-bundle checkpoints are not supported yet; "
-                                          "convert to the engine's .npz format")
+                # a TensorFlow tensor-bundle written by the reference (ModelCheckpoint / net.save_weights)
+                from debvader_amd.model import tf_checkpoint
+
+                tf_checkpoint.load_into_engine(self._core.engine, filepath, load_slots=True)
+                return self
             raise FileNotFoundError(path)
         eng = self._core.engine
         with np.load(path) as z:
@@ -357,7 +360,7 @@ def create_model_vae(input_shape, latent_dim, filters, kernels, conv_activation=
 
 
 def latest_checkpoint(directory):
-    """tf.train.latest_checkpoint for the engine's checkpoints: reads `<dir>/checkpoint`."""
+    """tf.train.latest_checkpoint: reads `<dir>/checkpoint` (same text format as TensorFlow's)."""
     f = os.path.join(directory, "checkpoint")
     if not os.path.exists(f):
         return None
@@ -369,7 +372,11 @@ def latest_checkpoint(directory):
 
 
 def weights_dir(survey):
-    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "weights", str(survey))
+    """data/weights/<survey> (model.py:262-263).  DEBVADER_WEIGHTS may point at another `weights` directory,
+    e.g. the reference package's src/debvader/data/weights with its TensorFlow checkpoints."""
+    root = os.environ.get("DEBVADER_WEIGHTS") or os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "weights")
+    return os.path.join(root, str(survey))
 
 
 def load_deblender(survey, input_shape, latent_dim, filters, kernels, return_encoder_decoder_z=False,
