@@ -335,6 +335,9 @@ struct dv_model {
   size_t arena_elems = 0, arena_off = 0;
   size_t ws4_elems = 0;
   hipStream_t wstream = nullptr;  // stream the weight-gradient kernels are queued on (aux or main)
+  hipStream_t cs = nullptr;       // stream of the forward lane being queued (null: main stream)
+  int b0 = 0;                     // first stamp of the forward lane being queued
+  bool split_forward = true;      // run the forward pass as two half-batch lanes on two streams (DV_NO_FWD_SPLIT)
   bool overlap_wgrad = true;
   bool no_fuse = true;        // DV_FUSE_PRELU_BWD=1 fuses the PReLU backward into the data-gradient epilogue (batch-major
                               // tiles); measured 3 % slower than the separate pass on MI355X (scattered 128-byte rows), so off
@@ -373,7 +376,8 @@ struct ProfScope {
   int klass;
   hipStream_t st;
   hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(dv_model* mm, int k, hipStream_t s = nullptr) : m(mm), klass(k), st(s ? s : mm->ctx->stream) {
+  ProfScope(dv_model* mm, int k, hipStream_t s = nullptr)
+      : m(mm), klass(k), st(s ? s : (mm->cs ? mm->cs : mm->ctx->stream)) {
     if (!m->prof_on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -433,6 +437,8 @@ static void fill_gconv_common(GConvParams& p, const Taps& t, int cin) {
   p.K = t.n * cin;
   p.cin_shift = ilog2_exact(cin);
 }
+
+static inline hipStream_t fwd_stream(dv_model* m) { return m->cs ? m->cs : m->ctx->stream; }
 
 // Optional fusion of the PReLU backward of the layer whose OUTPUT gradient a data-gradient launch produces:
 // the epilogue turns d(activation) into d(pre-activation) and reduces d(alpha) / d(bias) over the stamps of its
@@ -529,26 +535,28 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     const long tiles64 = ((q.cls[0].M + 63) / 64) * (long)((Cout + 63) / 64);
     const int nchunks = tp.n * (Cin / 32);
     if (single_tap && tiles64 < 256 && nchunks >= 32 && m->ws4) {
-      int ks = (int)std::min<long>(std::min<long>(16, nchunks / 8), (long)(m->ws4_elems / (size_t)MN));
+      const size_t ws4_cap = m->ws4_elems / 2;
+      float* ws4 = m->ws4 + (m->b0 ? ws4_cap : 0);   // each forward lane owns half of the split-K workspace
+      int ks = (int)std::min<long>(std::min<long>(16, nchunks / 8), (long)(ws4_cap / (size_t)MN));
       if (ks > 1) {
         q.ksplit = ks;
-        q.U = m->ws4;
+        q.U = ws4;
         q.A = nullptr;
         q.epi = 0;
         {
           ProfScope ps(m, 0);
-          DV_TRY(launch_gconv2(q, m->ctx->stream));
+          DV_TRY(launch_gconv2(q, fwd_stream(m)));
         }
         ProfScope ps(m, 2);
-        return launch_splitk_finish(m->ws4, ks, MN, Cout, epi >= 1 ? bias : nullptr, epi == 2 ? alpha : nullptr,
-                                    (long)Hout * Hout * Cout, U, epi == 2 ? Aout : nullptr, m->ctx->stream);
+        return launch_splitk_finish(ws4, ks, MN, Cout, epi >= 1 ? bias : nullptr, epi == 2 ? alpha : nullptr,
+                                    (long)Hout * Hout * Cout, U, epi == 2 ? Aout : nullptr, fwd_stream(m));
       }
     }
     long db_rows = 0;
     const bool fuse = fz && !m->no_fuse && fuse_setup(m, q, fz, &db_rows) == OK;
     {
       ProfScope ps(m, 0);
-      DV_TRY(launch_gconv2(q, m->ctx->stream));
+      DV_TRY(launch_gconv2(q, fwd_stream(m)));
     }
     if (fuse) {
       if (fused) *fused = true;
@@ -558,7 +566,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
   }
   fill_gconv_common(p, tp, Cin);
   ProfScope ps(m, 0);
-  return launch_gconv(p, m->ctx->stream);
+  return launch_gconv(p, fwd_stream(m));
 }
 
 // data-gradient-form gconv: target [NB,Ht,Ht,Ct] (s*s parity classes), source [NB,Hs,Hs,Cs];
@@ -597,7 +605,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
     const bool fuse = fz && !m->no_fuse && fuse_setup(m, q, fz, &db_rows) == OK;
     {
       ProfScope ps(m, 0);
-      DV_TRY(launch_gconv2(q, m->ctx->stream));
+      DV_TRY(launch_gconv2(q, fwd_stream(m)));
     }
     if (fuse) {
       if (fused) *fused = true;
@@ -638,7 +646,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
       }
       fill_gconv_common(p, t, Cs);
       ProfScope ps(m, 0);
-      DV_TRY(launch_gconv(p, m->ctx->stream));
+      DV_TRY(launch_gconv(p, fwd_stream(m)));
     }
   return OK;
 }
@@ -812,115 +820,130 @@ static int refresh_w1p(dv_model* m) {
 }
 
 // ---- forward ----------------------------------------------------------------------------------
-// encoder: xsrc rows (idx / first) -> t.  training: batch statistics (+ moving update when upd_moving).
-static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, int Bg, bool training,
-                           bool upd_moving, bool keep_u) {
+// All forward helpers work on the lane [m->b0, m->b0 + NB) of the batch and queue on fwd_stream(m); with b0 = 0 and
+// cs = null they are the plain whole-batch forms.
+#define LANE(ptr, per_stamp) ((ptr) + (size_t)m->b0 * (size_t)(per_stamp))
+
+// global batch statistics of the input BatchNorm (whole batch, main stream) -> m->bnstate
+static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first, int NB, int Bg, bool training,
+                      bool upd_moving) {
   const Arch& A = m->A;
   hipStream_t s = m->ctx->stream;
   const int HW = A.H * A.H;
   float* P = m->P;
   if (training) {
     int nblk = 0;
-    ProfScope ps(m, 2);
+    ProfScope ps(m, 2, s);
     DV_TRY(launch_bn_stats(xsrc, idx, first, NB, HW, A.C, m->ws3, &nblk, s));
     DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 16, m->bnsums, 1.0f, s));
     DV_TRY(allreduce_small(m->ctx, m->bnsums, 16));
   }
+  ProfScope ps(m, 2, s);
+  return launch_bn_finalize(m->bnsums, (float)((double)Bg * HW), A.C, P + A.specs[0].off, P + A.specs[1].off,
+                            P + A.specs[2].off, P + A.specs[3].off, A.cfg.bn_eps, A.cfg.bn_momentum,
+                            A.cfg.bn_moving_var_unbiased, training ? 1 : 0, upd_moving ? 1 : 0, m->bnstate, s);
+}
+
+// encoder: dataset rows (idx / first) of the lane -> t
+static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u) {
+  const Arch& A = m->A;
+  hipStream_t s = fwd_stream(m);
+  const int HW = A.H * A.H;
+  float* P = m->P;
+  float* xn = LANE(m->xn, (size_t)HW * 8);
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_bn_finalize(m->bnsums, (float)((double)Bg * HW), A.C, P + A.specs[0].off, P + A.specs[1].off,
-                              P + A.specs[2].off, P + A.specs[3].off, A.cfg.bn_eps, A.cfg.bn_momentum,
-                              A.cfg.bn_moving_var_unbiased, training ? 1 : 0, upd_moving ? 1 : 0, m->bnstate, s));
-    DV_TRY(launch_bn_apply(xsrc, idx, first, NB, HW, A.C, 8, m->bnstate, m->xn, s));
+    DV_TRY(launch_bn_apply(xsrc, idx ? idx + m->b0 : nullptr, first + m->b0, NB, HW, A.C, 8, m->bnstate, xn, s));
   }
-  const float* in = m->xn;
+  const float* in = xn;
   for (int j = 0; j < 2 * A.L; ++j) {
     int hin, cin, hout, cout, st;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
     int pb = same_pad_before(hin, 3, st, nullptr);
     const float* W = j == 0 ? m->W1p : P + A.specs[A.enc_k(j)].off;
     int cin_phys = j == 0 ? 8 : cin;
+    const size_t e_out = (size_t)hout * hout * cout;
     DV_TRY(gconv_fprop(m, in, W, false, P + A.specs[A.enc_b(j)].off, P + A.specs[A.enc_al(j)].off,
-                       keep_u ? m->enc_u[j] : nullptr, m->enc_a[j], 2, NB, hin, cin_phys, hout, cout, st, pb));
-    in = m->enc_a[j];
+                       keep_u ? LANE(m->enc_u[j], e_out) : nullptr, LANE(m->enc_a[j], e_out), 2, NB, hin, cin_phys,
+                       hout, cout, st, pb));
+    in = LANE(m->enc_a[j], e_out);
   }
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_prelu_fwd(in, P + A.specs[A.enc_flat_al()].off, m->flat_a, NB, A.flat, s));
+    DV_TRY(launch_prelu_fwd(in, P + A.specs[A.enc_flat_al()].off, LANE(m->flat_a, A.flat), NB, A.flat, s));
   }
-  return gconv_fprop(m, m->flat_a, P + A.specs[A.enc_dk()].off, false, P + A.specs[A.enc_db()].off, nullptr, m->t,
-                     nullptr, 1, NB, 1, A.flat, 1, A.tw, 1, 0, true);
+  return gconv_fprop(m, LANE(m->flat_a, A.flat), P + A.specs[A.enc_dk()].off, false, P + A.specs[A.enc_db()].off,
+                     nullptr, LANE(m->t, A.tw), nullptr, 1, NB, 1, A.flat, 1, A.tw, 1, 0, true);
 }
 
-static int decoder_forward(dv_model* m, const float* z, int NB, bool keep_u) {
+static int decoder_forward(dv_model* m, int NB, bool keep_u) {
   const Arch& A = m->A;
-  hipStream_t s = m->ctx->stream;
+  hipStream_t s = fwd_stream(m);
   float* P = m->P;
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_prelu_fwd(z, P + A.specs[A.D0].off, m->dec_ain, NB, A.d, s));
+    DV_TRY(launch_prelu_fwd(LANE(m->z, A.d), P + A.specs[A.D0].off, LANE(m->dec_ain, A.d), NB, A.d, s));
   }
-  DV_TRY(gconv_fprop(m, m->dec_ain, P + A.specs[A.D0 + 1].off, false, P + A.specs[A.D0 + 2].off,
-                     P + A.specs[A.D0 + 3].off, keep_u ? m->dec_uh : nullptr, m->dec_ah, 2, NB, 1, A.d, 1,
-                     A.dec_hidden, 1, 0, true));
+  DV_TRY(gconv_fprop(m, LANE(m->dec_ain, A.d), P + A.specs[A.D0 + 1].off, false, P + A.specs[A.D0 + 2].off,
+                     P + A.specs[A.D0 + 3].off, keep_u ? LANE(m->dec_uh, A.dec_hidden) : nullptr,
+                     LANE(m->dec_ah, A.dec_hidden), 2, NB, 1, A.d, 1, A.dec_hidden, 1, 0, true));
   int r = A.w0 * A.w0 * A.cfg.filters[A.L - 1];
-  DV_TRY(gconv_fprop(m, m->dec_ah, P + A.specs[A.D0 + 4].off, false, P + A.specs[A.D0 + 5].off,
-                     P + A.specs[A.D0 + 6].off, keep_u ? m->dec_ur : nullptr, m->dec_ar, 2, NB, 1, A.dec_hidden, 1, r,
-                     1, 0, true));
-  const float* in = m->dec_ar;
+  DV_TRY(gconv_fprop(m, LANE(m->dec_ah, A.dec_hidden), P + A.specs[A.D0 + 4].off, false, P + A.specs[A.D0 + 5].off,
+                     P + A.specs[A.D0 + 6].off, keep_u ? LANE(m->dec_ur, r) : nullptr, LANE(m->dec_ar, r), 2, NB, 1,
+                     A.dec_hidden, 1, r, 1, 0, true));
+  const float* in = LANE(m->dec_ar, r);
   for (int j = 0; j < 2 * A.L; ++j) {
     int hin, cin, hout, cout, st;
     A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
     int pb = same_pad_before(hout, 3, st, nullptr);
+    const size_t e_out = (size_t)hout * hout * cout;
     // Conv2DTranspose = data gradient of a SAME conv over the output grid; kernel (kh,kw,cout,cin) is n-major
     DV_TRY(gconv_dgrad(m, in, P + A.specs[A.dec_k(j)].off, true, P + A.specs[A.dec_b(j)].off,
-                       P + A.specs[A.dec_al(j)].off, keep_u ? m->dec_u[j] : nullptr, m->dec_a[j], 2, NB, hin, cin,
-                       hout, cout, st, pb));
-    in = m->dec_a[j];
+                       P + A.specs[A.dec_al(j)].off, keep_u ? LANE(m->dec_u[j], e_out) : nullptr,
+                       LANE(m->dec_a[j], e_out), 2, NB, hin, cin, hout, cout, st, pb));
+    in = LANE(m->dec_a[j], e_out);
   }
-  return gconv_fprop(m, in, m->Whp, false, m->bhp, nullptr, m->tpre, nullptr, 1, NB, A.dec_out, A.cfg.filters[0],
-                     A.dec_out, A.C2p, 1, 1);
+  return gconv_fprop(m, in, m->Whp, false, m->bhp, nullptr, LANE(m->tpre, (size_t)A.dec_out * A.dec_out * A.C2p),
+                     nullptr, 1, NB, A.dec_out, A.cfg.filters[0], A.dec_out, A.C2p, 1, 1);
 }
 
-static int sampler_forward(dv_model* m, int NB, const float* eps_host, uint64_t seed, unsigned stream_id,
-                           unsigned row0, bool want_std) {
+// eps of the lane is already in m->eps when gen == false
+static int sampler_forward(dv_model* m, int NB, bool gen, uint64_t seed, unsigned stream_id, unsigned row0,
+                           bool want_std) {
   const Arch& A = m->A;
-  hipStream_t s = m->ctx->stream;
-  if (eps_host)
-    DV_HIP(hipMemcpyAsync(m->eps, eps_host, (size_t)NB * A.d * sizeof(float), hipMemcpyHostToDevice, s));
   SamplerParams sp;
   memset(&sp, 0, sizeof sp);
-  sp.t = m->t;
-  sp.eps = m->eps;
-  sp.z = m->z;
-  sp.kl = m->kl;
-  sp.stddev = want_std ? m->zstd : nullptr;
+  sp.t = LANE(m->t, A.tw);
+  sp.eps = LANE(m->eps, A.d);
+  sp.z = LANE(m->z, A.d);
+  sp.kl = LANE(m->kl, 1);
+  sp.stddev = want_std ? LANE(m->zstd, A.d) : nullptr;
   sp.NB = NB;
   sp.d = A.d;
   sp.diag_shift = A.cfg.diag_shift;
-  sp.gen = eps_host ? 0 : 1;
+  sp.gen = gen ? 1 : 0;
   sp.seed = seed;
   sp.stream = stream_id;
-  sp.row0 = row0;
+  sp.row0 = row0 + (unsigned)m->b0;
   ProfScope ps(m, 2);
-  return launch_sampler_fwd(sp, s);
+  return launch_sampler_fwd(sp, fwd_stream(m));
 }
 
-// head: loss partials -> scal[0..2] = (nll sum, squared-error sum, kl sum); optionally d(loss)/d(tpre) into gA
-static int head_and_loss(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
-                         bool want_out) {
+// head of the lane: per-block loss partials at part_off (blocks), optionally d(loss)/d(tpre) into gA
+static int head_lane(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
+                     bool want_out, int part_block0, int* nblk) {
   const Arch& A = m->A;
-  hipStream_t s = m->ctx->stream;
+  const size_t head_e = (size_t)A.dec_out * A.dec_out * A.C2p, stamp = (size_t)A.H * A.H * A.C;
   HeadParams hp;
   memset(&hp, 0, sizeof hp);
-  hp.tpre = m->tpre;
+  hp.tpre = LANE(m->tpre, head_e);
   hp.y = ysrc;
-  hp.idx = idx;
-  hp.first = first;
-  hp.dt = want_grad ? m->gA : nullptr;
-  hp.loc = want_out ? m->loc : nullptr;
-  hp.scale = want_out ? m->scale : nullptr;
-  hp.part = m->ws3;
+  hp.idx = idx ? idx + m->b0 : nullptr;
+  hp.first = first + m->b0;
+  hp.dt = want_grad ? LANE(m->gA, head_e) : nullptr;
+  hp.loc = want_out ? LANE(m->loc, stamp) : nullptr;
+  hp.scale = want_out ? LANE(m->scale, stamp) : nullptr;
+  hp.part = m->ws3 + (size_t)part_block0 * 2;
   hp.NB = NB;
   hp.Hd = A.dec_out;
   hp.H = A.H;
@@ -929,19 +952,60 @@ static int head_and_loss(dv_model* m, const float* ysrc, const int* idx, int fir
   hp.ld = A.C2p;
   hp.sigma_floor = A.cfg.sigma_floor;
   hp.gscale = (float)(1.0 / ((double)Bg * A.H * A.H * A.C));
-  int nblk = 0;
   ProfScope ps(m, 2);
-  if ((size_t)(((long)NB * A.dec_out * A.dec_out + 255) / 256) * 2 > m->ws3_elems) {
+  return launch_head(hp, fwd_stream(m), nblk);
+}
+
+// Whole forward pass of a step: BN statistics over the full batch, then the batch runs as one lane or (large batches)
+// as two half-batch lanes on the main and the aux stream, whose kernels fill each other's tails and store phases;
+// the loss sums are reduced after the join.  ysrc == null: inference outputs only.
+static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const int* idx, int first, int NB, int Bg,
+                       bool training, bool upd_moving, bool keep_u, const float* eps_host, uint64_t seed,
+                       unsigned stream_id, unsigned row0, bool want_std, bool want_grad, bool want_out,
+                       bool run_encoder = true) {
+  const Arch& A = m->A;
+  dv_ctx* cx = m->ctx;
+  hipStream_t s = cx->stream;
+  if (run_encoder) DV_TRY(bn_prepare(m, xsrc, idx, first, NB, Bg, training, upd_moving));
+  if (eps_host)
+    DV_HIP(hipMemcpyAsync(m->eps, eps_host, (size_t)NB * A.d * sizeof(float), hipMemcpyHostToDevice, s));
+  const long head_blocks_total = ((long)NB * A.dec_out * A.dec_out + 255) / 256 + 2;
+  if ((size_t)head_blocks_total * 2 > m->ws3_elems) {
     set_error("head workspace too small");
     return E_STATE;
   }
-  DV_TRY(launch_head(hp, s, &nblk));
+  const bool split = m->split_forward && !m->prof_on && cx->aux_stream && NB >= 64;
+  const int nlanes = split ? 2 : 1;
+  const int nb0 = split ? ((NB / 2 + 31) / 32) * 32 : NB;      // lane sizes; multiples of 32 keep float4 alignment trivial
+  int blk0 = 0, blk1 = 0, st = OK;
+  if (split) {
+    DV_HIP(hipEventRecord(cx->ev_ready, s));
+    DV_HIP(hipStreamWaitEvent(cx->aux_stream, cx->ev_ready, 0));
+  }
+  for (int lane = 0; lane < nlanes && st == OK; ++lane) {
+    m->b0 = lane == 0 ? 0 : nb0;
+    m->cs = lane == 0 ? nullptr : cx->aux_stream;
+    const int nb = lane == 0 ? nb0 : NB - nb0;
+    if (run_encoder) st = encoder_forward(m, xsrc, idx, first, nb, keep_u);
+    if (st == OK && run_encoder) st = sampler_forward(m, nb, eps_host == nullptr, seed, stream_id, row0, want_std);
+    if (st == OK) st = decoder_forward(m, nb, keep_u);
+    if (st == OK) st = head_lane(m, ysrc, idx, first, nb, Bg, want_grad, want_out, lane == 0 ? 0 : blk0, lane == 0 ? &blk0 : &blk1);
+  }
+  m->b0 = 0;
+  m->cs = nullptr;
+  if (st != OK) return st;
+  if (split) {
+    DV_HIP(hipEventRecord(cx->ev_join, cx->aux_stream));
+    DV_HIP(hipStreamWaitEvent(s, cx->ev_join, 0));
+  }
   if (ysrc) {
-    DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 2, m->scal, 1.0f, s));
+    ProfScope ps(m, 2, s);
+    DV_TRY(launch_reduce_rows_f64(m->ws3, blk0 + blk1, 2, m->scal, 1.0f, s));
     DV_TRY(launch_reduce_rows_f64(m->kl, NB, 1, m->scal + 2, 1.0f, s));
   }
   return OK;
 }
+#undef LANE
 
 // ---- backward ---------------------------------------------------------------------------------
 static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* idx, int first) {
@@ -1180,11 +1244,9 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   const bool training = mode != MODE_EVAL;
   const bool bwd = mode != MODE_EVAL;
   m->lastB = B;
-  DV_TRY(encoder_forward(m, ds.x, idx, (int)first, B, Bg, training, mode == MODE_TRAIN, bwd));
   // Philox stream: one counter row per (rank-local) stamp; ranks are separated through the stream id
-  DV_TRY(sampler_forward(m, B, eps_host, seed, (unsigned)m->ctx->rank, 0u, false));
-  DV_TRY(decoder_forward(m, m->z, B, bwd));
-  DV_TRY(head_and_loss(m, ds.y, idx, (int)first, B, Bg, bwd, true));
+  DV_TRY(forward_all(m, ds.x, ds.y, idx, (int)first, B, Bg, training, mode == MODE_TRAIN, bwd, eps_host, seed,
+                     (unsigned)m->ctx->rank, 0u, false, bwd, true));
   DV_TRY(allreduce_small(m->ctx, m->scal, 4));
   if (bwd) {
     DV_TRY(backward(m, B, Bg, ds.x, idx, (int)first));
@@ -1541,11 +1603,12 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   max_w = std::max(max_w, (size_t)9 * 8 * cfg->filters[0]);
   m->ws1_elems = std::max((size_t)32 << 20, max_w * 2);
   ALLOC(m->ws1, m->ws1_elems);
-  m->ws4_elems = (size_t)16 * Bc * std::max((size_t)A.flat, (size_t)A.tw);
+  m->ws4_elems = (size_t)2 * 16 * Bc * std::max((size_t)A.flat, (size_t)A.tw);
   ALLOC(m->ws4, m->ws4_elems);
   m->wstream = ctx->stream;
   if (getenv("DV_NO_OVERLAP")) m->overlap_wgrad = false;
   if (getenv("DV_NO_ARENA")) m->arena_reduce = false;
+  if (getenv("DV_NO_FWD_SPLIT")) m->split_forward = false;
   if (getenv("DV_FUSE_PRELU_BWD")) m->no_fuse = false;
   m->arena_elems = 0;
   for (auto& sp : A.specs)
@@ -1797,11 +1860,8 @@ int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t 
   for (int64_t o = 0; o < N; o += m->Bc) {
     int nb = (int)std::min<int64_t>(m->Bc, N - o);
     DV_TRY(stage_host_batch(m, x + o * stamp, nb));
-    DV_TRY(encoder_forward(m, m->stage_x, nullptr, 0, nb, nb, false, false, false));
-    DV_TRY(sampler_forward(m, nb, eps ? eps + o * A.d : nullptr, seed, (unsigned)m->ctx->rank, (unsigned)o,
-                           zstd != nullptr));
-    DV_TRY(decoder_forward(m, m->z, nb, false));
-    DV_TRY(head_and_loss(m, nullptr, nullptr, 0, nb, nb, false, true));
+    DV_TRY(forward_all(m, m->stage_x, nullptr, nullptr, 0, nb, nb, false, false, false, eps ? eps + o * A.d : nullptr,
+                       seed, (unsigned)m->ctx->rank, (unsigned)o, zstd != nullptr, false, true));
     if (loc) DV_HIP(hipMemcpyAsync(loc + o * stamp, m->loc, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
     if (scale)
       DV_HIP(hipMemcpyAsync(scale + o * stamp, m->scale, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1825,7 +1885,8 @@ int dv_encode(dv_model* m, const float* x, int64_t N, float* t) {
   for (int64_t o = 0; o < N; o += m->Bc) {
     int nb = (int)std::min<int64_t>(m->Bc, N - o);
     DV_TRY(stage_host_batch(m, x + o * stamp, nb));
-    DV_TRY(encoder_forward(m, m->stage_x, nullptr, 0, nb, nb, false, false, false));
+    DV_TRY(bn_prepare(m, m->stage_x, nullptr, 0, nb, nb, false, false));
+    DV_TRY(encoder_forward(m, m->stage_x, nullptr, 0, nb, false));
     DV_HIP(hipMemcpyAsync(t + o * A.tw, m->t, (size_t)nb * A.tw * sizeof(float), hipMemcpyDeviceToHost, s));
     DV_HIP(hipStreamSynchronize(s));
   }
@@ -1841,8 +1902,8 @@ int dv_decode(dv_model* m, const float* z, int64_t N, float* loc, float* scale) 
   for (int64_t o = 0; o < N; o += m->Bc) {
     int nb = (int)std::min<int64_t>(m->Bc, N - o);
     DV_HIP(hipMemcpyAsync(m->z, z + o * A.d, (size_t)nb * A.d * sizeof(float), hipMemcpyHostToDevice, s));
-    DV_TRY(decoder_forward(m, m->z, nb, false));
-    DV_TRY(head_and_loss(m, nullptr, nullptr, 0, nb, nb, false, true));
+    DV_TRY(forward_all(m, nullptr, nullptr, nullptr, 0, nb, nb, false, false, false, nullptr, 0, 0u, 0u, false, false,
+                       true, /*run_encoder=*/false));
     if (loc) DV_HIP(hipMemcpyAsync(loc + o * stamp, m->loc, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
     if (scale)
       DV_HIP(hipMemcpyAsync(scale + o * stamp, m->scale, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));

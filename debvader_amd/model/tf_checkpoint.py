@@ -178,7 +178,7 @@ class TensorBundle:
         return f"{self.prefix}.data-{shard_id:05d}-of-{self.num_shards:05d}"
 
     def read(self, key: str, verify="auto") -> np.ndarray:
-        """verify: True / False / "auto" (checksum tensors up to 4 MiB: the pure-Python crc32c costs ~1 s per MiB)."""
+        """verify: True / False / "auto" (checksum tensors up to 256 KiB: the pure-Python crc32c costs ~1 s per MiB)."""
         e = self.entries[key]
         if e.dtype not in _NP_DTYPES:
             raise NotImplementedError(f"dtype {e.dtype} of {key} is not supported")
@@ -191,7 +191,7 @@ class TensorBundle:
         if len(raw) != e.size:
             raise ValueError(f"{path} is truncated ({key})")
         if verify == "auto":
-            verify = e.size <= (4 << 20)
+            verify = e.size <= (256 << 10)
         if verify and e.crc32c and masked_crc32c(raw) != e.crc32c:
             raise ValueError(f"checksum mismatch for {key}")
         return np.frombuffer(raw, dtype=_NP_DTYPES[e.dtype]).reshape(e.shape).copy()

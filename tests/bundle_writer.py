@@ -46,14 +46,16 @@ def _block(entries):
     return bytes(body)
 
 
-def write_bundle(prefix, tensors, num_shards=1):
-    """tensors: dict key -> ndarray (float32 / int64)."""
+def write_bundle(prefix, tensors, num_shards=1, crc_limit=1 << 16):
+    """tensors: dict key -> ndarray (float32 / int64).  Tensors above crc_limit bytes get crc32c = 0 (= unchecked),
+    because the pure-Python checksum is slow."""
     dt = {np.dtype(np.float32): 1, np.dtype(np.int64): 9}
     data, entries = bytearray(), [(b"", _field(1, 0, _vi(num_shards)) + _field(3, 2, _vi(2) + _field(1, 0, _vi(1))))]
     for k in sorted(tensors):
         a = np.ascontiguousarray(tensors[k])
         raw = a.tobytes()
-        entries.append((k.encode(), _entry_proto(dt[a.dtype], a.shape, 0, len(data), len(raw), masked_crc32c(raw))))
+        crc = masked_crc32c(raw) if len(raw) <= crc_limit else 0
+        entries.append((k.encode(), _entry_proto(dt[a.dtype], a.shape, 0, len(data), len(raw), crc)))
         data += raw
     with open(f"{prefix}.data-00000-of-{num_shards:05d}", "wb") as f:
         f.write(data)
