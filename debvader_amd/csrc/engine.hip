@@ -293,6 +293,8 @@ struct dv_ctx {
   hipStream_t stream = nullptr;
   hipStream_t comm_stream = nullptr;   // gradient all-reduce runs here, overlapped with the encoder backward
   hipStream_t aux_stream = nullptr;    // weight-gradient kernels run here, beside the data-gradient chain
+  hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};   // extra forward lanes
+  hipEvent_t ev_lane[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_buf[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_dec = nullptr, ev_enc = nullptr, ev_comm = nullptr, ev_small = nullptr, ev_small2 = nullptr;
   ncclComm_t comm = nullptr;
@@ -337,6 +339,7 @@ struct dv_model {
   hipStream_t wstream = nullptr;  // stream the weight-gradient kernels are queued on (aux or main)
   hipStream_t cs = nullptr;       // stream of the forward lane being queued (null: main stream)
   int b0 = 0;                     // first stamp of the forward lane being queued
+  int lane_id = 0;
   bool split_forward = true;      // run the forward pass as two half-batch lanes on two streams (DV_NO_FWD_SPLIT)
   bool overlap_wgrad = true;
   bool no_fuse = true;        // DV_FUSE_PRELU_BWD=1 fuses the PReLU backward into the data-gradient epilogue (batch-major
@@ -535,8 +538,8 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     const long tiles64 = ((q.cls[0].M + 63) / 64) * (long)((Cout + 63) / 64);
     const int nchunks = tp.n * (Cin / 32);
     if (single_tap && tiles64 < 256 && nchunks >= 32 && m->ws4) {
-      const size_t ws4_cap = m->ws4_elems / 2;
-      float* ws4 = m->ws4 + (m->b0 ? ws4_cap : 0);   // each forward lane owns half of the split-K workspace
+      const size_t ws4_cap = m->ws4_elems / 4;
+      float* ws4 = m->ws4 + (size_t)m->lane_id * ws4_cap;   // each forward lane owns a quarter of the split-K workspace
       int ks = (int)std::min<long>(std::min<long>(16, nchunks / 8), (long)(ws4_cap / (size_t)MN));
       if (ks > 1) {
         q.ksplit = ks;
@@ -974,30 +977,40 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
     set_error("head workspace too small");
     return E_STATE;
   }
-  const bool split = m->split_forward && !m->prof_on && cx->aux_stream && NB >= 64;
-  const int nlanes = split ? 2 : 1;
-  const int nb0 = split ? ((NB / 2 + 31) / 32) * 32 : NB;      // lane sizes; multiples of 32 keep float4 alignment trivial
-  int blk0 = 0, blk1 = 0, st = OK;
-  if (split) {
+  static const int want_lanes = getenv("DV_FWD_LANES") ? atoi(getenv("DV_FWD_LANES")) : 2;
+  int nlanes = (m->split_forward && !m->prof_on && cx->aux_stream && NB >= 64) ? std::max(1, std::min(want_lanes, 4)) : 1;
+  while (nlanes > 1 && NB / nlanes < 32) --nlanes;
+  const int per = nlanes > 1 ? ((NB / nlanes + 31) / 32) * 32 : NB;   // lane sizes: multiples of 32 stamps
+  int blk_done = 0, st = OK;
+  // lane 0 runs on the main stream, lane 1 on the aux stream, further lanes on their own streams
+  hipStream_t lstream[4] = {nullptr, cx->aux_stream, cx->lane_stream[0], cx->lane_stream[1]};
+  if (nlanes > 1) {
     DV_HIP(hipEventRecord(cx->ev_ready, s));
-    DV_HIP(hipStreamWaitEvent(cx->aux_stream, cx->ev_ready, 0));
+    for (int lane = 1; lane < nlanes; ++lane) DV_HIP(hipStreamWaitEvent(lstream[lane], cx->ev_ready, 0));
   }
   for (int lane = 0; lane < nlanes && st == OK; ++lane) {
-    m->b0 = lane == 0 ? 0 : nb0;
-    m->cs = lane == 0 ? nullptr : cx->aux_stream;
-    const int nb = lane == 0 ? nb0 : NB - nb0;
+    m->b0 = lane * per;
+    m->lane_id = lane;
+    m->cs = lstream[lane];
+    const int nb = std::min(per, NB - m->b0);
+    if (nb <= 0) break;
+    int nblk = 0;
     if (run_encoder) st = encoder_forward(m, xsrc, idx, first, nb, keep_u);
     if (st == OK && run_encoder) st = sampler_forward(m, nb, eps_host == nullptr, seed, stream_id, row0, want_std);
     if (st == OK) st = decoder_forward(m, nb, keep_u);
-    if (st == OK) st = head_lane(m, ysrc, idx, first, nb, Bg, want_grad, want_out, lane == 0 ? 0 : blk0, lane == 0 ? &blk0 : &blk1);
+    if (st == OK) st = head_lane(m, ysrc, idx, first, nb, Bg, want_grad, want_out, blk_done, &nblk);
+    blk_done += nblk;
+    if (st == OK && lane > 0) {
+      if (hipEventRecord(cx->ev_lane[lane - 1], lstream[lane]) != hipSuccess ||
+          hipStreamWaitEvent(s, cx->ev_lane[lane - 1], 0) != hipSuccess)
+        st = E_HIP;
+    }
   }
   m->b0 = 0;
+  m->lane_id = 0;
   m->cs = nullptr;
   if (st != OK) return st;
-  if (split) {
-    DV_HIP(hipEventRecord(cx->ev_join, cx->aux_stream));
-    DV_HIP(hipStreamWaitEvent(s, cx->ev_join, 0));
-  }
+  const int blk0 = blk_done, blk1 = 0;
   if (ysrc) {
     ProfScope ps(m, 2, s);
     DV_TRY(launch_reduce_rows_f64(m->ws3, blk0 + blk1, 2, m->scal, 1.0f, s));
@@ -1427,6 +1440,10 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
   DV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 3; ++i) {
+    DV_HIP(hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking));
+    DV_HIP(hipEventCreateWithFlags(&c->ev_lane[i], hipEventDisableTiming));
+  }
   DV_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   DV_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_buf[i], hipEventDisableTiming));
@@ -1471,6 +1488,10 @@ int dv_ctx_destroy(dv_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < 3; ++i)
     if (c->ev_buf[i]) (void)hipEventDestroy(c->ev_buf[i]);
+  for (int i = 0; i < 3; ++i) {
+    if (c->ev_lane[i]) (void)hipEventDestroy(c->ev_lane[i]);
+    if (c->lane_stream[i]) (void)hipStreamDestroy(c->lane_stream[i]);
+  }
   if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1603,7 +1624,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   max_w = std::max(max_w, (size_t)9 * 8 * cfg->filters[0]);
   m->ws1_elems = std::max((size_t)32 << 20, max_w * 2);
   ALLOC(m->ws1, m->ws1_elems);
-  m->ws4_elems = (size_t)2 * 16 * Bc * std::max((size_t)A.flat, (size_t)A.tw);
+  m->ws4_elems = (size_t)4 * 16 * Bc * std::max((size_t)A.flat, (size_t)A.tw);
   ALLOC(m->ws4, m->ws4_elems);
   m->wstream = ctx->stream;
   if (getenv("DV_NO_OVERLAP")) m->overlap_wgrad = false;
