@@ -358,6 +358,11 @@ struct dv_model {
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   int64_t prof_n[3] = {0, 0, 0};
+  int64_t prof_launches[3] = {0, 0, 0};
+  bool prof_open = false;
+  int prof_open_klass = 0;
+  hipStream_t prof_open_stream = nullptr;
+  hipEvent_t prof_open_ev = nullptr;
   double prof_ms[3] = {0, 0, 0};
   std::vector<void*> allocs;
 };
@@ -374,49 +379,59 @@ static int dalloc(dv_model* m, float** p, size_t elems) {
   return OK;
 }
 
-struct ProfScope {
-  dv_model* m;
-  int klass;
-  hipStream_t st;
-  hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(dv_model* mm, int k, hipStream_t s = nullptr)
-      : m(mm), klass(k), st(s ? s : (mm->cs ? mm->cs : mm->ctx->stream)) {
-    if (!m->prof_on) return;
-    auto get = [&]() {
-      hipEvent_t e;
-      if (!m->ev_pool.empty()) {
-        e = m->ev_pool.back();
-        m->ev_pool.pop_back();
-      } else {
-        (void)hipEventCreate(&e);
-      }
-      return e;
-    };
-    a = get();
-    b = get();
-    (void)hipEventRecord(a, st);
+// Per-class HIP-event timing.  Consecutive launches of one class on one stream share a single event pair (the
+// pair brackets the whole run, inter-kernel boundaries included), so that the events themselves add little.
+static hipEvent_t prof_event(dv_model* m) {
+  hipEvent_t e;
+  if (!m->ev_pool.empty()) {
+    e = m->ev_pool.back();
+    m->ev_pool.pop_back();
+  } else {
+    (void)hipEventCreate(&e);
   }
-  ~ProfScope() {
-    if (!a) return;
-    (void)hipEventRecord(b, st);
-    m->prof.push_back({klass, a, b});
+  return e;
+}
+static void prof_close(dv_model* m) {
+  if (!m->prof_open) return;
+  hipEvent_t b = prof_event(m);
+  (void)hipEventRecord(b, m->prof_open_stream);
+  m->prof.push_back({m->prof_open_klass, m->prof_open_ev, b});
+  m->prof_open = false;
+}
+struct ProfScope {
+  ProfScope(dv_model* m, int k, hipStream_t s = nullptr) {
+    if (!m->prof_on) return;
+    hipStream_t st = s ? s : (m->cs ? m->cs : m->ctx->stream);
+    m->prof_launches[k] += 1;
+    if (m->prof_open && m->prof_open_klass == k && m->prof_open_stream == st) return;   // extend the open run
+    prof_close(m);
+    m->prof_open_ev = prof_event(m);
+    (void)hipEventRecord(m->prof_open_ev, st);
+    m->prof_open = true;
+    m->prof_open_klass = k;
+    m->prof_open_stream = st;
   }
 };
 
 static int prof_flush(dv_model* m) {
+  prof_close(m);
   if (m->prof.empty()) return OK;
   DV_HIP(hipStreamSynchronize(m->ctx->stream));
   for (auto& r : m->prof) {
     float ms = 0.f;
     DV_HIP(hipEventElapsedTime(&ms, r.a, r.b));
-    m->prof_n[r.klass] += 1;
     m->prof_ms[r.klass] += ms;
     m->ev_pool.push_back(r.a);
     m->ev_pool.push_back(r.b);
   }
+  for (int k = 0; k < 3; ++k) {
+    m->prof_n[k] += m->prof_launches[k];
+    m->prof_launches[k] = 0;
+  }
   m->prof.clear();
   return OK;
 }
+
 
 static bool g_force_v1 = false;  // tuning aid: route everything through the first-generation kernel
 
