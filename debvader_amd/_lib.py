@@ -87,6 +87,7 @@ SIGNATURES = {
     "dv_grad_step": (C.c_int, [_p, C.c_int32, _i32, C.c_int64, C.c_int32, C.c_int32, _f, C.c_uint64, _f]),
     "dv_train_steps": (C.c_int, [_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _f]),
     "dv_infer": (C.c_int, [_p, _f, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
+    "dv_infer_mc": (C.c_int, [_p, _f, C.c_int64, C.c_int32, C.c_uint64, _f, _f]),
     "dv_encode": (C.c_int, [_p, _f, C.c_int64, _f]),
     "dv_decode": (C.c_int, [_p, _f, C.c_int64, _f, _f]),
     "dv_model_get_activation": (C.c_int, [_p, C.c_char_p, _f, C.c_size_t]),

@@ -1627,8 +1627,8 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   size_t head_e = (size_t)A.dec_out * A.dec_out * A.C2p;
   ALLOC(m->tpre, Bc * head_e);
   track(head_e);
-  ALLOC(m->loc, Bc * A.H * A.H * A.C);
-  ALLOC(m->scale, Bc * A.H * A.H * A.C);
+  ALLOC(m->loc, Bc * A.H * A.H * A.C + 4);
+  ALLOC(m->scale, Bc * A.H * A.H * A.C + 4);
   ALLOC(m->gA, Bc * max_act);
   ALLOC(m->gB, Bc * max_act);
   ALLOC(m->gC, Bc * max_act);
@@ -1906,6 +1906,38 @@ int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t 
                               hipMemcpyDeviceToHost, s));
     if (zstd) DV_HIP(hipMemcpyAsync(zstd + o * A.d, m->zstd, (size_t)nb * A.d * sizeof(float), hipMemcpyDeviceToHost, s));
     if (z) DV_HIP(hipMemcpyAsync(z + o * A.d, m->z, (size_t)nb * A.d * sizeof(float), hipMemcpyDeviceToHost, s));
+    DV_HIP(hipStreamSynchronize(s));
+    m->lastB = nb;
+  }
+  return prof_flush(m);
+}
+
+int dv_infer_mc(dv_model* m, const float* x, int64_t N, int32_t nsamples, uint64_t seed, float* mean_out,
+                float* std_out) {
+  if (!m || !x || N < 0 || nsamples < 1 || (!mean_out && !std_out)) return DV_E_INVALID;
+  const Arch& A = m->A;
+  DV_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  const size_t stamp = (size_t)A.H * A.H * A.C;
+  // running statistics live in the two gradient ping-pong buffers (unused during inference)
+  float* mean = m->gA;
+  float* m2 = m->gB;
+  for (int64_t o = 0; o < N; o += m->Bc) {
+    int nb = (int)std::min<int64_t>(m->Bc, N - o);
+    DV_TRY(stage_host_batch(m, x + o * stamp, nb));
+    DV_TRY(bn_prepare(m, m->stage_x, nullptr, 0, nb, nb, false, false));
+    DV_TRY(encoder_forward(m, m->stage_x, nullptr, 0, nb, false));           // once per chunk
+    for (int k = 0; k < nsamples; ++k) {                                      // nsamples stochastic decodes
+      int nblk = 0;
+      DV_TRY(sampler_forward(m, nb, true, seed + (uint64_t)k, (unsigned)m->ctx->rank, (unsigned)o, false));
+      DV_TRY(decoder_forward(m, nb, false));
+      DV_TRY(head_lane(m, nullptr, nullptr, 0, nb, nb, false, true, 0, &nblk));
+      DV_TRY(launch_welford_update(m->loc, mean, m2, ((long)(nb * stamp) + 3) & ~3L, k, s));   // buffers carry slack
+    }
+    DV_TRY(launch_welford_finish(m2, ((long)(nb * stamp) + 3) & ~3L, nsamples, s));
+    if (mean_out)
+      DV_HIP(hipMemcpyAsync(mean_out + o * stamp, mean, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (std_out) DV_HIP(hipMemcpyAsync(std_out + o * stamp, m2, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
     DV_HIP(hipStreamSynchronize(s));
     m->lastB = nb;
   }

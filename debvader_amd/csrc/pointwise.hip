@@ -787,6 +787,52 @@ int launch_take_cols(const float* src, float* dst, int rows, int nsrc, int ndst,
   return OK;
 }
 
+// Welford running mean / sum of squared deviations over Monte-Carlo decodes (epistemic uncertainty,
+// reference field_deblender.py:303-313: np.std(deblend(net, [stamp]*100)[0], axis=0))
+__global__ __launch_bounds__(256) void welford_update_kernel(const float* __restrict__ x, float* __restrict__ mean,
+                                                             float* __restrict__ m2, long n4, int k) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 mu = k == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : reinterpret_cast<f32x4*>(mean)[i];
+    f32x4 s2 = k == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : reinterpret_cast<f32x4*>(m2)[i];
+    const float inv = 1.0f / (float)(k + 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = v[c] - mu[c];
+      mu[c] += d * inv;
+      s2[c] += d * (v[c] - mu[c]);
+    }
+    reinterpret_cast<f32x4*>(mean)[i] = mu;
+    reinterpret_cast<f32x4*>(m2)[i] = s2;
+  }
+}
+__global__ __launch_bounds__(256) void welford_finish_kernel(float* __restrict__ m2, long n4, float inv_n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 s2 = reinterpret_cast<f32x4*>(m2)[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s2[c] = sqrtf(fmaxf(s2[c] * inv_n, 0.f));
+    reinterpret_cast<f32x4*>(m2)[i] = s2;
+  }
+}
+int launch_welford_update(const float* x, float* mean, float* m2, long n, int k, hipStream_t s) {
+  if (n & 3) return E_INVALID;
+  long n4 = n / 4;
+  if (n4 == 0) return OK;
+  hipLaunchKernelGGL(welford_update_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 4096)), dim3(256), 0, s, x,
+                     mean, m2, n4, k);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+int launch_welford_finish(float* m2, long n, int count, hipStream_t s) {
+  if ((n & 3) || count < 1) return E_INVALID;
+  long n4 = n / 4;
+  if (n4 == 0) return OK;
+  hipLaunchKernelGGL(welford_finish_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 4096)), dim3(256), 0, s, m2,
+                     n4, 1.0f / (float)count);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
 }

@@ -24,3 +24,19 @@ def deblend(net, images, normalise=False):
         mean = denormalize_non_linear(np.clip(out.mean().numpy(), -1 + 1e-7, 1 - 1e-7))
         return mean, Normal(mean, out.stddev().numpy())
     return out.mean().numpy(), out
+
+
+def deblend_epistemic(net, images, n_samples=100, normalise=False):
+    """Epistemic-uncertainty estimate of the reference's field deblender (deblend/field_deblender.py:303-313:
+    `np.std(deblend(net, [stamp] * 100)[0], axis=0)` in a Python loop over objects) as one engine call:
+    every stamp is encoded once and decoded `n_samples` times with fresh latent samples on the GPU.
+
+    returns (mean over samples of the predicted mean, std over samples), each (N, size, size, bands)
+    """
+    images = np.asarray(images)
+    if normalise:
+        images = normalize_non_linear(images)
+    mean, std = net._core.engine.infer_mc(images.astype(np.float32), n_samples, seed=net._core.next_seed())
+    if normalise:
+        mean = denormalize_non_linear(np.clip(mean, -1 + 1e-7, 1 - 1e-7))
+    return mean, std

@@ -275,6 +275,16 @@ class Engine:
                            _fp(bufs["mu"]), _fp(bufs["zstd"]), _fp(bufs["z"])))
         return {k: v for k, v in bufs.items() if v is not None}
 
+    def infer_mc(self, x, nsamples=100, seed=0):
+        """(mean, std) over `nsamples` stochastic decodes of every stamp (encoder runs once per stamp)."""
+        x = _f32c(x)
+        if x.ndim != 4 or x.shape[1:] != self.stamp_shape:
+            raise ValueError(f"expected images of shape (N,{self.stamp_shape}), got {x.shape}")
+        mean = np.empty(x.shape, np.float32)
+        std = np.empty(x.shape, np.float32)
+        check(lib.dv_infer_mc(self._h, _fp(x), x.shape[0], int(nsamples), int(seed), _fp(mean), _fp(std)))
+        return mean, std
+
     def encode(self, x) -> np.ndarray:
         x = _f32c(x)
         if x.ndim != 4 or x.shape[1:] != self.stamp_shape:

@@ -124,6 +124,11 @@ int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t 
  * mu [N,latent], zstd [N,latent] = z.mean()/z.stddev(); z [N,latent] = the sample fed to the decoder. */
 int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
              float* mu, float* zstd, float* z);
+/* Monte-Carlo epistemic uncertainty: encode each stamp once, decode it `nsamples` times with fresh eps, return the
+ * mean and the standard deviation (ddof 0) of the predicted means over the samples.  Replaces the per-object loop
+ * `np.std(deblend(net, [stamp]*100)[0], axis=0)` of deblend/field_deblender.py:303-313. */
+int dv_infer_mc(dv_model* m, const float* x, int64_t N, int32_t nsamples, uint64_t seed, float* mean_out,
+                float* std_out);
 /* encoder(x) -> t[N, latent + latent(latent+1)/2]  (model.py:61-100) */
 int dv_encode(dv_model* m, const float* x, int64_t N, float* t);
 /* decoder(z) -> loc, scale  (model.py:103-161) */

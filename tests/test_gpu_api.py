@@ -182,3 +182,26 @@ print(repr(out["loss"]), float(np.abs(w).sum()), float(np.abs(v).sum()), float(e
     assert outs[0].endswith(" 4.0")
     a, b = [float(v) for v in outs[0].split()], [float(v) for v in outs[2].split()]
     assert all(abs(x - y) <= 1e-4 * abs(x) for x, y in zip(a, b)), (outs[0], outs[2])
+
+
+def test_epistemic_monte_carlo_matches_the_reference_loop_statistically():
+    """deblend_epistemic (encode once, decode n times, Welford on the GPU) versus the reference's recipe
+    np.std(deblend(net, [stamp]*n)[0], axis=0) (field_deblender.py:303-313) run through the same engine."""
+    from debvader_amd.deblend_cutout.deblender import deblend, deblend_epistemic
+    from debvader_amd.model import model
+
+    net, enc, dec, z = model.create_model_vae(**ARCH, max_batch=64)
+    x, _ = _data(3, 11)
+    n = 256
+    mean, std = deblend_epistemic(net, x, n_samples=n)
+    assert mean.shape == x.shape and std.shape == x.shape and np.isfinite(mean).all() and (std >= 0).all()
+    ref_std = np.stack([np.std(deblend(net, np.repeat(x[i:i + 1], n, axis=0))[0], axis=0) for i in range(3)])
+    ref_mean = np.stack([np.mean(deblend(net, np.repeat(x[i:i + 1], n, axis=0))[0], axis=0) for i in range(3)])
+    big = ref_std > 0.1 * ref_std.max()
+    assert big.sum() > 10
+    # two independent Monte-Carlo estimates with n samples each: the std agrees within a few sigma/sqrt(2n)
+    assert np.abs(std[big] / ref_std[big] - 1).mean() < 0.1
+    assert np.abs(mean - ref_mean).max() <= 6 * (ref_std.max() / np.sqrt(n)) + 1e-6
+    # with one sample the spread is zero and the mean is a single decode
+    m1, s1 = deblend_epistemic(net, x, n_samples=1)
+    assert np.abs(s1).max() == 0 and np.isfinite(m1).all()
