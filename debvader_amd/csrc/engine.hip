@@ -2059,7 +2059,11 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   DV_HIP(hipMalloc((void**)&Y2, ny * sizeof(float)));
   m.ws1_elems = (size_t)16 << 20;
   DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
-  if (tile >= 3000) {
+  if (tile >= 4000) {
+    debug_set_gconv2_prio(4);   // 4: loads in front of the MFMA block (pre-interleave order)
+    tile -= 4000;
+    if (tile == 99) tile = -1;
+  } else if (tile >= 3000) {
     debug_set_gconv2_prio(2);
     tile -= 3000;
     if (tile == 99) tile = -1;

@@ -294,19 +294,31 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     store_lds(0);
   }
   __syncthreads();
-  if (p.dbg == 0) {
+  if (p.dbg == 0 && p.prio != 4 && SUB == 1) {
+    // steady-state iterations are one basic block (loads of chunk k+1, MFMAs of chunk k) and the scheduler is asked
+    // to spread the gather's VALU / VMEM instructions between the MFMAs (+2.7 % over issuing them in front,
+    // tools/layer_bench.py with tile code 4099 = old order)
+    for (int kc = 0; kc + 1 < nchunks; ++kc) {
+      const int cur = kc & 1;
+      load_global();
+      compute(cur);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);         // VALU
+      }
+      store_lds(cur ^ 1);
+      __syncthreads();
+    }
+    if (nchunks > 0) compute((nchunks - 1) & 1);
+    __syncthreads();
+  } else if (p.dbg == 0) {
     for (int kc = 0; kc < nchunks; ++kc) {
       const int cur = kc & 1;
-      // the gather's address arithmetic competes with the co-resident workgroup's MFMA stream for VALU issue
-      // slots; at default priority it trails behind it for thousands of cycles.  Raise it for the short
-      // issue phases so the loads (and later the LDS stores) go out early, MFMA phases run at priority 0.
-      if (p.prio) __builtin_amdgcn_s_setprio(2);
       if (kc + 1 < nchunks) load_global();
-      __builtin_amdgcn_s_setprio(0);
       compute(cur);
-      if (p.prio) __builtin_amdgcn_s_setprio(2);
       if (kc + 1 < nchunks) store_lds(cur ^ 1);
-      __builtin_amdgcn_s_setprio(0);
       __syncthreads();
     }
   } else {  // timing build path: same loop with s_memtime stamps per phase (block 5 reports)
