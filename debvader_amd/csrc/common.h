@@ -108,6 +108,26 @@ int launch_gconv2(const GConv2Params& p, hipStream_t s);
 void gconv2_tile_geometry(const GConv2Params& p, int* bm, int* wgm, long* mtiles);
 void debug_set_gconv2_tile(int code);
 
+// Stride-2 data-gradient form with the four parity classes fused per workgroup (gconv_s2.hip).
+// Class c = 2*[row parity has two taps] + [column parity has two taps]; neighbour e = 2*[dh == x] + [dw == x].
+struct GConvS2Params {
+  const float* X;
+  const float* W;      // n-major taps: W[wt][n][k]
+  float* U;
+  float* A;
+  const float* bias;
+  const float* alpha;
+  int NB, Hin, Win, Cin;
+  int Hout, Wout, Cout;
+  int Hc, Wc, M;       // base grid (ceil(Hout/2)) and NB*Hc*Wc
+  int epi;             // 0 raw, 1 +bias, 2 +bias then PReLU
+  int ndh[4], ndw[4];  // source offset of neighbour e
+  int cph[4], cpw[4];  // output parity of class c
+  int wt[4][4];        // weight tap index of (neighbour e, class c); unused pairs 0
+};
+int launch_gconv_s2(const GConvS2Params& p, hipStream_t s);
+void debug_set_gconv_s2_tile(int code);
+
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[(t, cx), cy] = sum_p Xg[p, t][cx] * dY[p][cy], split over pixel ranges into
 // partial slabs [nsplit][9*Cx][Cy] that reduce_partials() sums in a fixed order (deterministic).

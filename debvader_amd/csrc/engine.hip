@@ -593,6 +593,43 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
                        float* U, float* Aout, int epi, int NB, int Hs, int Cs, int Ht, int Ct, int s, int pb,
                        const FuseBwd* fz = nullptr, bool* fused = nullptr) {
   if (fused) *fused = false;
+  static const bool no_s2f = getenv("DV_NO_S2F") != nullptr;
+  if (s == 2 && Cs % 32 == 0 && Ct % 4 == 0 && nmajor && !g_force_v1 && !no_s2f && !(fz && !m->no_fuse)) {
+    // all four parity classes in one workgroup (gconv_s2.hip)
+    GConvS2Params q;
+    memset(&q, 0, sizeof q);
+    q.X = X; q.W = W; q.U = U; q.A = Aout; q.bias = bias; q.alpha = alpha;
+    q.NB = NB; q.Hin = q.Win = Hs; q.Cin = Cs; q.Hout = q.Wout = Ht; q.Cout = Ct;
+    q.Hc = q.Wc = (Ht + 1) / 2; q.M = NB * q.Hc * q.Wc; q.epi = epi;
+    // per dimension: the parity with two kernel taps, its extra source offset x, and the kernel index per (parity, offset)
+    int two = -1, x = 0, kk[2][2] = {{-1, -1}, {-1, -1}};
+    bool ok = true;
+    for (int ph = 0; ph < 2; ++ph) {
+      int n = 0;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int nh = ph + pb - kh;
+        if (nh & 1) continue;
+        const int d = nh / 2;
+        ++n;
+        if (d == 0) kk[ph][0] = kh; else { kk[ph][1] = kh; x = d; two = ph; }
+      }
+      if (kk[ph][0] < 0 || n > 2) ok = false;
+    }
+    if (ok && two >= 0 && kk[1 - two][1] < 0) {
+      for (int c = 0; c < 4; ++c) {
+        q.cph[c] = (c & 2) ? two : 1 - two;
+        q.cpw[c] = (c & 1) ? two : 1 - two;
+      }
+      for (int e = 0; e < 4; ++e) {
+        q.ndh[e] = (e & 2) ? x : 0;
+        q.ndw[e] = (e & 1) ? x : 0;
+        for (int c = 0; c < 4; ++c)
+          if ((e & ~c) == 0) q.wt[e][c] = kk[q.cph[c]][(e & 2) ? 1 : 0] * 3 + kk[q.cpw[c]][(e & 1) ? 1 : 0];
+      }
+      ProfScope ps(m, 0);
+      return launch_gconv_s2(q, fwd_stream(m));
+    }
+  }
   if ((Cs % 32 == 0 || ((Cs == 8 || Cs == 16) && Ct <= 32)) && s <= 2 && !g_force_v1) {
     GConv2Params q;
     memset(&q, 0, sizeof q);
@@ -2103,7 +2140,7 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
     float h[32];
     DV_HIP(hipMemcpy(h, m.ws1 + m.ws1_elems - 64, sizeof h, hipMemcpyDeviceToHost));
     for (int w = 0; w < 4; ++w)
-      fprintf(stderr, "  wave %d: load-issue %.0f  compute %.0f  wait+store %.0f  barrier %.0f cycles over %.0f chunks\n", w, h[8 * w], h[8 * w + 1], h[8 * w + 2], h[8 * w + 3], h[8 * w + 4]);
+      fprintf(stderr, "  wave %d: load-issue %.0f  compute %.0f  wait+store %.0f  barrier %.0f cycles over %.0f chunks; clock %.0f MHz\n", w, h[8 * w], h[8 * w + 1], h[8 * w + 2], h[8 * w + 3], h[8 * w + 4], h[8 * w + 6] > 0 ? h[8 * w + 5] / h[8 * w + 6] * 100.f : 0.f);
   }
   float ms = 0;
   DV_HIP(hipEventElapsedTime(&ms, a, b));

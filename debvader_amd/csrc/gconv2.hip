@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     }
   } else {  // timing build path: same loop with s_memtime stamps per phase (block 5 reports)
     unsigned long long tl = 0, tc = 0, ts = 0, tb = 0, t0 = __builtin_amdgcn_s_memtime(), t1;
+    const unsigned long long tbeg = t0, rbeg = __builtin_amdgcn_s_memrealtime();
     for (int kc = 0; kc < nchunks; ++kc) {
       const int cur = kc & 1;
       if (kc + 1 < nchunks) load_global();
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     if (bid == 5 && lane == 0 && p.dbg_out) {
       float* d = p.dbg_out + wave * 8;
       d[0] = (float)tl; d[1] = (float)tc; d[2] = (float)ts; d[3] = (float)tb; d[4] = (float)nchunks;
+      d[5] = (float)(__builtin_amdgcn_s_memtime() - tbeg); d[6] = (float)(__builtin_amdgcn_s_memrealtime() - rbeg);
     }
   }
 

@@ -6,16 +6,19 @@ from debvader_amd import engine as E
 from debvader_amd._lib import lib, check
 
 B = int(os.environ.get("LB_BATCH", "256"))
+ITERS = int(os.environ.get("LB_ITERS", "300"))   # long enough that clocks have ramped (10 iterations read ~12 % slow)
 ctx = E.Context()
 
 
-def gconv(Hs, Cs, Ht, Ct, s, pb, dgrad, nmajor, epi=2, single=0, tile=-1, iters=10):
+def gconv(Hs, Cs, Ht, Ct, s, pb, dgrad, nmajor, epi=2, single=0, tile=-1, iters=None):
+    iters = iters or ITERS
     ms = C.c_float()
     check(lib.dv_debug_gconv(ctx._h, B, Hs, Cs, Ht, Ct, s, pb, dgrad, nmajor, epi, single, tile, iters, C.byref(ms)))
     return ms.value
 
 
-def wgrad(Hx, Cx, Hy, Cy, sx, pb, single=0, iters=10):
+def wgrad(Hx, Cx, Hy, Cy, sx, pb, single=0, iters=None):
+    iters = iters or ITERS
     ms = C.c_float()
     check(lib.dv_debug_wgrad(ctx._h, B, Hx, Cx, Hy, Cy, sx, pb, single, iters, C.byref(ms)))
     return ms.value

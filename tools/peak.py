@@ -10,3 +10,8 @@ for blocks in (256, 512, 1024):
             for iters in (4000, 40000):
                 check(lib.dv_debug_mfma_peak(ctx._h, blocks, iters // (1 if nacc == 16 else 2), nacc, rnd, o))
                 print(f"blocks {blocks:5d} nacc {nacc} random {rnd} iters {iters:6d}: {o[0]:6.1f} TF  clock {o[1]:6.0f} MHz  {o[2]:5.1f} cyc/MFMA")
+# sustained: ~2 s of back-to-back launches on random operands, clock of the last launch
+for rnd in (0, 1):
+    for _ in range(200):
+        check(lib.dv_debug_mfma_peak(ctx._h, 1024, 40000, 16, rnd, o))
+    print(f"sustained random {rnd}: {o[0]:6.1f} TF  clock {o[1]:6.0f} MHz  {o[2]:5.1f} cyc/MFMA")
