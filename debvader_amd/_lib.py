@@ -51,6 +51,7 @@ lib = _load()
 
 _p = C.c_void_p
 _f = C.POINTER(C.c_float)
+_d = C.POINTER(C.c_double)
 _i32 = C.POINTER(C.c_int32)
 _i64 = C.POINTER(C.c_int64)
 
@@ -87,6 +88,8 @@ SIGNATURES = {
     "dv_grad_step": (C.c_int, [_p, C.c_int32, _i32, C.c_int64, C.c_int32, C.c_int32, _f, C.c_uint64, _f]),
     "dv_train_steps": (C.c_int, [_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _f]),
     "dv_infer": (C.c_int, [_p, _f, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
+    "dv_scene_extract": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _d]),
+    "dv_scene_composite": (C.c_int, [_p, _d, C.c_int32, C.c_int32, _d, _d, C.c_int32, C.c_int32, C.c_double]),
     "dv_infer_mc": (C.c_int, [_p, _f, C.c_int64, C.c_int32, C.c_uint64, _f, _f]),
     "dv_encode": (C.c_int, [_p, _f, C.c_int64, _f]),
     "dv_decode": (C.c_int, [_p, _f, C.c_int64, _f, _f]),

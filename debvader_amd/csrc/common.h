@@ -108,6 +108,12 @@ int launch_gconv2(const GConv2Params& p, hipStream_t s);
 void gconv2_tile_geometry(const GConv2Params& p, int* bm, int* wgm, long* mtiles);
 void debug_set_gconv2_tile(int code);
 
+// Scene compositing (scene.hip): host float64 buffers in, host float64 buffers out
+int scene_extract(const double* field_h, int F, int nb, const int32_t* starts_h, int N, int cs, double* out_h,
+                  hipStream_t s);
+int scene_composite(double* field_h, int F, int nb, const double* stamps_h, const double* pos_h, int N, int cs,
+                    double sign, hipStream_t s);
+
 // Stride-2 data-gradient form with the four parity classes fused per workgroup (gconv_s2.hip).
 // Class c = 2*[row parity has two taps] + [column parity has two taps]; neighbour e = 2*[dh == x] + [dw == x].
 struct GConvS2Params {

@@ -1557,6 +1557,20 @@ int dv_ctx_sync(dv_ctx* c) {
   return DV_OK;
 }
 
+int dv_scene_extract(dv_ctx* c, const double* field, int32_t F, int32_t nb, const int32_t* starts, int32_t N,
+                     int32_t cs, double* out) {
+  if (!c) return DV_E_INVALID;
+  DV_HIP(hipSetDevice(c->device));
+  return scene_extract(field, F, nb, starts, N, cs, out, c->stream);
+}
+
+int dv_scene_composite(dv_ctx* c, double* field, int32_t F, int32_t nb, const double* stamps, const double* pos,
+                       int32_t N, int32_t cs, double sign) {
+  if (!c) return DV_E_INVALID;
+  DV_HIP(hipSetDevice(c->device));
+  return scene_composite(field, F, nb, stamps, pos, N, cs, sign, c->stream);
+}
+
 int dv_ctx_allreduce_host(dv_ctx* c, float* buf, int32_t n) {
   if (!c || !buf || n < 0 || n > 4096) return DV_E_INVALID;
   if (!c->comm || n == 0) return DV_OK;

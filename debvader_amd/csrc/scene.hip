@@ -1,0 +1,262 @@
+// Scene compositing around the network: cutout gather and the residual / predicted fields.
+//
+// Reference behaviour restated:
+//  * extract/extraction.py:4-43       cutout i = field[0, xs:xs+cs, ys:ys+cs, :] (callers validate the window)
+//  * deblend/field_deblender.py:46-97   residual  = field - sum_i shift(pad(mean_i), (x_i, y_i))        (in object order)
+//  * deblend/field_deblender.py:99-189  predicted = sum_i shift(pad(stamp_i), (x_i, y_i)) for mean / stddev / epistemic
+//    where pad() centres the cs x cs stamp in a zero F x F image and shift() is scipy.ndimage.shift with its defaults
+//    (cubic B-spline, mode "constant", prefilter on).  The reference builds an F x F image per object and band and
+//    shifts it on the CPU (its own TODO at :82 calls this "super slow").
+//
+// Here: float64 like the reference's numpy arrays; one thread per field element walks the objects IN ORDER (same
+// summation order as the reference loop, so results are deterministic and agree to rounding).  An object whose two
+// shifts are integers is an exact translation (no spline needed: interpolating a spline at its knots returns the
+// samples).  Other objects get cubic B-spline coefficients of the zero-extended stamp (recursive prefilter, pole
+// sqrt(3)-2, margin T = 20 pixels: 0.268^20 = 4e-12) and are evaluated with the 4 x 4 B-spline weights.
+// HBM-bound byte work; nothing here wants MFMA.
+#include "common.h"
+
+namespace dv {
+
+namespace {
+constexpr int T_MARGIN = 20;
+
+struct SceneObj {
+  double sx, sy;     // shift of the stamp's top-left corner relative to field index 0 (po + pos), rows / cols
+  int ix, iy;        // the same as integers (integer objects)
+  int coef;          // index into the coefficient buffer, -1 for integer objects
+  int pad_;
+};
+
+__global__ __launch_bounds__(256) void scene_extract_kernel(const double* __restrict__ field, int F, int nb,
+                                                            const int* __restrict__ starts, long total, int cs,
+                                                            double* __restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int b = (int)(e % nb);
+  long r = e / nb;
+  const int j = (int)(r % cs);
+  r /= cs;
+  const int i = (int)(r % cs);
+  const int n = (int)(r / cs);
+  const int x = starts[2 * n] + i, y = starts[2 * n + 1] + j;
+  out[e] = field[((long)x * F + y) * nb + b];
+}
+
+// cubic B-spline coefficients of stamp `objs[o]` zero-extended by T on every side: coef[k][P][P][nb]
+__global__ __launch_bounds__(256) void scene_prefilter_kernel(const double* __restrict__ stamps,
+                                                              const int* __restrict__ which, int cs, int nb,
+                                                              double* __restrict__ coef) {
+  const int P = cs + 2 * T_MARGIN;
+  const double z1 = -0.26794919243112270647;   // sqrt(3) - 2
+  const double* st = stamps + (long)which[blockIdx.x] * cs * cs * nb;
+  double* c = coef + (long)blockIdx.x * P * P * nb;
+  // axis 0 (rows) for the cs stamp columns; the other columns of the extended image are zero and stay zero
+  for (int t = threadIdx.x; t < cs * nb; t += 256) {
+    const int j = t / nb, b = t - j * nb;
+    double* col = c + ((long)(T_MARGIN + j)) * nb + b;          // element [k][T+j][b] at col[k * P * nb]
+    const long ks = (long)P * nb;
+    double acc = 0.0;
+    for (int k = 0; k < P; ++k) {
+      const int i = k - T_MARGIN;
+      const double s = (i >= 0 && i < cs) ? st[((long)i * cs + j) * nb + b] : 0.0;
+      acc = 6.0 * s + z1 * acc;
+      col[k * ks] = acc;
+    }
+    double nxt = 0.0;
+    for (int k = P - 1; k >= 0; --k) {
+      nxt = z1 * (nxt - col[k * ks]);
+      col[k * ks] = nxt;
+    }
+  }
+  __syncthreads();
+  // axis 1 (columns) for every row
+  for (int t = threadIdx.x; t < P * nb; t += 256) {
+    const int k = t / nb, b = t - k * nb;
+    double* row = c + (long)k * P * nb + b;                       // element [k][j][b] at row[j * nb]
+    double acc = 0.0;
+    for (int j = 0; j < P; ++j) {
+      const int jj = j - T_MARGIN;
+      const double s = (jj >= 0 && jj < cs) ? row[(long)j * nb] : 0.0;
+      acc = 6.0 * s + z1 * acc;
+      row[(long)j * nb] = acc;
+    }
+    double nxt = 0.0;
+    for (int j = P - 1; j >= 0; --j) {
+      nxt = z1 * (nxt - row[(long)j * nb]);
+      row[(long)j * nb] = nxt;
+    }
+  }
+}
+
+__device__ __forceinline__ void bspline3(double t, double w[4]) {
+  const double u = 1.0 - t;
+  w[0] = u * u * u / 6.0;
+  w[1] = (3.0 * t * t * t - 6.0 * t * t + 4.0) / 6.0;
+  w[2] = (-3.0 * t * t * t + 3.0 * t * t + 3.0 * t + 1.0) / 6.0;
+  w[3] = t * t * t / 6.0;
+}
+
+__global__ __launch_bounds__(256) void scene_composite_kernel(double* __restrict__ field, int F, int nb,
+                                                              const double* __restrict__ stamps,
+                                                              const double* __restrict__ coef,
+                                                              const SceneObj* __restrict__ objs, int nobj, int cs,
+                                                              int po, double sign) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)F * F * nb) return;
+  const int b = (int)(e % nb);
+  const long px = e / nb;
+  const int c = (int)(px % F), r = (int)(px / F);
+  const int P = cs + 2 * T_MARGIN;
+  double acc = field[e];
+  for (int o = 0; o < nobj; ++o) {
+    const SceneObj ob = objs[o];
+    if (ob.coef < 0) {
+      const int rr = r - ob.ix, cc = c - ob.iy;
+      if ((unsigned)rr < (unsigned)cs && (unsigned)cc < (unsigned)cs)
+        acc += sign * stamps[(((long)o * cs + rr) * cs + cc) * nb + b];
+      continue;
+    }
+    // scipy.ndimage.shift, mode "constant": output is cval where the input coordinate leaves [0, F-1]; the spline
+    // coefficients are those of the F x F padded image with MIRROR boundaries at its edge samples, and nodes
+    // outside the image are looked up mirrored.  With the infinite-domain coefficients cinf of the zero-extended
+    // stamp (what the prefilter kernel computes) the mirrored ones are cm[i] = cinf[i] + cinf[-i] + cinf[2(F-1)-i].
+    // The reflected terms vanish unless the padded stamp sits within ~T pixels of the image edge (po < T).
+    const double xin = (double)r - (ob.sx - po), yin = (double)c - (ob.sy - po);
+    if (xin < 0.0 || yin < 0.0 || xin > F - 1.0 || yin > F - 1.0) continue;
+    const int off = po - T_MARGIN;                 // padded-image index of coefficient-image index 0
+    const bool refl = off < 2;
+    if (!refl && (xin - off < -2.0 || yin - off < -2.0 || xin - off > P + 1.0 || yin - off > P + 1.0)) continue;
+    const double fx = floor(xin), fy = floor(yin);
+    double wx[4], wy[4];
+    bspline3(xin - fx, wx);
+    bspline3(yin - fy, wy);
+    const double* cf = coef + (long)ob.coef * P * P * nb + b;
+    const int nr = refl ? 3 : 1;
+    double v = 0.0;
+    for (int a = 0; a < 4; ++a) {
+      int i = (int)fx - 1 + a;
+      i = i < 0 ? -i : (i > F - 1 ? 2 * (F - 1) - i : i);
+      const int ri[3] = {i - off, -i - off, 2 * (F - 1) - i - off};
+      for (int d = 0; d < 4; ++d) {
+        int j = (int)fy - 1 + d;
+        j = j < 0 ? -j : (j > F - 1 ? 2 * (F - 1) - j : j);
+        const int rj[3] = {j - off, -j - off, 2 * (F - 1) - j - off};
+        double cm = 0.0;
+        for (int u = 0; u < nr; ++u) {
+          if ((unsigned)ri[u] >= (unsigned)P) continue;
+          for (int w = 0; w < nr; ++w)
+            if ((unsigned)rj[w] < (unsigned)P) cm += cf[((long)ri[u] * P + rj[w]) * nb];
+        }
+        v += wx[a] * wy[d] * cm;
+      }
+    }
+    acc += sign * v;
+  }
+  field[e] = acc;
+}
+}  // namespace
+
+int scene_extract(const double* field_h, int F, int nb, const int32_t* starts_h, int N, int cs, double* out_h,
+                  hipStream_t s) {
+  if (!field_h || !starts_h || !out_h || F < 1 || nb < 1 || cs < 1 || N < 0) {
+    set_error("scene_extract: bad arguments");
+    return E_INVALID;
+  }
+  if (N == 0) return OK;
+  for (int i = 0; i < N; ++i) {
+    const int x = starts_h[2 * i], y = starts_h[2 * i + 1];
+    if (x < 0 || y < 0 || x + cs > F || y + cs > F) {
+      set_error("scene_extract: cutout %d (start %d,%d size %d) leaves the %d-pixel field", i, x, y, cs, F);
+      return E_INVALID;
+    }
+  }
+  const size_t fb = (size_t)F * F * nb * sizeof(double), ob = (size_t)N * cs * cs * nb * sizeof(double);
+  double *field = nullptr, *out = nullptr;
+  int* starts = nullptr;
+  int st = OK;
+  auto cleanup = [&]() { (void)hipFree(field); (void)hipFree(out); (void)hipFree(starts); };
+#define SC_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { st = hip_fail(e__, #call, __FILE__, __LINE__); cleanup(); return st; } } while (0)
+  SC_HIP(hipMalloc((void**)&field, fb));
+  SC_HIP(hipMalloc((void**)&out, ob));
+  SC_HIP(hipMalloc((void**)&starts, (size_t)N * 2 * sizeof(int)));
+  SC_HIP(hipMemcpyAsync(field, field_h, fb, hipMemcpyHostToDevice, s));
+  SC_HIP(hipMemcpyAsync(starts, starts_h, (size_t)N * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+  const long total = (long)N * cs * cs * nb;
+  hipLaunchKernelGGL(scene_extract_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, field, F, nb, starts,
+                     total, cs, out);
+  SC_HIP(hipGetLastError());
+  SC_HIP(hipMemcpyAsync(out_h, out, ob, hipMemcpyDeviceToHost, s));
+  SC_HIP(hipStreamSynchronize(s));
+  cleanup();
+  return OK;
+}
+
+int scene_composite(double* field_h, int F, int nb, const double* stamps_h, const double* pos_h, int N, int cs,
+                    double sign, hipStream_t s) {
+  if (!field_h || F < 1 || nb < 1 || cs < 1 || cs > F || N < 0 || (N > 0 && (!stamps_h || !pos_h))) {
+    set_error("scene_composite: bad arguments");
+    return E_INVALID;
+  }
+  if (N == 0) return OK;
+  const int P = cs + 2 * T_MARGIN;
+  const int po = (F - cs) / 2;                 // int((field_size - cutout_size) / 2), field_deblender.py:70
+  const int CHUNK = 256;                       // objects per pass (coefficient buffer <= 256 * P*P*nb doubles)
+  const size_t fb = (size_t)F * F * nb * sizeof(double);
+  const size_t stamp_elems = (size_t)cs * cs * nb;
+  double *field = nullptr, *stamps = nullptr, *coef = nullptr;
+  SceneObj* objs = nullptr;
+  int* which = nullptr;
+  int st = OK;
+  auto cleanup = [&]() {
+    (void)hipFree(field); (void)hipFree(stamps); (void)hipFree(coef); (void)hipFree(objs); (void)hipFree(which);
+  };
+  SC_HIP(hipMalloc((void**)&field, fb));
+  SC_HIP(hipMalloc((void**)&stamps, (size_t)CHUNK * stamp_elems * sizeof(double)));
+  SC_HIP(hipMalloc((void**)&objs, (size_t)CHUNK * sizeof(SceneObj)));
+  SC_HIP(hipMalloc((void**)&which, (size_t)CHUNK * sizeof(int)));
+  SC_HIP(hipMemcpyAsync(field, field_h, fb, hipMemcpyHostToDevice, s));
+  SceneObj hobj[256];
+  int hwhich[256];
+  for (int base = 0; base < N; base += CHUNK) {
+    const int n = N - base < CHUNK ? N - base : CHUNK;
+    int nsub = 0;
+    for (int i = 0; i < n; ++i) {
+      const double px = pos_h[2 * (base + i)], py = pos_h[2 * (base + i) + 1];
+      if (!(px == px) || !(py == py) || px > 1e9 || px < -1e9 || py > 1e9 || py < -1e9) {
+        set_error("scene_composite: object %d has a non-finite position", base + i);
+        cleanup();
+        return E_INVALID;
+      }
+      SceneObj o;
+      o.sx = po + px; o.sy = po + py;
+      const bool integer = px == floor(px) && py == floor(py);
+      o.ix = (int)floor(o.sx); o.iy = (int)floor(o.sy);
+      o.coef = integer ? -1 : nsub;
+      o.pad_ = 0;
+      if (!integer) hwhich[nsub++] = i;
+      hobj[i] = o;
+    }
+    SC_HIP(hipMemcpyAsync(stamps, stamps_h + (size_t)base * stamp_elems, (size_t)n * stamp_elems * sizeof(double),
+                          hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(objs, hobj, (size_t)n * sizeof(SceneObj), hipMemcpyHostToDevice, s));
+    if (nsub > 0) {
+      if (!coef) SC_HIP(hipMalloc((void**)&coef, (size_t)CHUNK * P * P * nb * sizeof(double)));
+      SC_HIP(hipMemcpyAsync(which, hwhich, (size_t)nsub * sizeof(int), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(scene_prefilter_kernel, dim3(nsub), dim3(256), 0, s, stamps, which, cs, nb, coef);
+      SC_HIP(hipGetLastError());
+    }
+    const long total = (long)F * F * nb;
+    hipLaunchKernelGGL(scene_composite_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, field, F, nb,
+                       stamps, coef, objs, n, cs, po, sign);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(s));           // hobj / hwhich are reused by the next chunk
+  }
+  SC_HIP(hipMemcpyAsync(field_h, field, fb, hipMemcpyDeviceToHost, s));
+  SC_HIP(hipStreamSynchronize(s));
+  cleanup();
+  return OK;
+#undef SC_HIP
+}
+
+}  // namespace dv

@@ -109,6 +109,38 @@ class Context:
         check(lib.dv_ctx_allreduce_host(self._h, _fp(a), a.size))
         return a
 
+    # -- scene compositing (float64 host arrays, like the reference's numpy fields) --------------
+    def scene_extract(self, field, starts, cutout_size: int) -> np.ndarray:
+        """cutouts[i] = field[starts[i,0]:+cs, starts[i,1]:+cs, :] for a field (F, F, bands)."""
+        field = np.ascontiguousarray(field, dtype=np.float64)
+        starts = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, 2)
+        if field.ndim != 3 or field.shape[0] != field.shape[1]:
+            raise ValueError(f"expected a square field (F, F, bands), got {field.shape}")
+        out = np.empty((starts.shape[0], cutout_size, cutout_size, field.shape[2]), np.float64)
+        dp = C.POINTER(C.c_double)
+        check(lib.dv_scene_extract(self._h, field.ctypes.data_as(dp), field.shape[0], field.shape[2],
+                                   starts.ctypes.data_as(C.POINTER(C.c_int32)), starts.shape[0], int(cutout_size),
+                                   out.ctypes.data_as(dp)))
+        return out
+
+    def scene_composite(self, field, stamps, positions, sign: float = 1.0) -> np.ndarray:
+        """field + sign * sum_i shift(pad(stamps[i]), positions[i]) (scipy.ndimage.shift semantics), in object order."""
+        out = np.array(field, dtype=np.float64, order="C", copy=True)
+        stamps = np.ascontiguousarray(stamps, dtype=np.float64)
+        positions = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 2)
+        if out.ndim != 3 or out.shape[0] != out.shape[1]:
+            raise ValueError(f"expected a square field (F, F, bands), got {out.shape}")
+        if stamps.shape[0] == 0:
+            return out
+        if stamps.ndim != 4 or stamps.shape[1] != stamps.shape[2] or stamps.shape[3] != out.shape[2] \
+                or stamps.shape[0] != positions.shape[0]:
+            raise ValueError(f"stamps {stamps.shape} / positions {positions.shape} do not fit field {out.shape}")
+        dp = C.POINTER(C.c_double)
+        check(lib.dv_scene_composite(self._h, out.ctypes.data_as(dp), out.shape[0], out.shape[2],
+                                     stamps.ctypes.data_as(dp), positions.ctypes.data_as(dp), stamps.shape[0],
+                                     stamps.shape[1], float(sign)))
+        return out
+
     def close(self):
         if self._h:
             lib.dv_ctx_destroy(self._h)

@@ -134,6 +134,19 @@ int dv_encode(dv_model* m, const float* x, int64_t N, float* t);
 /* decoder(z) -> loc, scale  (model.py:103-161) */
 int dv_decode(dv_model* m, const float* z, int64_t N, float* loc, float* scale);
 
+/* ---- scene compositing around the network ------------------------------
+ * Host buffers are float64 like the reference's numpy arrays; the library stages them through the GPU.
+ * dv_scene_extract: out[i] = field[starts[i][0] : +cs, starts[i][1] : +cs, :] for a field [F][F][nb]
+ * (extract/extraction.py:4-43; every window must lie inside the field, else DV_E_INVALID).
+ * dv_scene_composite: field += sign * sum_i shift(pad(stamps[i]), pos[i]) in object order, where pad() centres the
+ * cs x cs stamp in a zero F x F image and shift() is scipy.ndimage.shift with default arguments (order-3 spline,
+ * mode "constant"): deblend/field_deblender.py:46-97 (sign -1, the residual field) and :99-189 (sign +1, the
+ * predicted mean / stddev / epistemic fields).  pos[i] = {row shift, column shift}. */
+int dv_scene_extract(dv_ctx* ctx, const double* field, int32_t F, int32_t nb, const int32_t* starts, int32_t N,
+                     int32_t cs, double* out);
+int dv_scene_composite(dv_ctx* ctx, double* field, int32_t F, int32_t nb, const double* stamps, const double* pos,
+                       int32_t N, int32_t cs, double sign);
+
 /* ---- introspection for tests and bench ----------------------------------------------------- */
 /* copy a named activation of the last step to host: "t","z","kl","eps","loc","scale","head_pre" */
 int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t nbytes);

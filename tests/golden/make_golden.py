@@ -7,6 +7,10 @@
                so these vectors pin the ORACLE and are what the GPU box checks the HIP path against.
   helpers.npz  inputs/outputs of the reference's own importable helpers (normalize.py, metrics.mse),
                obtained by importing those two files by path.
+  scene.npz    cutouts produced by the reference's own extract_cutouts (extract/extraction.py imported by path) for
+               a seeded field, including windows that leave the field; plus residual / predicted fields of a small
+               scene computed by oracle/scene_oracle.py (scipy.ndimage.shift with the reference's arguments:
+               field_deblender.py itself needs `sep` and cannot be imported).
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -65,6 +69,19 @@ def main():
     n = nz.normalize_non_linear(a)
     np.savez_compressed(os.path.join(HERE, "helpers.npz"), a=a, b=b, normalized=n,
                         denormalized=nz.denormalize_non_linear(n), mse=np.array(mt.mse(a, b)))
+    ex = _load(os.path.join(REF, "extract/extraction.py"), "ref_extraction")
+    from oracle import scene_oracle as so
+    rng = np.random.default_rng(3)
+    F, cs, nb = 41, 11, 2
+    field = rng.normal(size=(1, F, F, nb))
+    dists = [[-4, -3], [15, 15], [-15, -15], [16, 2], [0, -16], [3.7, -2.2], [-15.9, 14.99], [0, 0], [-40, 3], [-36, -41]]
+    cut, idx = ex.extract_cutouts(field.copy(), F, dists, cs, nb)
+    stamps = rng.random((6, cs, cs, nb))
+    pos = np.array([[0, 0], [5, -7], [-14, 13], [2.5, 3.25], [-17.3, 16.8], [19, -19]], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "scene.npz"), field=field, dists=np.array(dists), cutouts=cut,
+                        list_idx=np.array(idx), stamps=stamps, pos=pos,
+                        residual=so.residual_field(field[0], stamps, pos, cs),
+                        predicted=so.predicted_field(F, nb, stamps, pos, cs))
     print("wrote", os.listdir(HERE))
 
 
