@@ -58,6 +58,7 @@ _i64 = C.POINTER(C.c_int64)
 # name -> (restype, argtypes); every symbol declared in include/debvader_hip.h
 SIGNATURES = {
     "dv_version": (C.c_int, []),
+    "dv_crc32c": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     "dv_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
     "dv_config_default": (C.c_int, [C.POINTER(DvConfig)]),
     "dv_arch_counts": (C.c_int, [C.POINTER(DvConfig), _i32, _i64, _i64, _i64]),

@@ -1376,6 +1376,38 @@ extern "C" {
 
 int dv_version(void) { return 100; }
 
+// CRC-32C (Castagnoli), slicing-by-8 on the host: the checksum TensorFlow tensor-bundle checkpoints carry per tensor
+// and per index block (debvader_amd/model/tf_checkpoint.py; reference call sites model.py:262-266, train.py:49-75).
+// Same contract as tensorflow::crc32c::Extend: pass 0 (or the value returned for the preceding bytes).
+uint32_t dv_crc32c(uint32_t crc, const void* data, size_t n) {
+  static uint32_t tbl[8][256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      tbl[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) tbl[t][i] = (tbl[t - 1][i] >> 8) ^ tbl[0][tbl[t - 1][i] & 0xFF];
+    init = true;
+  }
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  uint32_t l = crc ^ 0xFFFFFFFFu;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= l;
+    l = tbl[7][lo & 0xFF] ^ tbl[6][(lo >> 8) & 0xFF] ^ tbl[5][(lo >> 16) & 0xFF] ^ tbl[4][lo >> 24] ^
+        tbl[3][hi & 0xFF] ^ tbl[2][(hi >> 8) & 0xFF] ^ tbl[1][(hi >> 16) & 0xFF] ^ tbl[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) l = tbl[0][(l ^ *p++) & 0xFF] ^ (l >> 8);
+  return l ^ 0xFFFFFFFFu;
+}
+
 int dv_last_error(char* buf, size_t n) {
   if (!buf || n == 0) return DV_E_INVALID;
   strncpy(buf, g_err, n - 1);

@@ -121,6 +121,7 @@ class VAENet:
         eng = self._core.engine
         eng.set_trainable(bool(self.encoder.trainable), bool(self.decoder.trainable))
         eng.optimizer_reset(lr, b1, b2, eps)
+        self.optimizer = Adam(lr, b1, b2, eps)
         self._metrics = list(metrics or [])
         self._core.compiled = True
 
@@ -162,10 +163,25 @@ class VAENet:
             self._core.engine.set_param(i, w)
 
     def save_weights(self, filepath, overwrite=True, save_format=None):
-        """Writes <filepath>.npz (parameters, Adam slots, iteration) and a `checkpoint` index file next to
-        it, mirroring what ModelCheckpoint(save_weights_only=True) leaves on disk (train.py:54-71).
-        Writing TF tensor-bundles is not implemented (a loadable Keras checkpoint also needs the object graph)."""
+        """Keras `Model.save_weights`.  By default writes a TensorFlow tensor-bundle checkpoint (`<filepath>.index`,
+        `<filepath>.data-00000-of-00001`, `checkpoint`) with the Keras object graph, i.e. what
+        ModelCheckpoint(save_weights_only=True) leaves on disk in the reference (train.py:54-71) and what its
+        `net.load_weights(tf.train.latest_checkpoint(dir))` restores (model.py:262-266) - variables, Adam slots and
+        step counter included.  A path ending in `.npz` (or save_format="npz") writes a single numpy archive."""
         eng = self._core.engine
+        if not overwrite and (os.path.exists(filepath + ".index") or os.path.exists(filepath)):
+            raise FileExistsError(filepath)
+        if save_format in ("h5", "hdf5", "keras") or filepath.endswith((".h5", ".hdf5", ".keras")):
+            raise NotImplementedError("HDF5 / .keras weight files are not supported; use the TensorFlow checkpoint format")
+        if not (filepath.endswith(".npz") or save_format == "npz"):
+            from debvader_amd.model import tf_checkpoint
+
+            opt = getattr(self, "optimizer", None)
+            hyper = None
+            if opt is not None:
+                hyper = {"learning_rate": opt.learning_rate, "beta_1": opt.beta_1, "beta_2": opt.beta_2, "decay": 0.0}
+            tf_checkpoint.save_from_engine(eng, filepath, optimizer=hyper)
+            return
         path = filepath if filepath.endswith(".npz") else filepath + ".npz"
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         blob = {"__iter__": np.array(eng.iterations, dtype=np.int64)}
@@ -183,15 +199,15 @@ class VAENet:
         the reference (`<prefix>.index` + `.data-*` shards; debvader_amd/model/tf_checkpoint.py)."""
         if filepath is None:
             raise FileNotFoundError("no checkpoint found (latest_checkpoint returned None)")
+        if os.path.exists(filepath + ".index"):
+            # a TensorFlow tensor-bundle: written by the reference (ModelCheckpoint / net.save_weights) or by save_weights
+            from debvader_amd.model import tf_checkpoint
+
+            tf_checkpoint.load_into_engine(self._core.engine, filepath, load_slots=True)
+            return self
         path = filepath if filepath.endswith(".npz") else filepath + ".npz"
         if not os.path.exists(path):
-            if os.path.exists(filepath + ".index"):
-                # a TensorFlow tensor-bundle written by the reference (ModelCheckpoint / net.save_weights)
-                from debvader_amd.model import tf_checkpoint
-
-                tf_checkpoint.load_into_engine(self._core.engine, filepath, load_slots=True)
-                return self
-            raise FileNotFoundError(path)
+            raise FileNotFoundError(f"neither {filepath}.index nor {path} exists")
         eng = self._core.engine
         with np.load(path) as z:
             for i, (name, shape, tr) in enumerate(eng.specs):

@@ -56,6 +56,9 @@ typedef struct dv_config {
 enum { DV_S_LOSS = 0, DV_S_NLL_MEAN = 1, DV_S_KL_REG = 2, DV_S_MSE = 3, DV_N_SCALARS = 4 };
 
 int dv_version(void);
+/* CRC-32C of `n` bytes continuing from `crc` (0 to start): the checksum of TensorFlow tensor-bundle checkpoints,
+ * which load_weights / ModelCheckpoint read and write (model.py:262-266, train.py:49-75).  Host only. */
+uint32_t dv_crc32c(uint32_t crc, const void* data, size_t n);
 int dv_last_error(char* buf, size_t n);
 int dv_config_default(dv_config* cfg);
 

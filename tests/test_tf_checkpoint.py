@@ -105,3 +105,103 @@ def test_load_weights_from_tf_bundle(tmp_path, monkeypatch):
     np.testing.assert_array_equal(eng.get_slot("enc/conv1/kernel", 0), t[tfc.slot_key(keys["enc/conv1/kernel"], "m")])
     assert eng.iterations == 386
     assert not net.decoder.trainable
+
+
+# ---- writer ("+writer") -----------------------------------------------------------------------
+def _ref_object_graph():
+    with open(os.path.join(G, "dc2_weights_noisy_v4.ckpt.data-00000-of-00002"), "rb") as f:
+        raw = f.read()                      # the reference's shard 0: exactly one scalar string tensor
+    n, pos = tfc._varint(raw, 0)
+    return raw, raw[pos + 4:pos + 4 + n]
+
+
+def test_index_encoder_reproduces_reference_file_byte_for_byte(tmp_path):
+    b = tfc.TensorBundle(_ref_bundle(tmp_path))
+    with open(os.path.join(G, "dc2_weights_noisy_v4.ckpt.index"), "rb") as f:
+        assert tfc.encode_index(b.entries, b.num_shards) == f.read()
+
+
+def test_string_tensor_checksum_matches_reference_entry(tmp_path):
+    b = tfc.TensorBundle(_ref_bundle(tmp_path))
+    raw, body = _ref_object_graph()
+    e = b.entries["_CHECKPOINTABLE_OBJECT_GRAPH"]
+    assert e.size == len(raw) and tfc.string_tensor_crc(body) == e.crc32c
+    assert tfc._string_tensor_bytes(body) == raw
+
+
+def test_object_graph_matches_reference_checkpoint():
+    specs = E.arch_specs(E.make_config())
+    ours_paths, ours_slots = tfc.parse_object_graph(tfc.object_graph(specs, cropping=True, with_optimizer=True))
+    ref_paths, ref_slots = tfc.parse_object_graph(_ref_object_graph()[1])
+    assert len(ref_paths) == 64 + 5 and len(ref_slots) == 124
+    assert ours_paths == ref_paths          # path from the root -> (Keras variable name, checkpoint key)
+    assert ours_slots == ref_slots          # (variable key, m|v, slot variable name, slot key), in TensorFlow's order
+    assert ours_paths[("layer_with_weights-1", "layer_with_weights-19", "kernel")][0] == "conv2d_transpose_7/kernel"
+    assert ours_paths[("optimizer", "iter")] == ("training/Adam/iter", "optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE")
+
+
+def test_writer_round_trip_multi_block(tmp_path):
+    rng = np.random.default_rng(1)
+    t = {f"layer_with_weights-1/layer_with_weights-{i}/alpha/.ATTRIBUTES/VARIABLE_VALUE": rng.normal(size=(i + 1, 3)).astype(np.float32)
+         for i in range(60)}
+    t["optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE"] = np.array(7, dtype=np.int64)
+    t["_CHECKPOINTABLE_OBJECT_GRAPH"] = b"\x0a\x00" * 700
+    prefix = str(tmp_path / "d" / "w.ckpt")
+    tfc.write_bundle(prefix, t)
+    tfc.write_checkpoint_state(prefix)
+    assert tfc.latest_checkpoint_prefix(str(tmp_path / "d")) == prefix
+    b = tfc.TensorBundle(prefix)
+    assert b.read_string("_CHECKPOINTABLE_OBJECT_GRAPH") == t["_CHECKPOINTABLE_OBJECT_GRAPH"]
+    for k, v in t.items():
+        if not isinstance(v, bytes):
+            np.testing.assert_array_equal(b.read(k, verify=True), v)
+    # the same entries through several small data blocks (index block with separators)
+    with open(prefix + ".index", "wb") as f:
+        f.write(tfc.encode_index(b.entries, 1, block_size=512))
+    b2 = tfc.TensorBundle(prefix)
+    assert b2.keys() == b.keys()
+    for k in b.keys():
+        assert repr(b2.entries[k]) == repr(b.entries[k])
+    # corruption is detected
+    with open(prefix + ".data-00000-of-00001", "r+b") as f:
+        f.seek(b.entries["optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE"].offset)
+        f.write(b"\xff")
+    with pytest.raises(ValueError, match="checksum"):
+        tfc.TensorBundle(prefix).read("optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE", verify=True)
+
+
+@pytest.mark.gpu
+def test_save_weights_writes_reference_layout_and_resumes_bit_exact(tmp_path):
+    from debvader_amd.model import model
+    from debvader_amd.data import synthetic_stamps
+    from debvader_amd.training.metrics import vae_loss
+    x, y = synthetic_stamps(12, seed=3)
+    net, _, _, _ = model.create_model_vae((59, 59, 6), 32, [32, 64, 128, 256], [3, 3, 3, 3], max_batch=6)
+    net.compile(optimizer=model.Adam(learning_rate=1e-4), loss=vae_loss, metrics=["mse"])
+    net.fit(x, y, epochs=1, batch_size=6, verbose=0, shuffle=False)
+    prefix = str(tmp_path / "dc2" / "weights_noisy_v4.ckpt")
+    net.save_weights(prefix)
+    seed_at_save = net._core.seed_counter
+    # same keys, dtypes and shapes as the reference's own checkpoint (its index is the golden file)
+    ours, ref = tfc.TensorBundle(prefix), tfc.TensorBundle(_ref_bundle(tmp_path))
+    assert ours.keys() == ref.keys()
+    for k in ref.keys():
+        assert (ours.entries[k].dtype, ours.entries[k].shape) == (ref.entries[k].dtype, ref.entries[k].shape), k
+    assert tfc.parse_object_graph(ours.read_string("_CHECKPOINTABLE_OBJECT_GRAPH")) == \
+        tfc.parse_object_graph(_ref_object_graph()[1])
+    assert int(ours.read("optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE")) == 2
+    np.testing.assert_allclose(ours.read("optimizer/learning_rate/.ATTRIBUTES/VARIABLE_VALUE"), 1e-4, rtol=1e-7)
+    # resume: a fresh network restored from the checkpoint continues exactly like the original
+    net.fit(x, y, epochs=1, batch_size=6, verbose=0, shuffle=False)
+    net2, _, _, _ = model.create_model_vae((59, 59, 6), 32, [32, 64, 128, 256], [3, 3, 3, 3], max_batch=6)
+    net2.compile(optimizer=model.Adam(learning_rate=1e-4), loss=vae_loss, metrics=["mse"])
+    net2.load_weights(model.latest_checkpoint(str(tmp_path / "dc2")))
+    assert net2._core.engine.iterations == 2
+    net2._core.seed_counter = seed_at_save      # the latent-noise seed is host state, not part of a Keras checkpoint
+    net2.fit(x, y, epochs=1, batch_size=6, verbose=0, shuffle=False)
+    for a, b in zip(net.get_weights(), net2.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    eng, eng2 = net._core.engine, net2._core.engine
+    for i, (_, _, tr) in enumerate(eng.specs):
+        if tr:
+            np.testing.assert_array_equal(eng.get_slot(i, 1), eng2.get_slot(i, 1))
