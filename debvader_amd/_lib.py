@@ -89,6 +89,7 @@ SIGNATURES = {
     "dv_grad_step": (C.c_int, [_p, C.c_int32, _i32, C.c_int64, C.c_int32, C.c_int32, _f, C.c_uint64, _f]),
     "dv_train_steps": (C.c_int, [_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _f]),
     "dv_infer": (C.c_int, [_p, _f, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
+    "dv_infer_f64": (C.c_int, [_p, _d, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
     "dv_scene_extract": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _d]),
     "dv_scene_composite": (C.c_int, [_p, _d, C.c_int32, C.c_int32, _d, _d, C.c_int32, C.c_int32, C.c_double]),
     "dv_infer_mc": (C.c_int, [_p, _f, C.c_int64, C.c_int32, C.c_uint64, _f, _f]),

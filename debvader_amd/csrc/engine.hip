@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/debvader_hip.h"
@@ -288,6 +289,10 @@ static int ilog2_exact(int v) {
 // --------------------------------------------------------------------------------------------
 // handles
 // --------------------------------------------------------------------------------------------
+namespace dv {
+struct InferPipe;
+}
+
 struct dv_ctx {
   int device = 0, rank = 0, world = 1;
   hipStream_t stream = nullptr;
@@ -349,6 +354,7 @@ struct dv_model {
   size_t ws1_elems = 0, ws2_elems = 0, ws3_elems = 0;
   float *scal = nullptr, *bnstate = nullptr, *bnsums = nullptr;
   float* stage_x = nullptr;  // host-batch staging (infer / encode)
+  dv::InferPipe* pipe = nullptr;   // pinned staging + copy streams of the pipelined dv_infer (lazy)
   float* zero_page = nullptr;  // 256 B of zeros (LDS-DMA source for out-of-image pieces)
   int* idx_dev = nullptr;
   DataSlot slots[2];
@@ -1032,6 +1038,7 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
   static const int want_lanes = getenv("DV_FWD_LANES") ? atoi(getenv("DV_FWD_LANES")) : 2;
   int nlanes = (m->split_forward && !m->prof_on && cx->aux_stream && NB >= 64) ? std::max(1, std::min(want_lanes, 4)) : 1;
   while (nlanes > 1 && NB / nlanes < 32) --nlanes;
+  while (nlanes > 2 && !cx->lane_stream[nlanes - 3]) --nlanes;
   const int per = nlanes > 1 ? ((NB / nlanes + 31) / 32) * 32 : NB;   // lane sizes: multiples of 32 stamps
   int blk_done = 0, st = OK;
   // lane 0 runs on the main stream, lane 1 on the aux stream, further lanes on their own streams
@@ -1365,6 +1372,222 @@ static int stage_host_batch(dv_model* m, const float* x, int nb) {
   return OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined batched inference (deblend_cutout/deblender.py:18,24: `net(tf.cast(images, tf.float32))` on all N stamps).
+// The boundary hands over pageable host arrays: 83.5 KB in and 167 KB out per stamp, about what the forward pass
+// itself costs in time if the copies run serially.  Chunks therefore flow through a three-stage pipeline with
+// double buffers: host threads convert / copy the caller's array into pinned memory (float64 input is cast here, as
+// the reference's tf.cast does) -> H2D on a copy stream -> forward on the engine streams, outputs copied device to
+// device into a transfer buffer -> D2H on a second copy stream -> host threads copy into the caller's arrays.
+// ---------------------------------------------------------------------------------------------------------------
+struct InferPipe {
+  int cap = 0;                      // stamps per buffer
+  float *hin[2] = {}, *hloc[3] = {}, *hscale[3] = {}, *hsmall[3] = {};      // pinned host (outputs: three deep)
+  float *din[2] = {}, *dloc[2] = {}, *dscale[2] = {}, *dsmall[2] = {};      // device
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t ev_h2d[2] = {}, ev_comp[2] = {}, ev_d2h[3] = {};
+  int threads = 4;
+};
+
+static void pipe_free(InferPipe* p) {
+  if (!p) return;
+  for (int b = 0; b < 3; ++b) {
+    (void)hipHostFree(p->hloc[b]); (void)hipHostFree(p->hscale[b]); (void)hipHostFree(p->hsmall[b]);
+    if (p->ev_d2h[b]) (void)hipEventDestroy(p->ev_d2h[b]);
+  }
+  for (int b = 0; b < 2; ++b) {
+    (void)hipHostFree(p->hin[b]);
+    (void)hipFree(p->din[b]); (void)hipFree(p->dloc[b]); (void)hipFree(p->dscale[b]); (void)hipFree(p->dsmall[b]);
+    if (p->ev_h2d[b]) (void)hipEventDestroy(p->ev_h2d[b]);
+    if (p->ev_comp[b]) (void)hipEventDestroy(p->ev_comp[b]);
+  }
+  if (p->s_in) (void)hipStreamDestroy(p->s_in);
+  delete p;
+}
+
+static int pipe_get(dv_model* m, int cap, InferPipe** out) {
+  const Arch& A = m->A;
+  if (m->pipe && m->pipe->cap >= cap) {
+    *out = m->pipe;
+    return OK;
+  }
+  pipe_free(m->pipe);
+  m->pipe = nullptr;
+  InferPipe* p = new InferPipe();
+  p->cap = cap;
+  const size_t img = (size_t)cap * A.H * A.H * A.C * sizeof(float), small = (size_t)cap * 3 * A.d * sizeof(float);
+  int st = OK;
+#define PP_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { st = hip_fail(e__, #call, __FILE__, __LINE__); pipe_free(p); return st; } } while (0)
+  for (int b = 0; b < 3; ++b) {
+    PP_HIP(hipHostMalloc((void**)&p->hloc[b], img, hipHostMallocDefault));
+    PP_HIP(hipHostMalloc((void**)&p->hscale[b], img, hipHostMallocDefault));
+    PP_HIP(hipHostMalloc((void**)&p->hsmall[b], small, hipHostMallocDefault));
+    PP_HIP(hipEventCreateWithFlags(&p->ev_d2h[b], hipEventDisableTiming));
+  }
+  for (int b = 0; b < 2; ++b) {
+    PP_HIP(hipHostMalloc((void**)&p->hin[b], img, hipHostMallocDefault));
+    PP_HIP(hipMalloc((void**)&p->din[b], img + 64));
+    PP_HIP(hipMalloc((void**)&p->dloc[b], img + 64));
+    PP_HIP(hipMalloc((void**)&p->dscale[b], img + 64));
+    PP_HIP(hipMalloc((void**)&p->dsmall[b], small));
+    PP_HIP(hipEventCreateWithFlags(&p->ev_h2d[b], hipEventDisableTiming));
+    PP_HIP(hipEventCreateWithFlags(&p->ev_comp[b], hipEventDisableTiming));
+  }
+  PP_HIP(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+  p->s_out = m->ctx->comm_stream;     // idle during inference; a fifth stream would share a hardware queue
+#undef PP_HIP
+  const char* e = getenv("DV_COPY_THREADS");
+  int hw = (int)std::thread::hardware_concurrency();
+  p->threads = e ? std::max(1, atoi(e)) : std::max(1, std::min(8, hw > 0 ? hw / 2 : 4));
+  m->pipe = p;
+  *out = p;
+  return OK;
+}
+
+// dst[i] = (float)src[i] for n elements, split over `threads` host threads (src float32 or float64)
+static void host_copy(float* dst, const void* src, size_t n, bool src_f64, int threads) {
+  auto work = [=](size_t lo, size_t hi) {
+    if (src_f64) {
+      const double* sd = static_cast<const double*>(src);
+      for (size_t i = lo; i < hi; ++i) dst[i] = (float)sd[i];
+    } else {
+      memcpy(dst + lo, static_cast<const float*>(src) + lo, (hi - lo) * sizeof(float));
+    }
+  };
+  if (threads <= 1 || n < (size_t)1 << 18) {
+    work(0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t per = ((n + threads - 1) / threads + 15) & ~(size_t)15;
+  for (int t = 1; t < threads; ++t) {
+    const size_t lo = std::min(n, per * t), hi = std::min(n, per * (t + 1));
+    if (lo < hi) pool.emplace_back(work, lo, hi);
+  }
+  work(0, std::min(n, per));
+  for (auto& th : pool) th.join();
+}
+
+static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, const float* eps, uint64_t seed,
+                           float* loc, float* scale, float* mu, float* zstd, float* z) {
+  const Arch& A = m->A;
+  hipStream_t s = m->ctx->stream;
+  const size_t stamp = (size_t)A.H * A.H * A.C;
+  // chunk: the workspace capacity for long inputs, a quarter of the input (>= 128 stamps) for short ones
+  int chunk = m->Bc;
+  if (N < 2 * (int64_t)m->Bc) chunk = (int)std::min<int64_t>(m->Bc, std::max<int64_t>(128, ((N + 3) / 4 + 63) / 64 * 64));
+  InferPipe* p = nullptr;
+  DV_TRY(pipe_get(m, chunk, &p));
+  const int64_t K = (N + chunk - 1) / chunk;
+  const int d = A.d;
+  auto finish = [&](int64_t k) -> int {       // stage D: pinned -> caller's arrays
+    const int b = (int)(k % 3);
+    const int64_t o = k * chunk;
+    const int nb = (int)std::min<int64_t>(chunk, N - o);
+    DV_HIP(hipEventSynchronize(p->ev_d2h[b]));
+    if (loc) host_copy(loc + o * stamp, p->hloc[b], nb * stamp, false, p->threads);
+    if (scale) host_copy(scale + o * stamp, p->hscale[b], nb * stamp, false, p->threads);
+    if (mu) memcpy(mu + o * d, p->hsmall[b], (size_t)nb * d * sizeof(float));
+    if (zstd) memcpy(zstd + o * d, p->hsmall[b] + (size_t)chunk * d, (size_t)nb * d * sizeof(float));
+    if (z) memcpy(z + o * d, p->hsmall[b] + (size_t)2 * chunk * d, (size_t)nb * d * sizeof(float));
+    return OK;
+  };
+  auto stage_in = [&](int64_t k) -> int {     // stage A, host part: caller's array -> pinned (float64 cast here)
+    const int b = (int)(k & 1);
+    const int64_t o = k * chunk;
+    const int nb = (int)std::min<int64_t>(chunk, N - o);
+    if (k >= 2) DV_HIP(hipEventSynchronize(p->ev_h2d[b]));            // pinned input buffer b is free again
+    const char* xb = static_cast<const char*>(x) + (size_t)o * stamp * (x_f64 ? sizeof(double) : sizeof(float));
+    host_copy(p->hin[b], xb, nb * stamp, x_f64, p->threads);
+    return OK;
+  };
+  static const bool trace = getenv("DV_PIPE_TRACE") != nullptr;
+  std::vector<hipEvent_t> tev;
+  if (trace) {
+    tev.resize(6 * K);
+    for (auto& e : tev) DV_HIP(hipEventCreate(&e));
+  }
+  auto h2d = [&](int64_t k) -> int {          // stage A, device part
+    const int b = (int)(k & 1);
+    const int nb = (int)std::min<int64_t>(chunk, N - k * chunk);
+    if (k >= 2) DV_HIP(hipStreamWaitEvent(p->s_in, p->ev_comp[b], 0));   // forward of chunk k-2 has read din[b]
+    if (trace) DV_HIP(hipEventRecord(tev[6 * k + 0], p->s_in));
+    DV_HIP(hipMemcpyAsync(p->din[b], p->hin[b], nb * stamp * sizeof(float), hipMemcpyHostToDevice, p->s_in));
+    if (trace) DV_HIP(hipEventRecord(tev[6 * k + 1], p->s_in));
+    DV_HIP(hipEventRecord(p->ev_h2d[b], p->s_in));
+    return OK;
+  };
+  if (K >= 1) {
+    DV_TRY(stage_in(0));
+    DV_TRY(h2d(0));
+  }
+  for (int64_t k = 0; k < K; ++k) {
+    const int b = (int)(k & 1);
+    const int64_t o = k * chunk;
+    const int nb = (int)std::min<int64_t>(chunk, N - o);
+    // the NEXT chunk's input goes into the copy queue before this chunk's outputs: copies issued later would
+    // otherwise sit behind a D2H that cannot start until this chunk's forward has finished
+    if (k + 1 < K) {
+      DV_TRY(stage_in(k + 1));
+      DV_TRY(h2d(k + 1));
+    }
+    // stage B: forward, then outputs into transfer buffer b
+    DV_HIP(hipStreamWaitEvent(s, p->ev_h2d[b], 0));
+    if (k >= 2) DV_HIP(hipStreamWaitEvent(s, p->ev_d2h[(k - 2) % 3], 0));   // D2H of chunk k-2 has drained device buffer b
+    if (trace) DV_HIP(hipEventRecord(tev[6 * k + 2], s));
+    {
+      // the head kernel writes loc / scale straight into transfer buffer b (a device-to-device hipMemcpyAsync of the
+      // two 171 MB images cost 3.7 ms each per 2048-stamp chunk)
+      float *keep_loc = m->loc, *keep_scale = m->scale;
+      m->loc = p->dloc[b];
+      m->scale = p->dscale[b];
+      const int st = forward_all(m, p->din[b], nullptr, nullptr, 0, nb, nb, false, false, false,
+                                 eps ? eps + o * d : nullptr, seed, (unsigned)m->ctx->rank, (unsigned)o, zstd != nullptr,
+                                 false, true);
+      m->loc = keep_loc;
+      m->scale = keep_scale;
+      DV_TRY(st);
+    }
+    if (mu)
+      DV_HIP(hipMemcpy2DAsync(p->dsmall[b], d * sizeof(float), m->t, A.tw * sizeof(float), d * sizeof(float), nb,
+                              hipMemcpyDeviceToDevice, s));
+    if (zstd)
+      DV_HIP(hipMemcpyAsync(p->dsmall[b] + (size_t)chunk * d, m->zstd, (size_t)nb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (z)
+      DV_HIP(hipMemcpyAsync(p->dsmall[b] + (size_t)2 * chunk * d, m->z, (size_t)nb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (trace) DV_HIP(hipEventRecord(tev[6 * k + 3], s));
+    DV_HIP(hipEventRecord(p->ev_comp[b], s));
+    // stage C: device -> pinned (three-deep ring) on the second copy stream
+    const int h = (int)(k % 3);
+    DV_HIP(hipStreamWaitEvent(p->s_out, p->ev_comp[b], 0));
+    if (trace) DV_HIP(hipEventRecord(tev[6 * k + 4], p->s_out));
+    if (loc) DV_HIP(hipMemcpyAsync(p->hloc[h], p->dloc[b], nb * stamp * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
+    if (scale) DV_HIP(hipMemcpyAsync(p->hscale[h], p->dscale[b], nb * stamp * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
+    if (mu || zstd || z)
+      DV_HIP(hipMemcpyAsync(p->hsmall[h], p->dsmall[b], (size_t)chunk * 3 * d * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
+    if (trace) DV_HIP(hipEventRecord(tev[6 * k + 5], p->s_out));
+    DV_HIP(hipEventRecord(p->ev_d2h[h], p->s_out));
+    m->lastB = nb;
+    // host work while the GPU runs: drain chunk k-2, whose D2H finished long ago - the host does not wait on the
+    // GPU in steady state and the GPU always has the next forward queued.  The pinned ring slot of chunk k-2 is
+    // reused by chunk k+1, which is enqueued after this drain.
+    if (k >= 2) DV_TRY(finish(k - 2));
+  }
+  if (K >= 2) DV_TRY(finish(K - 2));
+  if (K >= 1) DV_TRY(finish(K - 1));
+  DV_HIP(hipStreamSynchronize(s));
+  if (trace) {
+    for (int64_t k = 0; k < K; ++k) {
+      float t[6];
+      for (int i = 0; i < 6; ++i) DV_HIP(hipEventElapsedTime(&t[i], tev[0], tev[6 * k + i]));
+      fprintf(stderr, "chunk %ld: h2d %.2f-%.2f  fwd %.2f-%.2f  d2h %.2f-%.2f ms\n", (long)k, t[0], t[1], t[2], t[3], t[4], t[5]);
+    }
+    for (auto& e : tev) (void)hipEventDestroy(e);
+  }
+  return OK;
+}
+
 }  // namespace dv
 
 // ============================================================================================
@@ -1524,10 +1747,15 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
   DV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-  for (int i = 0; i < 3; ++i) {
-    DV_HIP(hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking));
-    DV_HIP(hipEventCreateWithFlags(&c->ev_lane[i], hipEventDisableTiming));
+  // HIP multiplexes streams onto a few hardware queues (4 by default) and work on streams that share a queue runs
+  // in submission order, so the engine keeps to four streams: main, comm (also the D2H stream of the inference
+  // pipeline), aux, and the pipeline's H2D stream.  More forward lanes (DV_FWD_LANES > 2) create theirs on demand.
+  {
+    const char* wl = getenv("DV_FWD_LANES");
+    const int extra = wl ? std::max(0, std::min(atoi(wl), 4) - 2) : 0;
+    for (int i = 0; i < extra; ++i) DV_HIP(hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking));
   }
+  for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_lane[i], hipEventDisableTiming));
   DV_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   DV_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_buf[i], hipEventDisableTiming));
@@ -1622,6 +1850,7 @@ int dv_model_destroy(dv_model* m) {
     if (m->slots[s].x) (void)hipFree(m->slots[s].x);
     if (m->slots[s].y) (void)hipFree(m->slots[s].y);
   }
+  pipe_free(m->pipe);
   for (auto e : m->ev_pool) (void)hipEventDestroy(e);
   for (auto& r : m->prof) {
     (void)hipEventDestroy(r.a);
@@ -1969,16 +2198,31 @@ int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t 
   return prof_flush(m);
 }
 
-int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
-             float* mu, float* zstd, float* z) {
+static int infer_entry(dv_model* m, const void* x, bool x_f64, int64_t N, const float* eps, uint64_t seed, float* loc,
+                       float* scale, float* mu, float* zstd, float* z) {
   if (!m || !x || N < 0) return DV_E_INVALID;
   const Arch& A = m->A;
   DV_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->stream;
   const size_t stamp = (size_t)A.H * A.H * A.C;
+  static const bool no_pipe = getenv("DV_NO_INFER_PIPE") != nullptr;
+  if (N > 256 && !no_pipe && !m->prof_on) {
+    DV_TRY(infer_pipelined(m, x, x_f64, N, eps, seed, loc, scale, mu, zstd, z));
+    return prof_flush(m);
+  }
+  std::vector<float> cast;
   for (int64_t o = 0; o < N; o += m->Bc) {
     int nb = (int)std::min<int64_t>(m->Bc, N - o);
-    DV_TRY(stage_host_batch(m, x + o * stamp, nb));
+    const float* xs;
+    if (x_f64) {
+      cast.resize((size_t)nb * stamp);
+      const double* xd = static_cast<const double*>(x) + o * stamp;
+      for (size_t i = 0; i < (size_t)nb * stamp; ++i) cast[i] = (float)xd[i];
+      xs = cast.data();
+    } else {
+      xs = static_cast<const float*>(x) + o * stamp;
+    }
+    DV_TRY(stage_host_batch(m, xs, nb));
     DV_TRY(forward_all(m, m->stage_x, nullptr, nullptr, 0, nb, nb, false, false, false, eps ? eps + o * A.d : nullptr,
                        seed, (unsigned)m->ctx->rank, (unsigned)o, zstd != nullptr, false, true));
     if (loc) DV_HIP(hipMemcpyAsync(loc + o * stamp, m->loc, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1993,6 +2237,16 @@ int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t 
     m->lastB = nb;
   }
   return prof_flush(m);
+}
+
+int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
+             float* mu, float* zstd, float* z) {
+  return infer_entry(m, x, false, N, eps, seed, loc, scale, mu, zstd, z);
+}
+
+int dv_infer_f64(dv_model* m, const double* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
+                 float* mu, float* zstd, float* z) {
+  return infer_entry(m, x, true, N, eps, seed, loc, scale, mu, zstd, z);
 }
 
 int dv_infer_mc(dv_model* m, const float* x, int64_t N, int32_t nsamples, uint64_t seed, float* mean_out,

@@ -19,7 +19,7 @@ def deblend(net, images, normalise=False):
     images = np.asarray(images)
     if normalise:
         images = normalize_non_linear(images)
-    out = net(images.astype(np.float32))          # one stochastic forward pass, BN in inference mode
+    out = net(images)     # one stochastic forward pass, BN in inference mode; the float32 cast happens in the engine
     if normalise:
         mean = denormalize_non_linear(np.clip(out.mean().numpy(), -1 + 1e-7, 1 - 1e-7))
         return mean, Normal(mean, out.stddev().numpy())

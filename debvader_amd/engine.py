@@ -291,20 +291,35 @@ class Engine:
         return {k: float(out[i]) for i, k in enumerate(_lib.SCALAR_NAMES)}
 
     # -- inference --------------------------------------------------------------------------
-    def infer(self, x, eps=None, seed=0, want=("loc", "scale")) -> Dict[str, np.ndarray]:
-        x = _f32c(x)
+    def infer(self, x, eps=None, seed=0, want=("loc", "scale"), out=None) -> Dict[str, np.ndarray]:
+        """One stochastic forward pass over all stamps.  float64 arrays (numpy's default, what the reference's callers
+        pass) go to the engine as they are: the float32 cast of deblender.py:18 happens while the library stages them."""
+        x = np.asarray(x)
+        f64 = x.dtype == np.float64 and x.flags.c_contiguous
+        if not f64:
+            x = _f32c(x)
         if x.ndim != 4 or x.shape[1:] != self.stamp_shape:
             raise ValueError(f"expected images of shape (N,{self.stamp_shape}), got {x.shape}")
         N = x.shape[0]
         bufs = {}
-        for k in ("loc", "scale"):
-            bufs[k] = np.empty((N,) + self.stamp_shape, np.float32) if k in want else None
-        for k in ("mu", "zstd", "z"):
-            bufs[k] = np.empty((N, self.latent), np.float32) if k in want else None
+        for k in ("loc", "scale", "mu", "zstd", "z"):
+            shape = (N,) + self.stamp_shape if k in ("loc", "scale") else (N, self.latent)
+            if k not in want:
+                bufs[k] = None
+            elif out is not None and k in out:      # caller-provided result array (reused across calls)
+                if out[k].shape != shape or out[k].dtype != np.float32 or not out[k].flags.c_contiguous:
+                    raise ValueError(f"out[{k!r}] must be a C-contiguous float32 array of shape {shape}")
+                bufs[k] = out[k]
+            else:
+                bufs[k] = np.empty(shape, np.float32)
         if eps is not None:
             eps = _f32c(eps, (N, self.latent))
-        check(lib.dv_infer(self._h, _fp(x), N, _fp(eps), int(seed), _fp(bufs["loc"]), _fp(bufs["scale"]),
-                           _fp(bufs["mu"]), _fp(bufs["zstd"]), _fp(bufs["z"])))
+        if f64:
+            check(lib.dv_infer_f64(self._h, x.ctypes.data_as(C.POINTER(C.c_double)), N, _fp(eps), int(seed),
+                                   _fp(bufs["loc"]), _fp(bufs["scale"]), _fp(bufs["mu"]), _fp(bufs["zstd"]), _fp(bufs["z"])))
+        else:
+            check(lib.dv_infer(self._h, _fp(x), N, _fp(eps), int(seed), _fp(bufs["loc"]), _fp(bufs["scale"]),
+                               _fp(bufs["mu"]), _fp(bufs["zstd"]), _fp(bufs["z"])))
         return {k: v for k, v in bufs.items() if v is not None}
 
     def infer_mc(self, x, nsamples=100, seed=0):

@@ -147,7 +147,9 @@ class VAENet:
 
     def __call__(self, x, training=False):
         """net(x): one stochastic forward pass in inference mode (deblender.py:18)."""
-        x = np.asarray(x.numpy() if hasattr(x, "numpy") else x, dtype=np.float32)
+        x = np.asarray(x.numpy() if hasattr(x, "numpy") else x)
+        if x.dtype != np.float64:
+            x = x.astype(np.float32, copy=False)
         r = self._core.engine.infer(x, seed=self._core.next_seed(), want=("loc", "scale"))
         return Normal(r["loc"], r["scale"])
 

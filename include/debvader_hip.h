@@ -127,6 +127,10 @@ int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t 
  * mu [N,latent], zstd [N,latent] = z.mean()/z.stddev(); z [N,latent] = the sample fed to the decoder. */
 int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
              float* mu, float* zstd, float* z);
+/* same, for float64 stamps (the reference's numpy default): the float32 cast of deblender.py:18 happens while the
+ * library stages the array */
+int dv_infer_f64(dv_model* m, const double* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
+             float* mu, float* zstd, float* z);
 /* Monte-Carlo epistemic uncertainty: encode each stamp once, decode it `nsamples` times with fresh eps, return the
  * mean and the standard deviation (ddof 0) of the predicted means over the samples.  Replaces the per-object loop
  * `np.std(deblend(net, [stamp]*100)[0], axis=0)` of deblend/field_deblender.py:303-313. */
