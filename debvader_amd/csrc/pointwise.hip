@@ -551,6 +551,13 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
   const int d = p.d;
   const int tw = d + d * (d + 1) / 2;
   const float* t = p.t + (size_t)b * tw;
+  // the row of t goes through LDS (coalesced): the lower-triangle gather below would otherwise be a chain of
+  // d dependent, divergent global loads per stamp (31 us per step at d = 32)
+  __shared__ float st_all[4][64 + 64 * 65 / 2];
+  float* st = st_all[threadIdx.x >> 6];
+  for (int i = lane; i < tw; i += 64) st[i] = t[i];
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
   float e = 0.f;
   if (lane < d) {
     if (p.gen) {
@@ -570,11 +577,11 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
     }
   }
   float z = 0.f, logd = 0.f, l2 = 0.f;
-  if (lane < d) z = t[lane];
+  if (lane < d) z = st[lane];
   for (int j = 0; j < d; ++j) {
     const float ej = __shfl(e, j, 64);
     if (lane < d && j <= lane) {
-      float l = t[d + tril_src(d, lane, j)];
+      float l = st[d + tril_src(d, lane, j)];
       if (j == lane) {
         l = softplus_f(l) + p.diag_shift;
         logd = logf(l);
@@ -613,11 +620,16 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
   const int tw = d + d * (d + 1) / 2;
   const float* tb = t + (size_t)b * tw;
   float* dtb = dt + (size_t)b * tw;
-  float e = 0.f, g = 0.f;
+  // the gradient row is assembled in LDS and written out coalesced (every element of the row is produced exactly
+  // once: fill_triangular is a bijection between the d(d+1)/2 inputs and the lower triangle)
+  __shared__ float st_all[4][64 + 64 * 65 / 2];
+  float* st = st_all[threadIdx.x >> 6];
+  float e = 0.f, g = 0.f, raw = 0.f;
   if (lane < d) {
     e = eps[(size_t)b * d + lane];
     g = dz[(size_t)b * d + lane] + kls * z[(size_t)b * d + lane];
-    dtb[lane] = g;
+    raw = tb[d + tril_src(d, lane, lane)];
+    st[lane] = g;
   }
   for (int j = 0; j < d; ++j) {
     const float ej = __shfl(e, j, 64);
@@ -625,14 +637,16 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
       const int src = d + tril_src(d, lane, j);
       float v = g * ej;
       if (j == lane) {
-        const float raw = tb[src];
         const float l = softplus_f(raw) + diag_shift;
         const float sg = 1.0f / (1.0f + expf(-raw));
         v = (v - kls / l) * sg;
       }
-      dtb[src] = v;
+      st[src] = v;
     }
   }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < tw; i += 64) dtb[i] = st[i];
 }
 
 int launch_sampler_bwd(const float* t, const float* eps, const float* z, const float* dz, float* dt, int NB, int d,
