@@ -64,6 +64,8 @@ SIGNATURES = {
     "dv_arch_counts": (C.c_int, [C.POINTER(DvConfig), _i32, _i64, _i64, _i64]),
     "dv_arch_describe": (C.c_int, [C.POINTER(DvConfig), C.c_int32, C.c_char_p, C.c_size_t, _i64, _i32, _i32]),
     "dv_arch_macs": (C.c_int, [C.POINTER(DvConfig), _i64, _i64]),
+    "dv_arch_buckets": (C.c_int, [C.POINTER(DvConfig), C.POINTER(C.c_int64)]),
+    "dv_arch_offset": (C.c_int, [C.POINTER(DvConfig), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dv_device_count": (C.c_int, [_i32]),
     "dv_comm_unique_id": (C.c_int, [_p]),
     "dv_ctx_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _p, C.POINTER(_p)]),

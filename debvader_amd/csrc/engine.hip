@@ -302,6 +302,7 @@ struct dv_ctx {
   hipEvent_t ev_lane[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_buf[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_dec = nullptr, ev_enc = nullptr, ev_comm = nullptr, ev_small = nullptr, ev_small2 = nullptr;
+  hipEvent_t ev_mid = nullptr;
   ncclComm_t comm = nullptr;
   float* red_dev = nullptr;  // small device buffer for host all-reduce
 };
@@ -354,7 +355,8 @@ struct dv_model {
   size_t ws1_elems = 0, ws2_elems = 0, ws3_elems = 0;
   float *scal = nullptr, *bnstate = nullptr, *bnsums = nullptr;
   float* stage_x = nullptr;  // host-batch staging (infer / encode)
-  dv::InferPipe* pipe = nullptr;   // pinned staging + copy streams of the pipelined dv_infer (lazy)
+  dv::InferPipe* pipe = nullptr;
+  size_t enc_reduced_from = 0;   // this step's encoder gradients [enc_reduced_from, n_enc_train) are already all-reduced   // pinned staging + copy streams of the pipelined dv_infer (lazy)
   float* zero_page = nullptr;  // 256 B of zeros (LDS-DMA source for out-of-image pieces)
   int* idx_dev = nullptr;
   DataSlot slots[2];
@@ -1080,6 +1082,21 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
 #undef LANE
 
 // ---- backward ---------------------------------------------------------------------------------
+// First flat offset of the encoder's deep half (conv L .. dense): the start of the middle gradient bucket, or
+// n_enc_train when the layout does not allow one (then the whole encoder goes into the final bucket).
+static size_t enc_bucket_split(const Arch& A) {
+  if (A.L < 2) return A.n_enc_train;
+  const int k0 = A.enc_k(A.L);
+  const size_t split = A.specs[k0].off;
+  if (split >= A.n_enc_train || (split & 3)) return A.n_enc_train;
+  for (int k = 0; k < (int)A.specs.size(); ++k) {
+    const auto& sp = A.specs[k];
+    if (!sp.trainable || sp.off >= A.n_enc_train) continue;
+    if (k < k0 ? sp.off + sp.count > split : sp.off < split) return A.n_enc_train;
+  }
+  return split;
+}
+
 static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* idx, int first) {
   const Arch& A = m->A;
   hipStream_t s = m->ctx->stream;
@@ -1201,6 +1218,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     DV_NCCL(ncclAllReduce(G + A.n_enc_train, G + A.n_enc_train, A.n_train - A.n_enc_train, ncclFloat, ncclSum,
                           m->ctx->comm, m->ctx->comm_stream));
   }
+  m->enc_reduced_from = A.n_enc_train;
   // sampler + KL
   float kls = (float)((double)A.cfg.kl_multiplicity * A.cfg.kl_weight / ((double)Bg * (double)Bg));
   {
@@ -1241,6 +1259,21 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     DV_TRY(wgrad(m, xin, hin, cin_phys, cur, hout, cout, NB, st, pb, false, G + A.specs[A.enc_k(j)].off, cin_phys,
                  cin_phys));
     DV_TRY(wgrad_read());
+    if (cx->comm && j == A.L && A.L >= 2) {
+      // Middle bucket: the gradients of the deep half of the encoder (conv L .. conv 2L-1, their PReLUs, the
+      // flatten PReLU and the dense layer - 13.8 of the encoder's 15 MB) are final once this layer's weight-gradient
+      // work has been queued; they are all-reduced while the shallow half is still being differentiated, so that
+      // only a ~1 MB bucket is left for the end of the step.
+      const size_t split = enc_bucket_split(A);
+      const bool ok = split < A.n_enc_train;
+      if (ok) {
+        hipStream_t ws = m->wstream ? m->wstream : s;
+        DV_HIP(hipEventRecord(cx->ev_mid, ws));      // parameter gradients are only ever written on this stream
+        DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_mid, 0));
+        DV_NCCL(ncclAllReduce(G + split, G + split, A.n_enc_train - split, ncclFloat, ncclSum, cx->comm, cx->comm_stream));
+        m->enc_reduced_from = split;
+      }
+    }
     const float* W = P + A.specs[A.enc_k(j)].off;
     DV_NEXT_OUT();
     FuseBwd fz{m->enc_u[j - 1], A.enc_al(j - 1), A.enc_b(j - 1), true};   // j >= 1 here (j == 0 left the loop above)
@@ -1305,7 +1338,6 @@ static int check_step_args(dv_model* m, int slot, const int32_t* idx, int64_t fi
 // enqueue one step (no host sync); scalars land in m->scal[0..2]
 static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx_host, int64_t first, int B, int Bg,
                         const float* eps_host, uint64_t seed) {
-  const Arch& A = m->A;
   hipStream_t s = m->ctx->stream;
   const DataSlot& ds = m->slots[slot];
   const int* idx = nullptr;
@@ -1326,8 +1358,8 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
       // encoder bucket (the decoder bucket was queued inside backward()); the optimizer waits for both
       DV_HIP(hipEventRecord(m->ctx->ev_enc, s));
       DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, m->ctx->ev_enc, 0));
-      if (A.n_enc_train > 0)
-        DV_NCCL(ncclAllReduce(m->G, m->G, A.n_enc_train, ncclFloat, ncclSum, m->ctx->comm, m->ctx->comm_stream));
+      if (m->enc_reduced_from > 0)
+        DV_NCCL(ncclAllReduce(m->G, m->G, m->enc_reduced_from, ncclFloat, ncclSum, m->ctx->comm, m->ctx->comm_stream));
       DV_HIP(hipEventRecord(m->ctx->ev_comm, m->ctx->comm_stream));
       DV_HIP(hipStreamWaitEvent(s, m->ctx->ev_comm, 0));
     }
@@ -1693,6 +1725,27 @@ int dv_arch_describe(const dv_config* cfg, int32_t i, char* name, size_t name_le
   return DV_OK;
 }
 
+int dv_arch_buckets(const dv_config* cfg, int64_t out[4]) {
+  if (!cfg || !out) return DV_E_INVALID;
+  Arch a;
+  DV_TRY(a.build(cfg));
+  out[0] = (int64_t)enc_bucket_split(a);
+  out[1] = (int64_t)a.n_enc_train;
+  out[2] = (int64_t)a.n_train;
+  out[3] = (int64_t)a.n_total;
+  return DV_OK;
+}
+
+int dv_arch_offset(const dv_config* cfg, int32_t i, int64_t* off, int64_t* count) {
+  if (!cfg || !off || !count) return DV_E_INVALID;
+  Arch a;
+  DV_TRY(a.build(cfg));
+  if (i < 0 || i >= (int)a.specs.size()) return DV_E_INVALID;
+  *off = (int64_t)a.specs[i].off;
+  *count = (int64_t)a.specs[i].count;
+  return DV_OK;
+}
+
 int dv_arch_macs(const dv_config* cfg, int64_t* enc, int64_t* dec) {
   if (!cfg || !enc || !dec) return DV_E_INVALID;
   Arch a;
@@ -1764,6 +1817,7 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
   DV_HIP(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
   DV_HIP(hipEventCreateWithFlags(&c->ev_small, hipEventDisableTiming));
   DV_HIP(hipEventCreateWithFlags(&c->ev_small2, hipEventDisableTiming));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
   DV_HIP(hipMalloc((void**)&c->red_dev, 4096 * sizeof(float)));
   if (world == 1 && getenv("DV_FORCE_COMM")) {
     // test hook: a one-rank communicator, so that the collective code paths (streams, events, in-place all-reduces)
@@ -1796,6 +1850,7 @@ int dv_ctx_destroy(dv_ctx* c) {
   if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
   if (c->ev_small) (void)hipEventDestroy(c->ev_small);
   if (c->ev_small2) (void)hipEventDestroy(c->ev_small2);
+  if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < 3; ++i)

@@ -67,6 +67,12 @@ int dv_arch_counts(const dv_config* cfg, int32_t* n_tensors, int64_t* n_encoder,
                    int64_t* n_trainable);
 int dv_arch_describe(const dv_config* cfg, int32_t i, char* name, size_t name_len, int64_t shape[4], int32_t* ndim,
                      int32_t* trainable);
+/* flat layout of the gradient buffer the data-parallel step all-reduces: tensor i occupies
+ * [off, off+count) floats; the buckets are, in the order they are reduced, [n_enc_train, n_train) (decoder, queued
+ * when the decoder backward is done), [split, n_enc_train) (deep half of the encoder, queued mid-backward) and
+ * [0, split) (shallow half, at the end).  out = {split, n_enc_train, n_train, n_total} */
+int dv_arch_buckets(const dv_config* cfg, int64_t out[4]);
+int dv_arch_offset(const dv_config* cfg, int32_t i, int64_t* off, int64_t* count);
 /* forward multiply-accumulates per stamp (padding taps counted), for roofline accounting */
 int dv_arch_macs(const dv_config* cfg, int64_t* encoder_macs, int64_t* decoder_macs);
 

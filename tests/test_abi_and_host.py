@@ -147,3 +147,39 @@ def test_synthetic_stamps_are_deterministic_and_in_range():
     x2, _ = synthetic_stamps(8, seed=0)
     np.testing.assert_array_equal(x, x2)
     assert x.shape == (8, 59, 59, 6) and x.dtype == np.float32 and y.min() >= 0 and x.max() < 60
+
+
+def test_gradient_buckets_partition_the_trainable_buffer():
+    """the three all-reduce buckets (decoder, deep encoder, shallow encoder) tile [0, n_train) exactly
+    and every tensor lies inside one bucket."""
+    import ctypes as C
+    from debvader_amd import engine as E
+    from debvader_amd._lib import lib, check
+    for args in ((), ((13, 13, 4), 8, (8, 16), (3, 3)), ((128, 128, 6), 32, (32, 64, 128, 256, 512, 512), (3,) * 6)):
+        cfg = E.make_config(*args)
+        out = (C.c_int64 * 4)()
+        check(lib.dv_arch_buckets(C.byref(cfg), out))
+        split, n_enc, n_train, n_total = list(out)
+        assert 0 < split < n_enc < n_train <= n_total and split % 4 == 0
+        specs = E.arch_specs(cfg)
+        sizes = {"dec": 0, "mid": 0, "last": 0}
+        for i, (name, shape, trainable) in enumerate(specs):
+            off, cnt = C.c_int64(), C.c_int64()
+            check(lib.dv_arch_offset(C.byref(cfg), i, C.byref(off), C.byref(cnt)))
+            assert cnt.value == int(np.prod(shape))
+            if not trainable:
+                assert off.value >= n_train
+                continue
+            lo, hi = off.value, off.value + cnt.value
+            if name.startswith("dec/"):
+                assert n_enc <= lo and hi <= n_train
+                sizes["dec"] += cnt.value
+            elif lo >= split:
+                assert hi <= n_enc
+                sizes["mid"] += cnt.value
+            else:
+                assert hi <= split
+                sizes["last"] += cnt.value
+        # the deep half holds the dense layer and the deep convolutions: most of the encoder
+        assert sizes["mid"] > 5 * sizes["last"] > 0
+        assert any(n == "enc/dense/kernel" for n, _, _ in specs)
