@@ -445,13 +445,16 @@ static bool g_force_v1 = false;  // tuning aid: route everything through the fir
 
 // Every collective of a context is issued on ONE stream (comm_stream), the usual single-stream-per-communicator
 // pattern; the main stream hands data over and takes it back through events.
-static int allreduce_small(dv_ctx* c, float* buf, size_t n) {
+// wait = false: the main stream does not wait for the result (the caller joins the comm stream later anyway).
+static int allreduce_small(dv_ctx* c, float* buf, size_t n, bool wait = true) {
   if (!c->comm) return OK;
   DV_HIP(hipEventRecord(c->ev_small, c->stream));
   DV_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_small, 0));
   DV_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, c->comm, c->comm_stream));
-  DV_HIP(hipEventRecord(c->ev_small2, c->comm_stream));
-  DV_HIP(hipStreamWaitEvent(c->stream, c->ev_small2, 0));
+  if (wait) {
+    DV_HIP(hipEventRecord(c->ev_small2, c->comm_stream));
+    DV_HIP(hipStreamWaitEvent(c->stream, c->ev_small2, 0));
+  }
   return OK;
 }
 
@@ -1351,7 +1354,9 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   // Philox stream: one counter row per (rank-local) stamp; ranks are separated through the stream id
   DV_TRY(forward_all(m, ds.x, ds.y, idx, (int)first, B, Bg, training, mode == MODE_TRAIN, bwd, eps_host, seed,
                      (unsigned)m->ctx->rank, 0u, false, bwd, true));
-  DV_TRY(allreduce_small(m->ctx, m->scal, 4));
+  // the loss sums are only read after the step: with a backward pass the main stream joins the comm stream behind
+  // the last gradient bucket anyway, so it does not stop here for this latency-bound collective
+  DV_TRY(allreduce_small(m->ctx, m->scal, 4, !bwd));
   if (bwd) {
     DV_TRY(backward(m, B, Bg, ds.x, idx, (int)first));
     if (m->ctx->comm) {
