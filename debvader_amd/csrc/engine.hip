@@ -2456,6 +2456,13 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   DV_HIP(hipMalloc((void**)&Y2, ny * sizeof(float)));
   m.ws1_elems = (size_t)16 << 20;
   DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
+  const bool timeline = tile >= 7000;
+  if (timeline) {
+    tile -= 7000;
+    if (tile == 99) tile = -1;
+    DV_HIP(hipMemsetAsync(m.ws1 + m.ws1_elems - (1 << 16), 0, (1 << 16) * sizeof(float), ctx->stream));
+    debug_set_gconv2_dbg(2, m.ws1 + m.ws1_elems - (1 << 16));
+  }
   if (tile >= 4000) {
     debug_set_gconv2_prio(4);   // 4: loads in front of the MFMA block (pre-interleave order)
     tile -= 4000;
@@ -2496,6 +2503,25 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   debug_set_gconv2_dbg(0, nullptr);
   debug_set_gconv2_prio(0);
   g_force_v1 = false;
+  if (timeline) {
+    // per-workgroup timeline of the LAST launch (s_memrealtime ticks of 10 ns): start, loop start, loop end, end
+    std::vector<unsigned> h(1 << 16);
+    DV_HIP(hipMemcpy(h.data(), m.ws1 + m.ws1_elems - (1 << 16), h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    unsigned t0 = 0xffffffffu, t3 = 0;
+    int n = 0;
+    for (int i = 0; i < (1 << 14); ++i)
+      if (h[4 * i + 3]) { t0 = std::min(t0, h[4 * i]); t3 = std::max(t3, h[4 * i + 3]); ++n; }
+    double sp = 0, sl = 0, se = 0, last_start = 0, first_end = 1e9;
+    for (int i = 0; i < (1 << 14); ++i)
+      if (h[4 * i + 3]) {
+        sp += h[4 * i + 1] - h[4 * i]; sl += h[4 * i + 2] - h[4 * i + 1]; se += h[4 * i + 3] - h[4 * i + 2];
+        last_start = std::max(last_start, (double)(h[4 * i] - t0)); first_end = std::min(first_end, (double)(h[4 * i + 3] - t0));
+      }
+    fprintf(stderr, "  timeline: %d workgroups, span %.1f us; mean prologue %.2f us, loop %.2f us, epilogue %.2f us; last start at %.1f us, first end at %.1f us\n",
+            n, (t3 - t0) * 0.01, sp / n * 0.01, sl / n * 0.01, se / n * 0.01, last_start * 0.01, first_end * 0.01);
+    for (int i = 0; i < n && i < 1 << 14; i += std::max(1, n / 16))
+      fprintf(stderr, "    wg %5d: start %.1f loop %.1f-%.1f end %.1f us\n", i, (h[4 * i] - t0) * 0.01, (h[4 * i + 1] - t0) * 0.01, (h[4 * i + 2] - t0) * 0.01, (h[4 * i + 3] - t0) * 0.01);
+  }
   if (stamps) {
     float h[32];
     DV_HIP(hipMemcpy(h, m.ws1 + m.ws1_elems - 64, sizeof h, hipMemcpyDeviceToHost));

@@ -17,6 +17,10 @@ namespace dv {
 
 namespace {
 constexpr int BK2 = 32;
+template <int V>
+struct SetC {
+  static constexpr int value = V;
+};
 
 __device__ __forceinline__ int t_dh(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 3) - 1; }
 __device__ __forceinline__ int t_dw(unsigned long long code, int t) { return (int)((code >> (4 * t + 2)) & 3) - 1; }
@@ -51,6 +55,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
   int* s_out = s_mask + BM;                                               // [BM] output pixel offset (elements) or -1
   int* s_al = s_out + BM;                                                 // [BM] alpha pixel offset
 
+  const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -133,23 +138,26 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     }
   }
 
-  f32x4 areg[AROWS];
-  f32x4 breg[NMAJOR ? BROWS_N : BPASS];
-  unsigned amask = 0, bmaskv = 0xffffffffu;
+  // two register sets: a chunk's global loads are issued TWO iterations before its LDS store (SUB == 1 loop), so a
+  // lone workgroup is not paced by the L2 / HBM latency of its gather
+  f32x4 areg[2][AROWS];
+  f32x4 breg[2][NMAJOR ? BROWS_N : BPASS];
+  unsigned amask2[2] = {0, 0}, bmaskv2[2] = {0xffffffffu, 0xffffffffu};
   const int cpt = SUB == 1 ? p.Cin / BK2 : 1;     // chunks per tap
   int tap = 0, cc = 0;                            // chunk -> (tap, channel slab), advanced incrementally
 
-  auto load_global = [&]() {                      // loads chunk (tap, cc), then advances
+  auto load_global = [&](auto setc) {             // loads chunk (tap, cc) into register set S, then advances
+    constexpr int S = decltype(setc)::value;
+    unsigned amask = 0, bmaskv = 0xffffffffu;
     if constexpr (SUB == 1) {
       const int dh = t_dh(cl.tapcode, tap), dw = t_dw(cl.tapcode, tap);
       const int wt = t_wt(cl.wtcode, tap);
       const int tapoff = (dh * p.Win + dw) * p.Cin + cc * BK2;
-      amask = 0;
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         const bool ok = (rmask[i] >> tap) & 1;
         const unsigned off = ok ? (unsigned)(rin[i] + tapoff) : 0u;
-        areg[i] = *reinterpret_cast<const f32x4*>(p.X + off);
+        areg[S][i] = *reinterpret_cast<const f32x4*>(p.X + off);
         amask |= (ok ? 1u : 0u) << i;
       }
       if (NMAJOR) {
@@ -157,14 +165,14 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
 #pragma unroll
         for (int i = 0; i < BROWS_N; ++i) {
           const unsigned off = ((wok >> i) & 1u) ? (unsigned)(wbase + wthr[i]) : 0u;
-          breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+          breg[S][i] = *reinterpret_cast<const f32x4*>(p.W + off);
         }
       } else {
         const int wbase = (wt * p.Cin + cc * BK2) * p.Cout;
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
           const unsigned off = ((wok >> i) & 1u) ? (unsigned)(wbase + wthr[i]) : 0u;
-          breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+          breg[S][i] = *reinterpret_cast<const f32x4*>(p.W + off);
         }
       }
       if (++cc == cpt) {
@@ -177,12 +185,11 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
       const int tcl = min(mytap, 8);
       const int dh = t_dh(cl.tapcode, tcl), dw = t_dw(cl.tapcode, tcl);
       const int tapoff = (dh * p.Win + dw) * p.Cin;
-      amask = 0;
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         const bool ok = mytap < cl.ntaps && ((rmask[i] >> tcl) & 1);
         const unsigned off = ok ? (unsigned)(rin[i] + tapoff) : 0u;
-        areg[i] = *reinterpret_cast<const f32x4*>(p.X + off);
+        areg[S][i] = *reinterpret_cast<const f32x4*>(p.X + off);
         amask |= (ok ? 1u : 0u) << i;
       }
       bmaskv = 0;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
         for (int i = 0; i < BROWS_N; ++i) {
           const bool ok = ((wok >> i) & 1u) && mytap < cl.ntaps;
           const unsigned off = ok ? (unsigned)(wt * p.Cout * p.Cin + wthr[i]) : 0u;
-          breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+          breg[S][i] = *reinterpret_cast<const f32x4*>(p.W + off);
           bmaskv |= (ok ? 1u : 0u) << i;
         }
       } else {
@@ -204,33 +211,37 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
           const int bcl = min(btap, 8);
           const bool ok = ((wok >> i) & 1u) && btap < cl.ntaps;
           const unsigned off = ok ? (unsigned)(t_wt(cl.wtcode, bcl) * p.Cin * p.Cout + wthr[i]) : 0u;
-          breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
+          breg[S][i] = *reinterpret_cast<const f32x4*>(p.W + off);
           bmaskv |= (ok ? 1u : 0u) << i;
         }
       }
       tap += SUB;
     }
+    amask2[S] = amask;
+    bmaskv2[S] = bmaskv;
   };
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const int sw_w = (r0 >> 1) & 7;                 // swizzle of the rows this thread writes (r0 + 32 i: same value)
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](auto setc, int buf) {
+    constexpr int S = decltype(setc)::value;
+    const unsigned amask = amask2[S], bmaskv = bmaskv2[S];
     float* a = As + buf * A_ELEMS;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i)
-      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * BK2 + ((kq ^ sw_w) << 2)) = ((amask >> i) & 1u) ? areg[i] : zero4;
+      *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * BK2 + ((kq ^ sw_w) << 2)) = ((amask >> i) & 1u) ? areg[S][i] : zero4;
     float* b = Bs + buf * B_ELEMS;
     if (NMAJOR) {
 #pragma unroll
       for (int i = 0; i < BROWS_N; ++i)
         if (r0 + 32 * i < BN)
-          *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * BK2 + ((kq ^ sw_w) << 2)) = (((wok & bmaskv) >> i) & 1u) ? breg[i] : zero4;
+          *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * BK2 + ((kq ^ sw_w) << 2)) = (((wok & bmaskv) >> i) & 1u) ? breg[S][i] : zero4;
     } else {
       const int nq = tid % BQ, kr0 = tid / BQ;
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
         const int kr = kr0 + BKR * i;
-        if (kr < BK2) *reinterpret_cast<f32x4*>(b + kr * LDBK + nq * 4) = (((wok & bmaskv) >> i) & 1u) ? breg[i] : zero4;
+        if (kr < BK2) *reinterpret_cast<f32x4*>(b + kr * LDBK + nq * 4) = (((wok & bmaskv) >> i) & 1u) ? breg[S][i] : zero4;
       }
     }
   };
@@ -289,18 +300,22 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     cc = kbeg - tap * cpt;
     Uout += (size_t)blockIdx.y * p.NB * p.Hout * p.Wout * p.Cout;
   }
+  const bool deep = p.dbg != 1 && p.prio != 4 && SUB == 1;   // distance-2 register prefetch (see areg / breg)
   if (nchunks > 0) {
-    load_global();
-    store_lds(0);
+    load_global(SetC<0>{});
+    store_lds(SetC<0>{}, 0);
+    if (deep && nchunks > 1) load_global(SetC<1>{});
   }
   __syncthreads();
-  if (p.dbg == 0 && p.prio != 4 && SUB == 1) {
-    // steady-state iterations are one basic block (loads of chunk k+1, MFMAs of chunk k) and the scheduler is asked
-    // to spread the gather's VALU / VMEM instructions between the MFMAs (+2.7 % over issuing them in front,
-    // tools/layer_bench.py with tile code 4099 = old order)
-    for (int kc = 0; kc + 1 < nchunks; ++kc) {
-      const int cur = kc & 1;
-      load_global();
+  unsigned long long tl1 = 0, tl2 = 0;
+  if (p.dbg == 2) tl1 = __builtin_amdgcn_s_memrealtime();
+  if (deep) {
+    // Steady-state iterations are one basic block: the global loads of chunk k+2 (into the register set chunk k
+    // vacated), the MFMAs of chunk k, then the LDS store of chunk k+1, whose loads were issued one iteration
+    // earlier.  The scheduler is asked to spread the gather's VALU / VMEM instructions between the MFMAs.
+    // (Loads one chunk ahead paced a lone workgroup at 8.6k cycles per chunk against 4.1k of MFMA work.)
+    auto iter = [&](auto ld, auto st, int cur) {
+      load_global(ld);
       compute(cur);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -308,17 +323,36 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // VMEM read
         __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);         // VALU
       }
-      store_lds(cur ^ 1);
+      store_lds(st, cur ^ 1);
       __syncthreads();
+    };
+    int kc = 0;                                    // even here and after every pass of the loop
+    for (; kc + 3 < nchunks; kc += 2) {
+      iter(SetC<0>{}, SetC<1>{}, 0);               // chunk kc in buffer 0: load kc+2 -> set 0, store kc+1 (set 1)
+      iter(SetC<1>{}, SetC<0>{}, 1);               // chunk kc+1 in buffer 1: load kc+3 -> set 1, store kc+2 (set 0)
     }
-    if (nchunks > 0) compute((nchunks - 1) & 1);
+    int r = nchunks - kc;                          // 0 (nchunks == 0), 1, 2 or 3 chunks left, chunk kc in buffer 0
+    if (r == 3) {
+      iter(SetC<0>{}, SetC<1>{}, 0);
+      compute(1);
+      store_lds(SetC<0>{}, 0);
+      __syncthreads();
+      compute(0);
+    } else if (r == 2) {
+      compute(0);
+      store_lds(SetC<1>{}, 1);
+      __syncthreads();
+      compute(1);
+    } else if (r == 1) {
+      compute(0);
+    }
     __syncthreads();
-  } else if (p.dbg == 0) {
+  } else if (p.dbg != 1) {
     for (int kc = 0; kc < nchunks; ++kc) {
       const int cur = kc & 1;
-      if (kc + 1 < nchunks) load_global();
+      if (kc + 1 < nchunks) load_global(SetC<0>{});
       compute(cur);
-      if (kc + 1 < nchunks) store_lds(cur ^ 1);
+      if (kc + 1 < nchunks) store_lds(SetC<0>{}, cur ^ 1);
       __syncthreads();
     }
   } else {  // timing build path: same loop with s_memtime stamps per phase (block 5 reports)
@@ -326,12 +360,12 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     const unsigned long long tbeg = t0, rbeg = __builtin_amdgcn_s_memrealtime();
     for (int kc = 0; kc < nchunks; ++kc) {
       const int cur = kc & 1;
-      if (kc + 1 < nchunks) load_global();
+      if (kc + 1 < nchunks) load_global(SetC<0>{});
       t1 = __builtin_amdgcn_s_memtime(); tl += t1 - t0; t0 = t1;
       compute(cur);
       asm volatile("" ::"v"(acc[0][0]), "v"(acc[TM - 1][TN - 1]));
       t1 = __builtin_amdgcn_s_memtime(); tc += t1 - t0; t0 = t1;
-      if (kc + 1 < nchunks) store_lds(cur ^ 1);
+      if (kc + 1 < nchunks) store_lds(SetC<0>{}, cur ^ 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       t1 = __builtin_amdgcn_s_memtime(); ts += t1 - t0; t0 = t1;
       __syncthreads();
@@ -344,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
     }
   }
 
+  if (p.dbg == 2) tl2 = __builtin_amdgcn_s_memrealtime();
   // ---- epilogue: accumulators -> per-wave LDS staging -> float4 rows --------------------------
   float* stg = smem + wave * (STG_ROWS * LDC);    // operand buffers are free after the last barrier
   constexpr int F4_PER_ROW = WN / 4;
@@ -423,6 +458,11 @@ __global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
       if (p.db_part)
         *reinterpret_cast<f32x4*>(p.db_part + ((size_t)(bid / ntn) * WGM + wmi) * p.Cout + colq) = pdb;
     }
+  }
+  if (p.dbg == 2 && p.dbg_out && tid == 0 && blockIdx.y == 0) {
+    __builtin_amdgcn_s_waitcnt(0);      // this wave's stores have been acknowledged
+    unsigned* d = reinterpret_cast<unsigned*>(p.dbg_out) + (size_t)blockIdx.x * 4;
+    d[0] = (unsigned)tl_start; d[1] = (unsigned)tl1; d[2] = (unsigned)tl2; d[3] = (unsigned)__builtin_amdgcn_s_memrealtime();
   }
 }
 

@@ -1,0 +1,14 @@
+"""Per-workgroup timeline of one gather-GEMM launch (debug stamps).  GPU only."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from debvader_amd import engine as E
+from debvader_amd._lib import lib, check
+ctx = E.Context()
+ms = C.c_float()
+cases = {"convt3_fwd_s1": (16, 128, 16, 128, 1, 1, 1, 1, 2), "convt7_fwd_s1": (64, 32, 64, 32, 1, 1, 1, 1, 2),
+         "conv4_fwd_s1": (15, 64, 15, 128, 1, 1, 0, 0, 2), "convt5_fwd_s1": (32, 64, 32, 64, 1, 1, 1, 1, 2)}
+for name, a in cases.items():
+    check(lib.dv_debug_gconv(ctx._h, 256, *a, 0, -1, 2000, C.byref(ms)))
+    print(name, "plain", ms.value * 1e3, "us", flush=True)
+    check(lib.dv_debug_gconv(ctx._h, 256, *a, 0, 7099, 200, C.byref(ms)))
+    print(name, "with stamps", ms.value * 1e3, "us", flush=True)
