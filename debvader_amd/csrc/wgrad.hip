@@ -18,6 +18,11 @@ __device__ __forceinline__ int wtap_dh(unsigned long long code, int t) { return 
 __device__ __forceinline__ int wtap_dw(unsigned long long code, int t) { return (int)((code >> (4 * t + 2)) & 3) - 1; }
 __device__ __forceinline__ int wtap_wt(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 15); }
 
+template <int V>
+struct WSet {
+  static constexpr int value = V;
+};
+
 template <int BMW, int BNW, int WGM, int WGN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
   static_assert(WGM * WGN == 4, "4 waves");
@@ -58,10 +63,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
   }
   const int HcWc = p.Hc * p.Wc;
 
-  f32x4 areg[AQ], breg[BQ];
-  unsigned amask = 0, bmask = 0;
+  // two register sets: a chunk's loads are issued two iterations before its LDS store (see gconv2.hip)
+  f32x4 areg[2][AQ], breg[2][BQ];
+  unsigned amask2[2] = {0, 0}, bmask2[2] = {0, 0};
   // unconditional loads from clamped addresses, masked at the LDS store (see gconv.hip)
-  auto load_global = [&](int kc) {
+  auto load_global = [&](auto setc, int kc) {
+    constexpr int S = decltype(setc)::value;
+    unsigned amask = 0, bmask = 0;
     const int pp = pstart + kc * BKP + ps;
     const bool pv = pp < pend;
     int nb = 0, ii = 0, jj = 0;
@@ -71,36 +79,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
       ii = rem / p.Wc;
       jj = rem - ii * p.Wc;
     }
-    amask = 0;
 #pragma unroll
     for (int i = 0; i < AQ; ++i) {
       int ih = ii * p.sx + adh[i], iw = jj * p.sx + adw[i];
       bool ok = pv && aok[i] && (unsigned)ih < (unsigned)p.Hx && (unsigned)iw < (unsigned)p.Wx;
       size_t off = ok ? ((size_t)((nb * p.Hx + ih) * p.Wx + iw)) * p.Cx + acx[i] : 0;
-      areg[i] = *reinterpret_cast<const f32x4*>(p.X + off);
+      areg[S][i] = *reinterpret_cast<const f32x4*>(p.X + off);
       amask |= (ok ? 1u : 0u) << i;
     }
     const size_t ypix = (size_t)((nb * p.Hy + ii * p.sy + p.ph) * p.Wy + jj * p.sy + p.pw) * p.Cy;
-    bmask = 0;
 #pragma unroll
     for (int i = 0; i < BQ; ++i) {
       int cl = 4 * (q + 8 * i);
       int c = n0 + cl;
       bool ok = pv && cl < BNW && c < p.Cy;
-      breg[i] = *reinterpret_cast<const f32x4*>(p.Y + (ok ? ypix + c : 0));
+      breg[S][i] = *reinterpret_cast<const f32x4*>(p.Y + (ok ? ypix + c : 0));
       bmask |= (ok ? 1u : 0u) << i;
     }
+    amask2[S] = amask;
+    bmask2[S] = bmask;
   };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](auto setc, int buf) {
+    constexpr int S = decltype(setc)::value;
+    const unsigned amask = amask2[S], bmask = bmask2[S];
     float* a = As + buf * A_ELEMS + ps * LDAW;
     float* b = Bs + buf * B_ELEMS + ps * LDBW;
 #pragma unroll
     for (int i = 0; i < AQ; ++i)
-      if (4 * (q + 8 * i) < BMW) *reinterpret_cast<f32x4*>(a + 4 * (q + 8 * i)) = ((amask >> i) & 1u) ? areg[i] : zero4;
+      if (4 * (q + 8 * i) < BMW) *reinterpret_cast<f32x4*>(a + 4 * (q + 8 * i)) = ((amask >> i) & 1u) ? areg[S][i] : zero4;
 #pragma unroll
     for (int i = 0; i < BQ; ++i)
-      if (4 * (q + 8 * i) < BNW) *reinterpret_cast<f32x4*>(b + 4 * (q + 8 * i)) = ((bmask >> i) & 1u) ? breg[i] : zero4;
+      if (4 * (q + 8 * i) < BNW) *reinterpret_cast<f32x4*>(b + 4 * (q + 8 * i)) = ((bmask >> i) & 1u) ? breg[S][i] : zero4;
   };
 
   f32x4 acc[TM][TN];
@@ -130,16 +140,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
   const int npix = max(pend - pstart, 0);
   const int nchunks = (npix + BKP - 1) / BKP;
   if (nchunks > 0) {
-    load_global(0);
-    store_lds(0);
+    load_global(WSet<0>{}, 0);
+    store_lds(WSet<0>{}, 0);
+    if (nchunks > 1) load_global(WSet<1>{}, 1);
   }
   __syncthreads();
-  for (int kc = 0; kc < nchunks; ++kc) {
-    const int cur = kc & 1;
-    if (kc + 1 < nchunks) load_global(kc + 1);
-    compute(cur);
-    if (kc + 1 < nchunks) store_lds(cur ^ 1);
-    __syncthreads();
+  {
+    auto iter = [&](auto ld, auto st, int kc, int cur) {   // loads chunk kc+2, computes chunk kc, stores chunk kc+1
+      load_global(ld, kc + 2);
+      compute(cur);
+      store_lds(st, cur ^ 1);
+      __syncthreads();
+    };
+    int kc = 0;
+    for (; kc + 3 < nchunks; kc += 2) {
+      iter(WSet<0>{}, WSet<1>{}, kc, 0);
+      iter(WSet<1>{}, WSet<0>{}, kc + 1, 1);
+    }
+    const int r = nchunks - kc;
+    if (r == 3) {
+      iter(WSet<0>{}, WSet<1>{}, kc, 0);
+      compute(1);
+      store_lds(WSet<0>{}, 0);
+      __syncthreads();
+      compute(0);
+    } else if (r == 2) {
+      compute(0);
+      store_lds(WSet<1>{}, 1);
+      __syncthreads();
+      compute(1);
+    } else if (r == 1) {
+      compute(0);
+    }
   }
 
   float* slab = p.part + (size_t)split * p.rows_total * p.Cy;
