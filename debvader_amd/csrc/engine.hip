@@ -2517,6 +2517,17 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
         sp += h[4 * i + 1] - h[4 * i]; sl += h[4 * i + 2] - h[4 * i + 1]; se += h[4 * i + 3] - h[4 * i + 2];
         last_start = std::max(last_start, (double)(h[4 * i] - t0)); first_end = std::min(first_end, (double)(h[4 * i + 3] - t0));
       }
+    {
+      double a = 0, b = 0, c = 0, dd = 0;
+      int k = 0;
+      for (int i = 0; i < (1 << 13); ++i)
+        if (h[4 * i + 3] && h[(1 << 15) + 4 * i]) {
+          a += h[(1 << 15) + 4 * i] - h[4 * i]; b += h[(1 << 15) + 4 * i + 1] - h[(1 << 15) + 4 * i];
+          c += h[(1 << 15) + 4 * i + 2] - h[(1 << 15) + 4 * i + 1]; dd += h[4 * i + 1] - h[(1 << 15) + 4 * i + 2]; ++k;
+        }
+      if (k) fprintf(stderr, "  prologue split: row table + barrier %.2f us, address setup + first load issue %.2f us, load latency %.2f us, LDS store + second load + barrier %.2f us\n",
+                     a / k * 0.01, b / k * 0.01, c / k * 0.01, dd / k * 0.01);
+    }
     fprintf(stderr, "  timeline: %d workgroups, span %.1f us; mean prologue %.2f us, loop %.2f us, epilogue %.2f us; last start at %.1f us, first end at %.1f us\n",
             n, (t3 - t0) * 0.01, sp / n * 0.01, sl / n * 0.01, se / n * 0.01, last_start * 0.01, first_end * 0.01);
     for (int i = 0; i < n && i < 1 << 14; i += std::max(1, n / 16))

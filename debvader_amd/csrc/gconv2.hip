@@ -29,7 +29,9 @@ __device__ __forceinline__ int t_wt(unsigned long long code, int t) { return (in
 
 // SUB = taps per 32-wide K chunk: 1 for Cin % 32 == 0, 2 for Cin == 16, 4 for Cin == 8 (tap then varies per lane)
 template <int BM, int BN, int WGM, int WGN, bool NMAJOR, int SUB = 1>
-__global__ __launch_bounds__(256, 2) void gconv2_kernel(const GConv2Params p) {
+// occupancy target: two workgroups per CU for the 128 x 128 tile (LDS-limited anyway), three for the smaller ones -
+// with the second register set the compiler otherwise settles just above the 168-register line of three waves / SIMD
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || BM >= 256) ? 2 : 3) void gconv2_kernel(const GConv2Params p) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 16, TN = WN / 16;

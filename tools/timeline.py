@@ -8,7 +8,8 @@ ms = C.c_float()
 cases = {"convt3_fwd_s1": (16, 128, 16, 128, 1, 1, 1, 1, 2), "convt7_fwd_s1": (64, 32, 64, 32, 1, 1, 1, 1, 2),
          "conv4_fwd_s1": (15, 64, 15, 128, 1, 1, 0, 0, 2), "convt5_fwd_s1": (32, 64, 32, 64, 1, 1, 1, 1, 2)}
 for name, a in cases.items():
-    check(lib.dv_debug_gconv(ctx._h, 256, *a, 0, -1, 2000, C.byref(ms)))
+    NBATCH = int(os.environ.get("TL_BATCH", "256"))
+    check(lib.dv_debug_gconv(ctx._h, NBATCH, *a, 0, -1, 2000, C.byref(ms)))
     print(name, "plain", ms.value * 1e3, "us", flush=True)
-    check(lib.dv_debug_gconv(ctx._h, 256, *a, 0, 7099, 200, C.byref(ms)))
+    check(lib.dv_debug_gconv(ctx._h, NBATCH, *a, 0, int(os.environ.get("TL_CODE", "7099")), 200, C.byref(ms)))
     print(name, "with stamps", ms.value * 1e3, "us", flush=True)
