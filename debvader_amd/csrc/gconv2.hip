@@ -505,10 +505,10 @@ static int choose_tile(const GConv2Params& p) {
   for (int c = 0; c < p.nclass; ++c) Mtot += p.cls[c].M;
   if (N <= 16) return 5;
   if (N <= 32) return 3;
-  if (N <= 64) return (Mtot + 127) / 128 >= 512 ? 1 : 2;
+  if (N <= 64) return (Mtot + 127) / 128 >= 384 ? 1 : 2;
   // aim for at least two resident workgroups per CU before growing the tile; parity-class launches have
   // short K loops (1-4 taps), so they want twice as many, smaller tiles (measured per layer, tools/layer_bench.py)
-  const long want = p.nclass > 1 ? 1024 : 512;
+  const long want = p.nclass > 1 ? 1024 : 384;   // 1.5 workgroups per CU (re-measured with the two-chunk prefetch)
   const long t128 = ((Mtot + 127) / 128) * ((N + 127) / 128);
   if (t128 >= want) return 0;
   const long t12864 = ((Mtot + 127) / 128) * ((N + 63) / 64);
