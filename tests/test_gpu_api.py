@@ -205,3 +205,30 @@ def test_epistemic_monte_carlo_matches_the_reference_loop_statistically():
     # with one sample the spread is zero and the mean is a single decode
     m1, s1 = deblend_epistemic(net, x, n_samples=1)
     assert np.abs(s1).max() == 0 and np.isfinite(m1).all()
+
+
+def test_pipelined_inference_matches_chunked_calls_bit_for_bit():
+    """dv_infer stages long inputs through a pinned three-stage pipeline (engine.hip: infer_pipelined); short inputs
+    take the plain path.  Same kernels, same per-stamp noise: the results must be identical, for float32 and for
+    float64 input (the cast of deblender.py:18 then happens inside the library), ragged last chunk included."""
+    from debvader_amd.model import model
+
+    net, enc, dec, z = model.create_model_vae(**ARCH, max_batch=128)
+    eng = net._core.engine
+    N = 128 * 4 + 37
+    x, _ = _data(64, 21)
+    x = np.concatenate([x] * 9)[:N] * np.linspace(0.5, 1.5, N, dtype=np.float32)[:, None, None, None]
+    eps = np.random.default_rng(5).normal(size=(N, 32)).astype(np.float32)
+    want = ("loc", "scale", "mu", "zstd", "z")
+    full = eng.infer(x, eps=eps, want=want)                       # N > 256: pipelined, chunks of 128
+    parts = [eng.infer(x[o:o + 200], eps=eps[o:o + 200], want=want) for o in range(0, N, 200)]   # <= 256: plain path
+    for k in want:
+        np.testing.assert_array_equal(full[k], np.concatenate([p[k] for p in parts]), err_msg=k)
+    full64 = eng.infer(x.astype(np.float64), eps=eps, want=want)  # dv_infer_f64
+    for k in want:
+        np.testing.assert_array_equal(full64[k], full[k], err_msg=k + " (float64 input)")
+    # engine-generated noise: rows are numbered globally, so the chunking does not change the sample either
+    a = eng.infer(x, seed=9, want=("loc", "z"))
+    b = eng.infer(x, seed=9, want=("loc", "z"), out={"loc": np.empty_like(a["loc"])})
+    np.testing.assert_array_equal(a["loc"], b["loc"])
+    np.testing.assert_array_equal(a["z"][:200], eng.infer(x[:200], seed=9, want=("z",))["z"])
