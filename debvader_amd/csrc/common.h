@@ -235,6 +235,7 @@ int launch_pad_w1(const float* w, const float* gamma, const float* beta, float* 
 int launch_bn_conv0_grads(const float* G, const float* w, const float* gamma, const float* beta, float* dW,
                           float* dgamma, float* dbeta, int taps, int cin, int cpad, int cout, hipStream_t s);
 int launch_fill(float* p, long n, float v, hipStream_t s);
+int launch_normalise(float* x, long n, bool inverse, hipStream_t s);
 int launch_welford_update(const float* x, float* mean, float* m2, long n, int k, hipStream_t s);
 int launch_welford_finish(float* m2, long n, int count, hipStream_t s);
 int launch_pad_cols(const float* src, float* dst, int rows, int nsrc, int ndst, hipStream_t s);

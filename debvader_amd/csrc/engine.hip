@@ -356,6 +356,7 @@ struct dv_model {
   float *scal = nullptr, *bnstate = nullptr, *bnsums = nullptr;
   float* stage_x = nullptr;  // host-batch staging (infer / encode)
   dv::InferPipe* pipe = nullptr;
+  bool normalise = false;        // dv_model_set_normalise: tanh(arcsinh) on inference inputs, inverse on the mean
   size_t enc_reduced_from = 0;   // this step's encoder gradients [enc_reduced_from, n_enc_train) are already all-reduced   // pinned staging + copy streams of the pipelined dv_infer (lazy)
   float* zero_page = nullptr;  // 256 B of zeros (LDS-DMA source for out-of-image pieces)
   int* idx_dev = nullptr;
@@ -1575,6 +1576,7 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
     DV_HIP(hipStreamWaitEvent(s, p->ev_h2d[b], 0));
     if (k >= 2) DV_HIP(hipStreamWaitEvent(s, p->ev_d2h[(k - 2) % 3], 0));   // D2H of chunk k-2 has drained device buffer b
     if (trace) DV_HIP(hipEventRecord(tev[6 * k + 2], s));
+    if (m->normalise) DV_TRY(launch_normalise(p->din[b], (long)nb * stamp, false, s));
     {
       // the head kernel writes loc / scale straight into transfer buffer b (a device-to-device hipMemcpyAsync of the
       // two 171 MB images cost 3.7 ms each per 2048-stamp chunk)
@@ -1588,6 +1590,7 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
       m->scale = keep_scale;
       DV_TRY(st);
     }
+    if (m->normalise && loc) DV_TRY(launch_normalise(p->dloc[b], (long)nb * stamp, true, s));
     if (mu)
       DV_HIP(hipMemcpy2DAsync(p->dsmall[b], d * sizeof(float), m->t, A.tw * sizeof(float), d * sizeof(float), nb,
                               hipMemcpyDeviceToDevice, s));
@@ -2285,8 +2288,10 @@ static int infer_entry(dv_model* m, const void* x, bool x_f64, int64_t N, const 
       xs = static_cast<const float*>(x) + o * stamp;
     }
     DV_TRY(stage_host_batch(m, xs, nb));
+    if (m->normalise) DV_TRY(launch_normalise(m->stage_x, (long)nb * stamp, false, s));
     DV_TRY(forward_all(m, m->stage_x, nullptr, nullptr, 0, nb, nb, false, false, false, eps ? eps + o * A.d : nullptr,
                        seed, (unsigned)m->ctx->rank, (unsigned)o, zstd != nullptr, false, true));
+    if (m->normalise && loc) DV_TRY(launch_normalise(m->loc, (long)nb * stamp, true, s));
     if (loc) DV_HIP(hipMemcpyAsync(loc + o * stamp, m->loc, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
     if (scale)
       DV_HIP(hipMemcpyAsync(scale + o * stamp, m->scale, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -2299,6 +2304,12 @@ static int infer_entry(dv_model* m, const void* x, bool x_f64, int64_t N, const 
     m->lastB = nb;
   }
   return prof_flush(m);
+}
+
+int dv_model_set_normalise(dv_model* m, int32_t on) {
+  if (!m) return DV_E_INVALID;
+  m->normalise = on != 0;
+  return DV_OK;
 }
 
 int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
@@ -2324,6 +2335,7 @@ int dv_infer_mc(dv_model* m, const float* x, int64_t N, int32_t nsamples, uint64
   for (int64_t o = 0; o < N; o += m->Bc) {
     int nb = (int)std::min<int64_t>(m->Bc, N - o);
     DV_TRY(stage_host_batch(m, x + o * stamp, nb));
+    if (m->normalise) DV_TRY(launch_normalise(m->stage_x, (long)nb * stamp, false, s));
     DV_TRY(bn_prepare(m, m->stage_x, nullptr, 0, nb, nb, false, false));
     DV_TRY(encoder_forward(m, m->stage_x, nullptr, 0, nb, false));           // once per chunk
     for (int k = 0; k < nsamples; ++k) {                                      // nsamples stochastic decodes
@@ -2334,6 +2346,7 @@ int dv_infer_mc(dv_model* m, const float* x, int64_t N, int32_t nsamples, uint64
       DV_TRY(launch_welford_update(m->loc, mean, m2, ((long)(nb * stamp) + 3) & ~3L, k, s));   // buffers carry slack
     }
     DV_TRY(launch_welford_finish(m2, ((long)(nb * stamp) + 3) & ~3L, nsamples, s));
+    if (m->normalise) DV_TRY(launch_normalise(mean, (long)nb * stamp, true, s));   // the mean only, as deblend() does
     if (mean_out)
       DV_HIP(hipMemcpyAsync(mean_out + o * stamp, mean, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
     if (std_out) DV_HIP(hipMemcpyAsync(std_out + o * stamp, m2, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));

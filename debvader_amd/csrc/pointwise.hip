@@ -847,6 +847,28 @@ int launch_welford_finish(float* m2, long n, int count, hipStream_t s) {
   return OK;
 }
 
+// tanh(arcsinh(x)) stamp normalisation and its inverse (reference normalize/normalize.py:3-7) around inference
+// (deblend_cutout/deblender.py:14-22).  tanh(arcsinh x) = x / sqrt(1 + x^2) and sinh(arctanh y) = y / sqrt(1 - y^2);
+// the inverse clamps |y| below 1 as the host path does.
+__global__ void normalise_kernel(float* __restrict__ x, long n, int inverse) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = x[i];
+    if (inverse) {
+      v = fminf(fmaxf(v, -0.99999988f), 0.99999988f);
+      x[i] = v / sqrtf(1.0f - v * v);
+    } else {
+      x[i] = v / sqrtf(1.0f + v * v);
+    }
+  }
+}
+int launch_normalise(float* x, long n, bool inverse, hipStream_t s) {
+  if (n <= 0) return OK;
+  int blocks = (int)min((n + 255) / 256, (long)4096);
+  hipLaunchKernelGGL(normalise_kernel, dim3(blocks), dim3(256), 0, s, x, n, inverse ? 1 : 0);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
 }

@@ -1,10 +1,6 @@
 """Batched inference entry point (reference: src/debvader/deblend_cutout/deblender.py:6-24)."""
 import numpy as np
 
-from debvader_amd.distributions import Normal
-from debvader_amd.normalize.normalize import denormalize_non_linear, normalize_non_linear
-
-
 def deblend(net, images, normalise=False):
     """Deblend stamps with the network.
 
@@ -17,14 +13,16 @@ def deblend(net, images, normalise=False):
     returns (mean ndarray (N,size,size,bands), distribution)
     """
     images = np.asarray(images)
-    if normalise:
-        images = normalize_non_linear(images)
-    out = net(images)     # one stochastic forward pass, BN in inference mode; the float32 cast happens in the engine
-    if normalise:
-        mean = denormalize_non_linear(np.clip(out.mean().numpy(), -1 + 1e-7, 1 - 1e-7))
-        return mean, Normal(mean, out.stddev().numpy())
-    return out.mean().numpy(), out
-
+    if not normalise:
+        out = net(images)  # one stochastic forward pass, BN in inference mode; the float32 cast happens in the engine
+        return out.mean().numpy(), out
+    eng = net._core.engine
+    eng.set_normalise(True)                        # both transforms run on the GPU around the forward pass
+    try:
+        out = net(images)
+    finally:
+        eng.set_normalise(False)
+    return out.mean().numpy(), out                 # mean in flux units, stddev in normalised units
 
 def deblend_epistemic(net, images, n_samples=100, normalise=False):
     """Epistemic-uncertainty estimate of the reference's field deblender (deblend/field_deblender.py:303-313:
@@ -34,9 +32,10 @@ def deblend_epistemic(net, images, n_samples=100, normalise=False):
     returns (mean over samples of the predicted mean, std over samples), each (N, size, size, bands)
     """
     images = np.asarray(images)
-    if normalise:
-        images = normalize_non_linear(images)
-    mean, std = net._core.engine.infer_mc(images.astype(np.float32), n_samples, seed=net._core.next_seed())
-    if normalise:
-        mean = denormalize_non_linear(np.clip(mean, -1 + 1e-7, 1 - 1e-7))
+    eng = net._core.engine
+    eng.set_normalise(bool(normalise))
+    try:
+        mean, std = eng.infer_mc(images.astype(np.float32), n_samples, seed=net._core.next_seed())
+    finally:
+        eng.set_normalise(False)
     return mean, std

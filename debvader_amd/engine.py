@@ -291,6 +291,10 @@ class Engine:
         return {k: float(out[i]) for i, k in enumerate(_lib.SCALAR_NAMES)}
 
     # -- inference --------------------------------------------------------------------------
+    def set_normalise(self, on: bool):
+        """tanh(arcsinh) on inference inputs and the inverse on the predicted mean, on the GPU (deblend(normalise=True))."""
+        check(lib.dv_model_set_normalise(self._h, 1 if on else 0))
+
     def infer(self, x, eps=None, seed=0, want=("loc", "scale"), out=None) -> Dict[str, np.ndarray]:
         """One stochastic forward pass over all stamps.  float64 arrays (numpy's default, what the reference's callers
         pass) go to the engine as they are: the float32 cast of deblender.py:18 happens while the library stages them."""

@@ -129,6 +129,10 @@ int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t 
                    uint64_t seed, float* out);
 
 /* ---- inference: replaces net(x) in deblend() (deblend_cutout/deblender.py:18,24) ----------- */
+/* normalise=True of deblend() (deblender.py:14-22, normalize/normalize.py:3-7): while set, dv_infer / dv_infer_f64 /
+ * dv_infer_mc apply tanh(arcsinh(x)) to the staged stamps on the GPU and the inverse, sinh(arctanh(.)), to the
+ * predicted mean (the scale stays in normalised units) */
+int dv_model_set_normalise(dv_model* m, int32_t on);
 /* x[N,H,W,C] host.  Outputs (any may be NULL): loc/scale [N,H,W,C] = distribution mean / stddev;
  * mu [N,latent], zstd [N,latent] = z.mean()/z.stddev(); z [N,latent] = the sample fed to the decoder. */
 int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,

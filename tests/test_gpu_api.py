@@ -232,3 +232,32 @@ def test_pipelined_inference_matches_chunked_calls_bit_for_bit():
     b = eng.infer(x, seed=9, want=("loc", "z"), out={"loc": np.empty_like(a["loc"])})
     np.testing.assert_array_equal(a["loc"], b["loc"])
     np.testing.assert_array_equal(a["z"][:200], eng.infer(x[:200], seed=9, want=("z",))["z"])
+
+
+def test_normalise_runs_on_the_gpu_and_matches_the_reference_transforms():
+    """deblend(normalise=True): tanh(arcsinh(x)) before the network and sinh(arctanh(.)) on the mean
+    (normalize/normalize.py:3-7), both as GPU kernels.  Checked against the same forward pass fed with inputs
+    normalised on the host by the reference-pinned functions (tests/golden/helpers.npz pins those)."""
+    from debvader_amd.deblend_cutout.deblender import deblend
+    from debvader_amd.model import model
+    from debvader_amd.normalize.normalize import denormalize_non_linear, normalize_non_linear
+
+    net, enc, dec, z = model.create_model_vae(**ARCH, max_batch=64)
+    eng = net._core.engine
+    x, _ = _data(6, 31)
+    x = x * 3.0                                   # reach the non-linear part of the transform
+    eps = np.random.default_rng(2).normal(size=(6, 32)).astype(np.float32)
+    ref = eng.infer(normalize_non_linear(x.astype(np.float64)).astype(np.float32), eps=eps)
+    eng.set_normalise(True)
+    try:
+        got = eng.infer(x, eps=eps)
+    finally:
+        eng.set_normalise(False)
+    want_mean = denormalize_non_linear(np.clip(ref["loc"].astype(np.float64), -1 + 1e-7, 1 - 1e-7))
+    np.testing.assert_allclose(got["loc"], want_mean, rtol=2e-5, atol=1e-6)     # float32 transforms on the device
+    np.testing.assert_allclose(got["scale"], ref["scale"], rtol=2e-5, atol=1e-7)
+    mean, dist = deblend(net, x, normalise=True)
+    assert mean.shape == x.shape and np.isfinite(mean).all() and (dist.stddev().numpy() > 0).all()
+    # the flag does not leak into later calls
+    np.testing.assert_array_equal(eng.infer(x, eps=eps)["loc"], eng.infer(x, eps=eps)["loc"])
+    assert np.abs(eng.infer(x, eps=eps)["loc"] - got["loc"]).max() > 0
