@@ -1,6 +1,7 @@
 """Batched inference entry point (reference: src/debvader/deblend_cutout/deblender.py:6-24)."""
 import numpy as np
 
+
 def deblend(net, images, normalise=False):
     """Deblend stamps with the network.
 
