@@ -89,6 +89,8 @@ SIGNATURES = {
     "dv_train_step": (C.c_int, [_p, C.c_int32, _i32, C.c_int64, C.c_int32, C.c_int32, _f, C.c_uint64, _f]),
     "dv_eval_step": (C.c_int, [_p, C.c_int32, _i32, C.c_int64, C.c_int32, C.c_int32, _f, C.c_uint64, _f]),
     "dv_grad_step": (C.c_int, [_p, C.c_int32, _i32, C.c_int64, C.c_int32, C.c_int32, _f, C.c_uint64, _f]),
+    "dv_train_step_async": (C.c_int, [_p, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_int32]),
+    "dv_step_result": (C.c_int, [_p, C.c_int32, _f]),
     "dv_train_steps": (C.c_int, [_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _f]),
     "dv_model_set_normalise": (C.c_int, [_p, C.c_int32]),
     "dv_infer": (C.c_int, [_p, _f, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),

@@ -356,6 +356,12 @@ struct dv_model {
   float *scal = nullptr, *bnstate = nullptr, *bnsums = nullptr;
   float* stage_x = nullptr;  // host-batch staging (infer / encode)
   dv::InferPipe* pipe = nullptr;
+  // deferred step results (dv_train_step_async / dv_step_result): pinned scalars and staged indices per ticket
+  float* ring_scal = nullptr;    // [4][4] pinned
+  int* ring_idx = nullptr;       // [4][Bc] pinned
+  hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int ring_bg[4] = {0, 0, 0, 0};
+  bool ring_used[4] = {false, false, false, false};
   bool normalise = false;        // dv_model_set_normalise: tanh(arcsinh) on inference inputs, inverse on the mean
   size_t enc_reduced_from = 0;   // this step's encoder gradients [enc_reduced_from, n_enc_train) are already all-reduced   // pinned staging + copy streams of the pipelined dv_infer (lazy)
   float* zero_page = nullptr;  // 256 B of zeros (LDS-DMA source for out-of-image pieces)
@@ -1376,11 +1382,18 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   return OK;
 }
 
+static void scalars_from_sums(const dv_model* m, const float* h, int Bg, float* out);
+
 static int fetch_scalars(dv_model* m, int Bg, float* out) {
-  const Arch& A = m->A;
   float h[4];
   DV_HIP(hipMemcpyAsync(h, m->scal, sizeof h, hipMemcpyDeviceToHost, m->ctx->stream));
   DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  scalars_from_sums(m, h, Bg, out);
+  return OK;
+}
+
+static void scalars_from_sums(const dv_model* m, const float* h, int Bg, float* out) {
+  const Arch& A = m->A;
   double npix = (double)A.H * A.H * A.C;
   double nll_mean = (double)h[0] / ((double)Bg * npix);
   double mse = (double)h[1] / ((double)Bg * npix);
@@ -1391,7 +1404,6 @@ static int fetch_scalars(dv_model* m, int Bg, float* out) {
     out[DV_S_KL_REG] = (float)kl_reg;
     out[DV_S_MSE] = (float)mse;
   }
-  return OK;
 }
 
 static int run_step(dv_model* m, StepMode mode, int slot, const int32_t* idx, int64_t first, int B, int Bg,
@@ -1916,6 +1928,10 @@ int dv_model_destroy(dv_model* m) {
     if (m->slots[s].y) (void)hipFree(m->slots[s].y);
   }
   pipe_free(m->pipe);
+  (void)hipHostFree(m->ring_scal);
+  (void)hipHostFree(m->ring_idx);
+  for (auto& e : m->ring_ev)
+    if (e) (void)hipEventDestroy(e);
   for (auto e : m->ev_pool) (void)hipEventDestroy(e);
   for (auto& r : m->prof) {
     (void)hipEventDestroy(r.a);
@@ -2238,6 +2254,52 @@ int dv_train_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, 
                   const float* eps, uint64_t seed, float* out) {
   return run_step(m, MODE_TRAIN, slot, idx, first, B, Bg, eps, seed, out);
 }
+// Deferred results: the step is queued and its loss sums are copied to a pinned ring slot behind it; the host
+// collects them later (dv_step_result), so a fit() loop can queue step k+1 before it looks at step k and the GPU
+// does not idle while the host prepares the next batch (reference loop: train.py:27-37 Model.fit).
+int dv_train_step_async(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t Bg,
+                        uint64_t seed, int32_t ticket) {
+  DV_TRY(check_step_args(m, slot, idx, first, B));
+  if (ticket < 0 || ticket > 3) {
+    set_error("ticket %d outside [0, 3]", ticket);
+    return DV_E_INVALID;
+  }
+  if (m->ring_used[ticket]) {
+    set_error("ticket %d has an uncollected result", ticket);
+    return DV_E_STATE;
+  }
+  if (Bg <= 0) Bg = B;
+  DV_HIP(hipSetDevice(m->ctx->device));
+  if (!m->ring_scal) {
+    DV_HIP(hipHostMalloc((void**)&m->ring_scal, 16 * sizeof(float), hipHostMallocDefault));
+    DV_HIP(hipHostMalloc((void**)&m->ring_idx, (size_t)4 * m->Bc * sizeof(int), hipHostMallocDefault));
+    for (auto& e : m->ring_ev) DV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int32_t* idx_staged = nullptr;
+  if (idx) {     // the caller's index array may be gone before the copy runs: stage it in pinned memory
+    int* dst = m->ring_idx + (size_t)ticket * m->Bc;
+    memcpy(dst, idx, (size_t)B * sizeof(int));
+    idx_staged = dst;
+  }
+  DV_TRY(enqueue_step(m, MODE_TRAIN, slot, idx_staged, first, B, Bg, nullptr, seed));
+  DV_HIP(hipMemcpyAsync(m->ring_scal + 4 * ticket, m->scal, 4 * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
+  DV_HIP(hipEventRecord(m->ring_ev[ticket], m->ctx->stream));
+  m->ring_bg[ticket] = Bg;
+  m->ring_used[ticket] = true;
+  return prof_flush(m);
+}
+
+int dv_step_result(dv_model* m, int32_t ticket, float* out) {
+  if (!m || ticket < 0 || ticket > 3 || !m->ring_used[ticket]) {
+    set_error("no queued step under ticket %d", ticket);
+    return DV_E_STATE;
+  }
+  DV_HIP(hipEventSynchronize(m->ring_ev[ticket]));
+  scalars_from_sums(m, m->ring_scal + 4 * ticket, m->ring_bg[ticket], out);
+  m->ring_used[ticket] = false;
+  return DV_OK;
+}
+
 int dv_eval_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t Bg, const float* eps,
                  uint64_t seed, float* out) {
   return run_step(m, MODE_EVAL, slot, idx, first, B, Bg, eps, seed, out);

@@ -284,6 +284,20 @@ class Engine:
     def grad_step(self, slot=0, idx=None, first=0, B=None, global_batch=None, eps=None, seed=0):
         return self._step(lib.dv_grad_step, slot, idx, first, B, global_batch, eps, seed)
 
+    def train_step_async(self, ticket, slot=0, idx=None, first=0, B=None, global_batch=None, seed=0):
+        """Queues a training step under `ticket` (0..3); step_result(ticket) returns its scalars later."""
+        ip = None
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            B = idx.size
+            ip = idx.ctypes.data_as(C.POINTER(C.c_int32))
+        check(lib.dv_train_step_async(self._h, slot, ip, int(first), int(B), int(global_batch or 0), int(seed), int(ticket)))
+
+    def step_result(self, ticket) -> Dict[str, float]:
+        out = np.zeros(_lib.DV_N_SCALARS, dtype=np.float32)
+        check(lib.dv_step_result(self._h, int(ticket), _fp(out)))
+        return {k: float(out[i]) for i, k in enumerate(_lib.SCALAR_NAMES)}
+
     def train_steps(self, slot, first, B, steps, global_batch=None, seed=0) -> Dict[str, float]:
         out = np.zeros(_lib.DV_N_SCALARS, dtype=np.float32)
         check(lib.dv_train_steps(self._h, slot, int(first), int(B), int(global_batch or 0), int(steps), int(seed),

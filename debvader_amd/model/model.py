@@ -277,17 +277,33 @@ class VAENet:
             order = rng.permutation(n) if shuffle else np.arange(n)
             sums: Dict[str, float] = {}
             seen = 0
+            # Steps are queued two ahead of the one whose loss the host is reading (deferred results), so the GPU
+            # does not idle while Python slices the next batch; metrics are accumulated in step order as before.
+            pending = []
+            ticket = 0
+
+            def collect(item):
+                nonlocal seen
+                tk, count = item
+                scal = eng.step_result(tk)
+                self._set_losses(scal)
+                for k, v in self._metric_values(scal).items():
+                    sums[k] = sums.get(k, 0.0) + v * count
+                seen += count
+
             for b0 in range(0, n, batch_size):
                 gidx = order[b0:b0 + batch_size]
                 lo, hi = shard_range(len(gidx), rank, world)
                 if hi <= lo:
                     raise ValueError("a rank received an empty shard; use batch sizes >= number of ranks")
-                scal = eng.train_step(0, idx=gidx[lo:hi].astype(np.int32), global_batch=len(gidx),
-                                      seed=core.next_seed())
-                self._set_losses(scal)
-                for k, v in self._metric_values(scal).items():
-                    sums[k] = sums.get(k, 0.0) + v * len(gidx)
-                seen += len(gidx)
+                eng.train_step_async(ticket, 0, idx=gidx[lo:hi].astype(np.int32), global_batch=len(gidx),
+                                     seed=core.next_seed())
+                pending.append((ticket, len(gidx)))
+                ticket = (ticket + 1) % 4
+                if len(pending) > 2:
+                    collect(pending.pop(0))
+            while pending:
+                collect(pending.pop(0))
             logs = {k: v / seen for k, v in sums.items()}
             if nv:
                 steps = validation_steps if validation_steps else -(-nv // batch_size)

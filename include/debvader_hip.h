@@ -123,6 +123,12 @@ int dv_eval_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, i
 /* gradients only (training-mode forward + backward, no Adam, no moving-stat update): parity tests */
 int dv_grad_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t global_batch,
                  const float* eps, uint64_t seed, float* out);
+/* dv_train_step with a deferred result: the step is queued under `ticket` (0..3) and dv_step_result(ticket) later
+ * waits for it and returns its scalars, so the host loop of Model.fit (train.py:27-37) can queue the next batch before
+ * it reads the previous loss.  The index array is copied before the call returns.  eps is engine-generated. */
+int dv_train_step_async(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t global_batch,
+                        uint64_t seed, int32_t ticket);
+int dv_step_result(dv_model* m, int32_t ticket, float* out_scalars /* DV_N_SCALARS */);
 /* queue K back-to-back training steps on consecutive batches of `slot` without host round trips
  * (bench.py timed region); scalars of the last step are returned */
 int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t global_batch, int32_t steps,
