@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || BM >= 256) ? 2 : 3) v
     cc = kbeg - tap * cpt;
     Uout += (size_t)blockIdx.y * p.NB * p.Hout * p.Wout * p.Cout;
   }
-  const bool deep = p.dbg != 1 && p.prio != 4 && SUB == 1;   // distance-2 register prefetch (see areg / breg)
+  const bool deep = p.dbg != 1 && p.prio != 4;   // distance-2 register prefetch (see areg / breg)
   if (nchunks > 0) {
     load_global(SetC<0>{});
     store_lds(SetC<0>{}, 0);
