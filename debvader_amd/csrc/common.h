@@ -97,7 +97,7 @@ struct GConv2Params {
   long alpha_elems;    // Hout*Wout*Cout
   int dbg;             // timing build: phase stamps
   float* dbg_out;
-  int prio;            // s_setprio level of the load-issue / LDS-store phases
+  int prio;            // ablation switch: 4 = one-chunk prefetch with the loads in front of the MFMA block
 };
 void debug_set_gconv2_dbg(int v, float* out);
 void debug_set_gconv2_prio(int v);

@@ -2544,14 +2544,6 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
     debug_set_gconv2_prio(4);   // 4: loads in front of the MFMA block (pre-interleave order)
     tile -= 4000;
     if (tile == 99) tile = -1;
-  } else if (tile >= 3000) {
-    debug_set_gconv2_prio(2);
-    tile -= 3000;
-    if (tile == 99) tile = -1;
-  } else if (tile >= 2000) {
-    debug_set_gconv2_prio(1);
-    tile -= 2000;
-    if (tile == 99) tile = -1;
   }
   const bool stamps = tile >= 500 && tile < 1000;
   if (stamps) {

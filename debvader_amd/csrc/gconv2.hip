@@ -288,12 +288,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || BM >= 256) ? 2 : 3) v
   // partial tile into slab blockIdx.y of U; splitk_finish_kernel sums the slabs in order and applies the epilogue
   int nchunks = SUB == 1 ? cl.ntaps * cpt : (cl.ntaps + SUB - 1) / SUB;
   float* Uout = p.U;
-  if (p.prio >= 2) {
-    // stagger experiment: the second resident workgroup of a CU (odd hardware wave slot) starts half a chunk late so
-    // that its memory phases fall under the partner's MFMA phases instead of running in lockstep with them
-    const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));   // HW_REG_HW_ID.wave_id
-    if (hwid & 1) __builtin_amdgcn_s_sleep(40);
-  }
   if (p.ksplit > 1) {
     const int cps = (nchunks + p.ksplit - 1) / p.ksplit;
     const int kbeg = blockIdx.y * cps;
