@@ -362,6 +362,15 @@ struct dv_model {
   hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int ring_bg[4] = {0, 0, 0, 0};
   bool ring_used[4] = {false, false, false, false};
+  // input-BN batch sums of the NEXT step, computed (and all-reduced) on the comm stream while this step runs
+  float* bn_pre_part = nullptr;
+  float* bn_pre_sums = nullptr;
+  size_t bn_pre_part_elems = 0;
+  bool bn_pre_valid = false;
+  const float* bn_pre_x = nullptr;
+  int64_t bn_pre_first = -1, hint_next_first = -1;
+  int bn_pre_B = 0;
+  hipEvent_t ev_bnpre = nullptr, ev_bnpre_go = nullptr;
   bool normalise = false;        // dv_model_set_normalise: tanh(arcsinh) on inference inputs, inverse on the mean
   size_t enc_reduced_from = 0;   // this step's encoder gradients [enc_reduced_from, n_enc_train) are already all-reduced   // pinned staging + copy streams of the pipelined dv_infer (lazy)
   float* zero_page = nullptr;  // 256 B of zeros (LDS-DMA source for out-of-image pieces)
@@ -906,15 +915,24 @@ static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first,
   hipStream_t s = m->ctx->stream;
   const int HW = A.H * A.H;
   float* P = m->P;
+  const float* sums = m->bnsums;
   if (training) {
-    int nblk = 0;
-    ProfScope ps(m, 2, s);
-    DV_TRY(launch_bn_stats(xsrc, idx, first, NB, HW, A.C, m->ws3, &nblk, s));
-    DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 16, m->bnsums, 1.0f, s));
-    DV_TRY(allreduce_small(m->ctx, m->bnsums, 16));
+    if (m->bn_pre_valid && !idx && xsrc == m->bn_pre_x && first == m->bn_pre_first && NB == m->bn_pre_B && !m->prof_on) {
+      // the batch sums (they depend on the data only) were computed and all-reduced on the comm stream during the
+      // previous step: no reduction kernels and no latency-bound collective at the head of this step
+      DV_HIP(hipStreamWaitEvent(s, m->ev_bnpre, 0));
+      sums = m->bn_pre_sums;
+    } else {
+      int nblk = 0;
+      ProfScope ps(m, 2, s);
+      DV_TRY(launch_bn_stats(xsrc, idx, first, NB, HW, A.C, m->ws3, &nblk, s));
+      DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 16, m->bnsums, 1.0f, s));
+      DV_TRY(allreduce_small(m->ctx, m->bnsums, 16));
+    }
+    m->bn_pre_valid = false;
   }
   ProfScope ps(m, 2, s);
-  return launch_bn_finalize(m->bnsums, (float)((double)Bg * HW), A.C, P + A.specs[0].off, P + A.specs[1].off,
+  return launch_bn_finalize(sums, (float)((double)Bg * HW), A.C, P + A.specs[0].off, P + A.specs[1].off,
                             P + A.specs[2].off, P + A.specs[3].off, A.cfg.bn_eps, A.cfg.bn_momentum,
                             A.cfg.bn_moving_var_unbiased, training ? 1 : 0, upd_moving ? 1 : 0, m->bnstate, s);
 }
@@ -1347,6 +1365,32 @@ static int check_step_args(dv_model* m, int slot, const int32_t* idx, int64_t fi
   return OK;
 }
 
+// Batch sums of the input BatchNorm for the step that will read rows [first, first + NB) of `x`: queued on the comm
+// stream (idle between the collectives), all-reduced there, consumed by bn_prepare() of that step.
+static int bn_prefetch(dv_model* m, const float* x, int64_t first, int NB) {
+  const Arch& A = m->A;
+  dv_ctx* c = m->ctx;
+  if (!m->bn_pre_part || !c->comm_stream) return OK;
+  const int HW = A.H * A.H;
+  int nblk = 0;
+  // the previous consumer of bn_pre_sums (bn_finalize of the current step) is already queued on the main stream
+  DV_HIP(hipEventRecord(m->ev_bnpre_go, c->stream));
+  DV_HIP(hipStreamWaitEvent(c->comm_stream, m->ev_bnpre_go, 0));
+  DV_TRY(launch_bn_stats(x, nullptr, (int)first, NB, HW, A.C, m->bn_pre_part, &nblk, c->comm_stream));
+  if ((size_t)nblk * 16 > m->bn_pre_part_elems) {
+    set_error("bn prefetch workspace too small");
+    return E_STATE;
+  }
+  DV_TRY(launch_reduce_rows_f64(m->bn_pre_part, nblk, 16, m->bn_pre_sums, 1.0f, c->comm_stream));
+  if (c->comm) DV_NCCL(ncclAllReduce(m->bn_pre_sums, m->bn_pre_sums, 16, ncclFloat, ncclSum, c->comm, c->comm_stream));
+  DV_HIP(hipEventRecord(m->ev_bnpre, c->comm_stream));
+  m->bn_pre_valid = true;
+  m->bn_pre_x = x;
+  m->bn_pre_first = first;
+  m->bn_pre_B = NB;
+  return OK;
+}
+
 // enqueue one step (no host sync); scalars land in m->scal[0..2]
 static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx_host, int64_t first, int B, int Bg,
                         const float* eps_host, uint64_t seed) {
@@ -1366,6 +1410,10 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   // the loss sums are only read after the step: with a backward pass the main stream joins the comm stream behind
   // the last gradient bucket anyway, so it does not stop here for this latency-bound collective
   DV_TRY(allreduce_small(m->ctx, m->scal, 4, !bwd));
+  if (mode == MODE_TRAIN && m->hint_next_first >= 0 && !m->prof_on) {
+    DV_TRY(bn_prefetch(m, ds.x, m->hint_next_first, B));
+    m->hint_next_first = -1;
+  }
   if (bwd) {
     DV_TRY(backward(m, B, Bg, ds.x, idx, (int)first));
     if (m->ctx->comm) {
@@ -1928,6 +1976,8 @@ int dv_model_destroy(dv_model* m) {
     if (m->slots[s].y) (void)hipFree(m->slots[s].y);
   }
   pipe_free(m->pipe);
+  if (m->ev_bnpre) (void)hipEventDestroy(m->ev_bnpre);
+  if (m->ev_bnpre_go) (void)hipEventDestroy(m->ev_bnpre_go);
   (void)hipHostFree(m->ring_scal);
   (void)hipHostFree(m->ring_idx);
   for (auto& e : m->ring_ev)
@@ -2054,6 +2104,12 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   ALLOC(m->zero_page, 64);
   ALLOC(m->bnstate, 32);
   ALLOC(m->bnsums, 16);
+  ALLOC(m->bn_pre_sums, 16);
+  m->bn_pre_part_elems = (size_t)16 * (((size_t)Bc * A.H * A.H + 255) / 256 + 16);
+  ALLOC(m->bn_pre_part, m->bn_pre_part_elems);
+  if (hipEventCreateWithFlags(&m->ev_bnpre, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&m->ev_bnpre_go, hipEventDisableTiming) != hipSuccess)
+    return fail(E_HIP);
   {
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, Bc * sizeof(int));
@@ -2234,6 +2290,7 @@ int dv_data_upload(dv_model* m, int32_t slot, const float* x, const float* y, in
     return DV_E_INVALID;
   }
   DV_TRY(dv_data_free(m, slot));
+  m->bn_pre_valid = false;     // prefetched batch sums refer to the old rows
   size_t bytes = (size_t)n * A.H * A.H * A.C * sizeof(float);
   DataSlot& d = m->slots[slot];
   hipError_t e = hipMalloc((void**)&d.x, bytes);
@@ -2318,6 +2375,7 @@ int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t 
   int64_t span = std::max<int64_t>(1, m->slots[slot].n - B + 1);
   for (int k = 0; k < steps; ++k) {
     int64_t start = (first + (int64_t)k * B) % span;
+    m->hint_next_first = k + 1 < steps ? (first + (int64_t)(k + 1) * B) % span : -1;   // lets step k prefetch k+1's BN sums
     DV_TRY(enqueue_step(m, MODE_TRAIN, slot, nullptr, start, B, Bg, nullptr, seed + (uint64_t)k));
     if (m->prof_on) DV_TRY(prof_flush(m));
   }
