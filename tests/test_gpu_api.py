@@ -278,3 +278,31 @@ def test_training_reduces_the_loss_on_a_small_set():
     assert loss[-1] < 0.5 * loss[0], loss
     assert all(np.isfinite(v) for v in h.history["mse"])      # (mse compares with a SAMPLE of the output distribution)
     assert all(np.isfinite(w).all() for w in net.get_weights())
+
+
+def test_edge_cases_empty_and_ragged_inputs():
+    """Empty inputs, a single stamp, a data set smaller than the batch, the largest batch the workspace takes and one
+    more (which must be refused with a message, not crash)."""
+    from debvader_amd._lib import DvError
+    from debvader_amd.deblend_cutout.deblender import deblend
+    from debvader_amd.model import model
+    from debvader_amd.training.metrics import vae_loss
+
+    net, enc, dec, z = model.create_model_vae(**ARCH, max_batch=8)
+    x, y = _data(11, 51)
+    mean, dist = deblend(net, x[:0])
+    assert mean.shape == (0, 59, 59, 6) and dist.stddev().numpy().shape == (0, 59, 59, 6)
+    mean, _ = deblend(net, x[:1])
+    assert mean.shape == (1, 59, 59, 6) and np.isfinite(mean).all()
+    mean, _ = deblend(net, x)                      # 11 stamps through an 8-stamp workspace: two chunks
+    assert mean.shape == x.shape and np.isfinite(mean).all()
+    assert enc(x[:0]).numpy().shape == (0, 560)
+    net.compile(optimizer=model.Adam(learning_rate=1e-4), loss=vae_loss, metrics=["mse"])
+    h = net.fit(x[:3], y[:3], epochs=1, batch_size=8, verbose=0)          # data set smaller than the batch
+    assert np.isfinite(h.history["loss"][0])
+    h = net.fit(x, y, epochs=1, batch_size=8, verbose=0)                  # 8 + ragged 3
+    assert np.isfinite(h.history["loss"][0])
+    with pytest.raises((DvError, ValueError)):
+        net.fit(x, y, epochs=1, batch_size=9, verbose=0)                  # beyond max_batch
+    with pytest.raises(ValueError):
+        deblend(net, x[:, :58])                                           # wrong stamp size
