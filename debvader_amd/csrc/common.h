@@ -223,6 +223,7 @@ struct SamplerParams {
   unsigned long long seed;
   unsigned stream;
   unsigned row0;
+  int rep_nb;          // > 0: row r is Monte-Carlo sample r / rep_nb of stamp r % rep_nb (seed + sample, t row of the stamp)
 };
 int launch_sampler_fwd(const SamplerParams& p, hipStream_t s);
 int launch_sampler_bwd(const float* t, const float* eps, const float* z, const float* dz, float* dt, int NB, int d,
@@ -238,6 +239,8 @@ int launch_fill(float* p, long n, float v, hipStream_t s);
 int launch_normalise(float* x, long n, bool inverse, hipStream_t s);
 int launch_welford_update(const float* x, float* mean, float* m2, long n, int k, hipStream_t s);
 int launch_welford_finish(float* m2, long n, int count, hipStream_t s);
+// x holds `reps` consecutive blocks of n elements (samples k0 .. k0+reps-1 of the same n statistics), folded in order
+int launch_welford_update_multi(const float* x, float* mean, float* m2, long n, int reps, int k0, hipStream_t s);
 int launch_pad_cols(const float* src, float* dst, int rows, int nsrc, int ndst, hipStream_t s);
 int launch_take_cols(const float* src, float* dst, int rows, int nsrc, int ndst, hipStream_t s);
 int launch_gather_rows(const float* src, const int* idx, int first, int NB, long row_elems, float* dst,

@@ -1002,7 +1002,7 @@ static int decoder_forward(dv_model* m, int NB, bool keep_u) {
 
 // eps of the lane is already in m->eps when gen == false
 static int sampler_forward(dv_model* m, int NB, bool gen, uint64_t seed, unsigned stream_id, unsigned row0,
-                           bool want_std) {
+                           bool want_std, int rep_nb = 0) {
   const Arch& A = m->A;
   SamplerParams sp;
   memset(&sp, 0, sizeof sp);
@@ -1018,6 +1018,7 @@ static int sampler_forward(dv_model* m, int NB, bool gen, uint64_t seed, unsigne
   sp.seed = seed;
   sp.stream = stream_id;
   sp.row0 = row0 + (unsigned)m->b0;
+  sp.rep_nb = rep_nb;
   ProfScope ps(m, 2);
   return launch_sampler_fwd(sp, fwd_stream(m));
 }
@@ -2458,12 +2459,22 @@ int dv_infer_mc(dv_model* m, const float* x, int64_t N, int32_t nsamples, uint64
     if (m->normalise) DV_TRY(launch_normalise(m->stage_x, (long)nb * stamp, false, s));
     DV_TRY(bn_prepare(m, m->stage_x, nullptr, 0, nb, nb, false, false));
     DV_TRY(encoder_forward(m, m->stage_x, nullptr, 0, nb, false));           // once per chunk
-    for (int k = 0; k < nsamples; ++k) {                                      // nsamples stochastic decodes
+    // nsamples stochastic decodes, as many per pass as the workspace takes: the decoder runs on nb * reps rows, row r
+    // being sample k + r / nb of stamp r % nb (the sampler reads that stamp's t and draws the noise sample k + r / nb
+    // would get in a pass of its own), and the per-stamp statistics fold the samples in order.  A handful of objects
+    // with 100 samples each - the per-field use of the reference - is one or two decoder passes instead of 100.
+    const int per_pass = std::max(1, m->Bc / nb);
+    for (int k = 0; k < nsamples; k += per_pass) {
+      const int reps = std::min(per_pass, nsamples - k);
       int nblk = 0;
-      DV_TRY(sampler_forward(m, nb, true, seed + (uint64_t)k, (unsigned)m->ctx->rank, (unsigned)o, false));
-      DV_TRY(decoder_forward(m, nb, false));
-      DV_TRY(head_lane(m, nullptr, nullptr, 0, nb, nb, false, true, 0, &nblk));
-      DV_TRY(launch_welford_update(m->loc, mean, m2, ((long)(nb * stamp) + 3) & ~3L, k, s));   // buffers carry slack
+      DV_TRY(sampler_forward(m, nb * reps, true, seed + (uint64_t)k, (unsigned)m->ctx->rank, (unsigned)o, false,
+                             reps > 1 ? nb : 0));
+      DV_TRY(decoder_forward(m, nb * reps, false));
+      DV_TRY(head_lane(m, nullptr, nullptr, 0, nb * reps, nb * reps, false, true, 0, &nblk));
+      if (reps > 1)
+        DV_TRY(launch_welford_update_multi(m->loc, mean, m2, (long)nb * stamp, reps, k, s));
+      else
+        DV_TRY(launch_welford_update(m->loc, mean, m2, ((long)(nb * stamp) + 3) & ~3L, k, s));   // buffers carry slack
     }
     DV_TRY(launch_welford_finish(m2, ((long)(nb * stamp) + 3) & ~3L, nsamples, s));
     if (m->normalise) DV_TRY(launch_normalise(mean, (long)nb * stamp, true, s));   // the mean only, as deblend() does

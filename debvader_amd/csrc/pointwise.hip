@@ -550,7 +550,10 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
   if (b >= p.NB) return;
   const int d = p.d;
   const int tw = d + d * (d + 1) / 2;
-  const float* t = p.t + (size_t)b * tw;
+  // Monte-Carlo replication (dv_infer_mc): row b is sample b / rep_nb of stamp b % rep_nb
+  const int bs = p.rep_nb > 0 ? b % p.rep_nb : b;
+  const unsigned long long seed = p.seed + (p.rep_nb > 0 ? (unsigned long long)(b / p.rep_nb) : 0ull);
+  const float* t = p.t + (size_t)bs * tw;
   // the row of t goes through LDS (coalesced): the lower-triangle gather below would otherwise be a chain of
   // d dependent, divergent global loads per stamp (31 us per step at d = 32)
   __shared__ float st_all[4][64 + 64 * 65 / 2];
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
   if (lane < d) {
     if (p.gen) {
       unsigned r[4];
-      philox4x32_10(p.row0 + b, lane >> 2, p.stream, 0u, (unsigned)p.seed, (unsigned)(p.seed >> 32), r);
+      philox4x32_10(p.row0 + bs, lane >> 2, p.stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
       const int a = lane & 3;
       const float u1 = ((float)r[a & ~1] + 1.0f) * 2.3283064365386963e-10f;
       const float u2 = ((float)r[(a & ~1) + 1] + 1.0f) * 2.3283064365386963e-10f;
@@ -819,6 +822,29 @@ __global__ __launch_bounds__(256) void welford_update_kernel(const float* __rest
     reinterpret_cast<f32x4*>(mean)[i] = mu;
     reinterpret_cast<f32x4*>(m2)[i] = s2;
   }
+}
+__global__ __launch_bounds__(256) void welford_update_multi_kernel(const float* __restrict__ x, float* __restrict__ mean,
+                                                                   float* __restrict__ m2, long n, int reps, int k0) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float mu = k0 == 0 ? 0.f : mean[i];
+    float s2 = k0 == 0 ? 0.f : m2[i];
+    for (int r = 0; r < reps; ++r) {               // same fold order (and arithmetic) as one welford_update per sample
+      const float v = x[(long)r * n + i];
+      const float d = v - mu;
+      mu += d * (1.0f / (float)(k0 + r + 1));
+      s2 += d * (v - mu);
+    }
+    mean[i] = mu;
+    m2[i] = s2;
+  }
+}
+int launch_welford_update_multi(const float* x, float* mean, float* m2, long n, int reps, int k0, hipStream_t s) {
+  if (reps < 1) return E_INVALID;
+  if (n <= 0) return OK;
+  hipLaunchKernelGGL(welford_update_multi_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s,
+                     x, mean, m2, n, reps, k0);
+  DV_HIP(hipGetLastError());
+  return OK;
 }
 __global__ __launch_bounds__(256) void welford_finish_kernel(float* __restrict__ m2, long n4, float inv_n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {

@@ -306,3 +306,21 @@ def test_edge_cases_empty_and_ragged_inputs():
         net.fit(x, y, epochs=1, batch_size=9, verbose=0)                  # beyond max_batch
     with pytest.raises(ValueError):
         deblend(net, x[:, :58])                                           # wrong stamp size
+
+
+def test_monte_carlo_sample_batching_is_invisible():
+    """dv_infer_mc runs as many samples per decoder pass as the workspace takes; the statistics must be identical to
+    one pass per sample (same noise per (stamp, sample), same fold order), for odd element counts too."""
+    from debvader_amd.model import model
+
+    x, _ = _data(3, 61)
+    outs = []
+    for mb in (3, 8, 64):                       # 1, 2 and 21 samples per pass
+        net, _, _, _ = model.create_model_vae(**ARCH, max_batch=mb)
+        eng = net._core.engine
+        eng.init(seed=12)
+        outs.append(eng.infer_mc(x, nsamples=10, seed=77))
+    for mean, std in outs[1:]:
+        np.testing.assert_array_equal(mean, outs[0][0])
+        np.testing.assert_array_equal(std, outs[0][1])
+    assert (outs[0][1] > 0).any()
