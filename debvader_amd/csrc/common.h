@@ -114,6 +114,22 @@ int scene_extract(const double* field_h, int F, int nb, const int32_t* starts_h,
 int scene_composite(double* field_h, int F, int nb, const double* stamps_h, const double* pos_h, int N, int cs,
                     double sign, hipStream_t s);
 
+// Strip form of the stride-1 3x3 gather-GEMM for the 32-channel high-resolution layers (gconv_strip.hip)
+struct GStripParams {
+  const float* X;
+  const float* W;
+  float* U;
+  float* A;
+  const float* bias;
+  const float* alpha;
+  const float* zero;   // >= 16 bytes of zeros (source of the out-of-image patch slots)
+  int NB, H, Wd, Cin, Cout;
+  unsigned long long tapcode, wtcode;   // nine taps: (dh, dw) and weight index, as in GConvParams
+  int epi;             // 0 raw, 1 +bias, 2 +bias then PReLU
+  int R, patch_floats, strips_per_stamp, nstrips, strips_per_wg;   // filled by the launcher
+};
+int launch_gconv_strip(GStripParams p, bool nmajor, hipStream_t s);   // 1 = not taken (use gconv2)
+
 // Stride-2 data-gradient form with the four parity classes fused per workgroup (gconv_s2.hip).
 // Class c = 2*[row parity has two taps] + [column parity has two taps]; neighbour e = 2*[dh == x] + [dw == x].
 struct GConvS2Params {

@@ -566,6 +566,21 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
   Taps one;
   one.add(0, 0, 0);
   const Taps tp = single_tap ? one : taps_fprop(pb);
+  static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
+  if (Cin == 32 && (Cout == 16 || Cout == 32) && s == 1 && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
+      !single_tap && !g_force_v1 && !gs_off && !(fz && !m->no_fuse)) {
+    GStripParams g;
+    memset(&g, 0, sizeof g);
+    g.X = X; g.W = W; g.U = U; g.A = Aout; g.bias = bias; g.alpha = alpha; g.zero = m->zero_page;
+    g.NB = NB; g.H = Hout; g.Wd = Hout; g.Cin = Cin; g.Cout = Cout;
+    g.tapcode = tp.tapcode; g.wtcode = tp.wtcode; g.epi = epi;
+    int r;
+    {
+      ProfScope ps(m, 0);
+      r = launch_gconv_strip(g, nmajor, fwd_stream(m));
+    }
+    if (r <= 0) return r;
+  }
   if ((Cin % 32 == 0 || ((Cin == 8 || Cin == 16) && Cout <= 32 && !single_tap)) && !g_force_v1) {
     GConv2Params q;
     memset(&q, 0, sizeof q);
@@ -620,6 +635,24 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
                        float* U, float* Aout, int epi, int NB, int Hs, int Cs, int Ht, int Ct, int s, int pb,
                        const FuseBwd* fz = nullptr, bool* fused = nullptr) {
   if (fused) *fused = false;
+  static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
+  if (s == 1 && Cs == 32 && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !gs_off &&
+      !(fz && !m->no_fuse)) {
+    const Taps tp = taps_dgrad(1, pb, 0, 0);
+    if (tp.n == 9) {
+      GStripParams g;
+      memset(&g, 0, sizeof g);
+      g.X = X; g.W = W; g.U = U; g.A = Aout; g.bias = bias; g.alpha = alpha; g.zero = m->zero_page;
+      g.NB = NB; g.H = Ht; g.Wd = Ht; g.Cin = Cs; g.Cout = Ct;
+      g.tapcode = tp.tapcode; g.wtcode = tp.wtcode; g.epi = epi;
+      int r;
+      {
+        ProfScope ps(m, 0);
+        r = launch_gconv_strip(g, nmajor, fwd_stream(m));
+      }
+      if (r <= 0) return r;
+    }
+  }
   static const bool no_s2f = getenv("DV_NO_S2F") != nullptr;
   if (s == 2 && Cs % 32 == 0 && Ct % 4 == 0 && nmajor && !g_force_v1 && !no_s2f && !(fz && !m->no_fuse)) {
     // all four parity classes in one workgroup (gconv_s2.hip)
@@ -2602,6 +2635,8 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   DV_HIP(hipMalloc((void**)&Y2, ny * sizeof(float)));
   m.ws1_elems = (size_t)16 << 20;
   DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
+  DV_HIP(hipMalloc((void**)&m.zero_page, 256));
+  DV_HIP(hipMemsetAsync(m.zero_page, 0, 256, ctx->stream));
   const bool timeline = tile >= 7000;
   if (timeline) {
     tile -= 7000;
@@ -2680,7 +2715,7 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   float ms = 0;
   DV_HIP(hipEventElapsedTime(&ms, a, b));
   *ms_out = ms / iters;
-  (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(Y2); (void)hipFree(m.ws1);
+  (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(Y2); (void)hipFree(m.ws1); (void)hipFree(m.zero_page);
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   return st;
 }

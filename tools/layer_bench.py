@@ -58,8 +58,8 @@ for tile in tiles:
             print(f"dec convt{i} dgrad {ho:3d}x{co:3d}->{hi:3d}x{ci:3d} s{s}: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF")
             tot_ms += ms; tot_fl += fl
         fl = flops_conv(64, 32, 12)
-        ms = gconv(64, 32, 64, 12, 1, 1, 0, 0, epi=1, tile=tile); print(f"head fwd: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF"); tot_ms += ms; tot_fl += fl
-        ms = gconv(64, 12, 64, 32, 1, 1, 1, 1, epi=0, tile=tile); print(f"head dgrad: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF"); tot_ms += ms; tot_fl += fl
+        ms = gconv(64, 32, 64, 16, 1, 1, 0, 0, epi=1, tile=tile); print(f"head fwd: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF"); tot_ms += ms; tot_fl += fl
+        ms = gconv(64, 16, 64, 32, 1, 1, 1, 1, epi=0, tile=tile); print(f"head dgrad: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF"); tot_ms += ms; tot_fl += fl
         for (k, n) in ((4096, 560), (32, 560), (560, 4096)):
             fl = 2.0 * B * k * n
             ms = gconv(1, k, 1, n, 1, 0, 0, 0, epi=1, single=1, tile=tile); print(f"dense {k}->{n} fwd: {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF"); tot_ms += ms; tot_fl += fl
