@@ -636,7 +636,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
                        const FuseBwd* fz = nullptr, bool* fused = nullptr) {
   if (fused) *fused = false;
   static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
-  if (s == 1 && Cs == 32 && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !gs_off &&
+  if (s == 1 && (Cs == 32 || (Cs == 16 && Ct == 32)) && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !gs_off &&
       !(fz && !m->no_fuse)) {
     const Taps tp = taps_dgrad(1, pb, 0, 0);
     if (tp.n == 9) {

@@ -33,10 +33,16 @@ __device__ __forceinline__ int gs_dw(unsigned long long code, int t) { return (i
 __device__ __forceinline__ int gs_wt(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 15); }
 }  // namespace
 
-// COUT: columns held in LDS / accumulators (16 or 32, >= p.Cout); NMAJOR: weights stored W[wt][n][k] (else W[wt][k][n])
-template <int COUT, bool NMAJOR>
+// CIN: input channels (32, or 16 for the head's data gradient); COUT: columns held in LDS / accumulators (16 or 32,
+// >= p.Cout); NMAJOR: weights stored W[wt][n][k] (else W[wt][k][n])
+template <int CIN, int COUT, bool NMAJOR>
 __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStripParams p) {
-  constexpr int CIN = 32, CQ = CIN / 4;           // 8 channel quads per pixel
+  constexpr int CQ = CIN / 4;                     // channel quads per pixel (8 or 4)
+  constexpr int QG = CIN / 16;                    // 16-channel fragment groups per tap
+  constexpr int NSTEPS = 9 * QG;
+  // quad swizzle: rows (pixels, weight columns) are CQ*16 bytes apart; 16 consecutive rows must cover 256 bytes
+  constexpr int SWS = CQ == 8 ? 1 : 2;
+#define GS_SW(idx) (((idx) >> SWS) & (CQ - 1))
   constexpr int TN = COUT / 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* patch = smem;                                          // [2][patch_floats]
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStrip
       const int n = rem / CQ, kq = rem - n * CQ;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.W + ((size_t)(wt * p.Cout + n) * CIN + kq * 4));
-      *reinterpret_cast<f32x4*>(wts + ((t * COUT + n) * CQ + (kq ^ ((n >> 1) & 7))) * 4) = v;
+      *reinterpret_cast<f32x4*>(wts + ((t * COUT + n) * CQ + (kq ^ GS_SW(n))) * 4) = v;
     } else {
       // k-major source: a float4 along n is scattered to four rows of the [n][k] tile
       const int k = rem / (COUT / 4), n4 = rem - k * (COUT / 4);
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStrip
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = n4 * 4 + j;
-        wts[((t * COUT + n) * CQ + ((k >> 2) ^ ((n >> 1) & 7))) * 4 + (k & 3)] = v[j];
+        wts[((t * COUT + n) * CQ + ((k >> 2) ^ GS_SW(n))) * 4 + (k & 3)] = v[j];
       }
     }
   }
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStrip
     const int pr = L / PW, pc = L - pr * PW;
     const int gc = pc - 1;
     const bool ok = e < ptot && (unsigned)gc < (unsigned)W;
-    prel[k] = ((pr - 1) * W + gc) * CIN + ((s ^ ((L >> 1) & 7)) << 2);
+    prel[k] = ((pr - 1) * W + gc) * CIN + ((s ^ GS_SW(L)) << 2);
     prow[k] = ok ? pr - 1 : -100000;
   }
   auto issue_dma = [&](int sidx, int buf) {
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStrip
   for (int tn = 0; tn < TN; ++tn) {
     const int n = tn * 16 + l15;
     nbase[tn] = n * CIN;
-    nsw[tn] = (n >> 1) & 7;
+    nsw[tn] = GS_SW(n);
   }
 
   const int s_begin = blockIdx.x * p.strips_per_wg;
@@ -187,14 +193,14 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStrip
 #pragma unroll
       for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // 18 fragment steps (tap, 16-channel half), fragments of step s+1 read while the MFMAs of step s run
+    // NSTEPS fragment steps (tap, 16-channel group), fragments of step s+1 read while the MFMAs of step s run
     auto load_frags = [&](int step, f32x4 (&af)[2], f32x4 (&bf)[TN]) {
-      const int t = step >> 1, qg = step & 1;
+      const int t = step / QG, qg = step - t * QG;
       const int shift = gs_dh(p.tapcode, t) * PW + gs_dw(p.tapcode, t);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         const int L = L0[mb] + shift;
-        af[mb] = *reinterpret_cast<const f32x4*>(P + L * CIN + (((qg * 4 + lg) ^ ((L >> 1) & 7)) << 2));
+        af[mb] = *reinterpret_cast<const f32x4*>(P + L * CIN + (((qg * 4 + lg) ^ GS_SW(L)) << 2));
       }
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
@@ -213,15 +219,16 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStrip
     // steps of this strip: its instructions fill the issue slack behind the MFMAs instead of leaving the matrix pipe
     // idle while all eight waves store at the same time.
     f32x4 a0[2], b0[TN], a1[2], b1[TN];
+    constexpr int H1 = (NSTEPS / 4) & ~1, H2 = H1 + ((NSTEPS / 3) & ~1);
     load_frags(0, a0, b0);
 #pragma unroll
-    for (int step = 0; step < 18; step += 2) {
-      load_frags(step + 1, a1, b1);
+    for (int step = 0; step < NSTEPS; step += 2) {
+      if (step + 1 < NSTEPS) load_frags(step + 1, a1, b1);
       mfma_step(a0, b0);
-      if (step + 2 < 18) load_frags(step + 2, a0, b0);
-      mfma_step(a1, b1);
-      if (step == 4 && have_prev) epi_half(pacc, 0, pn, pi0);
-      if (step == 10 && have_prev) epi_half(pacc, 1, pn, pi0);
+      if (step + 2 < NSTEPS) load_frags(step + 2, a0, b0);
+      if (step + 1 < NSTEPS) mfma_step(a1, b1);
+      if (step == H1 && have_prev) epi_half(pacc, 0, pn, pi0);
+      if (step == H2 && have_prev) epi_half(pacc, 1, pn, pi0);
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -239,10 +246,12 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStrip
   }
 }
 
-template <int COUT, bool NMAJOR>
+#undef GS_SW
+
+template <int CIN, int COUT, bool NMAJOR>
 static int launch_gs(const GStripParams& p, int grid, size_t smem, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gconv_strip_kernel<COUT, NMAJOR>;
+  auto kern = gconv_strip_kernel<CIN, COUT, NMAJOR>;
   if (!attr_set) {
     DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
@@ -256,7 +265,8 @@ static int launch_gs(const GStripParams& p, int grid, size_t smem, hipStream_t s
 // Returns 1 when the layer is not one this kernel takes (the caller then uses gconv2).
 int launch_gconv_strip(GStripParams p, bool nmajor, hipStream_t s) {
   static const bool off = getenv("DV_NO_GSTRIP") != nullptr;
-  if (off || p.Cin != 32 || (p.Cout != 32 && p.Cout != 16 && p.Cout != 12) || (p.Cout & 3) || !p.zero) return 1;
+  if (off || (p.Cin != 32 && p.Cin != 16) || (p.Cout != 32 && p.Cout != 16) || !p.zero) return 1;
+  if (p.Cin == 16 && p.Cout != 32) return 1;
   if (p.Wd < 8 || p.Wd > 64 || p.H < 1 || p.epi < 0 || p.epi > 2) return 1;
   if ((long)p.NB * p.H * p.Wd * 32 >= (1L << 30)) return 1;
   const int cout_pad = p.Cout <= 16 ? 16 : 32;
@@ -264,7 +274,7 @@ int launch_gconv_strip(GStripParams p, bool nmajor, hipStream_t s) {
   if (R > p.H) R = p.H;
   if (R < 1) return 1;
   const int PW = p.Wd + 2;
-  const int slots = (R + 2) * PW * 8;
+  const int slots = (R + 2) * PW * (p.Cin / 4);
   if ((slots + 63) / 64 > GS_MAXG * GS_WAVES) return 1;
   p.R = R;
   p.patch_floats = ((slots + 63) / 64) * 256;
@@ -279,10 +289,11 @@ int launch_gconv_strip(GStripParams p, bool nmajor, hipStream_t s) {
   }
   p.strips_per_wg = (p.nstrips + cus - 1) / cus;
   const int grid = (p.nstrips + p.strips_per_wg - 1) / p.strips_per_wg;
-  const size_t smem = ((size_t)2 * p.patch_floats + (size_t)9 * cout_pad * 32 + (size_t)GS_WAVES * 16 * GS_LDC) * sizeof(float);
+  const size_t smem = ((size_t)2 * p.patch_floats + (size_t)9 * cout_pad * p.Cin + (size_t)GS_WAVES * 16 * GS_LDC) * sizeof(float);
   if (smem > 160 * 1024) return 1;
-  if (cout_pad == 16) return nmajor ? launch_gs<16, true>(p, grid, smem, s) : launch_gs<16, false>(p, grid, smem, s);
-  return nmajor ? launch_gs<32, true>(p, grid, smem, s) : launch_gs<32, false>(p, grid, smem, s);
+  if (p.Cin == 16) return nmajor ? launch_gs<16, 32, true>(p, grid, smem, s) : launch_gs<16, 32, false>(p, grid, smem, s);
+  if (cout_pad == 16) return nmajor ? launch_gs<32, 16, true>(p, grid, smem, s) : launch_gs<32, 16, false>(p, grid, smem, s);
+  return nmajor ? launch_gs<32, 32, true>(p, grid, smem, s) : launch_gs<32, 32, false>(p, grid, smem, s);
 }
 
 }  // namespace dv
