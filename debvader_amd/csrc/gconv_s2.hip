@@ -237,11 +237,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
   run_phase(IC<3>{}, IC<3>{}, true);
 
   // ---- epilogue: per class, accumulators -> per-wave LDS staging (32 x 32) -> float4 rows -------------------
+  // The PReLU slopes of class c+1 are loaded while class c is staged and stored (the loop is unrolled, the two
+  // register sets alternate): a class's epilogue otherwise starts with a global-load latency nothing hides.
   float* stg = smem + wave * (32 * LDC);
   const int f4 = lane & 7;
   const int col = n0 + wn0 + f4 * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.epi >= 1 && col < p.Cout) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+  int orow[4], arow[4];                            // output / alpha offsets of this lane's four rows (class (0,0) pixel)
+  unsigned rowok = 0;                              // bits 4*i + c: row i stores class c
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wm0 + (lane >> 3) + 8 * i;
+    orow[i] = s_out[row];
+    arow[i] = s_al[row];
+    rowok |= (unsigned)((s_nm[row] >> 4) & 15) << (4 * i);
+  }
+  if (col >= p.Cout) rowok = 0;
+  f32x4 alr[2][4];
+  auto load_alpha = [&](int c, f32x4 (&dst)[4]) {
+    const int coff = (p.cph[c] * p.Wout + p.cpw[c]) * p.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = (rowok >> (4 * i + c)) & 1;
+      dst[i] = *reinterpret_cast<const f32x4*>(p.alpha + (ok ? (unsigned)(arow[i] + coff + col) : 0u));
+    }
+  };
+  if (p.epi == 2) load_alpha(0, alr[0]);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
+    if (p.epi == 2 && c + 1 < 4) load_alpha(c + 1, alr[(c + 1) & 1]);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -252,15 +277,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
     __builtin_amdgcn_wave_barrier();
     const int coff = (p.cph[c] * p.Wout + p.cpw[c]) * p.Cout;
 #pragma unroll
-    for (int rr = lane >> 3; rr < 32; rr += 8) {
-      const int row = wm0 + rr;
-      if (!((s_nm[row] >> (4 + c)) & 1) || col >= p.Cout) continue;
-      const unsigned ooff = (unsigned)(s_out[row] + coff + col);
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (lane >> 3) + 8 * i;
+      if (!((rowok >> (4 * i + c)) & 1)) continue;
+      const unsigned ooff = (unsigned)(orow[i] + coff + col);
       f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * LDC + f4 * 4);
-      if (p.epi >= 1) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+      v += bias4;
       if (p.U) *reinterpret_cast<f32x4*>(p.U + ooff) = v;
       if (p.epi == 2) {
-        const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + (unsigned)(s_al[row] + coff + col));
+        const f32x4 al = alr[c & 1][i];
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = v[k] > 0.f ? v[k] : al[k] * v[k];
