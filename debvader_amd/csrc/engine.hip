@@ -458,6 +458,7 @@ static int prof_flush(dv_model* m) {
 
 
 static bool g_force_v1 = false;  // tuning aid: route everything through the first-generation kernel
+static bool g_no_special = false; // cross-check aid: skip the strip / fused stride-2 kernels (general gconv2 path only)
 
 // Every collective of a context is issued on ONE stream (comm_stream), the usual single-stream-per-communicator
 // pattern; the main stream hands data over and takes it back through events.
@@ -568,7 +569,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
   const Taps tp = single_tap ? one : taps_fprop(pb);
   static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
   if (Cin == 32 && (Cout == 16 || Cout == 32) && s == 1 && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
-      !single_tap && !g_force_v1 && !gs_off && !(fz && !m->no_fuse)) {
+      !single_tap && !g_force_v1 && !gs_off && !g_no_special && !(fz && !m->no_fuse)) {
     GStripParams g;
     memset(&g, 0, sizeof g);
     g.X = X; g.W = W; g.U = U; g.A = Aout; g.bias = bias; g.alpha = alpha; g.zero = m->zero_page;
@@ -636,7 +637,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
                        const FuseBwd* fz = nullptr, bool* fused = nullptr) {
   if (fused) *fused = false;
   static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
-  if (s == 1 && (Cs == 32 || (Cs == 16 && Ct == 32)) && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !gs_off &&
+  if (s == 1 && (Cs == 32 || (Cs == 16 && Ct == 32)) && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !gs_off && !g_no_special &&
       !(fz && !m->no_fuse)) {
     const Taps tp = taps_dgrad(1, pb, 0, 0);
     if (tp.n == 9) {
@@ -654,7 +655,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
     }
   }
   static const bool no_s2f = getenv("DV_NO_S2F") != nullptr;
-  if (s == 2 && Cs % 32 == 0 && Ct % 4 == 0 && nmajor && !g_force_v1 && !no_s2f && !(fz && !m->no_fuse)) {
+  if (s == 2 && Cs % 32 == 0 && Ct % 4 == 0 && nmajor && !g_force_v1 && !no_s2f && !g_no_special && !(fz && !m->no_fuse)) {
     // all four parity classes in one workgroup (gconv_s2.hip)
     GConvS2Params q;
     memset(&q, 0, sizeof q);
@@ -2717,6 +2718,58 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   *ms_out = ms / iters;
   (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(Y2); (void)hipFree(m.ws1); (void)hipFree(m.zero_page);
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  return st;
+}
+
+// Cross-check of the specialised gather-GEMM kernels (gconv_strip, gconv_s2) against the general gconv2 path on the
+// same pseudo-random operands: out2 = {max |difference| over both outputs, max |reference|}.
+int dv_debug_gconv_check(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, int32_t Ct, int32_t stride,
+                         int32_t pb, int32_t dgrad_form, int32_t nmajor, int32_t epi, float* out2) {
+  if (!ctx || !out2) return DV_E_INVALID;
+  dv_model m;
+  m.ctx = ctx;
+  float *X, *W, *Y;
+  const size_t nx = (size_t)NB * Hs * Hs * Cs, nw = (size_t)9 * Cs * Ct + 4096, ny = (size_t)NB * Ht * Ht * Ct;
+  const size_t nal = (size_t)Ht * Ht * Ct;
+  DV_TRY(debug_buffers(ctx, nx, nw + nal, ny, &X, &W, &Y));
+  float* bias = W + 9 * (size_t)Cs * Ct;
+  float* alpha = bias + 4096;
+  float* bufs[3] = {nullptr, nullptr, nullptr};                  // A of the fast path, U and A of the reference
+  for (auto& b : bufs) DV_HIP(hipMalloc((void**)&b, ny * sizeof(float)));
+  m.ws1_elems = (size_t)1 << 20;
+  DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
+  DV_HIP(hipMalloc((void**)&m.zero_page, 256));
+  DV_HIP(hipMemsetAsync(m.zero_page, 0, 256, ctx->stream));
+  int st = OK;
+  for (int pass = 0; pass < 2 && st == OK; ++pass) {
+    g_no_special = pass == 1;
+    float* U = pass == 0 ? Y : bufs[1];
+    float* A = pass == 0 ? bufs[0] : bufs[2];
+    DV_HIP(hipMemsetAsync(U, 0, ny * sizeof(float), ctx->stream));
+    DV_HIP(hipMemsetAsync(A, 0, ny * sizeof(float), ctx->stream));
+    if (dgrad_form)
+      st = gconv_dgrad(&m, X, W, nmajor != 0, bias, alpha, U, A, epi, NB, Hs, Cs, Ht, Ct, stride, pb);
+    else
+      st = gconv_fprop(&m, X, W, nmajor != 0, bias, alpha, U, A, epi, NB, Hs, Cs, Ht, Ct, stride, pb, false);
+  }
+  g_no_special = false;
+  DV_HIP(hipStreamSynchronize(ctx->stream));
+  if (st == OK) {
+    std::vector<float> a(ny), b(ny);
+    double md = 0, mr = 0;
+    for (int k = 0; k < 2; ++k) {
+      DV_HIP(hipMemcpy(a.data(), k == 0 ? Y : bufs[0], ny * sizeof(float), hipMemcpyDeviceToHost));
+      DV_HIP(hipMemcpy(b.data(), k == 0 ? bufs[1] : bufs[2], ny * sizeof(float), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < ny; ++i) {
+        md = std::max(md, (double)fabsf(a[i] - b[i]));
+        mr = std::max(mr, (double)fabsf(b[i]));
+      }
+    }
+    out2[0] = (float)md;
+    out2[1] = (float)mr;
+  }
+  (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(m.ws1); (void)hipFree(m.zero_page);
+  for (auto& b : bufs) (void)hipFree(b);
   return st;
 }
 

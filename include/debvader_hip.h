@@ -183,6 +183,10 @@ int dv_prof_reset(dv_model* m);
 int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, int32_t Ct, int32_t stride,
                    int32_t pad_before, int32_t dgrad_form, int32_t nmajor, int32_t epi, int32_t single_tap,
                    int32_t tile, int32_t iters, float* ms_out);
+/* runs one layer through the specialised kernel the dispatcher picks (strip form, fused stride-2 form) and through the
+ * general gather-GEMM on the same pseudo-random operands: out2 = {max |difference|, max |reference|} over U and A */
+int dv_debug_gconv_check(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, int32_t Ct, int32_t stride,
+                         int32_t pad_before, int32_t dgrad_form, int32_t nmajor, int32_t epi, float* out2);
 /* issue-rate probe of v_mfma_f32_16x16x4_f32 (no memory traffic), nacc = 16 or 36 independent accumulators,
  * trivial or pseudo-random operands: out3 = {TFLOP/s, in-kernel clock MHz, shader cycles per MFMA} */
 int dv_debug_mfma_peak(dv_ctx* ctx, int32_t blocks, int32_t iters, int32_t nacc, int32_t randomize, float* out3);

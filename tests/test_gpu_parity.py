@@ -221,3 +221,31 @@ def test_bad_arguments_fail_loudly():
     with pytest.raises(ValueError):
         eng.infer(np.zeros((1, 12, 13, 4), np.float32))
     eng.close()
+
+
+def test_specialised_kernels_match_the_general_gather_gemm():
+    """gconv_strip (stride-1, <= 32 channels, W <= 64) and gconv_s2 (fused stride-2 classes) against gconv2 on the
+    same random operands, including image sizes that are not multiples of the strip / tile geometry, both weight
+    layouts and every epilogue.  fp32 sums in a different order: 2e-5 of the largest output."""
+    import ctypes as C
+    from debvader_amd import engine as E
+    from debvader_amd._lib import lib, check
+    ctx = E.default_context()
+    out = (C.c_float * 2)()
+    cases = []
+    for H in (64, 59, 40, 17, 8):
+        for (cs, ct) in ((32, 32), (32, 16), (16, 32)):
+            for dgrad, nmajor in ((0, 0), (1, 1)):
+                if cs == 16 and not dgrad:
+                    continue
+                for epi in (0, 1, 2):
+                    cases.append((3, H, cs, H, ct, 1, 1, dgrad, nmajor, epi))
+    # fused stride-2 form: Conv2DTranspose forward (out = 2 in, pad 0) and Conv2D data gradient (odd sizes, pad 0 / 1)
+    for (hs, cs, ht, ct, pb) in ((8, 64, 16, 32, 0), (16, 128, 32, 64, 0), (30, 32, 59, 32, 1), (15, 64, 30, 64, 0),
+                                 (4, 256, 8, 256, 0)):
+        for epi in (0, 2):
+            cases.append((3, hs, cs, ht, ct, 2, pb, 1, 1, epi))
+    for c in cases:
+        check(lib.dv_debug_gconv_check(ctx._h, *c, out))
+        assert out[1] > 0.1, c
+        assert out[0] <= 2e-5 * out[1], (c, out[0], out[1])
