@@ -377,15 +377,17 @@ static int launch_strip8(WStripParams p, hipStream_t s, int* nsplit_out) {
     return 2 * (xfl(r) + yfl(r)) * sizeof(float) <= 128 * 1024 && xfl(r) / 256 <= 4 * 8 && yfl(r) / 256 <= 4 * 12;
   };
   if (p.Wy < 4 || !fits(1)) return 1;   // fall back to wgrad_kernel
+  // this layer is a streaming reduction (142 MB in, 72 x 32 out): short strips and three workgroups per CU keep more
+  // DMA in flight than one workgroup with long strips (82 -> 69 us, tools/layer_bench.py)
   int R = 1;
-  while (R < p.Hy && R < 8 && fits(R + 1)) ++R;
+  while (R < p.Hy && R < 2 && fits(R + 1)) ++R;
   p.R = R;
   p.XR = R + 2;
   p.xs_floats = (int)xfl(R);
   p.ys_floats = (int)yfl(R);
   p.strips_per_stamp = (p.Hy + R - 1) / R;
   p.nstrips = p.NB * p.strips_per_stamp;
-  int wgs = std::min(p.nstrips, 256);
+  int wgs = std::min(p.nstrips, 768);
   wgs = std::max(1, std::min(wgs, (int)(p.part_capacity / ((size_t)72 * 32))));
   p.strips_per_wg = (p.nstrips + wgs - 1) / wgs;
   wgs = (p.nstrips + p.strips_per_wg - 1) / p.strips_per_wg;
