@@ -298,6 +298,8 @@ struct dv_ctx {
   hipStream_t stream = nullptr;
   hipStream_t comm_stream = nullptr;   // gradient all-reduce runs here, overlapped with the encoder backward
   hipStream_t aux_stream = nullptr;    // weight-gradient kernels run here, beside the data-gradient chain
+  hipStream_t red_stream = nullptr;    // small d(alpha) / d(bias) reductions (and the H2D copies of the inference pipeline)
+  hipEvent_t ev_red = nullptr;
   hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};   // extra forward lanes
   hipEvent_t ev_lane[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_buf[3] = {nullptr, nullptr, nullptr};
@@ -525,7 +527,7 @@ static int fuse_finish(dv_model* m, const GConv2Params& q, const FuseBwd* fz, lo
   if (!fz->want_grads) return OK;
   const Arch& A = m->A;
   hipStream_t s = m->ctx->stream;
-  hipStream_t rs = (m->arena_reduce && m->wstream && m->wstream != s) ? m->wstream : s;
+  hipStream_t rs = (m->arena_reduce && m->wstream && m->wstream != s) ? m->ctx->red_stream : s;
   if (rs != s) {
     DV_HIP(hipEventRecord(m->ctx->ev_ready, s));
     DV_HIP(hipStreamWaitEvent(rs, m->ctx->ev_ready, 0));
@@ -861,7 +863,9 @@ static int prelu_bwd(dv_model* m, float* da, const float* u, int alpha_spec, int
                      bool want_grads) {
   const Arch& A = m->A;
   hipStream_t s = m->ctx->stream;
-  hipStream_t rs = (m->arena_reduce && m->wstream && m->wstream != s) ? m->wstream : s;   // where the reductions go
+  // where the reductions go: a stream of their own, so that ~40 five-microsecond launches per step do not sit between
+  // the weight-gradient kernels of the aux stream
+  hipStream_t rs = (m->arena_reduce && m->wstream && m->wstream != s) ? m->ctx->red_stream : s;
   int gx = (E + 1023) / 1024;
   int nsplit = std::max(1, std::min(std::min(NB, 32), 1024 / std::max(gx, 1)));
   float *dal = nullptr, *dbp = nullptr;
@@ -1279,6 +1283,8 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     if (ovl) {                                       // ... and the decoder weight gradients on the aux stream
       DV_HIP(hipEventRecord(cx->ev_join, cx->aux_stream));
       DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, cx->ev_join, 0));
+      DV_HIP(hipEventRecord(cx->ev_red, cx->red_stream));   // ... and the d(alpha) / d(bias) reductions
+      DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, cx->ev_red, 0));
     }
     DV_NCCL(ncclAllReduce(G + A.n_enc_train, G + A.n_enc_train, A.n_train - A.n_enc_train, ncclFloat, ncclSum,
                           m->ctx->comm, m->ctx->comm_stream));
@@ -1333,8 +1339,12 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
       const bool ok = split < A.n_enc_train;
       if (ok) {
         hipStream_t ws = m->wstream ? m->wstream : s;
-        DV_HIP(hipEventRecord(cx->ev_mid, ws));      // parameter gradients are only ever written on this stream
+        DV_HIP(hipEventRecord(cx->ev_mid, ws));      // kernel gradients are written on this stream,
         DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_mid, 0));
+        if (ovl) {                                   // d(alpha) / d(bias) on the reduction stream
+          DV_HIP(hipEventRecord(cx->ev_red, cx->red_stream));
+          DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_red, 0));
+        }
         DV_NCCL(ncclAllReduce(G + split, G + split, A.n_enc_train - split, ncclFloat, ncclSum, cx->comm, cx->comm_stream));
         m->enc_reduced_from = split;
       }
@@ -1346,9 +1356,11 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
                        &cur_is_du));
     advance();
   }
-  if (ovl) {                                         // join: every weight gradient is final past this point
+  if (ovl) {                                         // join: every parameter gradient is final past this point
     DV_HIP(hipEventRecord(cx->ev_join, cx->aux_stream));
     DV_HIP(hipStreamWaitEvent(s, cx->ev_join, 0));
+    DV_HIP(hipEventRecord(cx->ev_red, cx->red_stream));
+    DV_HIP(hipStreamWaitEvent(s, cx->ev_red, 0));
   }
   m->wstream = s;
 #undef DV_NEXT_OUT
@@ -1537,7 +1549,6 @@ static void pipe_free(InferPipe* p) {
     if (p->ev_h2d[b]) (void)hipEventDestroy(p->ev_h2d[b]);
     if (p->ev_comp[b]) (void)hipEventDestroy(p->ev_comp[b]);
   }
-  if (p->s_in) (void)hipStreamDestroy(p->s_in);
   delete p;
 }
 
@@ -1569,8 +1580,8 @@ static int pipe_get(dv_model* m, int cap, InferPipe** out) {
     PP_HIP(hipEventCreateWithFlags(&p->ev_h2d[b], hipEventDisableTiming));
     PP_HIP(hipEventCreateWithFlags(&p->ev_comp[b], hipEventDisableTiming));
   }
-  PP_HIP(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
-  p->s_out = m->ctx->comm_stream;     // idle during inference; a fifth stream would share a hardware queue
+  p->s_in = m->ctx->red_stream;       // both idle during inference; a fifth stream would share a hardware queue
+  p->s_out = m->ctx->comm_stream;
 #undef PP_HIP
   const char* e = getenv("DV_COPY_THREADS");
   int hw = (int)std::thread::hardware_concurrency();
@@ -1905,9 +1916,11 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
   DV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+  DV_HIP(hipStreamCreateWithFlags(&c->red_stream, hipStreamNonBlocking));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_red, hipEventDisableTiming));
   // HIP multiplexes streams onto a few hardware queues (4 by default) and work on streams that share a queue runs
   // in submission order, so the engine keeps to four streams: main, comm (also the D2H stream of the inference
-  // pipeline), aux, and the pipeline's H2D stream.  More forward lanes (DV_FWD_LANES > 2) create theirs on demand.
+  // pipeline), aux, and the reduction stream (also the pipeline's H2D stream).  More forward lanes (DV_FWD_LANES > 2) create theirs on demand.
   {
     const char* wl = getenv("DV_FWD_LANES");
     const int extra = wl ? std::max(0, std::min(atoi(wl), 4) - 2) : 0;
@@ -1958,6 +1971,8 @@ int dv_ctx_destroy(dv_ctx* c) {
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_red) (void)hipEventDestroy(c->ev_red);
+  if (c->red_stream) (void)hipStreamDestroy(c->red_stream);
   for (int i = 0; i < 3; ++i)
     if (c->ev_buf[i]) (void)hipEventDestroy(c->ev_buf[i]);
   for (int i = 0; i < 3; ++i) {
