@@ -373,6 +373,12 @@ struct dv_model {
   int64_t bn_pre_first = -1, hint_next_first = -1;
   int bn_pre_B = 0;
   hipEvent_t ev_bnpre = nullptr, ev_bnpre_go = nullptr;
+  // weight-gradient partial slabs rotate through three regions of ws1 so that a layer's slab reduction (reduction
+  // stream) can run beside the next layer's weight-gradient kernel (aux stream)
+  int ws_region = 0;
+  bool ws_pending[3] = {false, false, false};
+  hipEvent_t ev_wk[3] = {nullptr, nullptr, nullptr}, ev_rk[3] = {nullptr, nullptr, nullptr};
+  int ws_last = -1;              // region whose reduction produced the most recent weight gradient
   bool normalise = false;        // dv_model_set_normalise: tanh(arcsinh) on inference inputs, inverse on the mean
   size_t enc_reduced_from = 0;   // this step's encoder gradients [enc_reduced_from, n_enc_train) are already all-reduced   // pinned staging + copy streams of the pipelined dv_infer (lazy)
   float* zero_page = nullptr;  // 256 B of zeros (LDS-DMA source for out-of-image pieces)
@@ -787,10 +793,42 @@ static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, in
 
 static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB,
                       int sx, int pb, bool single_tap, float* out, int cpad, int creal) {
+  // slab region and the stream that sums the slabs: with the weight gradients on the aux stream the reduction goes to
+  // the reduction stream and the slabs rotate through three regions of ws1
+  dv_ctx* cx = m->ctx;
+  const bool rot = ws != cx->stream && m->arena_reduce && cx->red_stream && m->ev_wk[0];
+  float* part = m->ws1;
+  size_t part_cap = m->ws1_elems;
+  hipStream_t rs = ws;
+  int reg = -1;
+  if (rot) {
+    reg = m->ws_region;
+    m->ws_region = (reg + 1) % 3;
+    part_cap = m->ws1_elems / 3;
+    part = m->ws1 + (size_t)reg * part_cap;
+    rs = cx->red_stream;
+    if (m->ws_pending[reg]) {            // the reduction that last read this region must be done before it is rewritten
+      DV_HIP(hipStreamWaitEvent(ws, m->ev_rk[reg], 0));
+      m->ws_pending[reg] = false;
+    }
+  }
+  auto hand_over = [&]() -> int {        // slabs written on ws -> reduction on rs
+    if (!rot) return OK;
+    DV_HIP(hipEventRecord(m->ev_wk[reg], ws));
+    DV_HIP(hipStreamWaitEvent(rs, m->ev_wk[reg], 0));
+    return OK;
+  };
+  auto reduced = [&]() -> int {
+    if (!rot) return OK;
+    DV_HIP(hipEventRecord(m->ev_rk[reg], rs));
+    m->ws_pending[reg] = true;
+    m->ws_last = reg;
+    return OK;
+  };
   if (!single_tap && !g_force_v1 && cpad == creal && wgrad_strip_supported(Cx, Cy, sx, 9)) {
     WStripParams sp;
     memset(&sp, 0, sizeof sp);
-    sp.X = X; sp.Y = Y; sp.part = m->ws1; sp.part_capacity = m->ws1_elems;
+    sp.X = X; sp.Y = Y; sp.part = part; sp.part_capacity = part_cap;
     sp.NB = NB; sp.Hx = sp.Wx = Hx; sp.Hy = sp.Wy = Hy; sp.pb = pb;
     sp.zero = m->zero_page;
     int ns = 0, st;
@@ -800,8 +838,12 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
     }
     if (st < 0) return st;
     if (st == 0) {
-      ProfScope ps(m, 2, ws);
-      return launch_reduce_partials(m->ws1, out, ns, (long)9 * Cx * Cy, Cy, cpad, creal, ws);
+      DV_TRY(hand_over());
+      {
+        ProfScope ps(m, 2, rs);
+        DV_TRY(launch_reduce_partials(part, out, ns, (long)9 * Cx * Cy, Cy, cpad, creal, rs));
+      }
+      return reduced();
     }
     // st > 0: the strip form does not fit this geometry (very wide rows): use the tiled kernel below
   }
@@ -814,7 +856,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
     t = taps_fprop(pb);
   p.X = X;
   p.Y = Y;
-  p.part = m->ws1;
+  p.part = part;
   p.NB = NB;
   p.Hx = p.Wx = Hx;
   p.Cx = Cx;
@@ -837,9 +879,9 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   long ns = std::max(1L, target / tiles);
   ns = std::min(ns, (long)std::max(1, p.P / 256));
   ns = std::min(ns, 256L);
-  ns = std::min(ns, (long)(m->ws1_elems / (size_t)slab));
+  ns = std::min(ns, (long)(part_cap / (size_t)slab));
   ns = std::max(ns, 1L);
-  if ((size_t)slab > m->ws1_elems) {
+  if ((size_t)slab > part_cap) {
     set_error("wgrad workspace too small");
     return E_STATE;
   }
@@ -852,8 +894,18 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
     ProfScope ps(m, 1, ws);
     DV_TRY(launch_wgrad(p, ws));
   }
-  ProfScope ps(m, 2, ws);
-  return launch_reduce_partials(m->ws1, out, p.nsplit, slab, Cy, cpad, creal, ws);
+  DV_TRY(hand_over());
+  {
+    ProfScope ps(m, 2, rs);
+    DV_TRY(launch_reduce_partials(part, out, p.nsplit, slab, Cy, cpad, creal, rs));
+  }
+  return reduced();
+}
+
+// makes `ws` wait for the reduction that produced the most recent weight gradient (its consumer runs on ws)
+static int wgrad_result_ready(dv_model* m, hipStream_t ws) {
+  if (m->ws_last >= 0 && m->ws_pending[m->ws_last]) DV_HIP(hipStreamWaitEvent(ws, m->ev_rk[m->ws_last], 0));
+  return OK;
 }
 
 // PReLU backward with optional parameter gradients.  du is needed by the next launches of the main stream; the
@@ -1215,6 +1267,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   if (dg) {
     hipStream_t ws = m->wstream ? m->wstream : s;
     DV_TRY(wgrad(m, m->dec_a[2 * A.L - 1], Hd, f0, cur, Hd, C2p, NB, 1, 1, false, m->Ghs, f0, f0));
+    DV_TRY(wgrad_result_ready(m, ws));
     {
       ProfScope ps(m, 2, ws);
       DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, C2p, C2, ws));
@@ -1320,6 +1373,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
       // d(beta) directly (bn_conv0_grads_kernel), so this layer needs no data-gradient pass at all
       hipStream_t ws = m->wstream ? m->wstream : s;
       DV_TRY(wgrad(m, xin, hin, 8, cur, hout, cout, NB, st, pb, false, m->G0s, 8, 8));
+      DV_TRY(wgrad_result_ready(m, ws));
       ProfScope ps(m, 2, ws);
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
                                    G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, 9, A.C, 8,
@@ -2026,6 +2080,10 @@ int dv_model_destroy(dv_model* m) {
     if (m->slots[s].y) (void)hipFree(m->slots[s].y);
   }
   pipe_free(m->pipe);
+  for (int k = 0; k < 3; ++k) {
+    if (m->ev_wk[k]) (void)hipEventDestroy(m->ev_wk[k]);
+    if (m->ev_rk[k]) (void)hipEventDestroy(m->ev_rk[k]);
+  }
   if (m->ev_bnpre) (void)hipEventDestroy(m->ev_bnpre);
   if (m->ev_bnpre_go) (void)hipEventDestroy(m->ev_bnpre_go);
   (void)hipHostFree(m->ring_scal);
@@ -2157,6 +2215,10 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   ALLOC(m->bn_pre_sums, 16);
   m->bn_pre_part_elems = (size_t)16 * (((size_t)Bc * A.H * A.H + 255) / 256 + 16);
   ALLOC(m->bn_pre_part, m->bn_pre_part_elems);
+  for (int k = 0; k < 3; ++k)
+    if (hipEventCreateWithFlags(&m->ev_wk[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_rk[k], hipEventDisableTiming) != hipSuccess)
+      return fail(E_HIP);
   if (hipEventCreateWithFlags(&m->ev_bnpre, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_bnpre_go, hipEventDisableTiming) != hipSuccess)
     return fail(E_HIP);
