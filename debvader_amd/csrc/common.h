@@ -146,9 +146,11 @@ struct GConvS2Params {
   int ndh[4], ndw[4];  // source offset of neighbour e
   int cph[4], cpw[4];  // output parity of class c
   int wt[4][4];        // weight tap index of (neighbour e, class c); unused pairs 0
+  unsigned* dbg_out;   // per-workgroup timeline stamps (tuning aid) or null
 };
 int launch_gconv_s2(const GConvS2Params& p, hipStream_t s);
 void debug_set_gconv_s2_tile(int code);
+void debug_set_gconv_s2_dbg(unsigned* out);
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[(t, cx), cy] = sum_p Xg[p, t][cx] * dY[p][cy], split over pixel ranges into

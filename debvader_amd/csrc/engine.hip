@@ -2721,6 +2721,7 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
     if (tile == 99) tile = -1;
     DV_HIP(hipMemsetAsync(m.ws1 + m.ws1_elems - (1 << 16), 0, (1 << 16) * sizeof(float), ctx->stream));
     debug_set_gconv2_dbg(2, m.ws1 + m.ws1_elems - (1 << 16));
+    debug_set_gconv_s2_dbg(reinterpret_cast<unsigned*>(m.ws1 + m.ws1_elems - (1 << 16)));
   }
   if (tile >= 4000) {
     debug_set_gconv2_prio(4);   // 4: loads in front of the MFMA block (pre-interleave order)
@@ -2752,6 +2753,7 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   debug_set_gconv_tile(-1);
   debug_set_gconv2_tile(-1);
   debug_set_gconv2_dbg(0, nullptr);
+  debug_set_gconv_s2_dbg(nullptr);
   debug_set_gconv2_prio(0);
   g_force_v1 = false;
   if (timeline) {

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
   int* s_out = s_nm + BM;                                  // [BM] output offset of the 2x2 block's (0,0) pixel
   int* s_al = s_out + BM;                                  // [BM] same, inside one stamp (alpha)
 
+  const unsigned long long tl0 = p.dbg_out ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WGN) * 32, wn0 = (wave % WGN) * 32;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
   load_global(IC<0>{}, 0);
   store_lds(IC<0>{}, 0);
   __syncthreads();
+  const unsigned long long tl1 = p.dbg_out ? __builtin_amdgcn_s_memrealtime() : 0ull;
   auto run_phase = [&](auto ph, auto pn, bool last) {
     for (int cc = 0; cc + 1 < cpt; ++cc) {
       step(ph, ph, cc + 1, cur);
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
   run_phase(IC<1>{}, IC<2>{}, false);
   run_phase(IC<2>{}, IC<3>{}, false);
   run_phase(IC<3>{}, IC<3>{}, true);
+  const unsigned long long tl2 = p.dbg_out ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   // ---- epilogue: per class, accumulators -> per-wave LDS staging (32 x 32) -> float4 rows -------------------
   // The PReLU slopes of class c+1 are loaded while class c is staged and stored (the loop is unrolled, the two
@@ -294,6 +297,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (p.dbg_out && tid == 0 && blockIdx.x < (1 << 14)) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned* d = p.dbg_out + (size_t)blockIdx.x * 4;
+    d[0] = (unsigned)tl0; d[1] = (unsigned)tl1; d[2] = (unsigned)tl2; d[3] = (unsigned)__builtin_amdgcn_s_memrealtime();
+  }
 }
 
 template <int WGM, int WGN>
@@ -316,9 +324,13 @@ static int launch_s2_cfg(const GConvS2Params& p, hipStream_t s) {
 
 static int s2_tile_override = -1;
 void debug_set_gconv_s2_tile(int code) { s2_tile_override = code; }
+static unsigned* s2_dbg_out = nullptr;
+void debug_set_gconv_s2_dbg(unsigned* out) { s2_dbg_out = out; }
 
 // tile codes: 0 = 64 x 64 (2x2 waves), 1 = 128 x 32 (4x1), 2 = 64 x 32 (2x1), 3 = 32 x 64 (1x2)
-int launch_gconv_s2(const GConvS2Params& p, hipStream_t s) {
+int launch_gconv_s2(const GConvS2Params& p0, hipStream_t s) {
+  GConvS2Params p = p0;
+  p.dbg_out = s2_dbg_out;
   if ((p.Cin % BKS) || (p.Cout & 3) || p.M <= 0) {
     set_error("gconv_s2: unsupported shape (Cin=%d Cout=%d M=%d)", p.Cin, p.Cout, p.M);
     return E_INVALID;
