@@ -35,16 +35,19 @@ __host__ __device__ constexpr int nbr_mask(int e) {   // classes that use neighb
 __host__ __device__ constexpr int popc4(int m) { return (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1) + ((m >> 3) & 1); }
 }  // namespace
 
-template <int WGM, int WGN>
+// TMW: 16-row MFMA blocks per wave along M (2: 32 base pixels per wave; 1: 16, half the LDS and accumulators, so
+// three workgroups fit a CU)
+template <int WGM, int WGN, int TMW = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2Params p) {
   constexpr int NW = WGM * WGN, NT = 64 * NW;
-  constexpr int BM = 32 * WGM, BN = 32 * WGN;
+  constexpr int WMR = 16 * TMW;                   // rows per wave
+  constexpr int BM = WMR * WGM, BN = 32 * WGN;
   constexpr int RP = NT / 8;                      // tile rows filled per pass (8 lanes x 16 B per row)
   constexpr int AROWS = BM / RP, BROWS = BN / RP;
   constexpr int A_ELEMS = BM * BKS, B_ELEMS = BN * BKS;
   constexpr int STAGE = A_ELEMS + 4 * B_ELEMS;
   constexpr int LDC = 36;                         // epilogue staging row stride (floats)
-  static_assert(NW * 32 * LDC <= 2 * STAGE, "staging must fit in the operand buffers");
+  static_assert(NW * WMR * LDC <= 2 * STAGE, "staging must fit in the operand buffers");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* s_in = reinterpret_cast<int*>(smem + 2 * STAGE);   // [BM] gather base (elements)
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
 
   const unsigned long long tl0 = p.dbg_out ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WGN) * 32, wn0 = (wave % WGN) * 32;
+  const int wm0 = (wave / WGN) * WMR, wn0 = (wave % WGN) * 32;
   const int l15 = lane & 15, lg = lane >> 4;
 
   int bid = blockIdx.x;
@@ -160,11 +163,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
     }
   };
 
-  f32x4 acc[4][2][2];
+  f32x4 acc[4][TMW][2];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TMW; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[c][a][b] = zero4;
 
@@ -175,9 +178,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int quad = ((q * 4 + lg) ^ sw_r) << 2;
-      f32x4 af[2], bf[4][2];
+      f32x4 af[TMW], bf[4][2];
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) af[tm] = *reinterpret_cast<const f32x4*>(a + (wm0 + tm * 16 + l15) * BKS + quad);
+      for (int tm = 0; tm < TMW; ++tm) af[tm] = *reinterpret_cast<const f32x4*>(a + (wm0 + tm * 16 + l15) * BKS + quad);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if ((MK >> c) & 1) {
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
         for (int c = 0; c < 4; ++c)
           if ((MK >> c) & 1) {
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
               for (int tn = 0; tn < 2; ++tn)
                 acc[c][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][jj], bf[c][tn][jj], acc[c][tm][tn], 0, 0, 0);
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
   // one K step of phase PH whose prefetch belongs to phase PN: a single basic block, the gather's VALU / VMEM
   // instructions spread between the MFMAs
   auto step = [&](auto ph, auto pn, int cc_next, int cur) {
-    constexpr int NMF = 32 * popc4(nbr_mask(phase_nbr(decltype(ph)::value)));
+    constexpr int NMF = 16 * TMW * popc4(nbr_mask(phase_nbr(decltype(ph)::value)));
     load_global(pn, cc_next);
     compute(ph, cur);
 #pragma unroll
@@ -242,26 +245,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
   // ---- epilogue: per class, accumulators -> per-wave LDS staging (32 x 32) -> float4 rows -------------------
   // The PReLU slopes of class c+1 are loaded while class c is staged and stored (the loop is unrolled, the two
   // register sets alternate): a class's epilogue otherwise starts with a global-load latency nothing hides.
-  float* stg = smem + wave * (32 * LDC);
+  float* stg = smem + wave * (WMR * LDC);
+  constexpr int RPLE = WMR / 8;                    // rows per lane in the epilogue
   const int f4 = lane & 7;
   const int col = n0 + wn0 + f4 * 4;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (p.epi >= 1 && col < p.Cout) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
-  int orow[4], arow[4];                            // output / alpha offsets of this lane's four rows (class (0,0) pixel)
+  int orow[RPLE], arow[RPLE];                            // output / alpha offsets of this lane's four rows (class (0,0) pixel)
   unsigned rowok = 0;                              // bits 4*i + c: row i stores class c
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RPLE; ++i) {
     const int row = wm0 + (lane >> 3) + 8 * i;
     orow[i] = s_out[row];
     arow[i] = s_al[row];
     rowok |= (unsigned)((s_nm[row] >> 4) & 15) << (4 * i);
   }
   if (col >= p.Cout) rowok = 0;
-  f32x4 alr[2][4];
-  auto load_alpha = [&](int c, f32x4 (&dst)[4]) {
+  f32x4 alr[2][RPLE];
+  auto load_alpha = [&](int c, f32x4 (&dst)[RPLE]) {
     const int coff = (p.cph[c] * p.Wout + p.cpw[c]) * p.Cout;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RPLE; ++i) {
       const bool ok = (rowok >> (4 * i + c)) & 1;
       dst[i] = *reinterpret_cast<const f32x4*>(p.alpha + (ok ? (unsigned)(arow[i] + coff + col) : 0u));
     }
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
   for (int c = 0; c < 4; ++c) {
     if (p.epi == 2 && c + 1 < 4) load_alpha(c + 1, alr[(c + 1) & 1]);
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
     __builtin_amdgcn_wave_barrier();
     const int coff = (p.cph[c] * p.Wout + p.cpw[c]) * p.Cout;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RPLE; ++i) {
       const int rr = (lane >> 3) + 8 * i;
       if (!((rowok >> (4 * i + c)) & 1)) continue;
       const unsigned ooff = (unsigned)(orow[i] + coff + col);
@@ -304,12 +308,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gconv_s2_kernel(const GConvS2P
   }
 }
 
-template <int WGM, int WGN>
+template <int WGM, int WGN, int TMW = 2>
 static int launch_s2_cfg(const GConvS2Params& p, hipStream_t s) {
-  constexpr int BM = 32 * WGM, BN = 32 * WGN;
+  constexpr int BM = 16 * TMW * WGM, BN = 32 * WGN;
   constexpr size_t smem = (size_t)2 * (BM * BKS + 4 * BN * BKS) * sizeof(float) + 4 * BM * sizeof(int);
   static bool attr_set = false;
-  auto kern = gconv_s2_kernel<WGM, WGN>;
+  auto kern = gconv_s2_kernel<WGM, WGN, TMW>;
   if (!attr_set) {
     DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
@@ -352,11 +356,17 @@ int launch_gconv_s2(const GConvS2Params& p0, hipStream_t s) {
   int t = s2_tile_override >= 0 ? s2_tile_override : env_tile;
   // 128 x 32 (four waves stacked along M, all sharing the class's 32-column weight tile) measured fastest on every
   // stride-2 layer of the network (tools/layer_bench.py with DV_S2_TILE=0..3): 64 x 64 is 20-45 % slower
-  if (t < 0) t = 1;
+  if (t < 0) {
+    // deep layers with few base pixels: half-height workgroups (64 x 32, three per CU) double the workgroup count
+    // (4x4x256 -> 8x8x256: 66 -> 54 us); everywhere else the 128 x 32 tile wins
+    const long wgs128 = (long)((p.M + 127) / 128) * ((p.Cout + 31) / 32);
+    t = wgs128 < 512 ? 4 : 1;
+  }
   switch (t) {
     case 0: return launch_s2_cfg<2, 2>(p, s);
     case 1: return launch_s2_cfg<4, 1>(p, s);
     case 2: return launch_s2_cfg<2, 1>(p, s);
+    case 4: return launch_s2_cfg<4, 1, 1>(p, s);
     default: return launch_s2_cfg<1, 2>(p, s);
   }
 }
