@@ -380,6 +380,9 @@ struct dv_model {
   hipEvent_t ev_wk[3] = {nullptr, nullptr, nullptr}, ev_rk[3] = {nullptr, nullptr, nullptr};
   int ws_last = -1;              // region whose reduction produced the most recent weight gradient
   bool normalise = false;        // dv_model_set_normalise: tanh(arcsinh) on inference inputs, inverse on the mean
+  bool early_adam = false;       // this step updates finished parameter ranges on the comm stream while the backward runs
+  float lr_t_step = 0.f;         // bias-corrected step size of this step
+  size_t adam_done_from = 0;     // ranges [adam_done_from, n_train) have been updated already (this step)
   size_t enc_reduced_from = 0;   // this step's encoder gradients [enc_reduced_from, n_enc_train) are already all-reduced   // pinned staging + copy streams of the pipelined dv_infer (lazy)
   float* zero_page = nullptr;  // 256 B of zeros (LDS-DMA source for out-of-image pieces)
   int* idx_dev = nullptr;
@@ -981,10 +984,11 @@ static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int 
   return launch_reduce_rows_f64(m->ws3, nr, ncols_out, m->G + m->A.specs[bias_spec].off, 1.0f, m->ctx->stream, C);
 }
 
-static int refresh_head_pad(dv_model* m) {
+static int refresh_head_pad(dv_model* m, hipStream_t st = nullptr) {
   const Arch& A = m->A;
-  DV_TRY(launch_pad_cols(m->P + A.specs[A.head_k()].off, m->Whp, 9 * A.cfg.filters[0], 2 * A.C, A.C2p, m->ctx->stream));
-  return launch_pad_cols(m->P + A.specs[A.head_b()].off, m->bhp, 1, 2 * A.C, A.C2p, m->ctx->stream);
+  if (!st) st = m->ctx->stream;
+  DV_TRY(launch_pad_cols(m->P + A.specs[A.head_k()].off, m->Whp, 9 * A.cfg.filters[0], 2 * A.C, A.C2p, st));
+  return launch_pad_cols(m->P + A.specs[A.head_b()].off, m->bhp, 1, 2 * A.C, A.C2p, st);
 }
 
 static int refresh_w1p(dv_model* m) {
@@ -1203,6 +1207,8 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
 #undef LANE
 
 // ---- backward ---------------------------------------------------------------------------------
+static int adam_range(dv_model* m, size_t beg, size_t end, hipStream_t st);
+
 // First flat offset of the encoder's deep half (conv L .. dense): the start of the middle gradient bucket, or
 // n_enc_train when the layout does not allow one (then the whole encoder goes into the final bucket).
 static size_t enc_bucket_split(const Arch& A) {
@@ -1329,8 +1335,10 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
                      1, A.d, 1, 0, true));
   advance();
   DV_TRY(prelu_bwd(m, cur, m->z, A.D0, -1, NB, A.d, A.d, dg));
-  // every decoder gradient is final here: all-reduce that bucket on the comm stream while the encoder backward runs
-  if (m->ctx->comm && dg && A.n_train > A.n_enc_train) {
+  // every decoder gradient is final here and no later kernel of the step reads a decoder parameter: the bucket is
+  // all-reduced on the comm stream while the encoder backward runs, and (early_adam) updated there right behind it
+  const bool early = m->early_adam && ovl;
+  if ((m->ctx->comm || early) && dg && A.n_train > A.n_enc_train) {
     DV_HIP(hipEventRecord(m->ctx->ev_dec, s));
     DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, m->ctx->ev_dec, 0));
     if (ovl) {                                       // ... and the decoder weight gradients on the aux stream
@@ -1339,8 +1347,14 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
       DV_HIP(hipEventRecord(cx->ev_red, cx->red_stream));   // ... and the d(alpha) / d(bias) reductions
       DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, cx->ev_red, 0));
     }
-    DV_NCCL(ncclAllReduce(G + A.n_enc_train, G + A.n_enc_train, A.n_train - A.n_enc_train, ncclFloat, ncclSum,
-                          m->ctx->comm, m->ctx->comm_stream));
+    if (m->ctx->comm)
+      DV_NCCL(ncclAllReduce(G + A.n_enc_train, G + A.n_enc_train, A.n_train - A.n_enc_train, ncclFloat, ncclSum,
+                            m->ctx->comm, m->ctx->comm_stream));
+    if (early && m->opt_dec) {
+      DV_TRY(adam_range(m, A.n_enc_train, A.n_train, cx->comm_stream));
+      DV_TRY(refresh_head_pad(m, cx->comm_stream));
+      m->adam_done_from = A.n_enc_train;
+    }
   }
   m->enc_reduced_from = A.n_enc_train;
   // sampler + KL
@@ -1384,31 +1398,39 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     DV_TRY(wgrad(m, xin, hin, cin_phys, cur, hout, cout, NB, st, pb, false, G + A.specs[A.enc_k(j)].off, cin_phys,
                  cin_phys));
     DV_TRY(wgrad_read());
-    if (cx->comm && j == A.L && A.L >= 2) {
-      // Middle bucket: the gradients of the deep half of the encoder (conv L .. conv 2L-1, their PReLUs, the
-      // flatten PReLU and the dense layer - 13.8 of the encoder's 15 MB) are final once this layer's weight-gradient
-      // work has been queued; they are all-reduced while the shallow half is still being differentiated, so that
-      // only a ~1 MB bucket is left for the end of the step.
-      const size_t split = enc_bucket_split(A);
-      const bool ok = split < A.n_enc_train;
-      if (ok) {
-        hipStream_t ws = m->wstream ? m->wstream : s;
-        DV_HIP(hipEventRecord(cx->ev_mid, ws));      // kernel gradients are written on this stream,
-        DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_mid, 0));
-        if (ovl) {                                   // d(alpha) / d(bias) on the reduction stream
-          DV_HIP(hipEventRecord(cx->ev_red, cx->red_stream));
-          DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_red, 0));
-        }
-        DV_NCCL(ncclAllReduce(G + split, G + split, A.n_enc_train - split, ncclFloat, ncclSum, cx->comm, cx->comm_stream));
-        m->enc_reduced_from = split;
-      }
-    }
     const float* W = P + A.specs[A.enc_k(j)].off;
     DV_NEXT_OUT();
     FuseBwd fz{m->enc_u[j - 1], A.enc_al(j - 1), A.enc_b(j - 1), true};   // j >= 1 here (j == 0 left the loop above)
     DV_TRY(gconv_dgrad(m, cur, W, true, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout, hin, cin_phys, st, pb, &fz,
                        &cur_is_du));
     advance();
+    if ((cx->comm || early) && j == A.L && A.L >= 2) {
+      // Middle bucket: the gradients of the deep half of the encoder (conv L .. conv 2L-1, their PReLUs, the
+      // flatten PReLU and the dense layer - 13.8 of the encoder's 15 MB) are final once this layer's weight-gradient
+      // work has been queued, and its data-gradient kernel (just queued) was the last reader of those parameters.
+      // They are all-reduced - and with early_adam updated - while the shallow half is still being differentiated,
+      // so that only a ~1 MB bucket is left for the end of the step.
+      const size_t split = enc_bucket_split(A);
+      if (split < A.n_enc_train) {
+        hipStream_t ws = m->wstream ? m->wstream : s;
+        DV_HIP(hipEventRecord(cx->ev_mid, ws));      // kernel gradients are written on this stream,
+        DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_mid, 0));
+        if (ovl) {                                   // d(alpha) / d(bias) on the reduction stream,
+          DV_HIP(hipEventRecord(cx->ev_red, cx->red_stream));
+          DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_red, 0));
+          DV_HIP(hipEventRecord(cx->ev_dec, s));     // and the main stream has finished reading the parameters
+          DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_dec, 0));
+        }
+        if (cx->comm) {
+          DV_NCCL(ncclAllReduce(G + split, G + split, A.n_enc_train - split, ncclFloat, ncclSum, cx->comm, cx->comm_stream));
+          m->enc_reduced_from = split;
+        }
+        if (early && m->opt_enc) {
+          DV_TRY(adam_range(m, split, A.n_enc_train, cx->comm_stream));
+          m->adam_done_from = std::min(m->adam_done_from, split);
+        }
+      }
+    }
   }
   if (ovl) {                                         // join: every parameter gradient is final past this point
     DV_HIP(hipEventRecord(cx->ev_join, cx->aux_stream));
@@ -1421,19 +1443,29 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   return OK;
 }
 
+// legacy Adam on the flat range [beg, end) (clipped to what this model is training), on stream st
+static int adam_range(dv_model* m, size_t beg, size_t end, hipStream_t st) {
+  const Arch& A = m->A;
+  beg = std::max(beg, m->opt_enc ? (size_t)0 : A.n_enc_train);
+  end = std::min(end, m->opt_dec ? A.n_train : A.n_enc_train);
+  if (end <= beg) return OK;
+  ProfScope ps(m, 2, st);
+  return launch_adam(m->P + beg, m->Mm + beg, m->Vv + beg, m->G + beg, (long)(end - beg), m->lr_t_step, m->b1, m->b2,
+                     m->aeps, st);
+}
+
+static void begin_update(dv_model* m) {     // step counter and bias-corrected step size of this update
+  m->iter += 1;
+  const double t = (double)m->iter;
+  m->lr_t_step = (float)((double)m->lr * sqrt(1.0 - pow((double)m->b2, t)) / (1.0 - pow((double)m->b1, t)));
+}
+
+// what is left of the update at the end of the step: the ranges below adam_done_from, then the derived tensors
 static int optimizer_step(dv_model* m) {
   const Arch& A = m->A;
-  m->iter += 1;
-  double t = (double)m->iter;
-  float lr_t = (float)((double)m->lr * sqrt(1.0 - pow((double)m->b2, t)) / (1.0 - pow((double)m->b1, t)));
-  size_t beg = m->opt_enc ? 0 : A.n_enc_train;
-  size_t end = m->opt_dec ? A.n_train : A.n_enc_train;
-  if (end <= beg) return OK;
-  ProfScope ps(m, 2);
-  DV_TRY(launch_adam(m->P + beg, m->Mm + beg, m->Vv + beg, m->G + beg, (long)(end - beg), lr_t, m->b1, m->b2,
-                     m->aeps, m->ctx->stream));
+  DV_TRY(adam_range(m, 0, std::min(m->adam_done_from, A.n_train), m->ctx->stream));
   if (m->opt_enc) DV_TRY(refresh_w1p(m));
-  if (m->opt_dec) DV_TRY(refresh_head_pad(m));
+  if (m->opt_dec && m->adam_done_from > A.n_enc_train) DV_TRY(refresh_head_pad(m));
   return OK;
 }
 
@@ -1515,8 +1547,17 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
     DV_TRY(bn_prefetch(m, ds.x, m->hint_next_first, B));
     m->hint_next_first = -1;
   }
+  if (mode == MODE_TRAIN) begin_update(m);
+  m->adam_done_from = m->A.n_train;
+  static const bool no_early = getenv("DV_NO_EARLY_ADAM") != nullptr;
+  m->early_adam = mode == MODE_TRAIN && !no_early && !m->prof_on;
   if (bwd) {
     DV_TRY(backward(m, B, Bg, ds.x, idx, (int)first));
+    if (!m->ctx->comm && m->adam_done_from < m->A.n_train) {
+      // parameter ranges were updated on the comm stream: everything after this step reads them
+      DV_HIP(hipEventRecord(m->ctx->ev_comm, m->ctx->comm_stream));
+      DV_HIP(hipStreamWaitEvent(s, m->ctx->ev_comm, 0));
+    }
     if (m->ctx->comm) {
       // encoder bucket (the decoder bucket was queued inside backward()); the optimizer waits for both
       DV_HIP(hipEventRecord(m->ctx->ev_enc, s));
