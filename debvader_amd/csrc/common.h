@@ -183,7 +183,17 @@ struct WStripParams {
   const float* zero;      // >= 16 bytes of zeros in device memory (source of out-of-image LDS-DMA pieces)
   int R, XR, xs_floats, ys_floats, strips_per_stamp, nstrips, strips_per_wg;   // filled by the launcher
   int dbg;                // timing ablations (wrong results), bit flags: 1 no refill DMA, 2 no MFMA, 4 phase stamps, 8 MFMA only
+  // first-layer form only (Cx = 8): fuse the PReLU backward of the layer's output.  Y is then d(activation).
+  const float* U;         // pre-activation [NB,Hy,Wy,32]; null: Y already is d(pre-activation)
+  const float* alpha;     // PReLU slopes [Hy,Wy,32]
+  float* dal_part;        // d(alpha) partials [groups][Hy*Wy*32]
+  float* db_part;         // d(bias) partials [workgroups][32]
+  size_t dal_capacity, db_capacity;   // floats available in dal_part / db_part
+  long alpha_elems;       // Hy*Wy*32
+  int groups;             // filled by the launcher
+  int* groups_out;        // host: number of d(alpha) partial slabs written
 };
+bool wgrad_strip8_fusable(int Hy, int Wy);
 void debug_set_strip(int v);
 bool wgrad_strip_supported(int Cx, int Cy, int sx, int ntaps);
 int launch_wgrad_strip(const WStripParams& p, int Cx, int Cy, int sx, hipStream_t s, int* nsplit_out);

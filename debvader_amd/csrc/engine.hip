@@ -350,6 +350,7 @@ struct dv_model {
   int lane_id = 0;
   bool split_forward = true;      // run the forward pass as two half-batch lanes on two streams (DV_NO_FWD_SPLIT)
   bool overlap_wgrad = true;
+  bool fuse_first = true;     // DV_NO_FUSE_FIRST=1 keeps the first PReLU backward as a separate pass
   bool no_fuse = true;        // DV_FUSE_PRELU_BWD=1 fuses the PReLU backward into the data-gradient epilogue (batch-major
                               // tiles); measured 3 % slower than the separate pass on MI355X (scattered 128-byte rows), so off
   bool arena_reduce = true;   // queue d(alpha)/d(bias) reductions on the aux stream (tuning toggles: DV_NO_OVERLAP, DV_NO_ARENA)
@@ -379,6 +380,20 @@ struct dv_model {
   bool ws_pending[3] = {false, false, false};
   hipEvent_t ev_wk[3] = {nullptr, nullptr, nullptr}, ev_rk[3] = {nullptr, nullptr, nullptr};
   int ws_last = -1;              // region whose reduction produced the most recent weight gradient
+  // "no reuse" mode (allocated at the first overlapped backward, DV_NO_STEP_POOL=1 keeps the rotating form): every
+  // data-gradient launch of a step gets its own output buffer and every weight-gradient launch its own slab region,
+  // so that neither stream has to wait for the other to release one - each such wait, even on a long-completed
+  // event, costs its queue ~5 us (a barrier packet), ~40 of them per step
+  std::vector<float*> gbufs;     // [0..2] = gA, gB, gC, then the pool
+  float* gpool = nullptr;
+  float* ws1x = nullptr;
+  int ws_nreg = 3;               // slab regions: 3 (rotating, with waits) or one per launch of a step
+  size_t ws_region_cap = 0;
+  int ws_count = 0;              // weight-gradient launches of this step so far
+  hipStream_t ws_last_rs = nullptr;
+  bool step_pool_tried = false;
+  size_t max_act_elems = 0;      // Bc * largest per-stamp activation
+  bool main_marked = false;      // ev_ready was recorded on the main stream right behind its last kernel
   bool normalise = false;        // dv_model_set_normalise: tanh(arcsinh) on inference inputs, inverse on the mean
   bool early_adam = false;       // this step updates finished parameter ranges on the comm stream while the backward runs
   float lr_t_step = 0.f;         // bias-corrected step size of this step
@@ -495,6 +510,22 @@ static void fill_gconv_common(GConvParams& p, const Taps& t, int cin) {
   p.cin_shift = ilog2_exact(cin);
 }
 
+// Flags of the events that only order streams of this GPU against each other.  By default a HIP event record carries
+// a system-scope release (cache write-back so that the host and peer GPUs see the data); these events have no such
+// readers behind them - results reach the host through copies and the events of the result ring, peers through
+// RCCL's own fences - so the fence is switched off (+0.7 % steps/s; tools/determinism_probe.py stays bit-identical
+// over repeated gradient and train steps).  DV_EVENT_SCOPE=system restores the default, =device asks for an explicit
+// device-scope release.
+static unsigned sync_event_flags() {
+  static const unsigned f = [] {
+    const char* e = getenv("DV_EVENT_SCOPE");
+    if (e && !strcmp(e, "system")) return (unsigned)hipEventDisableTiming;
+    if (e && !strcmp(e, "device")) return (unsigned)(hipEventDisableTiming | hipEventReleaseToDevice);
+    return (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+  }();
+  return f;
+}
+
 static inline hipStream_t fwd_stream(dv_model* m) { return m->cs ? m->cs : m->ctx->stream; }
 
 // Optional fusion of the PReLU backward of the layer whose OUTPUT gradient a data-gradient launch produces:
@@ -504,6 +535,10 @@ struct FuseBwd {
   const float* u;     // pre-activation of the target layer
   int alpha_spec, bias_spec;
   bool want_grads;    // false: frozen layer, only d(pre-activation) is needed
+  // debug harness (no Arch): explicit pointers instead of the spec indices
+  const float* alpha_ptr = nullptr;
+  float* dalpha_out = nullptr;
+  float* dbias_out = nullptr;
 };
 
 static int fuse_setup(dv_model* m, GConv2Params& q, const FuseBwd* fz, long* db_rows) {
@@ -780,49 +815,70 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
 
 // dW = sum_p Xg[p,t][cx] * Y[p][cy]; X pixel = grid*sx + k - pb; result rows (wt,cx) x cols cy into `out`
 static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB,
-                      int sx, int pb, bool single_tap, float* out, int cpad, int creal);
+                      int sx, int pb, bool single_tap, float* out, int cpad, int creal, const FuseBwd* fz);
 
 // Weight gradients are queued on m->wstream.  When that is the aux stream, the call first makes it wait for
 // everything the main stream has produced so far (the operand d(pre-activation) is final at this point).
+// on_main: queue this launch (and its slab reduction) on the main stream even when the weight gradients run on the
+// aux stream - used for the last one of the step, when the main stream has nothing else left to do.
 static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB, int sx, int pb,
-                 bool single_tap, float* out, int cpad, int creal) {
-  hipStream_t ws = m->wstream ? m->wstream : m->ctx->stream;
+                 bool single_tap, float* out, int cpad, int creal, const FuseBwd* fz = nullptr, bool on_main = false) {
+  hipStream_t ws = (m->wstream && !on_main) ? m->wstream : m->ctx->stream;
   if (ws != m->ctx->stream) {
-    DV_HIP(hipEventRecord(m->ctx->ev_ready, m->ctx->stream));
+    // the PReLU backward just queued may already have recorded the main stream's position (for its reductions)
+    if (!m->main_marked) DV_HIP(hipEventRecord(m->ctx->ev_ready, m->ctx->stream));
     DV_HIP(hipStreamWaitEvent(ws, m->ctx->ev_ready, 0));
   }
-  return wgrad_impl(m, ws, X, Hx, Cx, Y, Hy, Cy, NB, sx, pb, single_tap, out, cpad, creal);
+  m->main_marked = false;
+  return wgrad_impl(m, ws, X, Hx, Cx, Y, Hy, Cy, NB, sx, pb, single_tap, out, cpad, creal, fz);
 }
 
+// fz (first layer only, Cx == 8): Y is d(activation); the strip kernel applies the PReLU backward of fz on the fly
+// and also produces d(alpha) / d(bias), see wgrad_strip8_kernel<true>.
 static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB,
-                      int sx, int pb, bool single_tap, float* out, int cpad, int creal) {
+                      int sx, int pb, bool single_tap, float* out, int cpad, int creal, const FuseBwd* fz) {
   // slab region and the stream that sums the slabs: with the weight gradients on the aux stream the reduction goes to
   // the reduction stream and the slabs rotate through three regions of ws1
   dv_ctx* cx = m->ctx;
-  const bool rot = ws != cx->stream && m->arena_reduce && cx->red_stream && m->ev_wk[0];
+  // the regions rotate whenever weight-gradient work may be in flight on the aux stream, also for a launch that is
+  // itself queued on the main stream (which then reduces its own slabs: no stream hop)
+  const bool rot = m->wstream && m->wstream != cx->stream && m->arena_reduce && cx->red_stream && m->ev_wk[0];
+  const bool per_launch = m->ws_nreg > 3;      // one region per launch of the step: nothing to wait for
   float* part = m->ws1;
   size_t part_cap = m->ws1_elems;
   hipStream_t rs = ws;
   int reg = -1;
   if (rot) {
-    reg = m->ws_region;
-    m->ws_region = (reg + 1) % 3;
-    part_cap = m->ws1_elems / 3;
-    part = m->ws1 + (size_t)reg * part_cap;
-    rs = cx->red_stream;
-    if (m->ws_pending[reg]) {            // the reduction that last read this region must be done before it is rewritten
-      DV_HIP(hipStreamWaitEvent(ws, m->ev_rk[reg], 0));
-      m->ws_pending[reg] = false;
+    if (per_launch) {
+      if (m->ws_count >= m->ws_nreg) {
+        set_error("more weight-gradient launches in a step than slab regions (%d)", m->ws_nreg);
+        return E_STATE;
+      }
+      reg = m->ws_count++;
+      part_cap = m->ws_region_cap;
+      part = m->ws1x + (size_t)reg * part_cap;
+    } else {
+      reg = m->ws_region;
+      m->ws_region = (reg + 1) % 3;
+      part_cap = m->ws1_elems / 3;
+      part = m->ws1 + (size_t)reg * part_cap;
+      if (m->ws_pending[reg]) {          // the reduction that last read this region must be done before it is rewritten
+        DV_HIP(hipStreamWaitEvent(ws, m->ev_rk[reg], 0));
+        m->ws_pending[reg] = false;
+      }
     }
+    if (ws != cx->stream) rs = cx->red_stream;
   }
   auto hand_over = [&]() -> int {        // slabs written on ws -> reduction on rs
-    if (!rot) return OK;
-    DV_HIP(hipEventRecord(m->ev_wk[reg], ws));
-    DV_HIP(hipStreamWaitEvent(rs, m->ev_wk[reg], 0));
+    if (!rot || rs == ws) return OK;
+    DV_HIP(hipEventRecord(m->ev_wk[reg % 3], ws));
+    DV_HIP(hipStreamWaitEvent(rs, m->ev_wk[reg % 3], 0));
     return OK;
   };
   auto reduced = [&]() -> int {
     if (!rot) return OK;
+    m->ws_last_rs = rs;
+    if (per_launch) return OK;           // wgrad_result_ready records on demand
     DV_HIP(hipEventRecord(m->ev_rk[reg], rs));
     m->ws_pending[reg] = true;
     m->ws_last = reg;
@@ -834,17 +890,60 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
     sp.X = X; sp.Y = Y; sp.part = part; sp.part_capacity = part_cap;
     sp.NB = NB; sp.Hx = sp.Wx = Hx; sp.Hy = sp.Wy = Hy; sp.pb = pb;
     sp.zero = m->zero_page;
-    int ns = 0, st;
+    int ns = 0, st, groups = 0;
+    if (fz) {
+      // partial sums of d(alpha) ([groups][E]) and d(bias) ([workgroups][Cy]): from the per-step arena when another
+      // stream reduces them, else from ws2 / ws3
+      const Arch& A = m->A;
+      const long E = (long)Hy * Hy * Cy;
+      const bool arena = rs != ws;
+      const size_t dbcap = (size_t)1024 * Cy;
+      if (arena) {
+        if (m->arena_off + (size_t)E + dbcap > m->arena_elems) {
+          set_error("gradient-partial arena exhausted");
+          return E_STATE;
+        }
+        sp.db_part = m->arena + m->arena_off;
+        m->arena_off += dbcap;
+        sp.dal_part = m->arena + m->arena_off;
+        sp.dal_capacity = std::min(m->arena_elems - m->arena_off, (size_t)32 * E);
+        m->arena_off += sp.dal_capacity;
+      } else {
+        if (dbcap > m->ws3_elems) {
+          set_error("bias-gradient workspace too small");
+          return E_STATE;
+        }
+        sp.db_part = m->ws3;
+        sp.dal_part = m->ws2;
+        sp.dal_capacity = m->ws2_elems;
+      }
+      sp.db_capacity = dbcap;
+      sp.U = fz->u;
+      sp.alpha = fz->alpha_ptr ? fz->alpha_ptr : m->P + A.specs[fz->alpha_spec].off;
+      sp.alpha_elems = E;
+      sp.groups_out = &groups;
+    }
     {
       ProfScope ps(m, 1, ws);
       st = launch_wgrad_strip(sp, Cx, Cy, sx, ws, &ns);
     }
     if (st < 0) return st;
+    if (st > 0 && fz) {
+      set_error("fused first-layer weight gradient: geometry not supported");
+      return E_STATE;
+    }
     if (st == 0) {
       DV_TRY(hand_over());
       {
         ProfScope ps(m, 2, rs);
         DV_TRY(launch_reduce_partials(part, out, ns, (long)9 * Cx * Cy, Cy, cpad, creal, rs));
+        if (fz) {
+          const Arch& A = m->A;
+          float* dal_out = fz->dalpha_out ? fz->dalpha_out : m->G + A.specs[fz->alpha_spec].off;
+          float* db_out = fz->dbias_out ? fz->dbias_out : m->G + A.specs[fz->bias_spec].off;
+          DV_TRY(launch_reduce_partials(sp.dal_part, dal_out, groups, sp.alpha_elems, 4, 1, 1, rs));
+          DV_TRY(launch_reduce_rows_f64(sp.db_part, ns, Cy, db_out, 1.0f, rs));
+        }
       }
       return reduced();
     }
@@ -906,9 +1005,44 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
 }
 
 // makes `ws` wait for the reduction that produced the most recent weight gradient (its consumer runs on ws)
+// makes stream ws wait for the slab reduction of the weight gradient queued last
 static int wgrad_result_ready(dv_model* m, hipStream_t ws) {
+  if (m->ws_nreg > 3) {
+    if (m->ws_last_rs && m->ws_last_rs != ws) {
+      DV_HIP(hipEventRecord(m->ev_rk[0], m->ws_last_rs));
+      DV_HIP(hipStreamWaitEvent(ws, m->ev_rk[0], 0));
+    }
+    return OK;
+  }
   if (m->ws_last >= 0 && m->ws_pending[m->ws_last]) DV_HIP(hipStreamWaitEvent(ws, m->ev_rk[m->ws_last], 0));
   return OK;
+}
+
+// Allocates the per-step buffer pool of the "no reuse" mode (once; on failure the rotating forms stay in use).
+static void ensure_step_pool(dv_model* m) {
+  if (m->step_pool_tried) return;
+  m->step_pool_tried = true;
+  if (getenv("DV_NO_STEP_POOL")) return;
+  const Arch& A = m->A;
+  const int nbuf = 4 * A.L + 10, nreg = 4 * A.L + 8;
+  const size_t cap = m->ws1_elems / 3;
+  float *pool = nullptr, *slabs = nullptr;
+  if (hipMalloc((void**)&pool, (size_t)(nbuf - 3) * m->max_act_elems * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  if (hipMalloc((void**)&slabs, (size_t)nreg * cap * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(pool);
+    return;
+  }
+  m->allocs.push_back(pool);
+  m->allocs.push_back(slabs);
+  m->gpool = pool;
+  for (int k = 0; k < nbuf - 3; ++k) m->gbufs.push_back(pool + (size_t)k * m->max_act_elems);
+  m->ws1x = slabs;
+  m->ws_region_cap = cap;
+  m->ws_nreg = nreg;
 }
 
 // PReLU backward with optional parameter gradients.  du is needed by the next launches of the main stream; the
@@ -961,10 +1095,12 @@ static int prelu_bwd(dv_model* m, float* da, const float* u, int alpha_spec, int
     ProfScope ps(m, 2);
     DV_TRY(launch_prelu_bwd(da, u, m->P + A.specs[alpha_spec].off, NB, E, C, nsplit, dal, dbp, &rows, s));
   }
+  m->main_marked = false;
   if (want_grads) {
     if (rs != s) {
       DV_HIP(hipEventRecord(m->ctx->ev_ready, s));
       DV_HIP(hipStreamWaitEvent(rs, m->ctx->ev_ready, 0));
+      m->main_marked = true;           // a weight-gradient launch queued next can wait on the same record
     }
     ProfScope ps(m, 2, rs);
     DV_TRY(launch_reduce_partials(dal, m->G + A.specs[alpha_spec].off, nsplit, E, 4, 1, 1, rs));
@@ -1237,13 +1373,26 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   const bool ovl = m->overlap_wgrad && !m->prof_on && cx->aux_stream != nullptr;
   m->wstream = ovl ? cx->aux_stream : s;
   m->arena_off = 0;
-  float* bufs[3] = {m->gA, m->gB, m->gC};
+  if (ovl) ensure_step_pool(m);
+  // "no reuse" mode: as many buffers as data-gradient launches, so nothing below ever waits (or records)
+  const int K = (ovl && (int)m->gbufs.size() >= 4 * A.L + 10) ? (int)m->gbufs.size() : 3;
+  const bool no_reuse = K > 3;
+  m->ws_count = 0;
+  m->ws_last_rs = nullptr;
+  m->main_marked = false;
+  float* const* bufs = m->gbufs.data();
   bool pend[3] = {false, false, false};
   int ci = 0;                        // bufs[0] holds d(tpre)
   float* cur = bufs[0];
   float* oth = nullptr;
   auto next_out = [&]() -> int {     // pick the output buffer of the next data-gradient launch
-    const int o = (ci + 1) % 3;
+    const int o = (ci + 1) % K;
+    m->main_marked = false;
+    if (no_reuse) {
+      if (o == 0) return -2;         // wrapped: more launches than buffers
+      oth = bufs[o];
+      return o;
+    }
     if (pend[o]) {
       if (hipStreamWaitEvent(s, cx->ev_buf[o], 0) != hipSuccess) return -1;
       pend[o] = false;
@@ -1252,19 +1401,19 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     return o;
   };
   auto wgrad_read = [&]() -> int {   // the weight-gradient launch just queued reads bufs[ci]
-    if (!ovl) return OK;
+    if (!ovl || no_reuse) return OK;
     if (hipEventRecord(cx->ev_buf[ci], cx->aux_stream) != hipSuccess) return E_HIP;
     pend[ci] = true;
     return OK;
   };
   auto advance = [&]() {             // the data gradient just written becomes the current one
-    ci = (ci + 1) % 3;
+    ci = (ci + 1) % K;
     cur = bufs[ci];
   };
 #define DV_NEXT_OUT()                                  \
   do {                                                 \
     if (next_out() < 0) {                              \
-      set_error("hipStreamWaitEvent failed");          \
+      set_error("data-gradient buffer hand-over failed"); \
       return E_HIP;                                    \
     }                                                  \
   } while (0)
@@ -1379,14 +1528,23 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     int hin, cin, hout, cout, st;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
     int pb = same_pad_before(hin, 3, st, nullptr);
-    if (!cur_is_du) DV_TRY(prelu_bwd(m, cur, m->enc_u[j], A.enc_al(j), A.enc_b(j), NB, hout * hout * cout, cout, true));
+    // first layer: its PReLU backward is folded into the weight-gradient kernel (no data gradient follows it)
+    const bool fuse0 = j == 0 && !cur_is_du && m->fuse_first && cout == 32 && st == 1 && pb == 1 && !g_no_special &&
+                       wgrad_strip8_fusable(hout, hout);
+    if (!cur_is_du && !fuse0)
+      DV_TRY(prelu_bwd(m, cur, m->enc_u[j], A.enc_al(j), A.enc_b(j), NB, hout * hout * cout, cout, true));
     const float* xin = j == 0 ? m->xn : m->enc_a[j - 1];
     int cin_phys = j == 0 ? 8 : cin;
     if (j == 0) {
       // first conv + input BatchNorm: the gradient w.r.t. the folded 8-channel kernel gives d(kernel), d(gamma) and
       // d(beta) directly (bn_conv0_grads_kernel), so this layer needs no data-gradient pass at all
-      hipStream_t ws = m->wstream ? m->wstream : s;
-      DV_TRY(wgrad(m, xin, hin, 8, cur, hout, cout, NB, st, pb, false, m->G0s, 8, 8));
+      // the last weight gradient of the step goes to the main stream, which would otherwise idle while the aux
+      // stream works off its backlog (DV_LAST_ON_AUX=1: old placement)
+      static const bool last_on_main = !getenv("DV_LAST_ON_AUX");
+      hipStream_t ws = (m->wstream && !last_on_main) ? m->wstream : s;
+      FuseBwd f0{m->enc_u[0], A.enc_al(0), A.enc_b(0), true};
+      DV_TRY(wgrad(m, xin, hin, 8, cur, hout, cout, NB, st, pb, false, m->G0s, 8, 8, fuse0 ? &f0 : nullptr,
+                   last_on_main));
       DV_TRY(wgrad_result_ready(m, ws));
       ProfScope ps(m, 2, ws);
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
@@ -2012,7 +2170,7 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
   DV_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->red_stream, hipStreamNonBlocking));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_red, hipEventDisableTiming));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_red, sync_event_flags()));
   // HIP multiplexes streams onto a few hardware queues (4 by default) and work on streams that share a queue runs
   // in submission order, so the engine keeps to four streams: main, comm (also the D2H stream of the inference
   // pipeline), aux, and the reduction stream (also the pipeline's H2D stream).  More forward lanes (DV_FWD_LANES > 2) create theirs on demand.
@@ -2021,16 +2179,16 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
     const int extra = wl ? std::max(0, std::min(atoi(wl), 4) - 2) : 0;
     for (int i = 0; i < extra; ++i) DV_HIP(hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking));
   }
-  for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_lane[i], hipEventDisableTiming));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_buf[i], hipEventDisableTiming));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_dec, hipEventDisableTiming));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_enc, hipEventDisableTiming));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_small, hipEventDisableTiming));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_small2, hipEventDisableTiming));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
+  for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_lane[i], sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_ready, sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_join, sync_event_flags()));
+  for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_buf[i], sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_dec, sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_enc, sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_comm, sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_small, sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_small2, sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_mid, sync_event_flags()));
   DV_HIP(hipMalloc((void**)&c->red_dev, 4096 * sizeof(float)));
   if (world == 1 && getenv("DV_FORCE_COMM")) {
     // test hook: a one-rank communicator, so that the collective code paths (streams, events, in-place all-reduces)
@@ -2224,6 +2382,8 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   ALLOC(m->gA, Bc * max_act);
   ALLOC(m->gB, Bc * max_act);
   ALLOC(m->gC, Bc * max_act);
+  m->gbufs = {m->gA, m->gB, m->gC};
+  m->max_act_elems = Bc * max_act;
   // workspaces: ws1 weight-gradient slabs, ws2 d(alpha) partials, ws3 small reductions
   size_t max_w = 0;
   for (auto& s : A.specs)
@@ -2238,6 +2398,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   if (getenv("DV_NO_ARENA")) m->arena_reduce = false;
   if (getenv("DV_NO_FWD_SPLIT")) m->split_forward = false;
   if (getenv("DV_FUSE_PRELU_BWD")) m->no_fuse = false;
+  if (getenv("DV_NO_FUSE_FIRST")) m->fuse_first = false;
   m->arena_elems = 0;
   for (auto& sp : A.specs)
     if (sp.name.size() > 6 && sp.name.compare(sp.name.size() - 6, 6, "/alpha") == 0)
@@ -2257,11 +2418,11 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   m->bn_pre_part_elems = (size_t)16 * (((size_t)Bc * A.H * A.H + 255) / 256 + 16);
   ALLOC(m->bn_pre_part, m->bn_pre_part_elems);
   for (int k = 0; k < 3; ++k)
-    if (hipEventCreateWithFlags(&m->ev_wk[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_rk[k], hipEventDisableTiming) != hipSuccess)
+    if (hipEventCreateWithFlags(&m->ev_wk[k], sync_event_flags()) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_rk[k], sync_event_flags()) != hipSuccess)
       return fail(E_HIP);
-  if (hipEventCreateWithFlags(&m->ev_bnpre, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&m->ev_bnpre_go, hipEventDisableTiming) != hipSuccess)
+  if (hipEventCreateWithFlags(&m->ev_bnpre, sync_event_flags()) != hipSuccess ||
+      hipEventCreateWithFlags(&m->ev_bnpre_go, sync_event_flags()) != hipSuccess)
     return fail(E_HIP);
   {
     void* q = nullptr;
@@ -2935,12 +3096,33 @@ int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, 
   DV_HIP(hipEventCreate(&a));
   DV_HIP(hipEventCreate(&b));
   int st = OK;
+  // bit 8: the fused first-layer form (PReLU backward inside the kernel); Yb then plays d(activation)
+  const bool fused = (single_tap & 0x100) != 0 && Cx == 8;
+  single_tap &= 0xff;
+  float *U = nullptr, *al = nullptr, *gout = nullptr;
+  FuseBwd fz{nullptr, 0, 0, true};
+  if (fused) {
+    const size_t E = (size_t)Hy * Hy * Cy;
+    DV_HIP(hipMalloc((void**)&U, ny * sizeof(float)));
+    DV_HIP(hipMemcpy(U, Yb, ny * sizeof(float), hipMemcpyDeviceToDevice));
+    DV_HIP(hipMalloc((void**)&al, E * sizeof(float)));
+    DV_HIP(hipMemset(al, 0, E * sizeof(float)));
+    DV_HIP(hipMalloc((void**)&gout, (E + 64) * sizeof(float)));
+    m.ws2_elems = 32 * E;
+    DV_HIP(hipMalloc((void**)&m.ws2, m.ws2_elems * sizeof(float)));
+    m.ws3_elems = (size_t)1024 * Cy;
+    DV_HIP(hipMalloc((void**)&m.ws3, m.ws3_elems * sizeof(float)));
+    fz.u = U;
+    fz.alpha_ptr = al;
+    fz.dalpha_out = gout;
+    fz.dbias_out = gout + E;
+  }
   DV_HIP(hipEventRecord(a, ctx->stream));
   for (int it = -2; it < iters && st == OK; ++it) {
     if (it == 0) DV_HIP(hipEventRecord(a, ctx->stream));
     g_force_v1 = (single_tap & 2) != 0;
     debug_set_strip(single_tap >> 2);
-    st = wgrad(&m, X, Hx, Cx, Yb, Hy, Cy, NB, sx, pb, (single_tap & 1) != 0, out, Cx, Cx);
+    st = wgrad(&m, X, Hx, Cx, Yb, Hy, Cy, NB, sx, pb, (single_tap & 1) != 0, out, Cx, Cx, fused ? &fz : nullptr);
     g_force_v1 = false;
     debug_set_strip(0);
   }
@@ -2956,6 +3138,10 @@ int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, 
       fprintf(stderr, "  wave %d: barrier %.0f  dma-issue %.0f  compute %.0f cycles over %.0f strips\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
   }
   (void)hipFree(X); (void)hipFree(Yb); (void)hipFree(out); (void)hipFree(m.ws1); (void)hipFree(m.zero_page);
+  if (fused) {
+    (void)hipFree(U); (void)hipFree(al); (void)hipFree(gout); (void)hipFree(m.ws2); (void)hipFree(m.ws3);
+    m.ws2 = m.ws3 = nullptr;
+  }
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   return st;
 }

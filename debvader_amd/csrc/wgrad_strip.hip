@@ -246,13 +246,21 @@ __global__ __launch_bounds__(256, 1) void wgrad_strip_kernel(const WStripParams 
 // First-layer variant: Cx = 8 (6 bands + the BN "ones" channel + 1 pad), Cy = 32, stride 1.  dW rows are
 // (tap, cx) = 72 -> five 16-row MFMA blocks, each spanning two taps (lanes 0-7 / 8-15); tap 9 does not exist and
 // contributes zeros.  Four waves split the pixels of a strip; the partial tiles are summed through LDS.
+//
+// FUSED: Y is d(activation) of the first PReLU and p.U its pre-activation.  The strip's rows of both are brought in,
+// d(pre-activation) = dA * (U > 0 ? 1 : alpha) is formed in LDS and never written to memory (this layer has no data
+// gradient, so the weight-gradient MFMAs are its only reader), and d(alpha) / d(bias) are accumulated in registers:
+// workgroup b owns row block b % strips_per_stamp of the stamps g, g + groups, ... (g = b / strips_per_stamp), so a
+// thread meets the same (pixel, channel) elements in every strip.  Replaces a 342 MB read-modify-write pass.
+template <bool FUSED>
 __global__ __launch_bounds__(256, 1) void wgrad_strip8_kernel(const WStripParams p) {
   constexpr int CX = 8, CY = 32, CX4 = 2, CY4 = 8, WKS = 4, MB = 5, NBK = 2;
-  constexpr int MAXGX = 8, MAXGY = 12;
+  constexpr int MAXGX = 8, MAXGY = 12, MAXE = 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XC = p.Wy + 2;
-  const int buf_floats = p.xs_floats + p.ys_floats;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int buf_floats = p.xs_floats + (FUSED ? 2 : 1) * p.ys_floats;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar loop control below
   const int wk = wave;
   const int l15 = lane & 15, lg = lane >> 4;
 
@@ -267,12 +275,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_strip8_kernel(const WStripParams
   const int kpw = (ksteps + WKS - 1) / WKS;
   const int ks0 = wk * kpw, ks1 = min(ksteps, ks0 + kpw);
 
-  // per-lane tap offsets of the five row blocks (floats inside the patch), -1: no such tap
+  // per-lane tap offsets of the five row blocks (floats inside the patch)
   int toff[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int tap = 2 * mb + (l15 >> 3);
-    toff[mb] = tap < 9 ? ((tap / 3) * XC + (tap % 3)) * CX + (l15 & 7) : -1;
+    const int t = min(tap, 8);            // tap 9 (rows 72..79 of dW) does not exist: any finite operand will do
+    toff[mb] = ((t / 3) * XC + (t % 3)) * CX + (l15 & 7);
   }
 
   const int xtot = p.XR * XC * CX4;
@@ -288,9 +297,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_strip8_kernel(const WStripParams
     xrel[k] = (xr * p.Wx + gc) * CX + c4 * 4;
     xrow[k] = ok ? xr : -100000;
   }
-  auto issue_dma = [&](int sidx, int buf) {
-    const int n = sidx / p.strips_per_stamp;
-    const int i0 = (sidx - n * p.strips_per_stamp) * p.R;
+  // strip (stamp n, first output row i0) -> LDS buffer buf
+  auto issue_dma = [&](int n, int i0, int buf) {
     const int gr0 = i0 - p.pb;
     const int xbase = (n * p.Hx + gr0) * p.Wx * CX;
     float* xs = smem + buf * buf_floats;
@@ -313,41 +321,137 @@ __global__ __launch_bounds__(256, 1) void wgrad_strip8_kernel(const WStripParams
         const int e = 64 * g + lane;
         const float* src = e < yvalid4 ? p.Y + ybase + (unsigned)(e * 4) : p.zero;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ys + g * 256), 16, 0, 0);
+        if (FUSED) {
+          const float* usrc = e < yvalid4 ? p.U + ybase + (unsigned)(e * 4) : p.zero;
+          __builtin_amdgcn_global_load_lds((gptr_t)usrc, (lptr_t)(ys + p.ys_floats + g * 256), 16, 0, 0);
+        }
       }
     }
   };
 
-  const int s_begin = blockIdx.x * p.strips_per_wg;
-  const int s_end = min(p.nstrips, s_begin + p.strips_per_wg);
-  if (s_begin < s_end) issue_dma(s_begin, 0);
+  // the sequence of strips of this workgroup: unfused, a contiguous range of (stamp, row block) pairs; fused, one
+  // row block of every groups-th stamp
+  int n_cur, i0_cur, s_cur, s_end;
+  const int rb = FUSED ? (int)blockIdx.x % p.strips_per_stamp : 0;
+  if (FUSED) {
+    s_cur = (int)blockIdx.x / p.strips_per_stamp;      // stamp index
+    s_end = p.NB;
+  } else {
+    s_cur = blockIdx.x * p.strips_per_wg;              // strip index
+    s_end = min(p.nstrips, s_cur + p.strips_per_wg);
+  }
+  const int s_step = FUSED ? p.groups : 1;
+  auto locate = [&](int sidx, int& n, int& i0) {
+    if (FUSED) {
+      n = sidx;
+      i0 = rb * p.R;
+    } else {
+      n = sidx / p.strips_per_stamp;
+      i0 = (sidx - n * p.strips_per_stamp) * p.R;
+    }
+  };
+
+  // fused: this thread's PReLU slopes and gradient accumulators for its (at most MAXE) float4 elements of the block
+  f32x4 al[MAXE], dal[MAXE], dbs = {0.f, 0.f, 0.f, 0.f};
+  int evalid = 0;
+  if (FUSED) {
+    const int i0 = rb * p.R;
+    evalid = min(p.R, p.Hy - i0) * p.Wy * CY4;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      const int e = tid + 256 * k;
+      dal[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      al[k] = e < evalid ? *reinterpret_cast<const f32x4*>(p.alpha + (size_t)i0 * p.Wy * CY + e * 4)
+                         : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  if (s_cur < s_end) {
+    locate(s_cur, n_cur, i0_cur);
+    issue_dma(n_cur, i0_cur, 0);
+  }
   int buf = 0;
-  for (int sidx = s_begin; sidx < s_end; ++sidx) {
+  for (int sidx = s_cur; sidx < s_end; sidx += s_step) {
+    // every wave's DMA pieces of this strip must have landed before any wave reads them: the wait is spelled out
+    // because the compiler does not reliably place one for LDS-DMA in front of the barrier (it left it out of the
+    // fused form, a race that showed up in 1 of ~20 runs)
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
     __syncthreads();
-    if (sidx + 1 < s_end) issue_dma(sidx + 1, buf ^ 1);
-    const float* Xs = smem + buf * buf_floats;
-    const float* Ys = Xs + p.xs_floats;
+    float* Xs = smem + buf * buf_floats;
+    float* Ys = Xs + p.xs_floats;
+    const bool more = sidx + s_step < s_end && !(p.dbg & 1);
+    if (more) {                                // in flight during the transform and the MFMA loop
+      int nn, ni0;
+      locate(sidx + s_step, nn, ni0);
+      issue_dma(nn, ni0, buf ^ 1);
+    }
+    if (FUSED && !(p.dbg & 16)) {
+      // dA -> dU in place (rows past the image arrive as zeros and stay zeros)
+      const float* Us = Ys + p.ys_floats;
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k) {
+        const int e = tid + 256 * k;
+        if (e < evalid) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(Ys + e * 4);
+          const f32x4 uv = *reinterpret_cast<const f32x4*>(Us + e * 4);
+          f32x4 d;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const bool pos = uv[c] > 0.f;
+            d[c] = pos ? g[c] : g[c] * al[k][c];
+            dal[k][c] += pos ? 0.f : g[c] * uv[c];
+            dbs[c] += d[c];
+          }
+          *reinterpret_cast<f32x4*>(Ys + e * 4) = d;
+        }
+      }
+      // LDS-only barrier: a __syncthreads() here would also wait for the DMA pieces issued just above
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     int q = 4 * ks0 + lg;
     int pr = q / p.Wy, pj = q - pr * p.Wy;
-    for (int ks = ks0; ks < ks1; ++ks) {
+    const int ks_end = (p.dbg & 2) ? ks0 : ks1;
+    // Fragment loads of k-step ks+1 are issued before the MFMAs of k-step ks (two register sets).  No masking of the
+    // operands: pixels past the strip read the zero-filled tail of Ys (their X address is clamped to a valid one), and
+    // the rows of the non-existent tap 9 (dW rows 72..79) are never written out.
+    const int qlast = 4 * ksteps - 1;
+    auto load = [&](float (&bf)[NBK], float (&af)[MB]) {
       const bool qv = q < strip_px;
       const int base = qv ? (pr * XC + pj) * CX : 0;
-      const float msk = qv ? 1.f : 0.f;
-      float bf[NBK], af[MB];
 #pragma unroll
-      for (int nb = 0; nb < NBK; ++nb) bf[nb] = Ys[(qv ? q : 0) * CY + nb * 16 + l15] * msk;
+      for (int nb = 0; nb < NBK; ++nb) bf[nb] = Ys[min(q, qlast) * CY + nb * 16 + l15];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) af[mb] = Xs[base + max(toff[mb], 0)] * (toff[mb] >= 0 ? 1.f : 0.f);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NBK; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bf[nb], acc[mb][nb], 0, 0, 0);
+      for (int mb = 0; mb < MB; ++mb) af[mb] = Xs[base + toff[mb]];
       q += 4;
       pj += 4;
       const int wrap = pj >= p.Wy ? 1 : 0;
       pj -= wrap ? p.Wy : 0;
       pr += wrap;
+    };
+    auto mma = [&](const float (&bf)[NBK], const float (&af)[MB]) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], bf[nb], acc[mb][nb], 0, 0, 0);
+    };
+    // branch-free pairs, so that the compiler can count the LDS reads in flight (a load past the last k-step
+    // re-reads the strip's zero tail and is not used)
+    float bf0[NBK], af0[MB], bf1[NBK], af1[MB];
+    const int nks = max(ks_end - ks0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // no scalar load in flight: lets the loop wait on LDS-read counts only
+    load(bf0, af0);
+    for (int i = 0; i < (nks >> 1); ++i) {
+      load(bf1, af1);
+      __builtin_amdgcn_sched_barrier(0);     // keep the reads ahead of the MFMAs they hide behind
+      mma(bf0, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(bf0, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(bf1, af1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (nks & 1) mma(bf0, af0);
     buf ^= 1;
   }
   __syncthreads();
@@ -367,14 +471,40 @@ __global__ __launch_bounds__(256, 1) void wgrad_strip8_kernel(const WStripParams
     for (int k = 1; k < WKS; ++k) v += T[k * 80 * CY + e];
     slab[e] = v;
   }
+  if (FUSED) {
+    const int g = (int)blockIdx.x / p.strips_per_stamp;
+    float* dst = p.dal_part + (size_t)g * p.alpha_elems + (size_t)rb * p.R * p.Wy * CY;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      const int e = tid + 256 * k;
+      if (e < evalid) *reinterpret_cast<f32x4*>(dst + e * 4) = dal[k];
+    }
+    // d(bias): a thread's elements all belong to channel quad tid % 8
+    __syncthreads();
+    f32x4* shv = reinterpret_cast<f32x4*>(smem);
+    shv[tid] = dbs;
+    __syncthreads();
+    if (tid < CY4) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int t = tid; t < 256; t += CY4) a += shv[t];
+      *reinterpret_cast<f32x4*>(p.db_part + (size_t)blockIdx.x * CY + tid * 4) = a;
+    }
+  }
+}
+
+bool wgrad_strip8_fusable(int Hy, int Wy) {
+  // the fused form keeps two output rows per strip: 2 * Wy * 8 float4 elements over 256 threads x 4
+  return Wy >= 4 && (size_t)std::min(Hy, 2) * Wy * 8 <= 1024;
 }
 
 static int launch_strip8(WStripParams p, hipStream_t s, int* nsplit_out) {
+  const bool fused = p.U != nullptr;
   const int XC = p.Wy + 2;
   auto xfl = [&](int r) { return (((size_t)(r + 2) * XC * 2 + 63) / 64) * 256; };
   auto yfl = [&](int r) { return (((size_t)r * p.Wy * 8 + 63) / 64) * 256; };
   auto fits = [&](int r) {
-    return 2 * (xfl(r) + yfl(r)) * sizeof(float) <= 128 * 1024 && xfl(r) / 256 <= 4 * 8 && yfl(r) / 256 <= 4 * 12;
+    return 2 * (xfl(r) + (fused ? 2 : 1) * yfl(r)) * sizeof(float) <= 128 * 1024 && xfl(r) / 256 <= 4 * 8 &&
+           yfl(r) / 256 <= 4 * 12;
   };
   if (p.Wy < 4 || !fits(1)) return 1;   // fall back to wgrad_kernel
   // this layer is a streaming reduction (142 MB in, 72 x 32 out): short strips and three workgroups per CU keep more
@@ -387,20 +517,36 @@ static int launch_strip8(WStripParams p, hipStream_t s, int* nsplit_out) {
   p.ys_floats = (int)yfl(R);
   p.strips_per_stamp = (p.Hy + R - 1) / R;
   p.nstrips = p.NB * p.strips_per_stamp;
-  int wgs = std::min(p.nstrips, 768);
-  wgs = std::max(1, std::min(wgs, (int)(p.part_capacity / ((size_t)72 * 32))));
-  p.strips_per_wg = (p.nstrips + wgs - 1) / wgs;
-  wgs = (p.nstrips + p.strips_per_wg - 1) / p.strips_per_wg;
-  const size_t smem = std::max((size_t)2 * (p.xs_floats + p.ys_floats), (size_t)4 * 80 * 32) * sizeof(float);
-  static size_t attr = 0;
-  if (smem > attr) {
-    DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_strip8_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr = smem;
+  int wgs;
+  if (fused) {
+    if ((size_t)R * p.Wy * 8 > 1024) return 1;
+    size_t cap = std::min(p.part_capacity / ((size_t)72 * 32), p.db_capacity / 32) / p.strips_per_stamp;
+    cap = std::min(cap, p.dal_capacity / (size_t)p.alpha_elems);
+    if (cap < 1) return 1;
+    // two 78 KB workgroups per CU: one full round of 512
+    static const int target = getenv("DV_W0_WGS") ? atoi(getenv("DV_W0_WGS")) : 512;
+    p.groups = (int)std::min<size_t>(std::min(p.NB, std::max(1, target / p.strips_per_stamp)), cap);
+    p.strips_per_wg = (p.NB + p.groups - 1) / p.groups;
+    wgs = p.groups * p.strips_per_stamp;
+  } else {
+    wgs = std::min(p.nstrips, 768);
+    wgs = std::max(1, std::min(wgs, (int)(p.part_capacity / ((size_t)72 * 32))));
+    p.strips_per_wg = (p.nstrips + wgs - 1) / wgs;
+    wgs = (p.nstrips + p.strips_per_wg - 1) / p.strips_per_wg;
   }
-  hipLaunchKernelGGL(wgrad_strip8_kernel, dim3(wgs), dim3(256), smem, s, p);
+  const size_t smem =
+      std::max((size_t)2 * (p.xs_floats + (fused ? 2 : 1) * p.ys_floats), (size_t)4 * 80 * 32) * sizeof(float);
+  auto kern = fused ? wgrad_strip8_kernel<true> : wgrad_strip8_kernel<false>;
+  static size_t attr[2] = {0, 0};
+  if (smem > attr[fused]) {
+    DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    attr[fused] = smem;
+  }
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), smem, s, p);
   DV_HIP(hipGetLastError());
   *nsplit_out = wgs;
+  if (fused) *p.groups_out = p.groups;
   return OK;
 }
 

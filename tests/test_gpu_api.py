@@ -124,6 +124,29 @@ def test_full_batch_determinism_and_permutation_invariance():
         assert np.abs(a - b).max() <= 1e-3 * np.abs(a).max()
 
 
+def test_queued_train_steps_are_bit_reproducible_at_full_batch():
+    """Six queued B=256 train steps (weight gradients on the aux stream, reductions and early Adam on two more
+    streams) on fresh engines: every parameter must come out bit-identical - a race between the streams would not."""
+    from debvader_amd import engine as E
+
+    B = 256
+    x, y = _data(2 * B, 11)
+    res = []
+    for _ in range(3):
+        eng = E.Engine(E.make_config(max_batch=B))
+        eng.init(seed=5)
+        eng.optimizer_reset(1e-4)
+        eng.upload(0, x, y)
+        out = eng.train_steps(0, 0, B, 6, seed=10)
+        res.append((out["loss"], [eng.get_param(n) for n, _, tr in eng.specs if tr]))
+        eng.close()
+    assert np.isfinite(res[0][0])
+    for loss, params in res[1:]:
+        assert loss == res[0][0]
+        for a, b in zip(res[0][1], params):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_train_steps_queue_matches_stepwise():
     from debvader_amd import engine as E
 
