@@ -516,14 +516,16 @@ static void fill_gconv_common(GConvParams& p, const Taps& t, int cin) {
 // RCCL's own fences - so the fence is switched off (+0.7 % steps/s; tools/determinism_probe.py stays bit-identical
 // over repeated gradient and train steps).  DV_EVENT_SCOPE=system restores the default, =device asks for an explicit
 // device-scope release.
+static bool g_multi_rank = false;      // set by dv_ctx_create (one context per process) before any event exists
 static unsigned sync_event_flags() {
-  static const unsigned f = [] {
-    const char* e = getenv("DV_EVENT_SCOPE");
-    if (e && !strcmp(e, "system")) return (unsigned)hipEventDisableTiming;
-    if (e && !strcmp(e, "device")) return (unsigned)(hipEventDisableTiming | hipEventReleaseToDevice);
-    return (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
-  }();
-  return f;
+  const char* e = getenv("DV_EVENT_SCOPE");
+  if (e && !strcmp(e, "system")) return (unsigned)hipEventDisableTiming;
+  if (e && !strcmp(e, "device")) return (unsigned)(hipEventDisableTiming | hipEventReleaseToDevice);
+  if (e && !strcmp(e, "none")) return (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+  // Default: no fence on one GPU.  With peers in the job the events in front of the RCCL launches keep the
+  // system-scope release: what the collectives read could not be tested here on more than one rank.
+  return g_multi_rank ? (unsigned)hipEventDisableTiming
+                      : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
 }
 
 static inline hipStream_t fwd_stream(dv_model* m) { return m->cs ? m->cs : m->ctx->stream; }
@@ -1310,6 +1312,28 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
     DV_HIP(hipEventRecord(cx->ev_ready, s));
     for (int lane = 1; lane < nlanes; ++lane) DV_HIP(hipStreamWaitEvent(lstream[lane], cx->ev_ready, 0));
   }
+  // DV_LANE_TRACE=1: GPU timestamps of the lanes' starts and ends (timing events, printed every 64th forward)
+  static const bool lane_trace = getenv("DV_LANE_TRACE") != nullptr;
+  static hipEvent_t lt[6] = {nullptr};
+  static long lt_count = 0;
+  const bool lt_on = lane_trace && nlanes == 2 && training;
+  if (lt_on && !lt[0])
+    for (auto& e : lt) DV_HIP(hipEventCreate(&e));
+  if (lt_on && lt_count > 0 && lt_count % 64 == 0) {
+    DV_HIP(hipEventSynchronize(lt[5]));
+    float a = 0, b = 0, c = 0, d = 0;
+    (void)hipEventElapsedTime(&a, lt[0], lt[1]);
+    (void)hipEventElapsedTime(&b, lt[0], lt[2]);
+    (void)hipEventElapsedTime(&c, lt[0], lt[3]);
+    (void)hipEventElapsedTime(&d, lt[0], lt[4]);
+    fprintf(stderr, "[lanes] lane1 start +%.0f us, lane0 end +%.0f us, lane1 end +%.0f us, joined +%.0f us\n", a * 1e3,
+            b * 1e3, c * 1e3, d * 1e3);
+  }
+  if (lt_on) {
+    ++lt_count;
+    DV_HIP(hipEventRecord(lt[0], s));
+    DV_HIP(hipEventRecord(lt[1], lstream[1]));
+  }
   for (int lane = 0; lane < nlanes && st == OK; ++lane) {
     m->b0 = lane * per;
     m->lane_id = lane;
@@ -1322,6 +1346,7 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
     if (st == OK) st = decoder_forward(m, nb, keep_u);
     if (st == OK) st = head_lane(m, ysrc, idx, first, nb, Bg, want_grad, want_out, blk_done, &nblk);
     blk_done += nblk;
+    if (lt_on) DV_HIP(hipEventRecord(lt[2 + lane], lane ? lstream[lane] : s));
     if (st == OK && lane > 0) {
       if (hipEventRecord(cx->ev_lane[lane - 1], lstream[lane]) != hipSuccess ||
           hipStreamWaitEvent(s, cx->ev_lane[lane - 1], 0) != hipSuccess)
@@ -1332,6 +1357,10 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
   m->lane_id = 0;
   m->cs = nullptr;
   if (st != OK) return st;
+  if (lt_on) {
+    DV_HIP(hipEventRecord(lt[4], s));
+    DV_HIP(hipEventRecord(lt[5], s));
+  }
   const int blk0 = blk_done, blk1 = 0;
   if (ysrc) {
     ProfScope ps(m, 2, s);
@@ -1464,6 +1493,23 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     advance();
   }
   // dense trunk of the decoder
+  // DV_MID_TRACE=1: GPU time of the latency-bound middle of the backward pass (dense layers, sampler, first strided
+  // encoder layer), printed every 64th step - the profiler's traces are host-bound there
+  static const bool mid_trace = getenv("DV_MID_TRACE") != nullptr;
+  static hipEvent_t mt[2] = {nullptr, nullptr};
+  static long mt_count = 0;
+  if (mid_trace) {
+    if (!mt[0])
+      for (auto& e : mt) DV_HIP(hipEventCreate(&e));
+    if (mt_count > 0 && mt_count % 64 == 0) {
+      DV_HIP(hipEventSynchronize(mt[1]));
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, mt[0], mt[1]);
+      fprintf(stderr, "[mid] dense trunk .. data gradient of the last encoder conv: %.0f us\n", ms * 1e3);
+    }
+    ++mt_count;
+    DV_HIP(hipEventRecord(mt[0], s));
+  }
   int r = A.w0 * A.w0 * A.cfg.filters[A.L - 1];
   DV_TRY(prelu_bwd(m, cur, m->dec_ur, A.D0 + 6, A.D0 + 5, NB, r, r, dg));
   if (dg) {
@@ -1562,6 +1608,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     DV_TRY(gconv_dgrad(m, cur, W, true, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout, hin, cin_phys, st, pb, &fz,
                        &cur_is_du));
     advance();
+    if (mid_trace && j == 2 * A.L - 1) DV_HIP(hipEventRecord(mt[1], s));
     if ((cx->comm || early) && j == A.L && A.L >= 2) {
       // Middle bucket: the gradients of the deep half of the encoder (conv L .. conv 2L-1, their PReLUs, the
       // flatten PReLU and the dense layer - 13.8 of the encoder's 15 MB) are final once this layer's weight-gradient
@@ -2166,6 +2213,7 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
   c->device = device;
   c->rank = rank;
   c->world = world;
+  g_multi_rank = world > 1;
   DV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
