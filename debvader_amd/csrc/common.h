@@ -129,6 +129,7 @@ struct GStripParams {
   int R, patch_floats, strips_per_stamp, nstrips, strips_per_wg;   // filled by the launcher
 };
 int launch_gconv_strip(GStripParams p, bool nmajor, hipStream_t s);   // 1 = not taken (use gconv2)
+int launch_gconv_strip8(GStripParams p, hipStream_t s);               // first layer (Cin 8 -> 32, k-major); 1 = not taken
 
 // Stride-2 data-gradient form with the four parity classes fused per workgroup (gconv_s2.hip).
 // Class c = 2*[row parity has two taps] + [column parity has two taps]; neighbour e = 2*[dh == x] + [dw == x].

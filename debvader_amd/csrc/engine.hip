@@ -630,6 +630,19 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     }
     if (r <= 0) return r;
   }
+  if (Cin == 8 && Cout == 32 && s == 1 && pb == 1 && !nmajor && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
+      !single_tap && !g_force_v1 && !gs_off && !g_no_special && !fz) {
+    GStripParams g;                                  // first layer: strip form
+    memset(&g, 0, sizeof g);
+    g.X = X; g.W = W; g.U = U; g.A = Aout; g.bias = bias; g.alpha = alpha; g.zero = m->zero_page;
+    g.NB = NB; g.H = Hout; g.Wd = Hout; g.Cin = Cin; g.Cout = Cout; g.epi = epi;
+    int r;
+    {
+      ProfScope ps(m, 0);
+      r = launch_gconv_strip8(g, fwd_stream(m));
+    }
+    if (r <= 0) return r;
+  }
   if ((Cin % 32 == 0 || ((Cin == 8 || Cin == 16) && Cout <= 32 && !single_tap)) && !g_force_v1) {
     GConv2Params q;
     memset(&q, 0, sizeof q);

@@ -248,6 +248,226 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStrip
 
 #undef GS_SW
 
+// ---------------------------------------------------------------------------------------------------------
+// First-layer form: 8 input channels (6 bands + the BatchNorm "ones" channel + 1 pad, see bn_apply_kernel),
+// 32 output channels, pad 1, weights k-major W[tap][8][32] (the folded W1p of fold_bn_w1_kernel).  The layer moves
+// 256 MB at B = 256 (28 MB in, 2 x 114 MB out) against 35 us of MFMA work, so the point of the strip form is that
+// the input is read once and the stores of one strip hide behind the next: a K step is a PAIR of taps (2 x 8
+// channels = the 16 k-values of four 16x16x4 MFMAs: lanes 0-31 of a fragment read belong to the even tap, lanes
+// 32-63 to the odd one), five steps per strip, the tenth tap has zero weights.
+// LDS: patch [pixel][2 quads] (quad ^= (pixel >> 3) & 1), weights [step][n][4 quads] (quad ^= (n >> 2) & 3).
+__global__ __launch_bounds__(GS_THREADS, 4) void gconv_strip8_kernel(const GStripParams p) {
+  constexpr int CIN = 8, COUT = 32, TN = 2, NST = 5;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                                          // [2][patch_floats]
+  float* wts = smem + 2 * p.patch_floats;                       // [5][32][16]
+  float* stage = wts + NST * COUT * 16;                         // [8 waves][16][GS_LDC]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int W = p.Wd, PW = W + 2;
+  const int strip_px = p.R * W;
+
+  // weights -> LDS: element (tap t, channel c, column n) at [t >> 1][n][(t & 1) * 8 + c]
+  for (int e = tid; e < NST * COUT * 16; e += GS_THREADS) {
+    const int st = e / (COUT * 16), rem = e - st * (COUT * 16);
+    const int n = rem >> 4, k16 = rem & 15;
+    const int t = 2 * st + (k16 >> 3), c = k16 & 7;
+    const float v = t < 9 ? p.W[(t * CIN + c) * COUT + n] : 0.f;
+    wts[(st * COUT + n) * 16 + ((((k16 >> 2) ^ ((n >> 2) & 3)) << 2) | (k16 & 3))] = v;
+  }
+
+  const int ptot = (p.R + 2) * PW * 2;             // 16-byte slots of one patch
+  const int ngp = (ptot + 63) / 64;
+  int prel[2], prow[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = 64 * (wave + GS_WAVES * k) + lane;
+    const int L = e >> 1, sl = e & 1;
+    const int pr = L / PW, pc = L - pr * PW;
+    const int gc = pc - 1;
+    const bool ok = e < ptot && (unsigned)gc < (unsigned)W;
+    prel[k] = ((pr - 1) * W + gc) * CIN + ((sl ^ ((L >> 3) & 1)) << 2);
+    prow[k] = ok ? pr - 1 : -100000;
+  }
+  auto issue_dma = [&](int sidx, int buf) {
+    const int n = sidx / p.strips_per_stamp;
+    const int i0 = (sidx - n * p.strips_per_stamp) * p.R;
+    const int base = (n * p.H + i0) * W * CIN;
+    float* dst = patch + buf * p.patch_floats;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int g = wave + GS_WAVES * k;
+      if (g < ngp) {
+        const bool ok = (unsigned)(i0 + prow[k]) < (unsigned)p.H;
+        const float* src = ok ? p.X + (unsigned)(base + prel[k]) : p.zero;
+        __builtin_amdgcn_global_load_lds((gs_gptr_t)src, (gs_lptr_t)(dst + g * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  // per-lane fragment addressing: patch pixel of (M block, tap pair step); the lane's tap is 2 * step + (lg >> 1)
+  int Lf[2][NST];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    int px = wave * 32 + mb * 16 + l15;
+    if (px >= strip_px) px = 0;                     // computed, never stored
+    const int pr = px / W, pc = px - pr * W;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int t = min(2 * st + (lg >> 1), 8);     // tap 9: zero weights, any valid address
+      Lf[mb][st] = (pr + t / 3) * PW + pc + t % 3;
+    }
+  }
+  int boff[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = tn * 16 + l15;
+    boff[tn] = n * 16 + ((lg ^ ((n >> 2) & 3)) << 2);
+  }
+
+  const int s_begin = blockIdx.x * p.strips_per_wg;
+  const int s_end = min(p.nstrips, s_begin + p.strips_per_wg);
+  if (s_begin < s_end) issue_dma(s_begin, 0);
+  int buf = 0;
+  float* stg = stage + wave * (16 * GS_LDC);
+  constexpr int F4 = COUT / 4, ROWS_IT = 64 / F4, NIT = 16 / ROWS_IT;
+  const int ecol = (lane % F4) * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.epi >= 1) bias4 = *reinterpret_cast<const f32x4*>(p.bias + ecol);
+  f32x4 alr[2][NIT];
+  auto prefetch_alpha = [&](int i0) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int px = wave * 32 + mb * 16 + lane / F4 + it * ROWS_IT;
+        const int pr = px / W, pc = px - pr * W;
+        const bool ok = px < strip_px && i0 + pr < p.H;
+        alr[mb][it] = *reinterpret_cast<const f32x4*>(p.alpha + (ok ? (unsigned)(((i0 + pr) * W + pc) * COUT + ecol) : 0u));
+      }
+  };
+  auto epi_half = [&](const f32x4 (&ac)[2][TN], int mb, int n, int i0) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stg[(lg * 4 + r) * GS_LDC + tn * 16 + l15] = ac[mb][tn][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): wave-private region
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int rr = lane / F4 + it * ROWS_IT;
+      const int px = wave * 32 + mb * 16 + rr;
+      const int pr = px / W, pc = px - pr * W;
+      if (px >= strip_px || i0 + pr >= p.H) continue;
+      const unsigned ooff = (unsigned)(n * p.H * W * COUT) + (unsigned)(((i0 + pr) * W + pc) * COUT + ecol);
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * GS_LDC + ecol);
+      v += bias4;
+      if (p.U) *reinterpret_cast<f32x4*>(p.U + ooff) = v;
+      if (p.epi == 2) {
+        const f32x4 al = alr[mb][it];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = v[k] > 0.f ? v[k] : al[k] * v[k];
+        *reinterpret_cast<f32x4*>(p.A + ooff) = o;
+      } else if (p.A) {
+        *reinterpret_cast<f32x4*>(p.A + ooff) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  f32x4 pacc[2][TN];
+  int pn = 0, pi0 = 0;
+  bool have_prev = false;
+  for (int sidx = s_begin; sidx < s_end; ++sidx) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): this wave's DMA pieces (see wgrad_strip8_kernel)
+    __syncthreads();
+    if (sidx + 1 < s_end) issue_dma(sidx + 1, buf ^ 1);
+    if (have_prev && p.epi == 2) prefetch_alpha(pi0);
+    const float* P = patch + buf * p.patch_floats;
+    f32x4 acc[2][TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragments of step st + 1 are read while the MFMAs of step st run (two register sets)
+    auto load_frags = [&](int st, f32x4 (&af)[2], f32x4 (&bf)[TN]) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const int L = Lf[mb][st];
+        af[mb] = *reinterpret_cast<const f32x4*>(P + L * CIN + (((lg & 1) ^ ((L >> 3) & 1)) << 2));
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<const f32x4*>(wts + st * COUT * 16 + boff[tn]);
+    };
+    auto mfma_step = [&](const f32x4 (&af)[2], const f32x4 (&bf)[TN]) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[mb][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb][jj], bf[tn][jj], acc[mb][tn], 0, 0, 0);
+    };
+    f32x4 a0[2], b0[TN], a1[2], b1[TN];
+    load_frags(0, a0, b0);
+    load_frags(1, a1, b1);
+    mfma_step(a0, b0);                               // step 0
+    load_frags(2, a0, b0);
+    mfma_step(a1, b1);                               // step 1
+    if (have_prev) epi_half(pacc, 0, pn, pi0);       // the previous strip's epilogue between the MFMA groups
+    load_frags(3, a1, b1);
+    mfma_step(a0, b0);                               // step 2
+    load_frags(4, a0, b0);
+    mfma_step(a1, b1);                               // step 3
+    if (have_prev) epi_half(pacc, 1, pn, pi0);
+    mfma_step(a0, b0);                               // step 4
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < TN; ++b2) pacc[a][b2] = acc[a][b2];
+    pn = sidx / p.strips_per_stamp;
+    pi0 = (sidx - pn * p.strips_per_stamp) * p.R;
+    have_prev = true;
+    buf ^= 1;
+  }
+  if (have_prev) {
+    if (p.epi == 2) prefetch_alpha(pi0);
+    epi_half(pacc, 0, pn, pi0);
+    epi_half(pacc, 1, pn, pi0);
+  }
+}
+
+// Returns 1 when the layer is not the first-layer shape (the caller then uses gconv2).
+int launch_gconv_strip8(GStripParams p, hipStream_t s) {
+  static const bool off = getenv("DV_NO_GSTRIP8") != nullptr;
+  if (off || p.Cin != 8 || p.Cout != 32 || !p.zero || p.Wd < 8 || p.Wd > 64 || p.H < 1 || p.epi < 0 || p.epi > 2) return 1;
+  if (p.epi == 2 && (!p.alpha || !p.A)) return 1;
+  if ((long)p.NB * p.H * p.Wd * 32 >= (1L << 30)) return 1;
+  int R = 256 / p.Wd;
+  if (R > p.H) R = p.H;
+  const int PW = p.Wd + 2;
+  const int slots = (R + 2) * PW * 2;
+  if ((slots + 63) / 64 > 2 * GS_WAVES) return 1;
+  p.R = R;
+  p.patch_floats = ((slots + 63) / 64) * 256;
+  p.strips_per_stamp = (p.H + R - 1) / R;
+  p.nstrips = p.NB * p.strips_per_stamp;
+  // bandwidth-bound: two workgroups per CU keep stores of one strip and the DMA of the next in flight
+  static const int target = getenv("DV_GSTRIP8_WGS") ? atoi(getenv("DV_GSTRIP8_WGS")) : 512;
+  p.strips_per_wg = (p.nstrips + target - 1) / target;
+  const int grid = (p.nstrips + p.strips_per_wg - 1) / p.strips_per_wg;
+  const size_t smem = ((size_t)2 * p.patch_floats + (size_t)5 * 32 * 16 + (size_t)GS_WAVES * 16 * GS_LDC) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gconv_strip8_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gconv_strip8_kernel, dim3(grid), dim3(GS_THREADS), smem, s, p);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
 template <int CIN, int COUT, bool NMAJOR>
 static int launch_gs(const GStripParams& p, int grid, size_t smem, hipStream_t s) {
   static bool attr_set = false;
