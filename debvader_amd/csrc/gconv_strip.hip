@@ -369,8 +369,6 @@ __global__ __launch_bounds__(GS_THREADS, 4) void gconv_strip8_kernel(const GStri
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = v[k] > 0.f ? v[k] : al[k] * v[k];
         *reinterpret_cast<f32x4*>(p.A + ooff) = o;
-      } else if (p.A) {
-        *reinterpret_cast<f32x4*>(p.A + ooff) = v;
       }
     }
     __builtin_amdgcn_wave_barrier();

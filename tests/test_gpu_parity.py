@@ -224,7 +224,7 @@ def test_bad_arguments_fail_loudly():
 
 
 def test_specialised_kernels_match_the_general_gather_gemm():
-    """gconv_strip (stride-1, <= 32 channels, W <= 64) and gconv_s2 (fused stride-2 classes) against gconv2 on the
+    """gconv_strip / gconv_strip8 (stride-1, <= 32 channels, W <= 64) and gconv_s2 (fused stride-2 classes) against gconv2 on the
     same random operands, including image sizes that are not multiples of the strip / tile geometry, both weight
     layouts and every epilogue.  fp32 sums in a different order: 2e-5 of the largest output."""
     import ctypes as C
@@ -240,6 +240,10 @@ def test_specialised_kernels_match_the_general_gather_gemm():
                     continue
                 for epi in (0, 1, 2):
                     cases.append((3, H, cs, H, ct, 1, 1, dgrad, nmajor, epi))
+    # first-layer strip form (8 physical input channels, k-major weights, forward only)
+    for H in (64, 59, 33, 9):
+        for epi in (0, 1, 2):
+            cases.append((3, H, 8, H, 32, 1, 1, 0, 0, epi))
     # fused stride-2 form: Conv2DTranspose forward (out = 2 in, pad 0) and Conv2D data gradient (odd sizes, pad 0 / 1)
     for (hs, cs, ht, ct, pb) in ((8, 64, 16, 32, 0), (16, 128, 32, 64, 0), (30, 32, 59, 32, 1), (15, 64, 30, 64, 0),
                                  (4, 256, 8, 256, 0)):
