@@ -253,6 +253,7 @@ struct SamplerParams {
   unsigned stream;
   unsigned row0;
   int rep_nb;          // > 0: row r is Monte-Carlo sample r / rep_nb of stamp r % rep_nb (seed + sample, t row of the stamp)
+  const unsigned long long* seed_ptr;   // non-null: the seed is read from device memory (replayed hipGraphs)
 };
 int launch_sampler_fwd(const SamplerParams& p, hipStream_t s);
 int launch_sampler_bwd(const float* t, const float* eps, const float* z, const float* dz, float* dt, int NB, int d,

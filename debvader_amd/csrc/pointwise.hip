@@ -552,7 +552,8 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
   const int tw = d + d * (d + 1) / 2;
   // Monte-Carlo replication (dv_infer_mc): row b is sample b / rep_nb of stamp b % rep_nb
   const int bs = p.rep_nb > 0 ? b % p.rep_nb : b;
-  const unsigned long long seed = p.seed + (p.rep_nb > 0 ? (unsigned long long)(b / p.rep_nb) : 0ull);
+  const unsigned long long seed =
+      (p.seed_ptr ? *p.seed_ptr : p.seed) + (p.rep_nb > 0 ? (unsigned long long)(b / p.rep_nb) : 0ull);
   const float* t = p.t + (size_t)bs * tw;
   // the row of t goes through LDS (coalesced): the lower-triangle gather below would otherwise be a chain of
   // d dependent, divergent global loads per stamp (31 us per step at d = 32)

@@ -139,6 +139,12 @@ int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t 
  * dv_infer_mc apply tanh(arcsinh(x)) to the staged stamps on the GPU and the inverse, sinh(arctanh(.)), to the
  * predicted mean (the scale stays in normalised units) */
 int dv_model_set_normalise(dv_model* m, int32_t on);
+
+/* Replay a captured hipGraph for the forward pass of small inference batches (< 64 stamps, one chunk, engine-drawn
+ * noise) instead of launching its ~45 kernels one by one: BASELINE configs[4] "hipGraph-captured decode" /
+ * SURVEY row A10.  Off by default: on MI355X the replay takes exactly as long as the eager launches (the chain is
+ * bound by dispatch latency on the GPU, not by host submission).  Same results either way. */
+int dv_model_set_infer_graph(dv_model* m, int32_t on);
 /* x[N,H,W,C] host.  Outputs (any may be NULL): loc/scale [N,H,W,C] = distribution mean / stddev;
  * mu [N,latent], zstd [N,latent] = z.mean()/z.stddev(); z [N,latent] = the sample fed to the decoder. */
 int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,

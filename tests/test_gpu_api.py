@@ -347,3 +347,24 @@ def test_monte_carlo_sample_batching_is_invisible():
         np.testing.assert_array_equal(mean, outs[0][0])
         np.testing.assert_array_equal(std, outs[0][1])
     assert (outs[0][1] > 0).any()
+
+
+def test_graph_replayed_small_batch_inference_equals_eager_launches():
+    """BASELINE configs[4] "hipGraph-captured decode": the forward of a small batch replayed from a captured graph
+    (third call onwards) returns what the eager launches return for the same seed, and the seed - read from device
+    memory by the replayed sampler - still changes the noise."""
+    from debvader_amd import engine as E
+
+    x, _ = _data(5, 21)
+    eng = E.Engine(E.make_config(max_batch=64))
+    eng.init(seed=2)
+    eager = [eng.infer(x, seed=s, want=("loc", "scale", "z")) for s in (7, 8)]
+    eng.set_infer_graph(True)
+    for s in (1, 2):                       # eager warm-up of this size, then the capture
+        eng.infer(x, seed=s, want=("loc", "scale", "z"))
+    replay = [eng.infer(x, seed=s, want=("loc", "scale", "z")) for s in (7, 8)]
+    for a, b in zip(eager, replay):
+        for k in ("loc", "scale", "z"):
+            np.testing.assert_array_equal(a[k], b[k])
+    assert np.abs(replay[0]["z"] - replay[1]["z"]).max() > 0
+    eng.close()

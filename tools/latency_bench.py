@@ -8,7 +8,8 @@ from debvader_amd.data import synthetic_stamps
 net, _, _, _ = model.create_model_vae((59, 59, 6), 32, [32, 64, 128, 256], [3, 3, 3, 3], max_batch=256)
 x, _ = synthetic_stamps(256, seed=1)
 for n in (1, 8, 32, 64, 128, 256):
-    deblend(net, x[:n])
+    for _ in range(3):
+        deblend(net, x[:n])
     t0 = time.perf_counter()
     for _ in range(20):
         deblend(net, x[:n])
