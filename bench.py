@@ -142,8 +142,8 @@ def main():
             "wgrad_kernel": (1.0 * fwd_flops * B, ms_w / args.steps, n_w // args.steps),
         }
         traffic = None
-        try:    # HBM bytes per step of the family from the committed PMC passes (profiles/r01_pmc_traffic_v9.json)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v9.json")) as fh:
+        try:    # HBM bytes per step of the family from the committed PMC passes (profiles/r01_pmc_traffic_v13.json)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v13.json")) as fh:
                 pmc = json.load(fh)["per_step_bytes"]
             traffic = {"gconv_kernel": next(v for k, v in pmc.items() if k.startswith("gconv"))["hbm_bytes"],
                        "wgrad_kernel": next(v for k, v in pmc.items() if k.startswith("wgrad"))["hbm_bytes"]}
