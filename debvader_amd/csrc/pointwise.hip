@@ -580,16 +580,18 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
       e = p.eps[(size_t)b * d + lane];
     }
   }
-  float z = 0.f, logd = 0.f, l2 = 0.f;
-  if (lane < d) z = st[lane];
+  float z = 0.f, logd = 0.f, l2 = 0.f, ldiag = 0.f;
+  if (lane < d) {
+    z = st[lane];
+    // the diagonal's softplus / log once per lane, outside the row loop (inside it the divergent branch made every
+    // iteration pay for the transcendental sequence of one lane: 33 -> 12 us per half batch)
+    ldiag = softplus_f(st[d + tril_src(d, lane, lane)]) + p.diag_shift;
+    logd = logf(ldiag);
+  }
   for (int j = 0; j < d; ++j) {
     const float ej = __shfl(e, j, 64);
     if (lane < d && j <= lane) {
-      float l = st[d + tril_src(d, lane, j)];
-      if (j == lane) {
-        l = softplus_f(l) + p.diag_shift;
-        logd = logf(l);
-      }
+      const float l = j == lane ? ldiag : st[d + tril_src(d, lane, j)];
       z += l * ej;
       l2 += l * l;
     }
@@ -635,16 +637,17 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
     raw = tb[d + tril_src(d, lane, lane)];
     st[lane] = g;
   }
+  float ldiag = 1.f, sg = 0.f;
+  if (lane < d) {                                    // diagonal terms once per lane (see sampler_fwd_kernel)
+    ldiag = softplus_f(raw) + diag_shift;
+    sg = 1.0f / (1.0f + expf(-raw));
+  }
   for (int j = 0; j < d; ++j) {
     const float ej = __shfl(e, j, 64);
     if (lane < d && j <= lane) {
       const int src = d + tril_src(d, lane, j);
       float v = g * ej;
-      if (j == lane) {
-        const float l = softplus_f(raw) + diag_shift;
-        const float sg = 1.0f / (1.0f + expf(-raw));
-        v = (v - kls / l) * sg;
-      }
+      if (j == lane) v = (v - kls / ldiag) * sg;
       st[src] = v;
     }
   }
