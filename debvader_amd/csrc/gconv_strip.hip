@@ -49,7 +49,8 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStrip
   float* wts = smem + 2 * p.patch_floats;                       // [9][COUT][32]
   float* stage = wts + 9 * COUT * CIN;                          // [8 waves][16][GS_LDC]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations (M0) and piece guards stay on the scalar unit
   const int l15 = lane & 15, lg = lane >> 4;
   const int W = p.Wd, PW = W + 2;
   const int strip_px = p.R * W;
@@ -262,7 +263,8 @@ __global__ __launch_bounds__(GS_THREADS, 4) void gconv_strip8_kernel(const GStri
   float* patch = smem;                                          // [2][patch_floats]
   float* wts = smem + 2 * p.patch_floats;                       // [5][32][16]
   float* stage = wts + NST * COUT * 16;                         // [8 waves][16][GS_LDC]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations (M0) and piece guards stay on the scalar unit
   const int l15 = lane & 15, lg = lane >> 4;
   const int W = p.Wd, PW = W + 2;
   const int strip_px = p.R * W;

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_strip_kernel(const WStripParams 
   const int XC = (p.Wy - 1) * SX + 3;
   const int buf_floats = p.xs_floats + p.ys_floats;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations (M0) and piece guards stay on the scalar unit
   const int wk = wave % WKS, wn = (wave / WKS) % WNS, wm = wave / (WKS * WNS);
   const int l15 = lane & 15, lg = lane >> 4;
 
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_strip_kernel(const WStripParams 
   unsigned long long tb = 0, td = 0, tc = 0, tmark = 0;   // dbg 4: cycles in barrier / DMA issue / compute
   for (int sidx = s_begin; sidx < s_end; ++sidx) {
     if ((p.dbg & 4)) tmark = __builtin_amdgcn_s_memtime();
-    // the barrier's vmcnt(0) retires this strip's DMA pieces of every wave; it also fences the previous strip's
-    // LDS reads, so the other buffer may be refilled right behind it
+    // vmcnt(0) + barrier retire this strip's DMA pieces of every wave (spelled out: see wgrad_strip8_kernel); the
+    // barrier also fences the previous strip's LDS reads, so the other buffer may be refilled right behind it
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     if ((p.dbg & 4)) {
       unsigned long long t = __builtin_amdgcn_s_memtime();
