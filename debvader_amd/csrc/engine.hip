@@ -400,6 +400,7 @@ struct dv_model {
   unsigned long long* seed_dev = nullptr;
   bool use_seed_dev = false;
   bool infer_graph = false;
+  bool keep_outputs = false;     // gradient / train steps also write loc and scale (introspection)
   std::map<int, hipGraphExec_t> infer_graphs;
   std::map<int, int> infer_seen;
   bool normalise = false;        // dv_model_set_normalise: tanh(arcsinh) on inference inputs, inverse on the mean
@@ -1278,11 +1279,10 @@ static int sampler_forward(dv_model* m, int NB, bool gen, uint64_t seed, unsigne
 }
 
 // head of the lane: per-block loss partials at part_off (blocks), optionally d(loss)/d(tpre) into gA
-static int head_lane(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
-                     bool want_out, int part_block0, int* nblk) {
+static void head_params(dv_model* m, HeadParams& hp, const float* ysrc, const int* idx, int first, int NB, int Bg,
+                        bool want_grad, bool want_out, int part_block0) {
   const Arch& A = m->A;
   const size_t head_e = (size_t)A.dec_out * A.dec_out * A.C2p, stamp = (size_t)A.H * A.H * A.C;
-  HeadParams hp;
   memset(&hp, 0, sizeof hp);
   hp.tpre = LANE(m->tpre, head_e);
   hp.y = ysrc;
@@ -1300,6 +1300,12 @@ static int head_lane(dv_model* m, const float* ysrc, const int* idx, int first, 
   hp.ld = A.C2p;
   hp.sigma_floor = A.cfg.sigma_floor;
   hp.gscale = (float)(1.0 / ((double)Bg * A.H * A.H * A.C));
+}
+
+static int head_lane(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
+                     bool want_out, int part_block0, int* nblk) {
+  HeadParams hp;
+  head_params(m, hp, ysrc, idx, first, NB, Bg, want_grad, want_out, part_block0);
   ProfScope ps(m, 2);
   return launch_head(hp, fwd_stream(m), nblk);
 }
@@ -1765,8 +1771,10 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   const bool bwd = mode != MODE_EVAL;
   m->lastB = B;
   // Philox stream: one counter row per (rank-local) stamp; ranks are separated through the stream id
+  // loc / scale of a gradient or train step are only written on request (dv_model_set_keep_outputs: the parity
+  // tests read them back) - 42 MB of stores per 256-stamp step that training has no reader for
   DV_TRY(forward_all(m, ds.x, ds.y, idx, (int)first, B, Bg, training, mode == MODE_TRAIN, bwd, eps_host, seed,
-                     (unsigned)m->ctx->rank, 0u, false, bwd, true));
+                     (unsigned)m->ctx->rank, 0u, false, bwd, !bwd || m->keep_outputs));
   // the loss sums are only read after the step: with a backward pass the main stream joins the comm stream behind
   // the last gradient bucket anyway, so it does not stop here for this latency-bound collective
   DV_TRY(allreduce_small(m->ctx, m->scal, 4, !bwd));
@@ -2860,6 +2868,12 @@ static int infer_entry(dv_model* m, const void* x, bool x_f64, int64_t N, const 
     m->lastB = nb;
   }
   return prof_flush(m);
+}
+
+int dv_model_set_keep_outputs(dv_model* m, int32_t on) {
+  if (!m) return DV_E_INVALID;
+  m->keep_outputs = on != 0;
+  return DV_OK;
 }
 
 int dv_model_set_infer_graph(dv_model* m, int32_t on) {

@@ -309,6 +309,11 @@ class Engine:
         """tanh(arcsinh) on inference inputs and the inverse on the predicted mean, on the GPU (deblend(normalise=True))."""
         check(lib.dv_model_set_normalise(self._h, 1 if on else 0))
 
+    def keep_outputs(self, on: bool):
+        """Gradient / train steps also write loc and scale of their forward pass (activation("loc"), activation("scale"));
+        off by default - a train step has no reader for them."""
+        check(lib.dv_model_set_keep_outputs(self._h, 1 if on else 0))
+
     def set_infer_graph(self, on: bool):
         """Replay a captured hipGraph for the forward pass of small inference batches (< 64 stamps).  Same results;
         measured no faster than the eager launches on MI355X, hence off by default."""

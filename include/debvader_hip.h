@@ -145,6 +145,11 @@ int dv_model_set_normalise(dv_model* m, int32_t on);
  * SURVEY row A10.  Off by default: on MI355X the replay takes exactly as long as the eager launches (the chain is
  * bound by dispatch latency on the GPU, not by host submission).  Same results either way. */
 int dv_model_set_infer_graph(dv_model* m, int32_t on);
+
+/* Gradient / train steps also write the output distribution (loc, scale) of their forward pass, for
+ * dv_model_get_activation("loc" / "scale") - what the parity tests compare with the oracle.  Off by default: the
+ * train step of the reference (train.py:27) has no reader for them (42 MB of stores per 256-stamp step). */
+int dv_model_set_keep_outputs(dv_model* m, int32_t on);
 /* x[N,H,W,C] host.  Outputs (any may be NULL): loc/scale [N,H,W,C] = distribution mean / stddev;
  * mu [N,latent], zstd [N,latent] = z.mean()/z.stddev(); z [N,latent] = the sample fed to the decoder. */
 int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,

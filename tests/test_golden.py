@@ -61,6 +61,10 @@ def test_engine_reproduces_golden_on_real_dc2_stamps():
     eng.set_params(p)
     eng.optimizer_reset(1e-4)
     eng.upload(0, z["x"], z["y"])
+    outf = eng.grad_step(0, first=0, B=4, eps=z["eps"])       # production form: the head kernel writes no loc / scale
+    for i, k in enumerate(("loss", "nll_mean", "kl_reg", "mse")):
+        assert abs(outf[k] - z["loss"][i]) <= 1e-4 * abs(z["loss"][i]), (k, outf[k], z["loss"][i])
+    eng.keep_outputs(True)                                   # loc / scale are read back below
     out = eng.grad_step(0, first=0, B=4, eps=z["eps"])
     rel = lambda a, b: np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-30)
     assert rel(eng.activation("t", (4, 560)), z["t"]) <= 2e-4

@@ -58,6 +58,7 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True):
     ref = vo.losses(arch, c, y64)
     g = vo.backward(arch, p, c, y64, train_decoder=train_decoder)
 
+    eng.keep_outputs(True)          # loc / scale of the step are compared below
     out = eng.grad_step(0, first=0, B=B, eps=eps)
     d = arch.latent_dim
     H, W, C = arch.input_shape
@@ -80,6 +81,17 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True):
         if e > worst[1]:
             worst = (name, e)
         assert e <= 1e-3, (name, e)
+
+    # the production form of the step: no loc / scale stores in the head kernel
+    eng.keep_outputs(False)
+    outf = eng.grad_step(0, first=0, B=B, eps=eps)
+    for k in ("loss", "nll_mean", "kl_reg", "mse"):
+        assert abs(outf[k] - ref[k]) <= 1e-4 * abs(ref[k]) + 1e-12, (k, outf[k], ref[k])
+    for name in g:
+        e = _relmax(eng.get_grad(name), g[name])
+        assert e <= 1e-3, ("without outputs", name, e)
+    eng.keep_outputs(True)
+    eng.grad_step(0, first=0, B=B, eps=eps)          # gradients of the form the train step below repeats
 
     # one full training step: Adam update + BN moving statistics.  The first Adam step moves every weight by
     # ~lr*sign(g), so weights whose gradient is at rounding level may legitimately differ by 2*lr from the
