@@ -16,3 +16,5 @@ t0 = time.perf_counter(); h = net.fit(x, y, epochs=1, batch_size=B, verbose=0); 
 print(f"net.fit: {NB} steps of {B} in {dt*1e3:.1f} ms = {B*NB/dt:.0f} stamps/s (includes the one-off upload of {x.nbytes*2/1e9:.2f} GB); loss {h.history['loss'][-1]:.4f}")
 t0 = time.perf_counter(); h = net.fit(x, y, epochs=2, batch_size=B, verbose=0); dt = time.perf_counter() - t0
 print(f"net.fit 2 epochs: {2*B*NB/dt:.0f} stamps/s")
+t0 = time.perf_counter(); h = net.fit(x, y, epochs=8, batch_size=B, verbose=0); dt = time.perf_counter() - t0
+print(f"net.fit 8 epochs: {8*B*NB/dt:.0f} stamps/s")
