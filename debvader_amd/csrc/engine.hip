@@ -372,6 +372,9 @@ struct dv_model {
   size_t bn_pre_part_elems = 0;
   bool bn_pre_valid = false;
   const float* bn_pre_x = nullptr;
+  const int* bn_pre_idx = nullptr;   // device index vector the prefetched sums belong to (null: contiguous rows)
+  int* idx_slots = nullptr;          // [4][Bc] device index vectors of queued train steps (filled on the comm stream)
+  unsigned idx_slot_next = 0;
   int64_t bn_pre_first = -1, hint_next_first = -1;
   int bn_pre_B = 0;
   hipEvent_t ev_bnpre = nullptr, ev_bnpre_go = nullptr;
@@ -1171,7 +1174,8 @@ static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first,
   float* P = m->P;
   const float* sums = m->bnsums;
   if (training) {
-    if (m->bn_pre_valid && !idx && xsrc == m->bn_pre_x && first == m->bn_pre_first && NB == m->bn_pre_B && !m->prof_on) {
+    if (m->bn_pre_valid && idx == m->bn_pre_idx && xsrc == m->bn_pre_x && first == m->bn_pre_first &&
+        NB == m->bn_pre_B && !m->prof_on) {
       // the batch sums (they depend on the data only) were computed and all-reduced on the comm stream during the
       // previous step: no reduction kernels and no latency-bound collective at the head of this step
       DV_HIP(hipStreamWaitEvent(s, m->ev_bnpre, 0));
@@ -1185,10 +1189,15 @@ static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first,
     }
     m->bn_pre_valid = false;
   }
-  ProfScope ps(m, 2, s);
-  return launch_bn_finalize(sums, (float)((double)Bg * HW), A.C, P + A.specs[0].off, P + A.specs[1].off,
-                            P + A.specs[2].off, P + A.specs[3].off, A.cfg.bn_eps, A.cfg.bn_momentum,
-                            A.cfg.bn_moving_var_unbiased, training ? 1 : 0, upd_moving ? 1 : 0, m->bnstate, s);
+  {
+    ProfScope ps(m, 2, s);
+    DV_TRY(launch_bn_finalize(sums, (float)((double)Bg * HW), A.C, P + A.specs[0].off, P + A.specs[1].off,
+                              P + A.specs[2].off, P + A.specs[3].off, A.cfg.bn_eps, A.cfg.bn_momentum,
+                              A.cfg.bn_moving_var_unbiased, training ? 1 : 0, upd_moving ? 1 : 0, m->bnstate, s));
+  }
+  // the prefetched sums have been consumed: the comm stream may compute the next batch's into the same buffer
+  if (sums == m->bn_pre_sums) DV_HIP(hipEventRecord(m->ev_bnpre_go, s));
+  return OK;
 }
 
 // encoder: dataset rows (idx / first) of the lane -> t
@@ -1733,16 +1742,21 @@ static int check_step_args(dv_model* m, int slot, const int32_t* idx, int64_t fi
 
 // Batch sums of the input BatchNorm for the step that will read rows [first, first + NB) of `x`: queued on the comm
 // stream (idle between the collectives), all-reduced there, consumed by bn_prepare() of that step.
-static int bn_prefetch(dv_model* m, const float* x, int64_t first, int NB) {
+// Batch sums of the input BatchNorm for a batch that is about to be (idx_host != null: the step being queued, whose
+// index vector is copied to idx_dev on the comm stream first) or will next be (contiguous rows from `first`) trained
+// on, computed on the comm stream while the previous step still runs.
+static int bn_prefetch(dv_model* m, const float* x, int64_t first, int NB, int* idx_dev = nullptr,
+                       const int32_t* idx_host = nullptr) {
   const Arch& A = m->A;
   dv_ctx* c = m->ctx;
   if (!m->bn_pre_part || !c->comm_stream) return OK;
   const int HW = A.H * A.H;
   int nblk = 0;
-  // the previous consumer of bn_pre_sums (bn_finalize of the current step) is already queued on the main stream
-  DV_HIP(hipEventRecord(m->ev_bnpre_go, c->stream));
+  // the previous consumer of bn_pre_sums (the bn_finalize of the step that used them) recorded ev_bnpre_go behind it
   DV_HIP(hipStreamWaitEvent(c->comm_stream, m->ev_bnpre_go, 0));
-  DV_TRY(launch_bn_stats(x, nullptr, (int)first, NB, HW, A.C, m->bn_pre_part, &nblk, c->comm_stream));
+  if (idx_host)
+    DV_HIP(hipMemcpyAsync(idx_dev, idx_host, (size_t)NB * sizeof(int), hipMemcpyHostToDevice, c->comm_stream));
+  DV_TRY(launch_bn_stats(x, idx_dev, (int)first, NB, HW, A.C, m->bn_pre_part, &nblk, c->comm_stream));
   if ((size_t)nblk * 16 > m->bn_pre_part_elems) {
     set_error("bn prefetch workspace too small");
     return E_STATE;
@@ -1752,6 +1766,7 @@ static int bn_prefetch(dv_model* m, const float* x, int64_t first, int NB) {
   DV_HIP(hipEventRecord(m->ev_bnpre, c->comm_stream));
   m->bn_pre_valid = true;
   m->bn_pre_x = x;
+  m->bn_pre_idx = idx_dev;
   m->bn_pre_first = first;
   m->bn_pre_B = NB;
   return OK;
@@ -1764,8 +1779,19 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   const DataSlot& ds = m->slots[slot];
   const int* idx = nullptr;
   if (idx_host) {
-    DV_HIP(hipMemcpyAsync(m->idx_dev, idx_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
-    idx = m->idx_dev;
+    static const bool no_idx_pre = getenv("DV_NO_IDX_PREFETCH") != nullptr;
+    if (mode == MODE_TRAIN && !no_idx_pre && !m->prof_on && m->idx_slots && m->bn_pre_part && m->ctx->comm_stream &&
+        m->overlap_wgrad) {
+      // shuffled batches (fit): index vector and BN batch sums of THIS step go through the comm stream, which the
+      // host reaches while the previous step is still running (steps are queued two ahead) - the forward pass below
+      // then starts with bn_finalize instead of a statistics pass over the batch
+      int* slotp = m->idx_slots + (size_t)(m->idx_slot_next++ & 3) * m->Bc;
+      DV_TRY(bn_prefetch(m, ds.x, first, B, slotp, idx_host));
+      idx = slotp;
+    } else {
+      DV_HIP(hipMemcpyAsync(m->idx_dev, idx_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+      idx = m->idx_dev;
+    }
   }
   const bool training = mode != MODE_EVAL;
   const bool bwd = mode != MODE_EVAL;
@@ -2514,6 +2540,11 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
     if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
     m->allocs.push_back(q);
     m->idx_dev = (int*)q;
+    q = nullptr;
+    e = hipMalloc(&q, (size_t)4 * Bc * sizeof(int));
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+    m->allocs.push_back(q);
+    m->idx_slots = (int*)q;
   }
 #undef ALLOC
   hipStream_t s = ctx->stream;
