@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <string>
@@ -2239,11 +2240,34 @@ int dv_device_count(int32_t* n) {
   return DV_OK;
 }
 
+// RCCL prints a five-line version banner on STDOUT when it initialises.  A process's stdout belongs to its caller
+// (bench.py's contract is one JSON line there), so file descriptor 1 points at stderr while RCCL starts up.
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() {
+    fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0 && dup2(2, 1) < 0) {
+      close(saved);
+      saved = -1;
+    }
+  }
+  ~StdoutToStderr() {
+    if (saved < 0) return;
+    fflush(stdout);
+    (void)dup2(saved, 1);
+    close(saved);
+  }
+};
+
 int dv_comm_unique_id(void* out_id) {
   if (!out_id) return DV_E_INVALID;
   static_assert(sizeof(ncclUniqueId) <= DV_UNIQUE_ID_BYTES, "unique id size");
   ncclUniqueId id;
-  DV_NCCL(ncclGetUniqueId(&id));
+  {
+    StdoutToStderr quiet;
+    DV_NCCL(ncclGetUniqueId(&id));
+  }
   memset(out_id, 0, DV_UNIQUE_ID_BYTES);
   memcpy(out_id, &id, sizeof id);
   return DV_OK;
@@ -2298,6 +2322,7 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
     // test hook: a one-rank communicator, so that the collective code paths (streams, events, in-place all-reduces)
     // run on a single-GPU box; results must equal the communicator-free path bit for bit
     ncclUniqueId id;
+    StdoutToStderr quiet;
     DV_NCCL(ncclGetUniqueId(&id));
     DV_NCCL(ncclCommInitRank(&c->comm, 1, id, 0));
   }
@@ -2309,6 +2334,7 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
     }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
+    StdoutToStderr quiet;
     DV_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
   }
   *out = c;
