@@ -26,7 +26,11 @@ class DvConfig(C.Structure):
         ("kl_weight", C.c_float), ("kl_multiplicity", C.c_int32),
         ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("bn_moving_var_unbiased", C.c_int32),
         ("sigma_floor", C.c_float), ("diag_shift", C.c_float),
+        ("dtype", C.c_int32),
     ]
+
+
+DV_DTYPE_F32, DV_DTYPE_BF16 = 0, 1
 
 
 class DvError(RuntimeError):

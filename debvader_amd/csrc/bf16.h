@@ -1,0 +1,102 @@
+// bf16 kernel family of the debvader_amd engine (gfx950 / MI355X only): BASELINE configs[2].
+//
+// Activations of the conv / conv-transpose stacks (model.py:79-98,112-137) are stored in bf16, STAMP-INNER:
+// a tensor is [H][W][NBp][C] (NBp = stamps per step padded to a multiple of 16), so that "the same pixel of 16
+// consecutive stamps" is one contiguous [16][C] block.  Every contraction then has a tap validity that is uniform
+// over a 16-row MFMA block (no row tables, no zero-padding MACs), one 1-KiB LDS-DMA instruction moves one
+// (16 stamps x 32 channels) operand block, and the batch reductions of the PReLU backward (d(alpha) over stamps)
+// are sums over the rows of an accumulator tile.  MFMA: v_mfma_f32_16x16x32_bf16, fp32 accumulation.
+// fp32 stay: master weights / Adam, the dense trunk + sampler (SURVEY hard part 4), the head conv output and the
+// relu / crop / Normal-NLL head.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace dv {
+
+enum { BEPI_RAW32 = 0, BEPI_FWD = 1, BEPI_RAWBF = 2, BEPI_BWD = 3 };
+
+// Gather-GEMM over stamp-inner tensors: out[pix][b][n] = sum_{tap,c} X[src(pix,tap)][b][c] * W[n][tap*Cin + c]
+//   form 0 (Conv2D forward, Conv2DTranspose data gradient): source pixel = out*s + k - pb
+//   form 1 (Conv2DTranspose forward, Conv2D data gradient): out + pb = s*source + k
+struct BConvParams {
+  const void* X;       // bf16 [Hin*Hin][NBp][Cin]
+  const void* W;       // bf16 [Cout][Kpad], k = tap*Cin + c, zero padded to Kpad (multiple of 32)
+  const void* zero;    // >= 1 KiB of zeros (source of out-of-image operand blocks)
+  void* U;             // bf16 [Hout*Hout][NBp][Cout]: FWD pre-activation, RAWBF raw sums, BWD d(pre-activation)
+  void* A;             // bf16, FWD: PReLU output
+  float* Uf;           // fp32 [Hout*Hout][NBp][Cout] (RAW32, + bias)
+  const float* bias;   // [Cout] (FWD, RAW32) or null
+  const float* alpha;  // [Hout*Hout][Cout] (FWD, BWD)
+  const void* Uin;     // bf16 (BWD): pre-activation of the layer whose output gradient this launch produces
+  float* dal_part;     // (BWD, may be null) d(alpha) partials [nparts][Hout*Hout][Cout], nparts = NBp/64
+  float* db_part;      // (BWD, may be null) d(bias)  partials, same shape
+  int Hin, Hout, Cin, Cout, NBp;
+  int form, s, pb;
+  int Kpad;
+  int epi;
+};
+int launch_bconv(const BConvParams& p, hipStream_t s);
+// BWD epilogue is usable (a wave's four 16-stamp groups share one pixel)
+static inline bool bconv_bwd_fusable(int NBp) { return (NBp & 63) == 0; }
+
+// Weight gradient over stamp-inner tensors:
+//   out[tap][cx][cy] = sum_{gy pixel, stamp} X[gy*s + tap - pb][stamp][cx] * Y[gy][stamp][cy]
+// written as nsplit partial slabs [nsplit][9][Cx][Cy] (fp32) that reduce_partials() sums in a fixed order.
+struct BWgradParams {
+  const void* X;       // bf16 [Hx*Hx][NBp][Cx]
+  const void* Y;       // bf16 [Hy*Hy][NBp][Cy]
+  const void* zero;
+  float* part;         // [nsplit][9*Cx*Cy]
+  size_t part_capacity;
+  int Hx, Cx, Hy, Cy, NBp;
+  int s, pb;
+};
+int launch_bwgrad(const BWgradParams& p, hipStream_t s, int* nsplit_out);
+
+// ---- pointwise kernels of the family (bf16_point.hip) -------------------------------------------------------
+// dataset rows (fp32 [*, HW, C], row = idx ? idx[b] : first + b) -> normalised input, bf16 [HW][NBp][16]:
+// channels 0..C-1 = (x - mean) * inv_std (bnstate[2C..4C)), channel C = 1, rest 0; stamps >= NB are zero
+int launch_bf_input(const float* x, const int* idx, int first, int NB, int NBp, int HW, int C, const float* bnstate,
+                    void* xh, hipStream_t s);
+// bf16 [P][NBp][C] -> fp32 [NB][P*C]
+int launch_bf_to_rows(const void* src, float* dst, int NB, int NBp, int P, int C, hipStream_t s);
+// fp32 [NB][P*C] -> bf16 [P][NBp][C] (stamps >= NB zero)
+int launch_bf_from_rows(const float* src, void* dst, int NB, int NBp, int P, int C, hipStream_t s);
+// PReLU backward over a stamp-inner tensor: du = da * (u > 0 ? 1 : alpha[pix][c]) (in place allowed);
+// dalpha[pix][c] = sum_b da * min(u, 0) written directly (may be null); dbias partial rows [P][C] (may be null)
+int launch_bf_prelu_bwd(const void* da, const void* u, const float* alpha, void* du, float* dalpha, float* db_rows,
+                        int NBp, int P, int C, hipStream_t s);
+// column sums of a bf16 [rows][C] tensor into partial rows [nrows_out][C] (fp32)
+int launch_bf_colsum(const void* x, long rows, int C, float* part, int* nrows_out, hipStream_t s);
+
+struct BHeadParams {
+  const float* tpre;   // fp32 [Hd*Hd][NBp][16] head conv output before relu
+  const float* y;      // dataset labels [*,H,H,nb] (null: no loss)
+  const int* idx;
+  int first;
+  void* dt;            // bf16 [Hd*Hd][NBp][16] gradient wrt tpre (null: none); zero outside the crop / pad rows
+  float* loc;          // fp32 [NB,H,H,nb] or null
+  float* scale;
+  float* part;         // [nblocks][2]
+  int NB, NBp, Hd, H, nb, crop0;
+  float sigma_floor, gscale;
+};
+int launch_bf_head(const BHeadParams& p, hipStream_t s, int* nblocks_out);
+
+// one weight matrix of the family, produced from the fp32 master tensor by bf_cast_weights
+struct BCastDesc {
+  const float* src;    // master tensor [9][A][B] (taps, then two channel axes), or null (descriptor unused)
+  void* dst;           // bf16 [N][Kpad]
+  int A, B;            // master axes after the tap axis
+  int n_is_b;          // 1: n = B index, c = A index (dst[n][tap*A + c] = src[tap][c][n]); 0: n = A, c = B
+  int N, Cin, Kpad;    // N rows written (>= real n count: extra rows zero), Cin = c extent in dst (>= real: zero)
+  // first conv with the input BatchNorm folded in: c < nbands scaled by gamma[c], c == nbands = sum_c w*beta
+  const float* gamma;
+  const float* beta;
+  int nbands;
+};
+int launch_bf_cast_weights(const BCastDesc* descs_dev, const BCastDesc* descs_host, int n, hipStream_t s);
+
+}  // namespace dv

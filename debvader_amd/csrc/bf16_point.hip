@@ -1,0 +1,363 @@
+// Bandwidth-bound kernels of the bf16 family (see bf16.h): layout changes at the fp32 <-> bf16 seams, the relu / crop /
+// Normal-NLL head (model.py:137-159, metrics.py:16-26) over stamp-inner tensors, the unfused PReLU backward, and the
+// fp32 -> bf16 weight matrices.
+#include "common.h"
+#include "bf16.h"
+
+namespace dv {
+
+typedef __bf16 bp_bf16;
+typedef __bf16 bp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bp_bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ float bp_block_sum(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+  return r;
+}
+}  // namespace
+
+// ---- input: dataset rows -> normalised, stamp-inner, 16 channels ------------------------------------------------
+__global__ __launch_bounds__(256) void bf_input_kernel(const float* __restrict__ x, const int* __restrict__ idx, int first,
+                                                       int NB, int NBp, int HW, int C, const float* __restrict__ bn,
+                                                       bp_bf16* __restrict__ xh) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;   // (pixel, stamp), stamp fastest
+  if (e >= (long)HW * NBp) return;
+  const int pix = (int)(e / NBp), b = (int)(e - (long)pix * NBp);
+  bp_bf16x8 lo, hi;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lo[j] = hi[j] = (bp_bf16)0.f;
+  if (b < NB) {
+    const long row = idx ? idx[b] : first + b;
+    const float* xp = x + (row * HW + pix) * C;
+    for (int c = 0; c < C; ++c) {
+      const float v = (xp[c] - bn[2 * 8 + c]) * bn[3 * 8 + c];   // bnstate rows are 8 wide (pointwise.hip)
+      if (c < 8) lo[c] = (bp_bf16)v; else hi[c - 8] = (bp_bf16)v;
+    }
+    if (C < 8) lo[C] = (bp_bf16)1.f; else hi[C - 8] = (bp_bf16)1.f;
+  }
+  bp_bf16x8* o = reinterpret_cast<bp_bf16x8*>(xh + e * 16);
+  o[0] = lo;
+  o[1] = hi;
+}
+
+int launch_bf_input(const float* x, const int* idx, int first, int NB, int NBp, int HW, int C, const float* bnstate,
+                    void* xh, hipStream_t s) {
+  if (C > 7) {
+    set_error("bf_input: at most 7 bands");
+    return E_INVALID;
+  }
+  const long n = (long)HW * NBp;
+  hipLaunchKernelGGL(bf_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, idx, first, NB, NBp, HW, C,
+                     bnstate, reinterpret_cast<bp_bf16*>(xh));
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ---- stamp-inner bf16 <-> row-major fp32 (the dense trunk's side) -------------------------------------------------
+// one thread per 8 channels; consecutive threads walk channels, then stamps (the bf16 side is the coalesced one)
+__global__ __launch_bounds__(256) void bf_to_rows_kernel(const bp_bf16* __restrict__ src, float* __restrict__ dst, int NB,
+                                                         int NBp, int P, int C) {
+  const int c8n = C >> 3;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)P * NB * c8n) return;
+  const int c8 = (int)(e % c8n);
+  const long r = e / c8n;
+  const int b = (int)(r % NB), pix = (int)(r / NB);
+  const bp_bf16x8 v = *reinterpret_cast<const bp_bf16x8*>(src + ((size_t)pix * NBp + b) * C + c8 * 8);
+  float* o = dst + (size_t)b * P * C + (size_t)pix * C + c8 * 8;
+  f32x4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  f32x4 b4 = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+  reinterpret_cast<f32x4*>(o)[0] = a;
+  reinterpret_cast<f32x4*>(o)[1] = b4;
+}
+
+__global__ __launch_bounds__(256) void bf_from_rows_kernel(const float* __restrict__ src, bp_bf16* __restrict__ dst, int NB,
+                                                           int NBp, int P, int C) {
+  const int c8n = C >> 3;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)P * NBp * c8n) return;
+  const int c8 = (int)(e % c8n);
+  const long r = e / c8n;
+  const int b = (int)(r % NBp), pix = (int)(r / NBp);
+  bp_bf16x8 v;
+  if (b < NB) {
+    const float* i = src + (size_t)b * P * C + (size_t)pix * C + c8 * 8;
+    const f32x4 a = reinterpret_cast<const f32x4*>(i)[0], b4 = reinterpret_cast<const f32x4*>(i)[1];
+    v[0] = (bp_bf16)a[0]; v[1] = (bp_bf16)a[1]; v[2] = (bp_bf16)a[2]; v[3] = (bp_bf16)a[3];
+    v[4] = (bp_bf16)b4[0]; v[5] = (bp_bf16)b4[1]; v[6] = (bp_bf16)b4[2]; v[7] = (bp_bf16)b4[3];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bp_bf16)0.f;
+  }
+  *reinterpret_cast<bp_bf16x8*>(dst + ((size_t)pix * NBp + b) * C + c8 * 8) = v;
+}
+
+int launch_bf_to_rows(const void* src, float* dst, int NB, int NBp, int P, int C, hipStream_t s) {
+  if (C & 7) {
+    set_error("bf_to_rows: channels must be a multiple of 8");
+    return E_INVALID;
+  }
+  const long n = (long)P * NB * (C >> 3);
+  if (n == 0) return OK;
+  hipLaunchKernelGGL(bf_to_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const bp_bf16*>(src), dst, NB, NBp, P, C);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+int launch_bf_from_rows(const float* src, void* dst, int NB, int NBp, int P, int C, hipStream_t s) {
+  if (C & 7) {
+    set_error("bf_from_rows: channels must be a multiple of 8");
+    return E_INVALID;
+  }
+  const long n = (long)P * NBp * (C >> 3);
+  hipLaunchKernelGGL(bf_from_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src,
+                     reinterpret_cast<bp_bf16*>(dst), NB, NBp, P, C);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ---- unfused PReLU backward: one workgroup per pixel, thread (channel octet, stamp lane) --------------------------
+__global__ __launch_bounds__(256) void bf_prelu_bwd_kernel(const bp_bf16* __restrict__ da, const bp_bf16* __restrict__ u,
+                                                           const float* __restrict__ alpha, bp_bf16* __restrict__ du,
+                                                           float* __restrict__ dalpha, float* __restrict__ db_rows, int NBp,
+                                                           int C) {
+  extern __shared__ float sh[];                       // [2][lanes][C]
+  const int pix = blockIdx.x;
+  const int c8n = C >> 3;
+  const int nl = 256 / c8n;                            // stamp lanes (c8n divides 256: C in {16,32,64,...,2048})
+  const int c8 = threadIdx.x % c8n, sl = threadIdx.x / c8n;
+  float al[8], sa[8], sb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    al[j] = alpha[(size_t)pix * C + c8 * 8 + j];
+    sa[j] = sb[j] = 0.f;
+  }
+  if (sl < nl)
+    for (int b = sl; b < NBp; b += nl) {
+      const size_t e = ((size_t)pix * NBp + b) * C + c8 * 8;
+      const bp_bf16x8 dv = *reinterpret_cast<const bp_bf16x8*>(da + e);
+      const bp_bf16x8 uv = *reinterpret_cast<const bp_bf16x8*>(u + e);
+      bp_bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = (float)dv[j], uu = (float)uv[j];
+        const float g = d * (uu > 0.f ? 1.f : al[j]);
+        sa[j] += d * fminf(uu, 0.f);
+        sb[j] += g;
+        o[j] = (bp_bf16)g;
+      }
+      *reinterpret_cast<bp_bf16x8*>(du + e) = o;
+    }
+  if (!dalpha && !db_rows) return;
+  float* s0 = sh;
+  float* s1 = sh + nl * C;
+  if (sl < nl)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s0[sl * C + c8 * 8 + j] = sa[j];
+      s1[sl * C + c8 * 8 + j] = sb[j];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < nl; ++l) {
+      a += s0[l * C + c];
+      b += s1[l * C + c];
+    }
+    if (dalpha) dalpha[(size_t)pix * C + c] = a;
+    if (db_rows) db_rows[(size_t)pix * C + c] = b;
+  }
+}
+
+int launch_bf_prelu_bwd(const void* da, const void* u, const float* alpha, void* du, float* dalpha, float* db_rows,
+                        int NBp, int P, int C, hipStream_t s) {
+  const int c8n = C >> 3;
+  if ((C & 7) || c8n > 256 || 256 % c8n) {
+    set_error("bf_prelu_bwd: unsupported channel count %d", C);
+    return E_INVALID;
+  }
+  const int nl = 256 / c8n;
+  const size_t lds = (size_t)2 * nl * C * sizeof(float);
+  hipLaunchKernelGGL(bf_prelu_bwd_kernel, dim3((unsigned)P), dim3(256), lds, s, reinterpret_cast<const bp_bf16*>(da),
+                     reinterpret_cast<const bp_bf16*>(u), alpha, reinterpret_cast<bp_bf16*>(du), dalpha, db_rows, NBp, C);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ---- column sums of a bf16 [rows][C] tensor (C = 16): d(bias) of the head --------------------------------------------
+__global__ __launch_bounds__(256) void bf_colsum16_kernel(const bp_bf16* __restrict__ x, long rows, float* __restrict__ part) {
+  __shared__ float sh[256 * 16];
+  const long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long r0 = (long)blockIdx.x * per, r1 = min(rows, r0 + per);
+  float a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = 0.f;
+  for (long r = r0 + threadIdx.x; r < r1; r += 256) {
+    const bp_bf16x8 v0 = *reinterpret_cast<const bp_bf16x8*>(x + r * 16);
+    const bp_bf16x8 v1 = *reinterpret_cast<const bp_bf16x8*>(x + r * 16 + 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] += (float)v0[j];
+      a[8 + j] += (float)v1[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) sh[threadIdx.x * 16 + j] = a[j];
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float t = 0.f;
+    for (int i = 0; i < 256; ++i) t += sh[i * 16 + threadIdx.x];
+    part[blockIdx.x * 16 + threadIdx.x] = t;
+  }
+}
+
+int launch_bf_colsum(const void* x, long rows, int C, float* part, int* nrows_out, hipStream_t s) {
+  if (C != 16) {
+    set_error("bf_colsum: 16 channels only");
+    return E_INVALID;
+  }
+  const int nb = (int)std::min<long>(512, std::max<long>(1, rows / 1024));
+  hipLaunchKernelGGL(bf_colsum16_kernel, dim3(nb), dim3(256), 0, s, reinterpret_cast<const bp_bf16*>(x), rows, part);
+  if (nrows_out) *nrows_out = nb;
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ---- head: relu / crop / sigma floor / Normal NLL and its gradient, one thread per (pixel of the 2^L grid, stamp) -----
+// Same arithmetic as head_kernel (pointwise.hip): NLL uses (y - mu)/sigma; the gradient w.r.t. the head conv's
+// pre-activation is stored in bf16 (it feeds bf16 MFMA operands), zero outside the crop and for the pad stamps.
+__global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
+  __shared__ float sh[4];
+  const long total = (long)p.Hd * p.Hd * p.NBp;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  float nll = 0.f, se = 0.f;
+  if (e < total) {
+    const int pix = (int)(e / p.NBp), b = (int)(e - (long)pix * p.NBp);
+    const int oh = pix / p.Hd, ow = pix - oh * p.Hd;
+    const int h = oh - p.crop0, w = ow - p.crop0;
+    const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.H && b < p.NB;
+    float d[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d[j] = 0.f;
+    if (in) {
+      const f32x4* tp = reinterpret_cast<const f32x4*>(p.tpre + e * 16);
+      const f32x4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+      const float t[16] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3],
+                           t2[0], t2[1], t2[2], t2[3], t3[0], t3[1], t3[2], t3[3]};
+      const long opix = ((long)b * p.H + h) * p.H + w;
+      const float* yp = nullptr;
+      if (p.y) {
+        const long row = p.idx ? p.idx[b] : p.first + b;
+        yp = p.y + ((row * p.H + h) * p.H + w) * p.nb;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c >= p.nb) break;
+        float tl = 0.f, ts = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {             // static register indexing (runtime index = scratch)
+          if (j == c) tl = t[j];
+          if (j == p.nb + c) ts = t[j];
+        }
+        const float loc = fmaxf(tl, 0.f);
+        const float sig = p.sigma_floor + fmaxf(ts, 0.f);
+        if (p.loc) p.loc[opix * p.nb + c] = loc;
+        if (p.scale) p.scale[opix * p.nb + c] = sig;
+        if (yp) {
+          const float inv = 1.0f / sig;
+          const float df = yp[c] - loc;
+          const float r = df * inv;
+          nll += 0.5f * r * r + logf(sig) + 0.91893853320467274178f;
+          se += df * df;
+          const float dl = tl > 0.f ? -(r * inv) * p.gscale : 0.f;
+          const float ds = ts > 0.f ? (inv - r * r * inv) * p.gscale : 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            if (j == c) d[j] = dl;
+            if (j == p.nb + c) d[j] = ds;
+          }
+        }
+      }
+    }
+    if (p.dt) {
+      bp_bf16x8 o0, o1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o0[j] = (bp_bf16)d[j];
+        o1[j] = (bp_bf16)d[8 + j];
+      }
+      bp_bf16x8* o = reinterpret_cast<bp_bf16x8*>(reinterpret_cast<bp_bf16*>(p.dt) + e * 16);
+      o[0] = o0;
+      o[1] = o1;
+    }
+  }
+  const float a = bp_block_sum(nll, sh);
+  const float b2 = bp_block_sum(se, sh);
+  if (threadIdx.x == 0 && p.part) {
+    p.part[blockIdx.x * 2] = a;
+    p.part[blockIdx.x * 2 + 1] = b2;
+  }
+}
+
+int launch_bf_head(const BHeadParams& p, hipStream_t s, int* nblocks_out) {
+  if (p.nb > 8) {
+    set_error("bf_head: at most 8 bands");
+    return E_INVALID;
+  }
+  const long total = (long)p.Hd * p.Hd * p.NBp;
+  const int nb = (int)((total + 255) / 256);
+  if (nblocks_out) *nblocks_out = nb;
+  if (nb == 0) return OK;
+  hipLaunchKernelGGL(bf_head_kernel, dim3(nb), dim3(256), 0, s, p);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ---- fp32 master tensors -> bf16 [N][Kpad] matrices -------------------------------------------------------------
+// grid.y = descriptor; one thread per destination element
+__global__ __launch_bounds__(256) void bf_cast_kernel(const BCastDesc* __restrict__ descs) {
+  const BCastDesc d = descs[blockIdx.y];
+  if (!d.src) return;
+  bp_bf16* dst = reinterpret_cast<bp_bf16*>(d.dst);
+  const long total = (long)d.N * d.Kpad;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int n = (int)(e / d.Kpad), k = (int)(e - (long)n * d.Kpad);
+    float v = 0.f;
+    const int nreal = d.n_is_b ? d.B : d.A, creal = d.n_is_b ? d.A : d.B;
+    if (k < 9 * d.Cin && n < nreal) {
+      const int tap = k / d.Cin, c = k - tap * d.Cin;
+      if (d.gamma) {
+        // first conv: master [9][nbands][B], n = B index; folded input BatchNorm
+        if (c < d.nbands) {
+          v = d.src[((size_t)tap * d.A + c) * d.B + n] * d.gamma[c];
+        } else if (c == d.nbands) {
+          for (int cc = 0; cc < d.nbands; ++cc) v += d.src[((size_t)tap * d.A + cc) * d.B + n] * d.beta[cc];
+        }
+      } else if (c < creal) {
+        v = d.n_is_b ? d.src[((size_t)tap * d.A + c) * d.B + n] : d.src[((size_t)tap * d.A + n) * d.B + c];
+      }
+    }
+    dst[e] = (bp_bf16)v;
+  }
+}
+
+int launch_bf_cast_weights(const BCastDesc* descs_dev, const BCastDesc* descs_host, int n, hipStream_t s) {
+  if (n <= 0) return OK;
+  long mx = 0;
+  for (int i = 0; i < n; ++i) mx = std::max(mx, (long)descs_host[i].N * descs_host[i].Kpad);
+  const unsigned gx = (unsigned)std::min<long>(256, std::max<long>(1, (mx + 2047) / 2048));
+  hipLaunchKernelGGL(bf_cast_kernel, dim3(gx, (unsigned)n), dim3(256), 0, s, descs_dev);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+}  // namespace dv

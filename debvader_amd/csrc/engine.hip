@@ -24,6 +24,7 @@
 
 #include "../../include/debvader_hip.h"
 #include "common.h"
+#include "bf16.h"
 
 namespace dv {
 
@@ -322,10 +323,37 @@ struct DataSlot {
   int64_t n = 0;
 };
 
+// bf16 kernel family (BASELINE configs[2], bf16.h): stamp-inner bf16 activations of the conv stacks, bf16 weight
+// matrices cast from the fp32 master tensors, fp32 dense trunk / sampler / head
+struct BfW {
+  void* f = nullptr;   // forward form   [Cout][Kf]
+  void* d = nullptr;   // data-gradient form [Cin][Kd]
+  int Kf = 0, Kd = 0;
+};
+struct BfState {
+  bool on = false;
+  bool dirty = true;             // master weights changed since the bf16 matrices were cast
+  int NBp = 0;                   // stamps of the current pass padded to 16
+  void* xh = nullptr;            // normalised input [HW][NBp][16]
+  std::vector<void*> enc_u, enc_a, dec_u, dec_a;
+  void* dec_in = nullptr;        // decoder trunk output as a stamp-inner tensor [w0*w0][NBp][f_last]
+  float* tpre32 = nullptr;       // head conv output, fp32 [Hd*Hd][NBp][16]
+  void* dt = nullptr;            // d(loss)/d(tpre), bf16
+  float* flat_in = nullptr;      // encoder output as fp32 rows [NB][flat] (input of the flatten PReLU)
+  void *gA = nullptr, *gB = nullptr;   // activation-gradient ping-pong (bf16)
+  std::vector<BfW> enc_w, dec_w;
+  BfW head_w;
+  std::vector<dv::BCastDesc> descs;
+  dv::BCastDesc* descs_dev = nullptr;
+  float* G0s16 = nullptr;        // not used directly: slabs of the first layer reduce into G0s
+  void* zero = nullptr;          // 1 KiB of zeros
+};
+
 struct dv_model {
   dv_ctx* ctx = nullptr;
   dv::Arch A;
   int Bc = 0;
+  BfState bf;
   // flat parameter-shaped buffers
   float *P = nullptr, *G = nullptr, *Mm = nullptr, *Vv = nullptr;
   float* W1p = nullptr;  // first conv kernel with the input BatchNorm folded in, 8 input channels
@@ -1150,6 +1178,7 @@ static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int 
 
 static int refresh_head_pad(dv_model* m, hipStream_t st = nullptr) {
   const Arch& A = m->A;
+  m->bf.dirty = true;
   if (!st) st = m->ctx->stream;
   DV_TRY(launch_pad_cols(m->P + A.specs[A.head_k()].off, m->Whp, 9 * A.cfg.filters[0], 2 * A.C, A.C2p, st));
   return launch_pad_cols(m->P + A.specs[A.head_b()].off, m->bhp, 1, 2 * A.C, A.C2p, st);
@@ -1157,6 +1186,7 @@ static int refresh_head_pad(dv_model* m, hipStream_t st = nullptr) {
 
 static int refresh_w1p(dv_model* m) {
   const Arch& A = m->A;
+  m->bf.dirty = true;
   return launch_pad_w1(m->P + A.specs[A.enc_k(0)].off, m->P + A.specs[0].off, m->P + A.specs[1].off, m->W1p, 9, A.C, 8,
                        A.cfg.filters[0], m->ctx->stream);
 }
@@ -1201,8 +1231,15 @@ static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first,
   return OK;
 }
 
+static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u);
+static int bf_decoder_forward(dv_model* m, int NB, bool keep_u);
+static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
+                        bool want_out, int part_block0, int* nblk);
+static int bf_backward(dv_model* m, int NB, int Bg);
+
 // encoder: dataset rows (idx / first) of the lane -> t
 static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u) {
+  if (m->bf.on) return bf_encoder_forward(m, xsrc, idx, first, NB, keep_u);
   const Arch& A = m->A;
   hipStream_t s = fwd_stream(m);
   const int HW = A.H * A.H;
@@ -1234,6 +1271,7 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
 }
 
 static int decoder_forward(dv_model* m, int NB, bool keep_u) {
+  if (m->bf.on) return bf_decoder_forward(m, NB, keep_u);
   const Arch& A = m->A;
   hipStream_t s = fwd_stream(m);
   float* P = m->P;
@@ -1314,6 +1352,7 @@ static void head_params(dv_model* m, HeadParams& hp, const float* ysrc, const in
 
 static int head_lane(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
                      bool want_out, int part_block0, int* nblk) {
+  if (m->bf.on) return bf_head_lane(m, ysrc, idx, first, NB, Bg, want_grad, want_out, part_block0, nblk);
   HeadParams hp;
   head_params(m, hp, ysrc, idx, first, NB, Bg, want_grad, want_out, part_block0);
   ProfScope ps(m, 2);
@@ -1339,7 +1378,7 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
     return E_STATE;
   }
   static const int want_lanes = getenv("DV_FWD_LANES") ? atoi(getenv("DV_FWD_LANES")) : 2;
-  int nlanes = (m->split_forward && !m->prof_on && cx->aux_stream && NB >= 64) ? std::max(1, std::min(want_lanes, 4)) : 1;
+  int nlanes = (m->split_forward && !m->prof_on && !m->bf.on && cx->aux_stream && NB >= 64) ? std::max(1, std::min(want_lanes, 4)) : 1;
   while (nlanes > 1 && NB / nlanes < 32) --nlanes;
   while (nlanes > 2 && !cx->lane_stream[nlanes - 3]) --nlanes;
   const int per = nlanes > 1 ? ((NB / nlanes + 31) / 32) * 32 : NB;   // lane sizes: multiples of 32 stamps
@@ -1428,6 +1467,7 @@ static size_t enc_bucket_split(const Arch& A) {
 }
 
 static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* idx, int first) {
+  if (m->bf.on) return bf_backward(m, NB, Bg);
   const Arch& A = m->A;
   hipStream_t s = m->ctx->stream;
   float* P = m->P;
@@ -1686,6 +1726,8 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   return OK;
 }
 
+#include "engine_bf16.inl"
+
 // legacy Adam on the flat range [beg, end) (clipped to what this model is training), on stream st
 static int adam_range(dv_model* m, size_t beg, size_t end, hipStream_t st) {
   const Arch& A = m->A;
@@ -1707,6 +1749,7 @@ static void begin_update(dv_model* m) {     // step counter and bias-corrected s
 static int optimizer_step(dv_model* m) {
   const Arch& A = m->A;
   DV_TRY(adam_range(m, 0, std::min(m->adam_done_from, A.n_train), m->ctx->stream));
+  m->bf.dirty = true;
   if (m->opt_enc) DV_TRY(refresh_w1p(m));
   if (m->opt_dec && m->adam_done_from > A.n_enc_train) DV_TRY(refresh_head_pad(m));
   return OK;
@@ -2446,6 +2489,13 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   const Arch& A = m->A;
   const size_t Bc = (size_t)cfg->max_batch;
   m->Bc = cfg->max_batch;
+  if (cfg->dtype != DV_DTYPE_F32 && cfg->dtype != DV_DTYPE_BF16) {
+    set_error("unknown dtype %d", cfg->dtype);
+    delete m;
+    return DV_E_INVALID;
+  }
+  const bool bf16 = cfg->dtype == DV_DTYPE_BF16;
+  const size_t Ba = bf16 ? 0 : Bc;   // fp32 activations of the conv stacks: not allocated by the bf16 engine
   size_t max_act = 0;  // largest per-stamp activation (elements) for the gradient ping-pong buffers
   auto track = [&](size_t e) { max_act = std::max(max_act, e); };
   auto fail = [&](int s) {
@@ -2467,7 +2517,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   ALLOC(m->Ghs, 9 * cfg->filters[0] * A.C2p);
   ALLOC(m->bhp, A.C2p);
   size_t in_e = (size_t)A.H * A.H * 8;
-  ALLOC(m->xn, Bc * in_e);
+  ALLOC(m->xn, Ba * in_e);
   track(in_e);
   ALLOC(m->stage_x, Bc * A.H * A.H * A.C);
   m->enc_u.resize(2 * A.L);
@@ -2478,10 +2528,11 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
     int hin, cin, hout, cout, s;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &s);
     size_t e = (size_t)hout * hout * cout;
-    ALLOC(m->enc_u[j], Bc * e);
-    ALLOC(m->enc_a[j], Bc * e);
-    track(e);
+    ALLOC(m->enc_u[j], Ba * e);
+    ALLOC(m->enc_a[j], Ba * e);
+    if (!bf16) track(e);
   }
+  track(A.flat);
   ALLOC(m->flat_a, Bc * A.flat);
   ALLOC(m->t, Bc * A.tw);
   track(A.tw);
@@ -2501,13 +2552,13 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
     int hin, cin, hout, cout, s;
     A.dec_layer(j, &hin, &cin, &hout, &cout, &s);
     size_t e = (size_t)hout * hout * cout;
-    ALLOC(m->dec_u[j], Bc * e);
-    ALLOC(m->dec_a[j], Bc * e);
-    track(e);
+    ALLOC(m->dec_u[j], Ba * e);
+    ALLOC(m->dec_a[j], Ba * e);
+    if (!bf16) track(e);
   }
   size_t head_e = (size_t)A.dec_out * A.dec_out * A.C2p;
-  ALLOC(m->tpre, Bc * head_e);
-  track(head_e);
+  ALLOC(m->tpre, Ba * head_e);
+  if (!bf16) track(head_e);
   ALLOC(m->loc, Bc * A.H * A.H * A.C + 4);
   ALLOC(m->scale, Bc * A.H * A.H * A.C + 4);
   ALLOC(m->gA, Bc * max_act);
@@ -2582,6 +2633,10 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
       hipMemsetAsync(m->zero_page, 0, 64 * sizeof(float), s) != hipSuccess ||
       hipMemsetAsync(m->bnsums, 0, 16 * sizeof(float), s) != hipSuccess)
     return fail(E_HIP);
+  if (bf16) {
+    st = bf_alloc(m);
+    if (st != OK) return fail(st);
+  }
   st = dv_model_init(m, 0);
   if (st != OK) return fail(st);
   *out = m;
@@ -2669,6 +2724,7 @@ int dv_model_get_param(dv_model* m, int32_t i, float* host, size_t nbytes) {
 }
 int dv_model_set_param(dv_model* m, int32_t i, const float* host, size_t nbytes) {
   DV_TRY(tensor_io(m, m ? m->P : nullptr, i, const_cast<float*>(host), nbytes, false));
+  m->bf.dirty = true;
   if (i == m->A.head_k() || i == m->A.head_b()) {
     DV_TRY(refresh_head_pad(m));
     DV_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -3056,8 +3112,52 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
     }
     DV_HIP(hipSetDevice(m->ctx->device));
     DV_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (m->bf.on) {
+      // stamp-inner fp32 [Hd*Hd][NBp][16] -> [B][Hd][Hd][2C]
+      const size_t Pn = (size_t)A.dec_out * A.dec_out, NBp = (size_t)m->bf.NBp;
+      std::vector<float> tmp(Pn * NBp * 16);
+      DV_HIP(hipMemcpy(tmp.data(), m->bf.tpre32, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+      for (size_t b = 0; b < B; ++b)
+        for (size_t px = 0; px < Pn; ++px)
+          memcpy(host + (b * Pn + px) * 2 * A.C, tmp.data() + (px * NBp + b) * 16, 2 * A.C * sizeof(float));
+      return DV_OK;
+    }
     DV_HIP(hipMemcpy2D(host, 2 * A.C * sizeof(float), m->tpre, A.C2p * sizeof(float), 2 * A.C * sizeof(float),
                        B * A.dec_out * A.dec_out, hipMemcpyDeviceToHost));
+    return DV_OK;
+  }
+  else if (m->bf.on) {
+    // stamp-inner bf16 [P][NBp][C] -> fp32 [B][P][C] on the host (tests only)
+    const void* bsrc = nullptr;
+    size_t Pn = 0, Cn = 0;
+    if (n == "xn") { bsrc = m->bf.xh; Pn = (size_t)A.H * A.H; Cn = 16; }
+    else if (n.size() > 5 && (n.rfind("enc_u", 0) == 0 || n.rfind("enc_a", 0) == 0 || n.rfind("dec_u", 0) == 0 || n.rfind("dec_a", 0) == 0)) {
+      int j = atoi(n.c_str() + 5);
+      if (j < 0 || j >= 2 * A.L) return DV_E_INVALID;
+      int hin, cin, hout, cout, s;
+      if (n[0] == 'e') A.enc_layer(j, &hin, &cin, &hout, &cout, &s); else A.dec_layer(j, &hin, &cin, &hout, &cout, &s);
+      Pn = (size_t)hout * hout; Cn = cout;
+      bsrc = n[0] == 'e' ? (n[4] == 'u' ? m->bf.enc_u[j] : m->bf.enc_a[j]) : (n[4] == 'u' ? m->bf.dec_u[j] : m->bf.dec_a[j]);
+    } else {
+      set_error("activation '%s' is not exposed by the bf16 engine", name);
+      return DV_E_INVALID;
+    }
+    elems = B * Pn * Cn;
+    if (nbytes != elems * sizeof(float)) {
+      set_error("activation %s holds %zu bytes, caller passed %zu", name, elems * sizeof(float), nbytes);
+      return DV_E_INVALID;
+    }
+    const size_t NBp = (size_t)m->bf.NBp;
+    std::vector<uint16_t> tmp(Pn * NBp * Cn);
+    DV_HIP(hipSetDevice(m->ctx->device));
+    DV_HIP(hipStreamSynchronize(m->ctx->stream));
+    DV_HIP(hipMemcpy(tmp.data(), bsrc, tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < B; ++b)
+      for (size_t px = 0; px < Pn; ++px)
+        for (size_t c = 0; c < Cn; ++c) {
+          const uint32_t bits = (uint32_t)tmp[(px * NBp + b) * Cn + c] << 16;
+          memcpy(host + (b * Pn + px) * Cn + c, &bits, 4);
+        }
     return DV_OK;
   }
   else if (n == "xn") { src = m->xn; elems = B * A.H * A.H * 8; }

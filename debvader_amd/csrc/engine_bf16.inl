@@ -1,0 +1,423 @@
+// bf16 pipeline of the engine (included by engine.hip inside namespace dv): the conv / conv-transpose stacks of
+// create_encoder / create_decoder (model.py:79-98,112-137) on the bf16 kernel family of bf16.h, the dense trunk,
+// the sampler and the head arithmetic on the fp32 kernels the f32 engine uses.  Seams: the encoder's last
+// activation leaves the stamp-inner bf16 layout as fp32 rows (input of the flatten PReLU, model.py:94-95), the
+// decoder's Reshape (model.py:119) enters it; the backward pass crosses the same two seams in reverse.
+// Everything runs on the main stream (no stream choreography: the kernels are short and bandwidth-bound).
+
+static int bf_pad32(int k) { return (k + 31) & ~31; }
+
+// ---- allocation + weight-matrix descriptors (dv_model_create) -----------------------------------------------------
+static int bf_alloc(dv_model* m) {
+  const Arch& A = m->A;
+  BfState& bf = m->bf;
+  const size_t Bp = ((size_t)m->Bc + 15) & ~(size_t)15;
+  for (int i = 0; i < A.L; ++i) {
+    const int f = A.cfg.filters[i];
+    if (!(f == 16 || f % 32 == 0)) {
+      set_error("bf16 engine: filters must be 16 or multiples of 32 (filters[%d]=%d)", i, f);
+      return E_INVALID;
+    }
+  }
+  if (A.cfg.filters[A.L - 1] & 7 || A.C2p != 16) {
+    set_error("bf16 engine: unsupported head / trunk geometry");
+    return E_INVALID;
+  }
+  auto balloc = [&](void** p, size_t bytes) -> int {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(bytes, 64));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    m->allocs.push_back(q);
+    *p = q;
+    return OK;
+  };
+  const size_t HW = (size_t)A.H * A.H;
+  DV_TRY(balloc(&bf.xh, HW * Bp * 16 * 2));
+  DV_TRY(balloc(&bf.zero, 1024));
+  DV_HIP(hipMemsetAsync(bf.zero, 0, 1024, m->ctx->stream));
+  size_t max_e = (size_t)A.dec_out * A.dec_out * 16;
+  bf.enc_u.resize(2 * A.L); bf.enc_a.resize(2 * A.L); bf.dec_u.resize(2 * A.L); bf.dec_a.resize(2 * A.L);
+  bf.enc_w.resize(2 * A.L); bf.dec_w.resize(2 * A.L);
+  for (int j = 0; j < 2 * A.L; ++j) {
+    int hin, cin, hout, cout, s;
+    A.enc_layer(j, &hin, &cin, &hout, &cout, &s);
+    const size_t e = (size_t)hout * hout * cout;
+    max_e = std::max(max_e, e);
+    DV_TRY(balloc(&bf.enc_u[j], e * Bp * 2));
+    DV_TRY(balloc(&bf.enc_a[j], e * Bp * 2));
+    A.dec_layer(j, &hin, &cin, &hout, &cout, &s);
+    const size_t e2 = (size_t)hout * hout * cout;
+    max_e = std::max(max_e, e2);
+    max_e = std::max(max_e, (size_t)hin * hin * cin);
+    DV_TRY(balloc(&bf.dec_u[j], e2 * Bp * 2));
+    DV_TRY(balloc(&bf.dec_a[j], e2 * Bp * 2));
+  }
+  const size_t r = (size_t)A.w0 * A.w0 * A.cfg.filters[A.L - 1];
+  DV_TRY(balloc(&bf.dec_in, r * Bp * 2));
+  DV_TRY(balloc((void**)&bf.tpre32, (size_t)A.dec_out * A.dec_out * Bp * 16 * 4));
+  DV_TRY(balloc(&bf.dt, (size_t)A.dec_out * A.dec_out * Bp * 16 * 2));
+  DV_TRY(balloc((void**)&bf.flat_in, (size_t)m->Bc * A.flat * 4));
+  DV_TRY(balloc(&bf.gA, max_e * Bp * 2));
+  DV_TRY(balloc(&bf.gB, max_e * Bp * 2));
+
+  // bf16 weight matrices and the descriptors the cast kernel walks
+  float* P = m->P;
+  auto add = [&](const float* src, int Aax, int Bax, int n_is_b, int N, int Cin, void** dst, int* Kout) -> int {
+    BCastDesc d;
+    memset(&d, 0, sizeof d);
+    d.src = src; d.A = Aax; d.B = Bax; d.n_is_b = n_is_b; d.N = N; d.Cin = Cin; d.Kpad = bf_pad32(9 * Cin);
+    DV_TRY(balloc(dst, (size_t)N * d.Kpad * 2));
+    d.dst = *dst;
+    *Kout = d.Kpad;
+    bf.descs.push_back(d);
+    return OK;
+  };
+  for (int j = 0; j < 2 * A.L; ++j) {
+    int hin, cin, hout, cout, s;
+    A.enc_layer(j, &hin, &cin, &hout, &cout, &s);
+    const float* k = P + A.specs[A.enc_k(j)].off;           // HWIO [9][cin][cout]
+    if (j == 0) {
+      DV_TRY(add(k, cin, cout, 1, cout, 16, &bf.enc_w[j].f, &bf.enc_w[j].Kf));
+      BCastDesc& d = bf.descs.back();
+      d.gamma = P + A.specs[0].off;
+      d.beta = P + A.specs[1].off;
+      d.nbands = A.C;
+    } else {
+      DV_TRY(add(k, cin, cout, 1, cout, cin, &bf.enc_w[j].f, &bf.enc_w[j].Kf));
+      DV_TRY(add(k, cin, cout, 0, cin, cout, &bf.enc_w[j].d, &bf.enc_w[j].Kd));
+    }
+    A.dec_layer(j, &hin, &cin, &hout, &cout, &s);
+    const float* kt = P + A.specs[A.dec_k(j)].off;           // (kh,kw,cout,cin)
+    DV_TRY(add(kt, cout, cin, 0, cout, cin, &bf.dec_w[j].f, &bf.dec_w[j].Kf));
+    DV_TRY(add(kt, cout, cin, 1, cin, cout, &bf.dec_w[j].d, &bf.dec_w[j].Kd));
+  }
+  {
+    const int f0 = A.cfg.filters[0];
+    const float* kh = P + A.specs[A.head_k()].off;           // HWIO [9][f0][2C]
+    DV_TRY(add(kh, f0, 2 * A.C, 1, 16, f0, &bf.head_w.f, &bf.head_w.Kf));
+    DV_TRY(add(kh, f0, 2 * A.C, 0, f0, 16, &bf.head_w.d, &bf.head_w.Kd));
+  }
+  DV_TRY(balloc((void**)&bf.descs_dev, bf.descs.size() * sizeof(BCastDesc)));
+  DV_HIP(hipMemcpyAsync(bf.descs_dev, bf.descs.data(), bf.descs.size() * sizeof(BCastDesc), hipMemcpyHostToDevice,
+                        m->ctx->stream));
+  DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  bf.on = true;
+  bf.dirty = true;
+  return OK;
+}
+
+static int bf_refresh_weights(dv_model* m, hipStream_t s) {
+  BfState& bf = m->bf;
+  if (!bf.dirty) return OK;
+  ProfScope ps(m, 2, s);
+  DV_TRY(launch_bf_cast_weights(bf.descs_dev, bf.descs.data(), (int)bf.descs.size(), s));
+  bf.dirty = false;
+  return OK;
+}
+
+static int bf_conv(dv_model* m, const void* X, const void* W, int Kpad, int form, int Hin, int Cin, int Hout, int Cout,
+                   int s, int pb, int epi, void* U, void* Aout, float* Uf, const float* bias, const float* alpha,
+                   const void* Uin, float* dalp, float* dbp) {
+  BConvParams p;
+  memset(&p, 0, sizeof p);
+  p.X = X; p.W = W; p.zero = m->bf.zero; p.U = U; p.A = Aout; p.Uf = Uf; p.bias = bias; p.alpha = alpha; p.Uin = Uin;
+  p.dal_part = dalp; p.db_part = dbp;
+  p.Hin = Hin; p.Hout = Hout; p.Cin = Cin; p.Cout = Cout; p.NBp = m->bf.NBp;
+  p.form = form; p.s = s; p.pb = pb; p.Kpad = Kpad; p.epi = epi;
+  ProfScope ps(m, 0);
+  return launch_bconv(p, fwd_stream(m));
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------------
+static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u) {
+  const Arch& A = m->A;
+  BfState& bf = m->bf;
+  hipStream_t s = fwd_stream(m);
+  float* P = m->P;
+  bf.NBp = (NB + 15) & ~15;
+  DV_TRY(bf_refresh_weights(m, s));
+  {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_bf_input(xsrc, idx, first, NB, bf.NBp, A.H * A.H, A.C, m->bnstate, bf.xh, s));
+  }
+  const void* in = bf.xh;
+  for (int j = 0; j < 2 * A.L; ++j) {
+    int hin, cin, hout, cout, st;
+    A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
+    const int pb = same_pad_before(hin, 3, st, nullptr);
+    DV_TRY(bf_conv(m, in, bf.enc_w[j].f, bf.enc_w[j].Kf, 0, hin, j == 0 ? 16 : cin, hout, cout, st, pb, BEPI_FWD,
+                   keep_u ? bf.enc_u[j] : nullptr, bf.enc_a[j], nullptr, P + A.specs[A.enc_b(j)].off,
+                   P + A.specs[A.enc_al(j)].off, nullptr, nullptr, nullptr));
+    in = bf.enc_a[j];
+  }
+  const int sl = A.enc_sizes[A.L], fl = A.cfg.filters[A.L - 1];
+  {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_bf_to_rows(in, bf.flat_in, NB, bf.NBp, sl * sl, fl, s));
+    DV_TRY(launch_prelu_fwd(bf.flat_in, P + A.specs[A.enc_flat_al()].off, m->flat_a, NB, A.flat, s));
+  }
+  return gconv_fprop(m, m->flat_a, P + A.specs[A.enc_dk()].off, false, P + A.specs[A.enc_db()].off, nullptr, m->t,
+                     nullptr, 1, NB, 1, A.flat, 1, A.tw, 1, 0, true);
+}
+
+static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
+  const Arch& A = m->A;
+  BfState& bf = m->bf;
+  hipStream_t s = fwd_stream(m);
+  float* P = m->P;
+  bf.NBp = (NB + 15) & ~15;
+  DV_TRY(bf_refresh_weights(m, s));
+  {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_prelu_fwd(m->z, P + A.specs[A.D0].off, m->dec_ain, NB, A.d, s));
+  }
+  DV_TRY(gconv_fprop(m, m->dec_ain, P + A.specs[A.D0 + 1].off, false, P + A.specs[A.D0 + 2].off,
+                     P + A.specs[A.D0 + 3].off, keep_u ? m->dec_uh : nullptr, m->dec_ah, 2, NB, 1, A.d, 1, A.dec_hidden,
+                     1, 0, true));
+  const int fl = A.cfg.filters[A.L - 1];
+  const int r = A.w0 * A.w0 * fl;
+  DV_TRY(gconv_fprop(m, m->dec_ah, P + A.specs[A.D0 + 4].off, false, P + A.specs[A.D0 + 5].off,
+                     P + A.specs[A.D0 + 6].off, keep_u ? m->dec_ur : nullptr, m->dec_ar, 2, NB, 1, A.dec_hidden, 1, r, 1,
+                     0, true));
+  {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_bf_from_rows(m->dec_ar, bf.dec_in, NB, bf.NBp, A.w0 * A.w0, fl, s));
+  }
+  const void* in = bf.dec_in;
+  for (int j = 0; j < 2 * A.L; ++j) {
+    int hin, cin, hout, cout, st;
+    A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
+    const int pb = same_pad_before(hout, 3, st, nullptr);
+    DV_TRY(bf_conv(m, in, bf.dec_w[j].f, bf.dec_w[j].Kf, 1, hin, cin, hout, cout, st, pb, BEPI_FWD,
+                   keep_u ? bf.dec_u[j] : nullptr, bf.dec_a[j], nullptr, P + A.specs[A.dec_b(j)].off,
+                   P + A.specs[A.dec_al(j)].off, nullptr, nullptr, nullptr));
+    in = bf.dec_a[j];
+  }
+  return bf_conv(m, in, bf.head_w.f, bf.head_w.Kf, 0, A.dec_out, A.cfg.filters[0], A.dec_out, 16, 1, 1, BEPI_RAW32,
+                 nullptr, nullptr, bf.tpre32, m->bhp, nullptr, nullptr, nullptr, nullptr);
+}
+
+static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
+                        bool want_out, int part_block0, int* nblk) {
+  const Arch& A = m->A;
+  BfState& bf = m->bf;
+  BHeadParams hp;
+  memset(&hp, 0, sizeof hp);
+  hp.tpre = bf.tpre32;
+  hp.y = ysrc;
+  hp.idx = idx;
+  hp.first = first;
+  hp.dt = want_grad ? bf.dt : nullptr;
+  hp.loc = want_out ? m->loc : nullptr;
+  hp.scale = want_out ? m->scale : nullptr;
+  hp.part = m->ws3 + (size_t)part_block0 * 2;
+  hp.NB = NB;
+  hp.NBp = bf.NBp;
+  hp.Hd = A.dec_out;
+  hp.H = A.H;
+  hp.nb = A.C;
+  hp.crop0 = A.crop0;
+  hp.sigma_floor = A.cfg.sigma_floor;
+  hp.gscale = (float)(1.0 / ((double)Bg * A.H * A.H * A.C));
+  const long blocks = ((long)A.dec_out * A.dec_out * bf.NBp + 255) / 256;
+  if ((size_t)(part_block0 + blocks) * 2 > m->ws3_elems) {
+    set_error("head workspace too small");
+    return E_STATE;
+  }
+  ProfScope ps(m, 2);
+  return launch_bf_head(hp, fwd_stream(m), nblk);
+}
+
+// ---- backward -----------------------------------------------------------------------------------------------------
+static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, int Hy, int Cy, int s, int pb, float* out,
+                    int cpad, int creal) {
+  BWgradParams p;
+  memset(&p, 0, sizeof p);
+  p.X = X; p.Y = Y; p.zero = m->bf.zero; p.part = m->ws1; p.part_capacity = m->ws1_elems;
+  p.Hx = Hx; p.Cx = Cx; p.Hy = Hy; p.Cy = Cy; p.NBp = m->bf.NBp; p.s = s; p.pb = pb;
+  int ns = 0;
+  hipStream_t st = m->ctx->stream;
+  {
+    ProfScope ps(m, 1, st);
+    DV_TRY(launch_bwgrad(p, st, &ns));
+  }
+  ProfScope ps(m, 2, st);
+  return launch_reduce_partials(m->ws1, out, ns, 9L * Cx * Cy, Cy, cpad, creal, st);
+}
+
+// data gradient into `out` with the PReLU backward of the target layer (pre-activation u, slopes / bias specs) applied:
+// fused into the epilogue when the stamp padding allows it, else a separate pass
+static int bf_dgrad_prelu(dv_model* m, const void* X, const void* W, int Kpad, int form, int Hin, int Cin, int Hout,
+                          int Cout, int s, int pb, void* out, const void* u, int alpha_spec, int bias_spec,
+                          bool want_grads) {
+  const Arch& A = m->A;
+  BfState& bf = m->bf;
+  hipStream_t st = m->ctx->stream;
+  const long P = (long)Hout * Hout, E = P * Cout;
+  const float* alpha = m->P + A.specs[alpha_spec].off;
+  if (bconv_bwd_fusable(bf.NBp)) {
+    const int nparts = bf.NBp >> 6;
+    float *dal = nullptr, *db = nullptr;
+    if (want_grads) {
+      if (m->arena_off + (size_t)2 * nparts * E > m->arena_elems) {
+        set_error("gradient-partial arena exhausted");
+        return E_STATE;
+      }
+      dal = m->arena + m->arena_off;
+      db = dal + (size_t)nparts * E;
+      m->arena_off += (size_t)2 * nparts * E;
+    }
+    DV_TRY(bf_conv(m, X, W, Kpad, form, Hin, Cin, Hout, Cout, s, pb, BEPI_BWD, out, nullptr, nullptr, nullptr, alpha, u,
+                   dal, db));
+    if (want_grads) {
+      ProfScope ps(m, 2, st);
+      DV_TRY(launch_reduce_partials(dal, m->G + A.specs[alpha_spec].off, nparts, E, 4, 1, 1, st));
+      DV_TRY(launch_reduce_rows_f64(db, (int)(nparts * P), Cout, m->G + A.specs[bias_spec].off, 1.0f, st));
+    }
+    return OK;
+  }
+  DV_TRY(bf_conv(m, X, W, Kpad, form, Hin, Cin, Hout, Cout, s, pb, BEPI_RAWBF, out, nullptr, nullptr, nullptr, nullptr,
+                 nullptr, nullptr, nullptr));
+  float* dbr = nullptr;
+  if (want_grads) {
+    if (m->arena_off + (size_t)E > m->arena_elems) {
+      set_error("gradient-partial arena exhausted");
+      return E_STATE;
+    }
+    dbr = m->arena + m->arena_off;
+    m->arena_off += (size_t)E;
+  }
+  ProfScope ps(m, 2, st);
+  DV_TRY(launch_bf_prelu_bwd(out, u, alpha, out, want_grads ? m->G + A.specs[alpha_spec].off : nullptr, dbr, bf.NBp,
+                             (int)P, Cout, st));
+  if (want_grads) DV_TRY(launch_reduce_rows_f64(dbr, (int)P, Cout, m->G + A.specs[bias_spec].off, 1.0f, st));
+  return OK;
+}
+
+static int bf_backward(dv_model* m, int NB, int Bg) {
+  const Arch& A = m->A;
+  BfState& bf = m->bf;
+  hipStream_t s = m->ctx->stream;
+  float* P = m->P;
+  float* G = m->G;
+  const bool dg = m->dec_trainable;
+  m->wstream = s;
+  m->arena_off = 0;
+  m->ws_count = 0;
+  m->main_marked = false;
+  const int Hd = A.dec_out, f0 = A.cfg.filters[0], C2 = 2 * A.C;
+  void* cur = bf.gA;
+  void* oth = bf.gB;
+  // ---- head conv ----
+  if (dg) {
+    DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, 1, 1, m->Ghs, f0, f0));
+    ProfScope ps(m, 2, s);
+    DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, s));
+    int nr = 0;
+    DV_TRY(launch_bf_colsum(bf.dt, (long)Hd * Hd * bf.NBp, 16, m->ws3, &nr, s));
+    DV_TRY(launch_reduce_rows_f64(m->ws3, nr, C2, G + A.specs[A.head_b()].off, 1.0f, s, 16));
+  }
+  {
+    const int jl = 2 * A.L - 1;
+    DV_TRY(bf_dgrad_prelu(m, bf.dt, bf.head_w.d, bf.head_w.Kd, 1, Hd, 16, Hd, f0, 1, 1, cur, bf.dec_u[jl], A.dec_al(jl),
+                          A.dec_b(jl), dg));
+  }
+  // ---- decoder conv-transpose stack: cur = d(pre-activation) of layer j ----
+  for (int j = 2 * A.L - 1; j >= 0; --j) {
+    int hin, cin, hout, cout, st;
+    A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
+    const int pb = same_pad_before(hout, 3, st, nullptr);
+    const void* xin = j == 0 ? bf.dec_in : bf.dec_a[j - 1];
+    if (dg) DV_TRY(bf_wgrad(m, cur, hout, cout, xin, hin, cin, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout));
+    if (j > 0) {
+      DV_TRY(bf_dgrad_prelu(m, cur, bf.dec_w[j].d, bf.dec_w[j].Kd, 0, hout, cout, hin, cin, st, pb, oth, bf.dec_u[j - 1],
+                            A.dec_al(j - 1), A.dec_b(j - 1), dg));
+    } else {
+      DV_TRY(bf_conv(m, cur, bf.dec_w[j].d, bf.dec_w[j].Kd, 0, hout, cout, hin, cin, st, pb, BEPI_RAWBF, oth, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+    }
+    std::swap(cur, oth);
+  }
+  // ---- dense trunk of the decoder, sampler, encoder dense: fp32 rows in m->gA / m->gB ----
+  const int fl = A.cfg.filters[A.L - 1];
+  const int r = A.w0 * A.w0 * fl;
+  float* c32 = m->gA;
+  float* o32 = m->gB;
+  {
+    ProfScope ps(m, 2, s);
+    DV_TRY(launch_bf_to_rows(cur, c32, NB, bf.NBp, A.w0 * A.w0, fl, s));
+  }
+  DV_TRY(prelu_bwd(m, c32, m->dec_ur, A.D0 + 6, A.D0 + 5, NB, r, r, dg));
+  if (dg) DV_TRY(wgrad(m, m->dec_ah, 1, A.dec_hidden, c32, 1, r, NB, 1, 0, true, G + A.specs[A.D0 + 4].off, 1, 1));
+  DV_TRY(gconv_fprop(m, c32, P + A.specs[A.D0 + 4].off, true, nullptr, nullptr, o32, nullptr, 0, NB, 1, r, 1,
+                     A.dec_hidden, 1, 0, true));
+  std::swap(c32, o32);
+  DV_TRY(prelu_bwd(m, c32, m->dec_uh, A.D0 + 3, A.D0 + 2, NB, A.dec_hidden, A.dec_hidden, dg));
+  if (dg) DV_TRY(wgrad(m, m->dec_ain, 1, A.d, c32, 1, A.dec_hidden, NB, 1, 0, true, G + A.specs[A.D0 + 1].off, 1, 1));
+  DV_TRY(gconv_fprop(m, c32, P + A.specs[A.D0 + 1].off, true, nullptr, nullptr, o32, nullptr, 0, NB, 1, A.dec_hidden, 1,
+                     A.d, 1, 0, true));
+  std::swap(c32, o32);
+  DV_TRY(prelu_bwd(m, c32, m->z, A.D0, -1, NB, A.d, A.d, dg));
+  const float kls = (float)((double)A.cfg.kl_multiplicity * A.cfg.kl_weight / ((double)Bg * (double)Bg));
+  {
+    ProfScope ps(m, 2);
+    DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, c32, o32, NB, A.d, A.cfg.diag_shift, kls, s));
+  }
+  std::swap(c32, o32);   // d(t) [NB, tw]
+  DV_TRY(bias_grad_colsum(m, c32, NB, A.tw, A.tw, A.enc_db()));
+  DV_TRY(wgrad(m, m->flat_a, 1, A.flat, c32, 1, A.tw, NB, 1, 0, true, G + A.specs[A.enc_dk()].off, 1, 1));
+  DV_TRY(gconv_fprop(m, c32, P + A.specs[A.enc_dk()].off, true, nullptr, nullptr, o32, nullptr, 0, NB, 1, A.tw, 1, A.flat,
+                     1, 0, true));
+  std::swap(c32, o32);
+  DV_TRY(prelu_bwd(m, c32, bf.flat_in, A.enc_flat_al(), -1, NB, A.flat, A.flat, true));
+  // ---- back into the stamp-inner layout: d(activation) of the last encoder conv, then its PReLU backward ----
+  {
+    const int jl = 2 * A.L - 1;
+    const int sl = A.enc_sizes[A.L];
+    const long Pn = (long)sl * sl, E = Pn * fl;
+    cur = bf.gA;
+    oth = bf.gB;
+    if (m->arena_off + (size_t)E > m->arena_elems) {
+      set_error("gradient-partial arena exhausted");
+      return E_STATE;
+    }
+    float* dbr = m->arena + m->arena_off;
+    m->arena_off += (size_t)E;
+    ProfScope ps(m, 2, s);
+    DV_TRY(launch_bf_from_rows(c32, cur, NB, bf.NBp, (int)Pn, fl, s));
+    DV_TRY(launch_bf_prelu_bwd(cur, bf.enc_u[jl], P + A.specs[A.enc_al(jl)].off, cur, G + A.specs[A.enc_al(jl)].off, dbr,
+                               bf.NBp, (int)Pn, fl, s));
+    DV_TRY(launch_reduce_rows_f64(dbr, (int)Pn, fl, G + A.specs[A.enc_b(jl)].off, 1.0f, s));
+  }
+  // ---- encoder conv stack: cur = d(pre-activation) of layer j ----
+  for (int j = 2 * A.L - 1; j >= 0; --j) {
+    int hin, cin, hout, cout, st;
+    A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
+    const int pb = same_pad_before(hin, 3, st, nullptr);
+    if (j == 0) {
+      // first conv with the folded input BatchNorm: the gradient w.r.t. the 16-channel folded kernel (channels
+      // 0..C-1 = bands, C = the constant one) yields d(kernel), d(gamma), d(beta); no data gradient
+      DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8));
+      ProfScope ps(m, 2, s);
+      DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
+                                   G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, 9, A.C, 8, cout,
+                                   s));
+      break;
+    }
+    DV_TRY(bf_wgrad(m, bf.enc_a[j - 1], hin, cin, cur, hout, cout, st, pb, G + A.specs[A.enc_k(j)].off, cin, cin));
+    DV_TRY(bf_dgrad_prelu(m, cur, bf.enc_w[j].d, bf.enc_w[j].Kd, 1, hout, cout, hin, cin, st, pb, oth, bf.enc_u[j - 1],
+                          A.enc_al(j - 1), A.enc_b(j - 1), true));
+    std::swap(cur, oth);
+  }
+  m->enc_reduced_from = A.n_enc_train;
+  // data parallelism: one all-reduce of the whole gradient (the step is ~1 ms; bucketing it buys little)
+  if (m->ctx->comm) {
+    dv_ctx* cx = m->ctx;
+    DV_HIP(hipEventRecord(cx->ev_dec, s));
+    DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_dec, 0));
+    const size_t n = dg ? A.n_train : A.n_enc_train;
+    DV_NCCL(ncclAllReduce(G, G, n, ncclFloat, ncclSum, cx->comm, cx->comm_stream));
+    m->enc_reduced_from = 0;
+  }
+  return OK;
+}

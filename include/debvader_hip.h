@@ -50,7 +50,12 @@ typedef struct dv_config {
   int32_t bn_moving_var_unbiased;    /* fused-BN moving variance uses the Bessel-corrected batch variance (1) */
   float sigma_floor;                 /* model.py:156 (1e-4) */
   float diag_shift;                  /* model.py:49 (1e-5) */
+  int32_t dtype;                     /* DV_DTYPE_F32 (0, the reference's precision) or DV_DTYPE_BF16 (1): bf16 storage and
+                                        bf16 MFMA operands for the conv / conv-transpose stacks (model.py:79-98,112-137),
+                                        fp32 accumulation, fp32 master weights / Adam / dense trunk / sampler / head */
 } dv_config;
+#define DV_DTYPE_F32 0
+#define DV_DTYPE_BF16 1
 
 /* scalars written by the step functions */
 enum { DV_S_LOSS = 0, DV_S_NLL_MEAN = 1, DV_S_KL_REG = 2, DV_S_MSE = 3, DV_N_SCALARS = 4 };
