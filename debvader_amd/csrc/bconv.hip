@@ -15,6 +15,7 @@
 // stamp sums of the fused PReLU backward (d(alpha), d(bias)) are register adds plus two cross-lane steps.
 #include "common.h"
 #include "bf16.h"
+#include <stdlib.h>
 
 namespace dv {
 
@@ -27,6 +28,10 @@ typedef __bf16 bc_bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int BC_GT = 16;      // groups per tile
+#ifndef BC_NST_VALUE
+#define BC_NST_VALUE 3
+#endif
+constexpr int BC_NST = BC_NST_VALUE;   // LDS stages: 3 = DMA two steps ahead; 2 = one step ahead, but twice the workgroups per CU
 constexpr int BC_TABW = 12;    // table row: 9 tap offsets, output row base, pixel index, spare
 
 template <int N>
@@ -70,15 +75,17 @@ __device__ __forceinline__ void load_f32(const float* src, float* v) {
 // CINMODE 1: Cin == 8 or 16 (first conv, data gradient of the 16-channel head): a K step is four 16-byte pieces,
 //            piece q of step i is channels (i*4+q) % (Cin/8) * 8.. of tap (i*4+q) / (Cin/8); all nine taps are walked.
 template <int NBLK, int CINMODE>
-__global__ __launch_bounds__(256, 2) void bconv_kernel(const BConvParams p) {
+__global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const BConvParams p) {
   constexpr int STAGE = (BC_GT + NBLK) * 1024;
+  constexpr int BN = 16 * NBLK;
+  constexpr int NST = BC_NST;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  int* tab = reinterpret_cast<int*>(smem + 3 * STAGE);   // [16][12]
+  int* tab = reinterpret_cast<int*>(smem + NST * STAGE);   // [16][12]
   int* anyv = tab + BC_GT * BC_TABW;                      // [16]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntn = p.Cout / (16 * NBLK);
+  const int ntn = p.Cout / BN;
   int bid = blockIdx.x;
   {
     // XCD-contiguous tile order: the blocks one XCD receives (every 8th) walk neighbouring pixels, whose taps
@@ -87,62 +94,106 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const BConvParams p) {
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
   const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
-  const int n0 = tile_n * 16 * NBLK;
+  const int n0 = tile_n * BN;
   const int NSB = p.NBp >> 4;
-  const int M16 = p.Hout * p.Hout * NSB;
-
-  if (tid < BC_GT * 9) {
-    const int g = tid / 9, t = tid - g * 9;
-    const int m16 = tile_m * BC_GT + g;
-    int off = -1;
-    if (m16 < M16) {
-      const int pix = m16 / NSB, sb = m16 - pix * NSB;
-      const int oh = pix / p.Hout, ow = pix - oh * p.Hout;
-      const int kh = t / 3, kw = t - kh * 3;
-      int ih, iw;
-      bool ok = true;
-      if (p.form == 0) {
-        ih = oh * p.s + kh - p.pb;
-        iw = ow * p.s + kw - p.pb;
-      } else {
-        const int nh = oh + p.pb - kh, nw = ow + p.pb - kw;
-        ok = nh >= 0 && nw >= 0 && (nh % p.s) == 0 && (nw % p.s) == 0;
-        ih = nh / p.s;
-        iw = nw / p.s;
-      }
-      ok = ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Hin;
-      // offset of the group's [16][Cin] block in units of 8 elements (16 bytes)
-      if (ok) off = ((ih * p.Hin + iw) * p.NBp + sb * 16) * (p.Cin >> 3);
-      if (t == 0) {
-        tab[g * BC_TABW + 9] = pix * p.NBp + sb * 16;
-        tab[g * BC_TABW + 10] = pix;
-      }
-    } else if (t == 0) {
-      tab[g * BC_TABW + 9] = -1;
-      tab[g * BC_TABW + 10] = 0;
+  // Output pixels are walked in 8 x 8 blocks (virtual pixel index -> block, then row / column inside it; positions past
+  // the image edge are empty): neighbouring tiles of an XCD share their 3 x 3 input neighbourhoods in its L2.
+  const int nbx = (p.Hout + 7) >> 3;
+  const int M16 = nbx * nbx * 64 * NSB;
+  auto vpixel = [&](int vp, int* oh, int* ow) {
+    const int blk = vp >> 6, by = blk / nbx, bx = blk - by * nbx;
+    *oh = by * 8 + ((vp >> 3) & 7);
+    *ow = bx * 8 + (vp & 7);
+  };
+  // source pixel of tap t for output pixel (oh, ow), -1 when outside the image (or, form 1, between the strides)
+  auto src_pixel = [&](int oh, int ow, int t) -> int {
+    const int kh = (t * 11) >> 5, kw = t - kh * 3;       // t / 3 for t < 9
+    int ih, iw;
+    bool ok = true;
+    if (p.form == 0) {
+      ih = oh * p.s + kh - p.pb;
+      iw = ow * p.s + kw - p.pb;
+    } else {
+      const int nh = oh + p.pb - kh, nw = ow + p.pb - kw;
+      ok = nh >= 0 && nw >= 0 && (p.s == 1 || ((nh | nw) & 1) == 0);
+      ih = p.s == 1 ? nh : nh >> 1;
+      iw = p.s == 1 ? nw : nw >> 1;
     }
-    tab[g * BC_TABW + t] = off;
-  }
-  __syncthreads();
-  if (tid < 9) {
-    int a = 0;
-#pragma unroll
-    for (int g = 0; g < BC_GT; ++g) a |= tab[g * BC_TABW + tid] >= 0 ? 1 : 0;
-    anyv[tid] = a;
-  }
-  __syncthreads();
+    ok = ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Hin;
+    return ok ? ih * p.Hin + iw : -1;
+  };
+
+  // ---- which groups / taps: a tile that is ONE pixel (stamps padded to a multiple of 256) needs no table -------
+  const bool uni = (NSB & 15) == 0;
+  int u_oh = 0, u_ow = 0, u_sb0 = 0;                    // uniform tile: its pixel and first stamp block
   unsigned long long vcode = 0;
   int nvalid = 0;
+  if (uni) {
+    const int tpp = NSB >> 4;
+    const int vp = tile_m / tpp;
+    u_sb0 = (tile_m - vp * tpp) * 16;
+    vpixel(vp, &u_oh, &u_ow);
+    if (u_oh >= p.Hout || u_ow >= p.Hout) return;      // padding of the 8 x 8 blocks
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
-    if (anyv[t]) {
-      vcode |= (unsigned long long)t << (4 * nvalid);
-      ++nvalid;
+    for (int t = 0; t < 9; ++t)
+      if (src_pixel(u_oh, u_ow, t) >= 0) {
+        vcode |= (unsigned long long)t << (4 * nvalid);
+        ++nvalid;
+      }
+  } else {
+    if (tid < BC_GT * 9) {
+      const int g = tid / 9, t = tid - g * 9;
+      const int m16 = tile_m * BC_GT + g;
+      int off = -1;
+      const int vp = m16 / NSB, sb = m16 - vp * NSB;
+      int oh, ow;
+      vpixel(vp, &oh, &ow);
+      if (m16 < M16 && oh < p.Hout && ow < p.Hout) {
+        const int sp = src_pixel(oh, ow, t);
+        // offset of the group's [16][Cin] block in units of 8 elements (16 bytes)
+        if (sp >= 0) off = (sp * p.NBp + sb * 16) * (p.Cin >> 3);
+        if (t == 0) {
+          tab[g * BC_TABW + 9] = (oh * p.Hout + ow) * p.NBp + sb * 16;
+          tab[g * BC_TABW + 10] = oh * p.Hout + ow;
+        }
+      } else if (t == 0) {
+        tab[g * BC_TABW + 9] = -1;
+        tab[g * BC_TABW + 10] = 0;
+      }
+      tab[g * BC_TABW + t] = off;
     }
+    __syncthreads();
+    if (tid < 10) {                                     // taps 0..8; 9: any group inside the image
+      int a = 0;
+#pragma unroll
+      for (int g = 0; g < BC_GT; ++g) a |= tab[g * BC_TABW + tid] >= 0 ? 1 : 0;
+      anyv[tid] = a;
+    }
+    __syncthreads();
+    if (!anyv[9]) return;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      if (anyv[t]) {
+        vcode |= (unsigned long long)t << (4 * nvalid);
+        ++nvalid;
+      }
+  }
   nvalid = __builtin_amdgcn_readfirstlane(nvalid);
-  const unsigned vlo = __builtin_amdgcn_readfirstlane((unsigned)vcode);
-  const unsigned vhi = __builtin_amdgcn_readfirstlane((unsigned)(vcode >> 32));
-  vcode = ((unsigned long long)vhi << 32) | vlo;
+  {
+    const unsigned vlo = __builtin_amdgcn_readfirstlane((unsigned)vcode);
+    const unsigned vhi = __builtin_amdgcn_readfirstlane((unsigned)(vcode >> 32));
+    vcode = ((unsigned long long)vhi << 32) | vlo;
+  }
+  // block offset (units of 16 bytes) of group g for tap t, -1 outside; output row base and pixel of group g
+  auto group_off = [&](int g, int t) -> int {
+    if (uni) {
+      const int sp = src_pixel(u_oh, u_ow, t);
+      return sp >= 0 ? (sp * p.NBp + (u_sb0 + g) * 16) * (p.Cin >> 3) : -1;
+    }
+    return tab[g * BC_TABW + t];
+  };
+  auto group_rb = [&](int g) -> int { return uni ? (u_oh * p.Hout + u_ow) * p.NBp + (u_sb0 + g) * 16 : tab[g * BC_TABW + 9]; };
+  auto group_pix = [&](int g) -> int { return uni ? u_oh * p.Hout + u_ow : tab[g * BC_TABW + 10]; };
 
   const int cpt = p.Cin >> 5;         // chunks per tap (CINMODE 0)
   const int ppt = p.Cin >> 3;         // 16-byte pieces per tap (CINMODE 1: 1 or 2)
@@ -158,21 +209,51 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const BConvParams p) {
   const bc_bf16* wrow = Wb + (size_t)(n0 + NBLK * drow + jb) * p.Kpad + dq * 8;
   const int arow = drow * p.Cin;
 
+  // fused PReLU backward: this wave's [64 rows][BN] tile of the target layer's pre-activation is fetched now, 16 bytes
+  // per lane, and parked in registers until the epilogue
+  constexpr int NROWCH = BN / 8;                        // 16-byte pieces per lane that make up [64][BN] bf16
+  f32x4 uin[NROWCH];
+  if (p.epi == BEPI_BWD) {
+#pragma unroll
+    for (int k = 0; k < NROWCH; ++k) {
+      const int byte = (k * 64 + lane) * 16;
+      const int row = byte / (BN * 2), colb = byte - row * (BN * 2);
+      const int rb = group_rb(wave * 4 + (row >> 4));
+      uin[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (rb >= 0)
+        uin[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.Uin) +
+                                                 ((size_t)(rb + (row & 15)) * p.Cout + n0) * 2 + colb);
+    }
+  }
+
+  // DMA issue state (CINMODE 0): steps walk (valid tap, chunk) in order, so the four group sources of the current
+  // tap are worked out once per tap, not once per step
+  int is_ti = -1, is_cc = 0, is_tap = 0;
+  const unsigned char* gsrc[4] = {zlane, zlane, zlane, zlane};
+  bool gok[4] = {false, false, false, false};
   auto issue = [&](int step, int buf) {
     unsigned char* sA = smem + buf * STAGE;
     unsigned char* sB = sA + BC_GT * 1024;
     if constexpr (CINMODE == 0) {
-      const int ti = step / cpt, cc = step - ti * cpt;
-      const int tap = (int)((vcode >> (4 * ti)) & 15);
-      const int lo = arow + cc * 32 + dq * 8;
+      if (is_ti < 0 || is_cc + 1 == cpt) {
+        ++is_ti;
+        is_cc = 0;
+        is_tap = (int)((vcode >> (4 * is_ti)) & 15);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          const int off = group_off(wave * 4 + gi, is_tap);
+          gok[gi] = off >= 0;
+          gsrc[gi] = reinterpret_cast<const unsigned char*>(Xb + ((size_t)(off >= 0 ? off : 0) * 8 + arow + dq * 8));
+        }
+      } else {
+        ++is_cc;
+      }
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
-        const int g = wave * 4 + gi;
-        const int off = tab[g * BC_TABW + tap];
-        const void* src = off >= 0 ? (const void*)(Xb + ((size_t)off * 8 + lo)) : (const void*)zlane;
-        __builtin_amdgcn_global_load_lds((bc_gptr_t)src, (bc_lptr_t)(sA + g * 1024), 16, 0, 0);
+        const void* src = gok[gi] ? (const void*)(gsrc[gi] + is_cc * 64) : (const void*)zlane;
+        __builtin_amdgcn_global_load_lds((bc_gptr_t)src, (bc_lptr_t)(sA + (wave * 4 + gi) * 1024), 16, 0, 0);
       }
-      __builtin_amdgcn_global_load_lds((bc_gptr_t)(wrow + tap * p.Cin + cc * 32), (bc_lptr_t)(sB + jb * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((bc_gptr_t)(wrow + is_tap * p.Cin + is_cc * 32), (bc_lptr_t)(sB + jb * 1024), 16, 0, 0);
     } else {
       const int piece = step * 4 + dq;
       const int tap = ppt == 1 ? piece : piece >> 1;
@@ -182,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const BConvParams p) {
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
         const int g = wave * 4 + gi;
-        const int off = pv ? tab[g * BC_TABW + tap] : -1;
+        const int off = pv ? group_off(g, tap) : -1;
         const void* src = off >= 0 ? (const void*)(Xb + ((size_t)off * 8 + lo)) : (const void*)zlane;
         __builtin_amdgcn_global_load_lds((bc_gptr_t)src, (bc_lptr_t)(sA + g * 1024), 16, 0, 0);
       }
@@ -201,16 +282,20 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const BConvParams p) {
     for (int j = 0; j < NBLK; ++j) acc[gi][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (nsteps > 0) issue(0, 0);
-  if (nsteps > 1) issue(1, 1);
+  if (NST == 3 && nsteps > 1) issue(1, 1);
   int buf = 0;
   for (int i = 0; i < nsteps; ++i) {
     // five DMA instructions per wave and stage: all but the youngest stage have landed
-    if (i + 1 < nsteps)
+    if (NST == 3 && i + 1 < nsteps && !(p.dbg & 1))
       asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (i + 2 < nsteps) issue(i + 2, buf >= 1 ? buf - 1 : 2);   // (buf + 2) % 3: the stage read in step i - 1
+    if (NST == 3) {
+      if (i + 2 < nsteps && !(p.dbg & 1)) issue(i + 2, buf >= 1 ? buf - 1 : 2);   // (buf + 2) % 3: the stage read in step i - 1
+    } else {
+      if (i + 1 < nsteps && !(p.dbg & 1)) issue(i + 1, buf ^ 1);
+    }
     const unsigned char* sA = smem + buf * STAGE + wave * 4096 + fragoff;
     const unsigned char* sB = smem + buf * STAGE + BC_GT * 1024 + fragoff;
     bc_bf16x8 a[4], b[NBLK];
@@ -218,66 +303,161 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const BConvParams p) {
     for (int gi = 0; gi < 4; ++gi) a[gi] = *reinterpret_cast<const bc_bf16x8*>(sA + gi * 1024);
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) b[j] = *reinterpret_cast<const bc_bf16x8*>(sB + j * 1024);
+    if (!(p.dbg & 2)) {
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi)
+      for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
-      for (int j = 0; j < NBLK; ++j)
-        acc[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gi], b[j], acc[gi][j], 0, 0, 0);
-    buf = buf == 2 ? 0 : buf + 1;
+        for (int j = 0; j < NBLK; ++j)
+          acc[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gi], b[j], acc[gi][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) asm volatile("" ::"v"(a[gi]));
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) asm volatile("" ::"v"(b[j]));
+    }
+    buf = NST == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
   }
 
-  // ---- epilogue: lane (c, g4) owns channels ch0 .. ch0+NBLK-1 of stamps 4*g4 .. 4*g4+3 of each of its 4 groups ----
+  if (p.dbg & 4) {
+    if (acc[0][0][0] == 123.456f) reinterpret_cast<bc_bf16*>(p.U)[0] = (bc_bf16)1.f;
+    return;
+  }
+  // ---- epilogue ---------------------------------------------------------------------------------------------------
+  // Lane (c, g4) owns channels n0 + NBLK*c .. +NBLK-1 of stamps 4*g4 .. 4*g4+3 of each of its wave's 4 groups.  The
+  // values go through a per-wave LDS tile [64 rows][BN] (the stage buffers are free once every wave has left the
+  // loop) so that global memory sees 16-byte accesses of whole rows: the 2*NBLK-byte stores straight from the
+  // accumulators were the largest single cost of the kernel (store-issue bound, 32 instructions per wave and tensor).
+  __builtin_amdgcn_s_barrier();
+  constexpr int WREG = 64 * BN * (NBLK == 1 ? 4 : 2);
+  unsigned char* wreg = smem + wave * WREG;
   const int c = lane & 15, g4 = lane >> 4;
   const int ch0 = n0 + NBLK * c;
+  int rbs[4];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) rbs[gi] = group_rb(wave * 4 + gi);
+  // rows of the tile -> global memory, 16 bytes per lane; esz = bytes per element
+  auto flush = [&](void* dst, int esz) {
+    const int rowb = BN * esz;
+    const int npc = 64 * rowb / 1024;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k >= npc) break;
+      const int byte = (k * 64 + lane) * 16;
+      const int row = byte / rowb, colb = byte - row * rowb;
+      const int rb = rbs[0] < 0 && rbs[1] < 0 && rbs[2] < 0 && rbs[3] < 0 ? -1
+                     : ((row >> 4) == 0 ? rbs[0] : (row >> 4) == 1 ? rbs[1] : (row >> 4) == 2 ? rbs[2] : rbs[3]);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wreg + byte);
+      if (rb >= 0)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(dst) + ((size_t)(rb + (row & 15)) * p.Cout + n0) * esz + colb) = v;
+    }
+  };
   float bias[NBLK];
 #pragma unroll
   for (int j = 0; j < NBLK; ++j) bias[j] = 0.f;
   if (p.bias && (p.epi == BEPI_FWD || p.epi == BEPI_RAW32)) load_f32<NBLK>(p.bias + ch0, bias);
+
+  if (p.epi == BEPI_RAW32) {
+    if constexpr (NBLK == 1) {
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          reinterpret_cast<float*>(wreg)[(gi * 16 + 4 * g4 + r) * BN + c] = acc[gi][0][r] + bias[0];
+      flush(p.Uf, 4);
+    } else {
+      // fp32 output is only produced by the 16-channel head: wider tiles store straight from the accumulators
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        if (rbs[gi] < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j)
+            p.Uf[((size_t)rbs[gi] + 4 * g4 + r) * p.Cout + ch0 + j] = acc[gi][j][r] + bias[j];
+      }
+    }
+    return;
+  }
+  bc_bf16* wt = reinterpret_cast<bc_bf16*>(wreg);
+  if (p.epi == BEPI_RAWBF) {
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v[NBLK];
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) v[j] = acc[gi][j][r];
+        store_bf<NBLK>(wt + (gi * 16 + 4 * g4 + r) * BN + NBLK * c, v);
+      }
+    flush(p.U, 2);
+    return;
+  }
+  if (p.epi == BEPI_FWD) {
+    float al[4][NBLK];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) al[gi][j] = 0.f;
+      if (rbs[gi] >= 0) load_f32<NBLK>(p.alpha + (size_t)group_pix(wave * 4 + gi) * p.Cout + ch0, al[gi]);
+    }
+    if (p.U) {
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v[NBLK];
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j) v[j] = acc[gi][j][r] + bias[j];
+          store_bf<NBLK>(wt + (gi * 16 + 4 * g4 + r) * BN + NBLK * c, v);
+        }
+      flush(p.U, 2);
+    }
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a[NBLK];
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
+          const float v = acc[gi][j][r] + bias[j];
+          a[j] = v > 0.f ? v : al[gi][j] * v;
+        }
+        store_bf<NBLK>(wt + (gi * 16 + 4 * g4 + r) * BN + NBLK * c, a);
+      }
+    flush(p.A, 2);
+    return;
+  }
+  // ---- BEPI_BWD: d(pre-activation) = d(activation) * (u > 0 ? 1 : alpha), stamp sums for d(alpha) / d(bias) ----
+#pragma unroll
+  for (int k = 0; k < NROWCH; ++k) *reinterpret_cast<f32x4*>(wreg + (k * 64 + lane) * 16) = uin[k];
   float dal[NBLK], db[NBLK];
 #pragma unroll
   for (int j = 0; j < NBLK; ++j) dal[j] = db[j] = 0.f;
   int pix_w = 0, rb_w = -1;
 #pragma unroll
   for (int gi = 0; gi < 4; ++gi) {
-    const int G = wave * 4 + gi;
-    const int rb = tab[G * BC_TABW + 9];
-    if (rb < 0) continue;
-    const int pix = tab[G * BC_TABW + 10];
-    pix_w = pix;
-    rb_w = rb;
+    if (rbs[gi] < 0) continue;
+    pix_w = group_pix(wave * 4 + gi);
+    rb_w = rbs[gi];
     float al[NBLK];
-    if (p.epi == BEPI_FWD || p.epi == BEPI_BWD) load_f32<NBLK>(p.alpha + (size_t)pix * p.Cout + ch0, al);
+    load_f32<NBLK>(p.alpha + (size_t)pix_w * p.Cout + ch0, al);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t e = ((size_t)rb + 4 * g4 + r) * p.Cout + ch0;
-      float v[NBLK];
+      bc_bf16* q = wt + (gi * 16 + 4 * g4 + r) * BN + NBLK * c;
+      float u[NBLK], du[NBLK];
+      load_bf<NBLK>(q, u);
 #pragma unroll
-      for (int j = 0; j < NBLK; ++j) v[j] = acc[gi][j][r] + bias[j];
-      if (p.epi == BEPI_RAW32) {
-#pragma unroll
-        for (int j = 0; j < NBLK; ++j) p.Uf[e + j] = v[j];
-      } else if (p.epi == BEPI_RAWBF) {
-        store_bf<NBLK>(reinterpret_cast<bc_bf16*>(p.U) + e, v);
-      } else if (p.epi == BEPI_FWD) {
-        float a[NBLK];
-#pragma unroll
-        for (int j = 0; j < NBLK; ++j) a[j] = v[j] > 0.f ? v[j] : al[j] * v[j];
-        if (p.U) store_bf<NBLK>(reinterpret_cast<bc_bf16*>(p.U) + e, v);
-        store_bf<NBLK>(reinterpret_cast<bc_bf16*>(p.A) + e, a);
-      } else {
-        float u[NBLK], du[NBLK];
-        load_bf<NBLK>(reinterpret_cast<const bc_bf16*>(p.Uin) + e, u);
-#pragma unroll
-        for (int j = 0; j < NBLK; ++j) {
-          du[j] = v[j] * (u[j] > 0.f ? 1.f : al[j]);
-          dal[j] += v[j] * fminf(u[j], 0.f);
-          db[j] += du[j];
-        }
-        store_bf<NBLK>(reinterpret_cast<bc_bf16*>(p.U) + e, du);
+      for (int j = 0; j < NBLK; ++j) {
+        const float v = acc[gi][j][r];
+        du[j] = v * (u[j] > 0.f ? 1.f : al[j]);
+        dal[j] += v * fminf(u[j], 0.f);
+        db[j] += du[j];
       }
+      store_bf<NBLK>(q, du);
     }
   }
-  if (p.epi == BEPI_BWD && p.dal_part && rb_w >= 0) {
+  flush(p.U, 2);
+  if (p.dal_part && rb_w >= 0) {
     // the wave's four groups are 64 consecutive stamps of ONE pixel (NBp % 64 == 0): slab = stamp block / 4
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) {
@@ -298,8 +478,11 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const BConvParams p) {
   }
 }
 
-int launch_bconv(const BConvParams& p, hipStream_t s) {
-  if (p.NBp <= 0 || (p.NBp & 15) || p.Cout % 16 || p.Kpad % 32) {
+int launch_bconv(const BConvParams& p_in, hipStream_t s) {
+  BConvParams p = p_in;
+  static const int dbg = getenv("DV_BCONV_DBG") ? atoi(getenv("DV_BCONV_DBG")) : 0;
+  p.dbg = dbg;
+  if (p.NBp <= 0 || (p.NBp & 15) || p.Cout % 16 || p.Kpad % 32 || p.s < 1 || p.s > 2) {
     set_error("bconv: bad geometry (NBp %d, Cout %d, Kpad %d)", p.NBp, p.Cout, p.Kpad);
     return E_INVALID;
   }
@@ -317,10 +500,16 @@ int launch_bconv(const BConvParams& p, hipStream_t s) {
     set_error("bconv: tensor too large for 32-bit block offsets");
     return E_INVALID;
   }
-  const int nblk = p.Cout % 64 == 0 ? 4 : (p.Cout % 32 == 0 ? 2 : 1);
-  const long M16 = (long)p.Hout * p.Hout * (p.NBp >> 4);
+  int nblk = p.Cout % 64 == 0 ? 4 : (p.Cout % 32 == 0 ? 2 : 1);
+  const long nbx = (p.Hout + 7) / 8;
+  const long M16 = nbx * nbx * 64 * (p.NBp >> 4);   // 8 x 8 pixel blocks, see the kernel
+  // deep layers have few row tiles and a long K loop that one workgroup walks alone: narrower column tiles put a
+  // workgroup on every CU (their input is re-read from L2 once more per halving, which these latency-bound launches
+  // do not notice)
+  static const long want_tiles = getenv("DV_BCONV_MIN_TILES") ? atol(getenv("DV_BCONV_MIN_TILES")) : 512;
+  while (nblk > 1 && ((M16 + BC_GT - 1) / BC_GT) * (p.Cout / (16 * nblk)) < want_tiles) nblk >>= 1;
   const long tiles = ((M16 + BC_GT - 1) / BC_GT) * (p.Cout / (16 * nblk));
-  const size_t lds = (size_t)3 * (BC_GT + nblk) * 1024 + 1024;
+  const size_t lds = (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;
 #define BC_LAUNCH(NB_, MODE_)                                                                          \
   do {                                                                                                 \
     static bool attr_done = false;                                                                     \

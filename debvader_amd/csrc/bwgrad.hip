@@ -3,13 +3,20 @@
 // Kernel gradients of Conv2D (X = layer input, Y = d(pre-activation)) and Conv2DTranspose (X = d(pre-activation),
 // Y = layer input; kernel layout (kh,kw,cout,cin)) of model.py:81-91,121-137.
 //
-// The contraction index is the STAMP: for one Y pixel and one tap, both operands are [stamps][channels] blocks of the
-// stamp-inner layout, and v_mfma_f32_16x16x32_bf16 wants 8 consecutive k per lane for a fixed channel - a transposed
-// read, which ds_read_b64_tr_b16 delivers from the row-major LDS image (4 stamps x 16 channels per 16-lane group).
-// A workgroup owns a (32*WX) x (32*WY) channel tile, NT of the nine taps and a range of Y pixels; per (pixel,
-// 32-stamp k-step) the Y block and the X blocks of its valid taps arrive by LDS-DMA (double buffered), each wave
-// multiplies its 32 x 32 sub-tile for every tap.  Taps outside the image are skipped (uniform per pixel).
-// Results are fp32 partial slabs [split][9][Cx][Cy], summed in a fixed order by reduce_partials (deterministic).
+// The contraction index is the STAMP: for one Y pixel and one tap both operands are [16 stamps][32 channels] blocks
+// of the stamp-inner layout, and the MFMA wants 8 consecutive k per lane for a fixed channel - a transposed read,
+// which ds_read_b64_tr_b16 delivers from the row-major LDS image (4 stamps x 16 channels per 16-lane group).
+//
+// Every WAVE is a pipeline of its own (no workgroup barrier in the loop): it owns a 32 x 32 channel tile for all nine
+// taps (9 x 16 accumulator registers, v_mfma_f32_32x32x16_bf16), 16 stamps, and a range of Y rows.  It walks a row
+// pixel by pixel with a SLIDING WINDOW of X blocks in its private LDS (3 rows x 8 column slots of 1 KiB): a step
+// brings in only the s new columns (3*s blocks) and the next Y block by LDS-DMA, issued one step ahead of their use
+// (four pixels ahead at stride 1, two at stride 2; counted vmcnt), and multiplies the Y block with the nine X blocks
+// of the window - 4 KiB of DMA per 18 kFLOP x 16 instead of 10 KiB.  Taps outside the image are skipped (uniform per pixel).  The four waves of a workgroup are four
+// consecutive 16-stamp chunks; they sum their tiles through LDS in a fixed order and write one fp32 slab
+// [9][Cx][Cy] per workgroup, which reduce_partials adds up (deterministic).
+// Operands with 16 channels (the first conv's padded input, the head's gradient) fill half of the 32-wide tile; the
+// lanes of the other half read a zeroed LDS region.
 #include "common.h"
 #include "bf16.h"
 #include <algorithm>
@@ -22,239 +29,248 @@ typedef __attribute__((address_space(3))) void* bw_lptr_t;
 typedef __bf16 bw_bf16;
 typedef __bf16 bw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bw_bf16x4 __attribute__((ext_vector_type(4)));
+typedef float bw_f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) bw_bf16x4* bw_l4ptr_t;
 
 namespace {
+constexpr int BW_NCS = 8;                              // column slots of the X window
+constexpr int BW_NYS = 8;                              // Y slots
+constexpr int BW_WAVE_LDS = (3 * BW_NCS + BW_NYS + 1) * 1024;   // + 1 KiB of zeros
+constexpr int BW_RED_BYTES = 9 * 16 * 64 * 4;          // one wave's accumulators
+
 struct BWGeom {
-  int WX, WY;          // waves along cx / cy
-  int ntx, nty;        // channel tiles
-  int ntg;             // tap groups (9 / NT)
-  int nsplit, pix_per_split;
-  int kst;             // 32-stamp k-steps per pixel
-  int px, py;          // 1-KiB DMA pieces per k-step: X per tap, Y
-  int stage_bytes;
+  int ntx, nty;        // 32-channel tiles
+  int nrseg, rows_per; // Y row segments
+  int nsc4;            // groups of four 16-stamp chunks
 };
 
-// two transposed reads = the 8 k values (stamps 4*grp+0..3 and 16+4*grp+0..3) of channel (lane & 15)
-__device__ __forceinline__ bw_bf16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
-  const bw_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bw_l4ptr_t)(p0));
-  const bw_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bw_l4ptr_t)(p1));
-  bw_bf16x8 r;
-  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-  return r;
+// Transposed LDS reads go through inline asm: for the builtin (an LDS read with no alias information) hipcc waits
+// vmcnt(0) - every LDS-DMA in flight - in front of each step's first read, which serialises the pipeline; an asm
+// statement is invisible to that pass, and the counted vmcnt / lgkmcnt waits below are placed by hand
+// (cdna_hip_programming.md 5.7: hipcc neither counts nor orders what is inside asm).
+typedef unsigned bw_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bw_u32x2 tr_read(unsigned lds_addr) {
+  bw_u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
+  return v;
+}
+__device__ __forceinline__ bw_bf16x8 tr_join(bw_u32x2 lo, bw_u32x2 hi) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 q = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bw_bf16x8, q);
 }
 }  // namespace
 
-// XC16 / YC16: the operand has 16 channels (first conv's padded input, the head's 16-channel gradient): a DMA piece
-// is then [32 stamps][16 ch]; otherwise [16 stamps][32 ch] with the two 32-byte halves of rows 4-7 / 12-15 swapped
-// (on the source side) so that the transposed reads of a half-wave touch all 64 banks once.
-template <bool XC16, bool YC16, int NT>
-__global__ __launch_bounds__(256, 2) void bwgrad_kernel(const BWgradParams p, const BWGeom gm) {
-  constexpr int BX = XC16 ? 1 : 2, BY = YC16 ? 1 : 2;     // 16-channel blocks per wave
-  constexpr int CXW = 16 * BX, CYW = 16 * BY;
+template <bool XC16, bool YC16>
+__global__ __launch_bounds__(256, 1) void bwgrad_kernel(const BWgradParams p, const BWGeom gm) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nw = gm.WX * gm.WY;
-  const int wx = wave / gm.WY, wy = wave - wx * gm.WY;
   int bid = blockIdx.x;
+  {
+    // XCD-contiguous order (blocks b and b+8 share an XCD): an XCD's workgroups then walk NEIGHBOURING rows, whose
+    // X rows overlap two thirds, so the re-reads come out of that XCD's L2 instead of crossing the fabric three times
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
   const int tcy = bid % gm.nty; bid /= gm.nty;
   const int tcx = bid % gm.ntx; bid /= gm.ntx;
-  const int tg = bid % gm.ntg;
-  const int split = bid / gm.ntg;
-  const int cx0 = tcx * CXW * gm.WX, cy0 = tcy * CYW * gm.WY;
-  const int npy = p.Hy * p.Hy;
-  const int pix0 = split * gm.pix_per_split;
-  const int pix1 = min(npy, pix0 + gm.pix_per_split);
-  const int niter = (pix1 - pix0) * gm.kst;
+  const int rseg = bid % gm.nrseg;
+  const int sc4 = bid / gm.nrseg;
+  const int cx0 = tcx * 32, cy0 = tcy * 32;
+  const int st0 = (sc4 * 4 + wave) * 16;               // first stamp of this wave's chunk
+  const bool active = st0 < p.NBp;
+  const int r0 = rseg * gm.rows_per, r1 = min(p.Hy, r0 + gm.rows_per);
+
+  unsigned char* wl = smem + wave * BW_WAVE_LDS;
+  unsigned char* xwin = wl;                            // [3][BW_NCS] KiB
+  unsigned char* ywin = wl + 3 * BW_NCS * 1024;        // [BW_NYS] KiB
+  unsigned char* zreg = ywin + BW_NYS * 1024;          // 1 KiB of zeros
+  reinterpret_cast<f32x4*>(zreg)[lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bw_bf16* Xb = reinterpret_cast<const bw_bf16*>(p.X);
   const bw_bf16* Yb = reinterpret_cast<const bw_bf16*>(p.Y);
   const unsigned char* zlane = reinterpret_cast<const unsigned char*>(p.zero) + lane * 16;
 
-  // per-lane element offset inside a DMA piece, relative to (first stamp of the k-step, first channel of the piece)
-  // 32-ch piece: row = lane >> 2, 16-B quarter (lane & 3) with the halves swapped for rows 4-7, 12-15
-  const int d32_row = lane >> 2;
-  const int d32_q = (lane & 3) ^ ((((lane >> 2) >> 2) & 1) << 1);
-  const int d16_row = lane >> 1, d16_h = lane & 1;
-
-  // source pixel of tap t for Y pixel (gh, gw); -1 when outside
-  auto xpix = [&](int gh, int gw, int t) -> int {
-    const int kh = t / 3, kw = t - kh * 3;
-    const int xh = gh * p.s + kh - p.pb, xw = gw * p.s + kw - p.pb;
-    return (xh >= 0 && xh < p.Hx && xw >= 0 && xw < p.Hx) ? xh * p.Hx + xw : -1;
+  // DMA of one pixel block (16 stamps): 32-channel tile of a C-channel tensor, or a whole 16-channel tensor row set.
+  // The per-lane part of the source address is computed once; a block adds a scalar pixel offset.
+  const unsigned char* xlane = XC16 ? (lane < 32 ? reinterpret_cast<const unsigned char*>(Xb + ((size_t)st0 + (lane >> 1)) * 16 + (lane & 1) * 8) : zlane)
+                                    : reinterpret_cast<const unsigned char*>(Xb + ((size_t)st0 + (lane >> 2)) * p.Cx + cx0 + (lane & 3) * 8);
+  const unsigned char* ylane = YC16 ? (lane < 32 ? reinterpret_cast<const unsigned char*>(Yb + ((size_t)st0 + (lane >> 1)) * 16 + (lane & 1) * 8) : zlane)
+                                    : reinterpret_cast<const unsigned char*>(Yb + ((size_t)st0 + (lane >> 2)) * p.Cy + cy0 + (lane & 3) * 8);
+  const size_t xps = (size_t)p.NBp * p.Cx * 2, yps = (size_t)p.NBp * p.Cy * 2;   // bytes per pixel
+  const size_t xps_l = (XC16 && lane >= 32) ? 0 : xps, yps_l = (YC16 && lane >= 32) ? 0 : yps;
+  auto dma = [&](bool isx, int pix, unsigned char* dst) {
+    const void* src = zlane;
+    if (pix >= 0) src = isx ? (const void*)(xlane + (size_t)pix * xps_l) : (const void*)(ylane + (size_t)pix * yps_l);
+    __builtin_amdgcn_global_load_lds((bw_gptr_t)src, (bw_lptr_t)dst, 16, 0, 0);
   };
-
-  auto issue = [&](int it, int buf) {
-    unsigned char* sY = smem + buf * gm.stage_bytes;
-    unsigned char* sX = sY + gm.py * 1024;
-    const int pl = it / gm.kst, ks = it - pl * gm.kst;
-    const int gp = pix0 + pl;
-    const int gh = gp / p.Hy, gw = gp - gh * p.Hy;
-    const int st0 = ks * 32;                        // first stamp of the k-step
-    const int total = gm.py + NT * gm.px;
-    for (int q = wave; q < total; q += nw) {
-      const bool isy = q < gm.py;
-      int t = 0, pc = q;
-      if (!isy) {
-        t = (q - gm.py) / gm.px;
-        pc = (q - gm.py) - t * gm.px;
-      }
-      int spix = gp;
-      if (!isy) spix = xpix(gh, gw, tg * NT + t);
-      if (spix < 0) continue;                       // tap outside the image: never read either
-      const bool c16 = isy ? YC16 : XC16;
-      const int C = isy ? p.Cy : p.Cx;
-      const bw_bf16* base = (isy ? Yb : Xb) + (size_t)spix * p.NBp * C + (isy ? cy0 : cx0);
-      const void* src;
-      if (c16) {
-        const int stamp = st0 + d16_row;
-        src = stamp < p.NBp ? (const void*)(base + (size_t)stamp * C + d16_h * 8) : (const void*)zlane;
-      } else {
-        // piece pc = (32-channel block pc >> 1, stamp half pc & 1)
-        const int stamp = st0 + (pc & 1) * 16 + d32_row;
-        src = stamp < p.NBp ? (const void*)(base + (size_t)stamp * C + (pc >> 1) * 32 + d32_q * 8) : (const void*)zlane;
-      }
-      unsigned char* dst = (isy ? sY : sX + t * gm.px * 1024) + pc * 1024;
-      __builtin_amdgcn_global_load_lds((bw_gptr_t)src, (bw_lptr_t)dst, 16, 0, 0);
+  // column xc of the three window rows of Y row r (image rows r*s - pb + {0,1,2})
+  auto load_col = [&](int r, int xc) {
+    const bool cok = xc >= 0 && xc < p.Hx;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int xr = r * p.s - p.pb + kh;
+      const int pix = (cok && xr >= 0 && xr < p.Hx) ? xr * p.Hx + xc : -1;
+      dma(true, pix, xwin + (kh * BW_NCS + (xc & (BW_NCS - 1))) * 1024);
     }
   };
+  auto load_y = [&](int r, int w) {
+    dma(false, w < p.Hy ? r * p.Hy + w : -1, ywin + (w & (BW_NYS - 1)) * 1024);
+  };
 
-  // transposed-read lane roles: 16-lane group grp reads stamps 4*grp + q, lane 4q+pp supplies row q, columns 4pp..
-  const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int trow = 4 * grp + tq;
-  // byte offset inside a 32-ch piece for 16-channel half h: row*64 + ((h ^ (grp & 1)) * 32) + tp*8
-  const int t32_0 = trow * 64 + ((0 ^ (grp & 1)) * 32) + tp * 8;
-  const int t32_1 = trow * 64 + ((1 ^ (grp & 1)) * 32) + tp * 8;
-  const int t16 = trow * 32 + tp * 8;               // 16-ch piece: second read at +16 rows = +512
+  // transposed-read lane roles for a [16 stamps][32 ch] block: 16-lane group g = (channel half g & 1, stamp half g >> 1)
+  const int g = lane >> 4, li = lane & 15;
+  const int chalf = g & 1, khalf = g >> 1;
+  const int tq = li >> 2, tp = li & 3;
+  // 32-ch block: row*64 + chalf*32 + tp*8; 16-ch block: rows are 32 B, the second channel half reads zeros
+  const int o32 = (khalf * 8 + tq) * 64 + chalf * 32 + tp * 8;
+  const int o16 = (khalf * 8 + tq) * 32 + tp * 8;
+  const unsigned wl_addr = (unsigned)(size_t)(bw_lptr_t)wl;   // LDS byte address of the wave region
+  const unsigned zaddr = wl_addr + (unsigned)(zreg - wl) + 128 + li * 8;
+  // addresses of the two transposed reads of a block at wave-relative byte offset `boff`
+  auto fa0 = [&](unsigned boff, bool c16) -> unsigned {
+    if (c16) return chalf ? zaddr : wl_addr + boff + o16;
+    return wl_addr + boff + o32;
+  };
+  auto fa1 = [&](unsigned boff, bool c16) -> unsigned {
+    if (c16) return chalf ? zaddr : wl_addr + boff + o16 + 4 * 32;
+    return wl_addr + boff + o32 + 4 * 64;
+  };
+  const unsigned xwin_off = 0, ywin_off = 3 * BW_NCS * 1024;
 
-  f32x4 acc[NT][BX][BY];
+  bw_f32x16 acc[9];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int bx = 0; bx < BX; ++bx)
-#pragma unroll
-      for (int by = 0; by < BY; ++by) acc[t][bx][by] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  if (niter > 0) issue(0, 0);
-  for (int it = 0; it < niter; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
-    const unsigned char* sY = smem + (it & 1) * gm.stage_bytes;
-    const unsigned char* sX = sY + gm.py * 1024;
-    const int pl = it / gm.kst;
-    const int gp = pix0 + pl;
-    const int gh = gp / p.Hy, gw = gp - gh * p.Hy;
-    bw_bf16x8 b[BY];
-    if constexpr (YC16) {
-      b[0] = tr_frag(sY + t16, sY + t16 + 512);
-    } else {
-      // wave's 32-channel block wy: pieces (2*wy, 2*wy+1) = stamp halves
-      const unsigned char* y0 = sY + (2 * wy) * 1024;
-      b[0] = tr_frag(y0 + t32_0, y0 + 1024 + t32_0);
-      b[1] = tr_frag(y0 + t32_1, y0 + 1024 + t32_1);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (xpix(gh, gw, tg * NT + t) < 0) continue;
-      const unsigned char* xt = sX + t * gm.px * 1024;
-      bw_bf16x8 a[BX];
-      if constexpr (XC16) {
-        a[0] = tr_frag(xt + t16, xt + t16 + 512);
-      } else {
-        const unsigned char* x0 = xt + (2 * wx) * 1024;
-        a[0] = tr_frag(x0 + t32_0, x0 + 1024 + t32_0);
-        a[1] = tr_frag(x0 + t32_1, x0 + 1024 + t32_1);
+  if (active) {
+    // prefetch distance in pixels: the window's 8 column slots hold the 3 live columns and D*s incoming ones
+    const int D = p.s == 1 ? 4 : 2;
+    // loads of pixel w: its new columns (three for pixel 0) and its Y block; past the row's end the same number of
+    // DMA instructions is issued from the zero page (the counted waits below rely on fixed counts)
+    auto load_pixel = [&](int r, int w) {
+      const int nc = w * p.s - p.pb + 2;
+      if (w == 0) {
+        load_col(r, nc - 2);
+        load_col(r, nc - 1);
+      } else if (p.s == 2) {
+        load_col(r, nc - 1);
       }
+      load_col(r, nc);
+      load_y(r, w);
+    };
+    for (int r = r0; r < r1; ++r) {
+      for (int w = 0; w < D; ++w) load_pixel(r, w);
+      for (int w = 0; w < p.Hy; ++w) {
+        load_pixel(r, w + D);
+        // everything but the D youngest pixels' loads (3*s + 1 each) has landed
+        if (p.s == 2)
+          asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        // all twenty transposed reads of the step are issued back to back (taps outside the image read stale
+        // blocks that no MFMA consumes), then one wait
+        const unsigned yb = ywin_off + (w & (BW_NYS - 1)) * 1024;
+        const bw_u32x2 b0 = tr_read(fa0(yb, YC16)), b1 = tr_read(fa1(yb, YC16));
+        const int xc0 = w * p.s - p.pb;
+        bw_u32x2 a0[9], a1[9];
 #pragma unroll
-      for (int bx = 0; bx < BX; ++bx)
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int by = 0; by < BY; ++by)
-          acc[t][bx][by] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[bx], b[by], acc[t][bx][by], 0, 0, 0);
+          for (int kw = 0; kw < 3; ++kw) {
+            const unsigned xb = xwin_off + (kh * BW_NCS + ((xc0 + kw) & (BW_NCS - 1))) * 1024;
+            a0[kh * 3 + kw] = tr_read(fa0(xb, XC16));
+            a1[kh * 3 + kw] = tr_read(fa1(xb, XC16));
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const bw_bf16x8 b = tr_join(b0, b1);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int xr = r * p.s - p.pb + kh;
+          if (xr < 0 || xr >= p.Hx) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int xc = xc0 + kw;
+            if (xc < 0 || xc >= p.Hx) continue;
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(a0[kh * 3 + kw], a1[kh * 3 + kw]), b,
+                                                                       acc[kh * 3 + kw], 0, 0, 0);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing zero-page loads, before the next row reuses the slots
     }
   }
 
-  // slab[split][(tap*Cx + cx)*Cy + cy]; lane (c = lane & 15 -> cy, g = lane >> 4 -> cx rows 4g..4g+3)
-  float* slab = p.part + (size_t)split * 9 * p.Cx * p.Cy;
-  const int c = lane & 15, g = lane >> 4;
+  // ---- sum the four waves' tiles through LDS in wave order, then one slab per workgroup ----
+  float* red = reinterpret_cast<float*>(smem);         // reuses wave 0's window (all DMA has been waited for)
+  for (int wv = 0; wv < 4; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int bx = 0; bx < BX; ++bx)
-#pragma unroll
-      for (int by = 0; by < BY; ++by)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int cx = cx0 + wx * CXW + bx * 16 + 4 * g + r;
-          const int cy = cy0 + wy * CYW + by * 16 + c;
-          slab[((size_t)(tg * NT + t) * p.Cx + cx) * p.Cy + cy] = acc[t][bx][by][r];
+        for (int i = 0; i < 16; ++i) {
+          float* q = red + (t * 16 + i) * 64 + lane;
+          *q = wv == 0 ? acc[t][i] : *q + acc[t][i];
         }
+    }
+  }
+  __syncthreads();
+  float* slab = p.part + (size_t)(sc4 * gm.nrseg + rseg) * 9 * p.Cx * p.Cy;
+  for (int e = tid; e < 9 * 16 * 64; e += 256) {
+    const int ln = e & 63, ti = e >> 6;
+    const int i = ti & 15, t = ti >> 4;
+    const int cx = cx0 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);
+    const int cy = cy0 + (ln & 31);
+    if (cx < p.Cx && cy < p.Cy) slab[((size_t)t * p.Cx + cx) * p.Cy + cy] = red[e];
+  }
 }
 
 int launch_bwgrad(const BWgradParams& p, hipStream_t s, int* nsplit_out) {
   const bool xc16 = p.Cx == 16, yc16 = p.Cy == 16;
-  if ((!xc16 && p.Cx % 32) || (!yc16 && p.Cy % 32) || (p.NBp & 15)) {
-    set_error("bwgrad: channels must be 16 or multiples of 32 (Cx %d, Cy %d), stamps padded to 16 (%d)", p.Cx, p.Cy,
-              p.NBp);
+  if ((!xc16 && p.Cx % 32) || (!yc16 && p.Cy % 32) || (p.NBp & 15) || p.s < 1 || p.s > 2) {
+    set_error("bwgrad: channels must be 16 or multiples of 32 (Cx %d, Cy %d), stamps padded to 16 (%d), stride 1 or 2",
+              p.Cx, p.Cy, p.NBp);
     return E_INVALID;
   }
   BWGeom gm;
-  const int cxw = xc16 ? 16 : 32, cyw = yc16 ? 16 : 32;
-  const int bx_n = p.Cx / cxw, by_n = p.Cy / cyw;          // wave-sized blocks per axis
-  gm.WX = std::min(2, bx_n);
-  gm.WY = std::min(4 / gm.WX, by_n);
-  if (gm.WX * gm.WY < 4 && bx_n >= 4 && gm.WY == 1) gm.WX = 4;
-  while (bx_n % gm.WX) --gm.WX;
-  while (by_n % gm.WY) --gm.WY;
-  gm.ntx = bx_n / gm.WX;
-  gm.nty = by_n / gm.WY;
-  // taps per workgroup: all nine while the accumulators are few; deep layers split the taps over workgroups instead
-  // of the pixels (their slabs are megabytes each)
-  const long ce = (long)p.Cx * p.Cy;
-  const int nt = ce <= 64 * 64 ? 9 : (ce <= 128 * 128 ? 3 : 1);
-  gm.ntg = 9 / nt;
-  gm.kst = (p.NBp + 31) / 32;
-  gm.px = xc16 ? 1 : 2 * gm.WX;
-  gm.py = yc16 ? 1 : 2 * gm.WY;
-  gm.stage_bytes = (gm.py + nt * gm.px) * 1024;
-  const int npy = p.Hy * p.Hy;
-  const long slab = 9L * p.Cx * p.Cy;
-  static const long target = getenv("DV_BWGRAD_TARGET") ? atol(getenv("DV_BWGRAD_TARGET")) : 1024;
-  long ns = std::max(1L, target / ((long)gm.ntx * gm.nty * gm.ntg));
-  ns = std::min<long>(ns, npy);
-  ns = std::min<long>(ns, (long)(p.part_capacity / (size_t)slab));
-  if (ns < 1) {
+  gm.ntx = (p.Cx + 31) / 32;
+  gm.nty = (p.Cy + 31) / 32;
+  gm.nsc4 = (p.NBp + 63) / 64;
+  const size_t slab = (size_t)9 * p.Cx * p.Cy;
+  // Y rows per workgroup: as few as the slab budget allows (more workgroups), never fewer than what keeps the slabs of
+  // one launch under ~24 MB
+  static const long budget = getenv("DV_BWGRAD_SLAB_MB") ? atol(getenv("DV_BWGRAD_SLAB_MB")) << 20 : 24L << 20;
+  long copies = std::max<long>(1, budget / (long)(slab * sizeof(float)));
+  copies = std::min<long>(copies, (long)(p.part_capacity / slab));
+  if (copies < gm.nsc4) {
     set_error("bwgrad: slab workspace too small");
     return E_STATE;
   }
-  gm.pix_per_split = (int)((npy + ns - 1) / ns);
-  gm.nsplit = (npy + gm.pix_per_split - 1) / gm.pix_per_split;
-  if (nsplit_out) *nsplit_out = gm.nsplit;
-  const unsigned grid = (unsigned)((long)gm.nsplit * gm.ntg * gm.ntx * gm.nty);
-  const unsigned threads = 64u * gm.WX * gm.WY;
-  const size_t lds = (size_t)2 * gm.stage_bytes;
-#define BW_LAUNCH(XC, YC, NT_)                                                                                  \
+  int nrseg = (int)std::min<long>(p.Hy, copies / gm.nsc4);
+  gm.rows_per = (p.Hy + nrseg - 1) / nrseg;
+  gm.nrseg = (p.Hy + gm.rows_per - 1) / gm.rows_per;
+  if (nsplit_out) *nsplit_out = gm.nrseg * gm.nsc4;
+  const unsigned grid = (unsigned)((long)gm.nsc4 * gm.nrseg * gm.ntx * gm.nty);
+  const size_t lds = (size_t)4 * BW_WAVE_LDS;
+  static_assert(BW_RED_BYTES <= 4 * BW_WAVE_LDS, "reduction scratch must fit the windows");
+#define BW_LAUNCH(XC, YC)                                                                                       \
   do {                                                                                                          \
-    static size_t attr = 0;                                                                                     \
-    if (lds > attr) {                                                                                           \
-      DV_HIP(hipFuncSetAttribute((const void*)bwgrad_kernel<XC, YC, NT_>,                                       \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-      attr = lds;                                                                                               \
+    static bool attr = false;                                                                                   \
+    if (!attr) {                                                                                                \
+      DV_HIP(hipFuncSetAttribute((const void*)bwgrad_kernel<XC, YC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)lds));                                                                    \
+      attr = true;                                                                                              \
     }                                                                                                           \
-    hipLaunchKernelGGL((bwgrad_kernel<XC, YC, NT_>), dim3(grid), dim3(threads), lds, s, p, gm);                 \
+    hipLaunchKernelGGL((bwgrad_kernel<XC, YC>), dim3(grid), dim3(256), lds, s, p, gm);                          \
   } while (0)
-  if (xc16 && yc16) {
-    BW_LAUNCH(true, true, 9);
-  } else if (xc16) {
-    if (nt == 9) BW_LAUNCH(true, false, 9); else if (nt == 3) BW_LAUNCH(true, false, 3); else BW_LAUNCH(true, false, 1);
-  } else if (yc16) {
-    if (nt == 9) BW_LAUNCH(false, true, 9); else if (nt == 3) BW_LAUNCH(false, true, 3); else BW_LAUNCH(false, true, 1);
-  } else {
-    if (nt == 9) BW_LAUNCH(false, false, 9); else if (nt == 3) BW_LAUNCH(false, false, 3); else BW_LAUNCH(false, false, 1);
-  }
+  if (xc16 && yc16) BW_LAUNCH(true, true);
+  else if (xc16) BW_LAUNCH(true, false);
+  else if (yc16) BW_LAUNCH(false, true);
+  else BW_LAUNCH(false, false);
 #undef BW_LAUNCH
   DV_HIP(hipGetLastError());
   return OK;

@@ -340,7 +340,10 @@ struct BfState {
   float* tpre32 = nullptr;       // head conv output, fp32 [Hd*Hd][NBp][16]
   void* dt = nullptr;            // d(loss)/d(tpre), bf16
   float* flat_in = nullptr;      // encoder output as fp32 rows [NB][flat] (input of the flatten PReLU)
-  void *gA = nullptr, *gB = nullptr;   // activation-gradient ping-pong (bf16)
+  std::vector<void*> gpool;      // one activation-gradient buffer per data-gradient launch of a step (bf16): the
+                                 // weight gradients run on the aux stream and nothing ever waits for a buffer
+  float* slab = nullptr;         // weight-gradient partial slabs (aux stream)
+  size_t slab_elems = 0;
   std::vector<BfW> enc_w, dec_w;
   BfW head_w;
   std::vector<dv::BCastDesc> descs;

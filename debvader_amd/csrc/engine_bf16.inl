@@ -57,8 +57,12 @@ static int bf_alloc(dv_model* m) {
   DV_TRY(balloc((void**)&bf.tpre32, (size_t)A.dec_out * A.dec_out * Bp * 16 * 4));
   DV_TRY(balloc(&bf.dt, (size_t)A.dec_out * A.dec_out * Bp * 16 * 2));
   DV_TRY(balloc((void**)&bf.flat_in, (size_t)m->Bc * A.flat * 4));
-  DV_TRY(balloc(&bf.gA, max_e * Bp * 2));
-  DV_TRY(balloc(&bf.gB, max_e * Bp * 2));
+  bf.gpool.resize(4 * A.L + 4);
+  for (auto& g : bf.gpool) DV_TRY(balloc(&g, max_e * Bp * 2));
+  bf.slab_elems = (size_t)8 << 20;
+  for (auto& sp : A.specs)
+    if (sp.ndim == 4) bf.slab_elems = std::max(bf.slab_elems, sp.count * 4);
+  DV_TRY(balloc((void**)&bf.slab, bf.slab_elems * 4));
 
   // bf16 weight matrices and the descriptors the cast kernel walks
   float* P = m->P;
@@ -229,20 +233,29 @@ static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int firs
 }
 
 // ---- backward -----------------------------------------------------------------------------------------------------
+// Weight gradients are queued on the aux stream (beside the data-gradient chain of the main stream) once the main
+// stream has produced their operands; under the profiler's class timing everything stays on the main stream.
+static hipStream_t bf_wstream(dv_model* m) {
+  return (m->overlap_wgrad && !m->prof_on && m->ctx->aux_stream) ? m->ctx->aux_stream : m->ctx->stream;
+}
 static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, int Hy, int Cy, int s, int pb, float* out,
                     int cpad, int creal) {
   BWgradParams p;
   memset(&p, 0, sizeof p);
-  p.X = X; p.Y = Y; p.zero = m->bf.zero; p.part = m->ws1; p.part_capacity = m->ws1_elems;
+  p.X = X; p.Y = Y; p.zero = m->bf.zero; p.part = m->bf.slab; p.part_capacity = m->bf.slab_elems;
   p.Hx = Hx; p.Cx = Cx; p.Hy = Hy; p.Cy = Cy; p.NBp = m->bf.NBp; p.s = s; p.pb = pb;
   int ns = 0;
-  hipStream_t st = m->ctx->stream;
+  hipStream_t st = bf_wstream(m);
+  if (st != m->ctx->stream) {
+    DV_HIP(hipEventRecord(m->ctx->ev_ready, m->ctx->stream));
+    DV_HIP(hipStreamWaitEvent(st, m->ctx->ev_ready, 0));
+  }
   {
     ProfScope ps(m, 1, st);
     DV_TRY(launch_bwgrad(p, st, &ns));
   }
   ProfScope ps(m, 2, st);
-  return launch_reduce_partials(m->ws1, out, ns, 9L * Cx * Cy, Cy, cpad, creal, st);
+  return launch_reduce_partials(m->bf.slab, out, ns, 9L * Cx * Cy, Cy, cpad, creal, st);
 }
 
 // data gradient into `out` with the PReLU backward of the target layer (pre-activation u, slopes / bias specs) applied:
@@ -306,13 +319,19 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   m->ws_count = 0;
   m->main_marked = false;
   const int Hd = A.dec_out, f0 = A.cfg.filters[0], C2 = 2 * A.C;
-  void* cur = bf.gA;
-  void* oth = bf.gB;
+  size_t gnext = 0;
+  auto next_buf = [&]() -> void* { return bf.gpool[gnext++ % bf.gpool.size()]; };
+  void* cur = next_buf();
+  void* oth = nullptr;
+  hipStream_t ws = bf_wstream(m);
   // ---- head conv ----
   if (dg) {
     DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, 1, 1, m->Ghs, f0, f0));
+    {
+      ProfScope ps(m, 2, ws);
+      DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, ws));
+    }
     ProfScope ps(m, 2, s);
-    DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, s));
     int nr = 0;
     DV_TRY(launch_bf_colsum(bf.dt, (long)Hd * Hd * bf.NBp, 16, m->ws3, &nr, s));
     DV_TRY(launch_reduce_rows_f64(m->ws3, nr, C2, G + A.specs[A.head_b()].off, 1.0f, s, 16));
@@ -329,6 +348,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     const int pb = same_pad_before(hout, 3, st, nullptr);
     const void* xin = j == 0 ? bf.dec_in : bf.dec_a[j - 1];
     if (dg) DV_TRY(bf_wgrad(m, cur, hout, cout, xin, hin, cin, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout));
+    oth = next_buf();
     if (j > 0) {
       DV_TRY(bf_dgrad_prelu(m, cur, bf.dec_w[j].d, bf.dec_w[j].Kd, 0, hout, cout, hin, cin, st, pb, oth, bf.dec_u[j - 1],
                             A.dec_al(j - 1), A.dec_b(j - 1), dg));
@@ -336,7 +356,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       DV_TRY(bf_conv(m, cur, bf.dec_w[j].d, bf.dec_w[j].Kd, 0, hout, cout, hin, cin, st, pb, BEPI_RAWBF, oth, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
     }
-    std::swap(cur, oth);
+    cur = oth;
   }
   // ---- dense trunk of the decoder, sampler, encoder dense: fp32 rows in m->gA / m->gB ----
   const int fl = A.cfg.filters[A.L - 1];
@@ -375,8 +395,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     const int jl = 2 * A.L - 1;
     const int sl = A.enc_sizes[A.L];
     const long Pn = (long)sl * sl, E = Pn * fl;
-    cur = bf.gA;
-    oth = bf.gB;
+    cur = next_buf();
     if (m->arena_off + (size_t)E > m->arena_elems) {
       set_error("gradient-partial arena exhausted");
       return E_STATE;
@@ -398,16 +417,21 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       // first conv with the folded input BatchNorm: the gradient w.r.t. the 16-channel folded kernel (channels
       // 0..C-1 = bands, C = the constant one) yields d(kernel), d(gamma), d(beta); no data gradient
       DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8));
-      ProfScope ps(m, 2, s);
+      ProfScope ps(m, 2, ws);
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
                                    G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, 9, A.C, 8, cout,
-                                   s));
+                                   ws));
       break;
     }
     DV_TRY(bf_wgrad(m, bf.enc_a[j - 1], hin, cin, cur, hout, cout, st, pb, G + A.specs[A.enc_k(j)].off, cin, cin));
+    oth = next_buf();
     DV_TRY(bf_dgrad_prelu(m, cur, bf.enc_w[j].d, bf.enc_w[j].Kd, 1, hout, cout, hin, cin, st, pb, oth, bf.enc_u[j - 1],
                           A.enc_al(j - 1), A.enc_b(j - 1), true));
-    std::swap(cur, oth);
+    cur = oth;
+  }
+  if (ws != s) {                                         // join: every parameter gradient is final past this point
+    DV_HIP(hipEventRecord(m->ctx->ev_join, ws));
+    DV_HIP(hipStreamWaitEvent(s, m->ctx->ev_join, 0));
   }
   m->enc_reduced_from = A.n_enc_train;
   // data parallelism: one all-reduce of the whole gradient (the step is ~1 ms; bucketing it buys little)
