@@ -86,6 +86,22 @@ struct BHeadParams {
 };
 int launch_bf_head(const BHeadParams& p, hipStream_t s, int* nblocks_out);
 
+// Batched fixed-order reductions of the fused PReLU-backward partials of a whole backward pass (two launches instead of
+// two per layer): entry i sums nparts slabs of n floats, out[e] = sum_p src[p*n + e]; entries with cols > 0 are then
+// column-summed, final[c] = sum_r out[r*cols + c] (d(bias): out is a scratch [pixels][cols] image).
+#define DV_BF_MAX_RED 48
+struct BRedEntry {
+  const float* src;
+  float* out;
+  float* final_out;    // null: out is the result
+  int nparts, n, cols;
+};
+struct BRedBatch {
+  BRedEntry e[DV_BF_MAX_RED];
+  int count;
+};
+int launch_bf_reduce_batch(const BRedBatch& b, hipStream_t s);
+
 // one weight matrix of the family, produced from the fp32 master tensor by bf_cast_weights
 struct BCastDesc {
   const float* src;    // master tensor [9][A][B] (taps, then two channel axes), or null (descriptor unused)

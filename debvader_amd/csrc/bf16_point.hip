@@ -25,38 +25,56 @@ __device__ __forceinline__ float bp_block_sum(float v, float* sh) {
 }  // namespace
 
 // ---- input: dataset rows -> normalised, stamp-inner, 16 channels ------------------------------------------------
+// A workgroup moves 32 pixels x 16 stamps through LDS: the dataset side is read in whole stamp rows (32 pixels x C
+// floats, contiguous), the stamp-inner side is written 16 stamps x 32 bytes = 512 contiguous bytes per pixel.
+// (One thread per (pixel, stamp) without the tile read 24-byte pieces 83 KB apart: 92 us instead of ~20 for 256 stamps.)
+constexpr int BI_PX = 32, BI_ST = 16, BI_MAXC = 7;
 __global__ __launch_bounds__(256) void bf_input_kernel(const float* __restrict__ x, const int* __restrict__ idx, int first,
                                                        int NB, int NBp, int HW, int C, const float* __restrict__ bn,
                                                        bp_bf16* __restrict__ xh) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;   // (pixel, stamp), stamp fastest
-  if (e >= (long)HW * NBp) return;
-  const int pix = (int)(e / NBp), b = (int)(e - (long)pix * NBp);
-  bp_bf16x8 lo, hi;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) lo[j] = hi[j] = (bp_bf16)0.f;
-  if (b < NB) {
+  __shared__ float tile[BI_ST][BI_PX * BI_MAXC + 1];
+  const int p0 = blockIdx.x * BI_PX, b0 = blockIdx.y * BI_ST;
+  const int npx = min(BI_PX, HW - p0);
+  const int rowf = npx * C;                               // floats of one stamp's pixel run
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int sr = wave; sr < BI_ST; sr += 4) {
+    const int b = b0 + sr;
+    if (b >= NB) continue;
     const long row = idx ? idx[b] : first + b;
-    const float* xp = x + (row * HW + pix) * C;
-    for (int c = 0; c < C; ++c) {
-      const float v = (xp[c] - bn[2 * 8 + c]) * bn[3 * 8 + c];   // bnstate rows are 8 wide (pointwise.hip)
-      if (c < 8) lo[c] = (bp_bf16)v; else hi[c - 8] = (bp_bf16)v;
-    }
-    if (C < 8) lo[C] = (bp_bf16)1.f; else hi[C - 8] = (bp_bf16)1.f;
+    const float* src = x + (row * HW + p0) * C;
+    for (int f = lane; f < rowf; f += 64) tile[sr][f] = src[f];
   }
-  bp_bf16x8* o = reinterpret_cast<bp_bf16x8*>(xh + e * 16);
-  o[0] = lo;
-  o[1] = hi;
+  __syncthreads();
+  const int sr = threadIdx.x & 15;
+  const int b = b0 + sr;
+  for (int pp = threadIdx.x >> 4; pp < npx; pp += 16) {
+    bp_bf16x8 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lo[j] = hi[j] = (bp_bf16)0.f;
+    if (b < NB) {
+#pragma unroll
+      for (int c = 0; c < BI_MAXC; ++c)
+        if (c < C) lo[c] = (bp_bf16)((tile[sr][pp * C + c] - bn[2 * 8 + c]) * bn[3 * 8 + c]);   // bnstate rows are 8 wide
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c == C) lo[c] = (bp_bf16)1.f;
+    }
+    if (b < NBp) {
+      bp_bf16x8* o = reinterpret_cast<bp_bf16x8*>(xh + ((size_t)(p0 + pp) * NBp + b) * 16);
+      o[0] = lo;
+      o[1] = hi;
+    }
+  }
 }
 
 int launch_bf_input(const float* x, const int* idx, int first, int NB, int NBp, int HW, int C, const float* bnstate,
                     void* xh, hipStream_t s) {
-  if (C > 7) {
+  if (C > BI_MAXC) {
     set_error("bf_input: at most 7 bands");
     return E_INVALID;
   }
-  const long n = (long)HW * NBp;
-  hipLaunchKernelGGL(bf_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, idx, first, NB, NBp, HW, C,
-                     bnstate, reinterpret_cast<bp_bf16*>(xh));
+  hipLaunchKernelGGL(bf_input_kernel, dim3((unsigned)((HW + BI_PX - 1) / BI_PX), (unsigned)(NBp / BI_ST)), dim3(256), 0, s,
+                     x, idx, first, NB, NBp, HW, C, bnstate, reinterpret_cast<bp_bf16*>(xh));
   DV_HIP(hipGetLastError());
   return OK;
 }
@@ -235,16 +253,38 @@ int launch_bf_colsum(const void* x, long rows, int C, float* part, int* nrows_ou
 // ---- head: relu / crop / sigma floor / Normal NLL and its gradient, one thread per (pixel of the 2^L grid, stamp) -----
 // Same arithmetic as head_kernel (pointwise.hip): NLL uses (y - mu)/sigma; the gradient w.r.t. the head conv's
 // pre-activation is stored in bf16 (it feeds bf16 MFMA operands), zero outside the crop and for the pad stamps.
+// A workgroup is 16 consecutive pixels of one row of the 2^L grid x 16 stamps; the labels of the tile (16 stamps x a run of
+// 16 pixels x nb floats each, contiguous per stamp) arrive through LDS.
 __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
   __shared__ float sh[4];
-  const long total = (long)p.Hd * p.Hd * p.NBp;
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float ytile[16][16 * 8 + 1];
+  const int chunks = (p.Hd * p.Hd) >> 4;
+  const int pc = blockIdx.x % chunks, sc = blockIdx.x / chunks;
+  const int pix0 = pc * 16, b0 = sc * 16;
+  const int oh = pix0 / p.Hd, ow0 = pix0 - oh * p.Hd;       // Hd is a multiple of 16: a chunk never wraps a row
+  const int h = oh - p.crop0;
+  const bool rowin = (unsigned)h < (unsigned)p.H;
+  if (p.y && rowin) {
+    // label run of stamp b: pixels w in [w_lo, w_hi) of row h
+    const int w_lo = max(ow0 - p.crop0, 0), w_hi = min(ow0 + 16 - p.crop0, p.H);
+    const int nf = (w_hi - w_lo) * p.nb;
+    const int sr = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const int b = b0 + sr;
+    if (b < p.NB && nf > 0) {
+      const long row = p.idx ? p.idx[b] : p.first + b;
+      const float* src = p.y + ((row * p.H + h) * p.H + w_lo) * p.nb;
+      const int shift = (w_lo - (ow0 - p.crop0)) * p.nb;      // position of w_lo inside the tile row
+      for (int f = l16; f < nf; f += 16) ytile[sr][shift + f] = src[f];
+    }
+  }
+  __syncthreads();
+  const int sr = threadIdx.x & 15, pp = threadIdx.x >> 4;
+  const int b = b0 + sr;
+  const int ow = ow0 + pp, w = ow - p.crop0;
+  const long e = (long)(pix0 + pp) * p.NBp + b;
   float nll = 0.f, se = 0.f;
-  if (e < total) {
-    const int pix = (int)(e / p.NBp), b = (int)(e - (long)pix * p.NBp);
-    const int oh = pix / p.Hd, ow = pix - oh * p.Hd;
-    const int h = oh - p.crop0, w = ow - p.crop0;
-    const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.H && b < p.NB;
+  {
+    const bool in = rowin && (unsigned)w < (unsigned)p.H && b < p.NB;
     float d[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) d[j] = 0.f;
@@ -254,11 +294,6 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
       const float t[16] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3],
                            t2[0], t2[1], t2[2], t2[3], t3[0], t3[1], t3[2], t3[3]};
       const long opix = ((long)b * p.H + h) * p.H + w;
-      const float* yp = nullptr;
-      if (p.y) {
-        const long row = p.idx ? p.idx[b] : p.first + b;
-        yp = p.y + ((row * p.H + h) * p.H + w) * p.nb;
-      }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         if (c >= p.nb) break;
@@ -272,9 +307,9 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
         const float sig = p.sigma_floor + fmaxf(ts, 0.f);
         if (p.loc) p.loc[opix * p.nb + c] = loc;
         if (p.scale) p.scale[opix * p.nb + c] = sig;
-        if (yp) {
+        if (p.y) {
           const float inv = 1.0f / sig;
-          const float df = yp[c] - loc;
+          const float df = ytile[sr][pp * p.nb + c] - loc;
           const float r = df * inv;
           nll += 0.5f * r * r + logf(sig) + 0.91893853320467274178f;
           se += df * df;
@@ -309,15 +344,70 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
 }
 
 int launch_bf_head(const BHeadParams& p, hipStream_t s, int* nblocks_out) {
-  if (p.nb > 8) {
-    set_error("bf_head: at most 8 bands");
+  if (p.nb > 8 || (p.Hd & 15) || (p.NBp & 15)) {
+    set_error("bf_head: at most 8 bands, grid size and stamp padding multiples of 16");
     return E_INVALID;
   }
-  const long total = (long)p.Hd * p.Hd * p.NBp;
-  const int nb = (int)((total + 255) / 256);
+  const int nb = ((p.Hd * p.Hd) >> 4) * (p.NBp >> 4);
   if (nblocks_out) *nblocks_out = nb;
   if (nb == 0) return OK;
   hipLaunchKernelGGL(bf_head_kernel, dim3(nb), dim3(256), 0, s, p);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+// ---- batched partial-slab sums (grid.y = entry) and the column sums behind them ------------------------------------
+__global__ __launch_bounds__(256) void bf_reduce_batch_kernel(const BRedBatch b) {
+  const BRedEntry d = b.e[blockIdx.y];
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < d.n; e += (long)gridDim.x * 1024) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(d.src + e);
+    for (int p = 1; p < d.nparts; ++p) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(d.src + (size_t)p * d.n + e);
+      a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+    *reinterpret_cast<f32x4*>(d.out + e) = a;
+  }
+}
+// one workgroup per (32-column group, entry): 8 row lanes x 32 columns, fixed summation order
+__global__ __launch_bounds__(256) void bf_colsum_batch_kernel(const BRedBatch b) {
+  __shared__ float sh[8][33];
+  const BRedEntry d = b.e[blockIdx.y];
+  if (!d.final_out || d.cols <= 0) return;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  if (blockIdx.x * 32 >= d.cols) return;
+  const int rows = d.n / d.cols;
+  float a = 0.f;
+  if (c < d.cols)
+    for (int r = rl; r < rows; r += 8) a += d.out[(size_t)r * d.cols + c];
+  sh[rl][threadIdx.x & 31] = a;
+  __syncthreads();
+  if (rl == 0 && c < d.cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += sh[i][threadIdx.x & 31];
+    d.final_out[c] = t;
+  }
+}
+
+int launch_bf_reduce_batch(const BRedBatch& b, hipStream_t s) {
+  if (b.count <= 0) return OK;
+  if (b.count > DV_BF_MAX_RED) {
+    set_error("bf_reduce_batch: too many entries");
+    return E_INVALID;
+  }
+  int maxn = 0, maxc = 0;
+  for (int i = 0; i < b.count; ++i) {
+    if (b.e[i].n & 3) {
+      set_error("bf_reduce_batch: slab sizes must be multiples of 4");
+      return E_INVALID;
+    }
+    maxn = std::max(maxn, b.e[i].n);
+    if (b.e[i].final_out) maxc = std::max(maxc, b.e[i].cols);
+  }
+  const unsigned gx = (unsigned)std::min(64, std::max(1, (maxn + 1023) / 1024));
+  hipLaunchKernelGGL(bf_reduce_batch_kernel, dim3(gx, (unsigned)b.count), dim3(256), 0, s, b);
+  if (maxc > 0)
+    hipLaunchKernelGGL(bf_colsum_batch_kernel, dim3((unsigned)((maxc + 31) / 32), (unsigned)b.count), dim3(256), 0, s, b);
   DV_HIP(hipGetLastError());
   return OK;
 }

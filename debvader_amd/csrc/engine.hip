@@ -342,6 +342,7 @@ struct BfState {
   float* flat_in = nullptr;      // encoder output as fp32 rows [NB][flat] (input of the flatten PReLU)
   std::vector<void*> gpool;      // one activation-gradient buffer per data-gradient launch of a step (bf16): the
                                  // weight gradients run on the aux stream and nothing ever waits for a buffer
+  dv::BRedBatch red;             // fused-epilogue partials of the backward pass being queued (summed in two launches)
   float* slab = nullptr;         // weight-gradient partial slabs (aux stream)
   size_t slab_elems = 0;
   std::vector<BfW> enc_w, dec_w;
@@ -2592,7 +2593,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   m->arena_elems = 0;
   for (auto& sp : A.specs)
     if (sp.name.size() > 6 && sp.name.compare(sp.name.size() - 6, 6, "/alpha") == 0)
-      m->arena_elems += (size_t)33 * ((sp.count + 3) & ~(size_t)3) + 65536;
+      m->arena_elems += (size_t)std::max<size_t>(33, bf16 ? 2 * ((Bc + 63) / 64) + 2 : 0) * ((sp.count + 3) & ~(size_t)3) + 65536;
   ALLOC(m->arena, m->arena_elems);
   m->ws2_elems = std::max((size_t)1 << 20, max_act * 16);
   ALLOC(m->ws2, m->ws2_elems);

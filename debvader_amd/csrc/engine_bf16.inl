@@ -272,22 +272,22 @@ static int bf_dgrad_prelu(dv_model* m, const void* X, const void* W, int Kpad, i
     const int nparts = bf.NBp >> 6;
     float *dal = nullptr, *db = nullptr;
     if (want_grads) {
-      if (m->arena_off + (size_t)2 * nparts * E > m->arena_elems) {
+      // partial slabs + the [pixels][Cout] image the d(bias) column sum reads
+      if (m->arena_off + (size_t)(2 * nparts + 1) * E > m->arena_elems || bf.red.count + 2 > DV_BF_MAX_RED) {
         set_error("gradient-partial arena exhausted");
         return E_STATE;
       }
       dal = m->arena + m->arena_off;
       db = dal + (size_t)nparts * E;
-      m->arena_off += (size_t)2 * nparts * E;
+      float* dbimg = db + (size_t)nparts * E;
+      m->arena_off += (size_t)(2 * nparts + 1) * E;
+      BRedEntry& a = bf.red.e[bf.red.count++];
+      a.src = dal; a.out = m->G + A.specs[alpha_spec].off; a.final_out = nullptr; a.nparts = nparts; a.n = (int)E; a.cols = 0;
+      BRedEntry& b = bf.red.e[bf.red.count++];
+      b.src = db; b.out = dbimg; b.final_out = m->G + A.specs[bias_spec].off; b.nparts = nparts; b.n = (int)E; b.cols = Cout;
     }
-    DV_TRY(bf_conv(m, X, W, Kpad, form, Hin, Cin, Hout, Cout, s, pb, BEPI_BWD, out, nullptr, nullptr, nullptr, alpha, u,
-                   dal, db));
-    if (want_grads) {
-      ProfScope ps(m, 2, st);
-      DV_TRY(launch_reduce_partials(dal, m->G + A.specs[alpha_spec].off, nparts, E, 4, 1, 1, st));
-      DV_TRY(launch_reduce_rows_f64(db, (int)(nparts * P), Cout, m->G + A.specs[bias_spec].off, 1.0f, st));
-    }
-    return OK;
+    return bf_conv(m, X, W, Kpad, form, Hin, Cin, Hout, Cout, s, pb, BEPI_BWD, out, nullptr, nullptr, nullptr, alpha, u, dal,
+                   db);
   }
   DV_TRY(bf_conv(m, X, W, Kpad, form, Hin, Cin, Hout, Cout, s, pb, BEPI_RAWBF, out, nullptr, nullptr, nullptr, nullptr,
                  nullptr, nullptr, nullptr));
@@ -316,6 +316,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   const bool dg = m->dec_trainable;
   m->wstream = s;
   m->arena_off = 0;
+  bf.red.count = 0;
   m->ws_count = 0;
   m->main_marked = false;
   const int Hd = A.dec_out, f0 = A.cfg.filters[0], C2 = 2 * A.C;
@@ -428,6 +429,10 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     DV_TRY(bf_dgrad_prelu(m, cur, bf.enc_w[j].d, bf.enc_w[j].Kd, 1, hout, cout, hin, cin, st, pb, oth, bf.enc_u[j - 1],
                           A.enc_al(j - 1), A.enc_b(j - 1), true));
     cur = oth;
+  }
+  {
+    ProfScope ps(m, 2, s);
+    DV_TRY(launch_bf_reduce_batch(bf.red, s));           // d(alpha) / d(bias) of every fused epilogue of this pass
   }
   if (ws != s) {                                         // join: every parameter gradient is final past this point
     DV_HIP(hipEventRecord(m->ctx->ev_join, ws));
