@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdebvader_hip.so")
+# DEBVADER_AMD_LIB selects another build of the same library (the host-side AddressSanitizer build, `make asan`)
+LIB_PATH = os.environ.get("DEBVADER_AMD_LIB") or os.path.join(_HERE, "lib", "libdebvader_hip.so")
 
 DV_MAX_LEVELS = 8
 DV_UNIQUE_ID_BYTES = 128

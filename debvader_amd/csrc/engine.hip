@@ -566,11 +566,20 @@ static unsigned sync_event_flags() {
   const char* e = getenv("DV_EVENT_SCOPE");
   if (e && !strcmp(e, "system")) return (unsigned)hipEventDisableTiming;
   if (e && !strcmp(e, "device")) return (unsigned)(hipEventDisableTiming | hipEventReleaseToDevice);
+  // Default: no fence.  These events order streams of ONE GPU (main / aux / reduction stream, forward lanes, buffer
+  // hand-overs): the waiter runs on the same device and reads through the same L2, with one rank or with eight.
+  return (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+}
+// Events the COMM stream waits on in front of an RCCL launch (gradient buckets, BN sums, loss sums).  With peers in the
+// job what is recorded behind them is read by OTHER GPUs over xGMI, so the record keeps HIP's default system-scope
+// release; with one rank (or the one-rank test communicator) nothing leaves the device and the fence is dropped like
+// everywhere else.  Results come BACK from the comm stream through ev_comm / ev_small2 / ev_bnpre: RCCL's kernels
+// complete their own peer traffic before they retire, the waiter is a local stream - no fence.
+static unsigned comm_gate_event_flags() {
+  const char* e = getenv("DV_EVENT_SCOPE");
   if (e && !strcmp(e, "none")) return (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
-  // Default: no fence on one GPU.  With peers in the job the events in front of the RCCL launches keep the
-  // system-scope release: what the collectives read could not be tested here on more than one rank.
-  return g_multi_rank ? (unsigned)hipEventDisableTiming
-                      : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+  if (g_multi_rank) return (unsigned)hipEventDisableTiming;
+  return sync_event_flags();
 }
 
 static inline hipStream_t fwd_stream(dv_model* m) { return m->cs ? m->cs : m->ctx->stream; }
@@ -2320,6 +2329,53 @@ int dv_comm_unique_id(void* out_id) {
   return DV_OK;
 }
 
+int dv_ctx_destroy(dv_ctx* c);
+static int ctx_build(dv_ctx* c, int world, int rank, const void* unique_id) {
+  DV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  DV_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  DV_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+  DV_HIP(hipStreamCreateWithFlags(&c->red_stream, hipStreamNonBlocking));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_red, comm_gate_event_flags()));
+  // HIP multiplexes streams onto a few hardware queues (4 by default) and work on streams that share a queue runs
+  // in submission order, so the engine keeps to four streams: main, comm (also the D2H stream of the inference
+  // pipeline), aux, and the reduction stream (also the pipeline's H2D stream).  More forward lanes (DV_FWD_LANES > 2) create theirs on demand.
+  {
+    const char* wl = getenv("DV_FWD_LANES");
+    const int extra = wl ? std::max(0, std::min(atoi(wl), 4) - 2) : 0;
+    for (int i = 0; i < extra; ++i) DV_HIP(hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking));
+  }
+  for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_lane[i], sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_ready, sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_join, comm_gate_event_flags()));
+  for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_buf[i], sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_dec, comm_gate_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_enc, comm_gate_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_comm, sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_small, comm_gate_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_small2, sync_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_mid, comm_gate_event_flags()));
+  DV_HIP(hipMalloc((void**)&c->red_dev, 4096 * sizeof(float)));
+  if (world == 1 && getenv("DV_FORCE_COMM")) {
+    // test hook: a one-rank communicator, so that the collective code paths (streams, events, in-place all-reduces)
+    // run on a single-GPU box; results must equal the communicator-free path bit for bit
+    ncclUniqueId id;
+    StdoutToStderr quiet;
+    DV_NCCL(ncclGetUniqueId(&id));
+    DV_NCCL(ncclCommInitRank(&c->comm, 1, id, 0));
+  }
+  if (world > 1) {
+    if (!unique_id) {
+      set_error("world > 1 needs rank 0's unique id");
+      return DV_E_INVALID;
+    }
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    StdoutToStderr quiet;
+    DV_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+  }
+  return DV_OK;
+}
+
 int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* unique_id, dv_ctx** out) {
   if (!out || world < 1 || rank < 0 || rank >= world) {
     set_error("bad rank/world (%d/%d)", rank, world);
@@ -2341,48 +2397,11 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
   c->rank = rank;
   c->world = world;
   g_multi_rank = world > 1;
-  DV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  DV_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-  DV_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-  DV_HIP(hipStreamCreateWithFlags(&c->red_stream, hipStreamNonBlocking));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_red, sync_event_flags()));
-  // HIP multiplexes streams onto a few hardware queues (4 by default) and work on streams that share a queue runs
-  // in submission order, so the engine keeps to four streams: main, comm (also the D2H stream of the inference
-  // pipeline), aux, and the reduction stream (also the pipeline's H2D stream).  More forward lanes (DV_FWD_LANES > 2) create theirs on demand.
-  {
-    const char* wl = getenv("DV_FWD_LANES");
-    const int extra = wl ? std::max(0, std::min(atoi(wl), 4) - 2) : 0;
-    for (int i = 0; i < extra; ++i) DV_HIP(hipStreamCreateWithFlags(&c->lane_stream[i], hipStreamNonBlocking));
-  }
-  for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_lane[i], sync_event_flags()));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_ready, sync_event_flags()));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_join, sync_event_flags()));
-  for (int i = 0; i < 3; ++i) DV_HIP(hipEventCreateWithFlags(&c->ev_buf[i], sync_event_flags()));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_dec, sync_event_flags()));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_enc, sync_event_flags()));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_comm, sync_event_flags()));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_small, sync_event_flags()));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_small2, sync_event_flags()));
-  DV_HIP(hipEventCreateWithFlags(&c->ev_mid, sync_event_flags()));
-  DV_HIP(hipMalloc((void**)&c->red_dev, 4096 * sizeof(float)));
-  if (world == 1 && getenv("DV_FORCE_COMM")) {
-    // test hook: a one-rank communicator, so that the collective code paths (streams, events, in-place all-reduces)
-    // run on a single-GPU box; results must equal the communicator-free path bit for bit
-    ncclUniqueId id;
-    StdoutToStderr quiet;
-    DV_NCCL(ncclGetUniqueId(&id));
-    DV_NCCL(ncclCommInitRank(&c->comm, 1, id, 0));
-  }
-  if (world > 1) {
-    if (!unique_id) {
-      set_error("world > 1 needs rank 0's unique id");
-      delete c;
-      return DV_E_INVALID;
-    }
-    ncclUniqueId id;
-    memcpy(&id, unique_id, sizeof id);
-    StdoutToStderr quiet;
-    DV_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+  // every failure below releases what has been created so far (dv_ctx_destroy copes with a half-built context)
+  const int st = ctx_build(c, world, rank, unique_id);
+  if (st != DV_OK) {
+    dv_ctx_destroy(c);
+    return st;
   }
   *out = c;
   return DV_OK;
@@ -2613,7 +2632,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
         hipEventCreateWithFlags(&m->ev_rk[k], sync_event_flags()) != hipSuccess)
       return fail(E_HIP);
   if (hipEventCreateWithFlags(&m->ev_bnpre, sync_event_flags()) != hipSuccess ||
-      hipEventCreateWithFlags(&m->ev_bnpre_go, sync_event_flags()) != hipSuccess)
+      hipEventCreateWithFlags(&m->ev_bnpre_go, comm_gate_event_flags()) != hipSuccess)
     return fail(E_HIP);
   {
     void* q = nullptr;

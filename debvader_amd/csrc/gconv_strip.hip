@@ -181,8 +181,11 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gconv_strip_kernel(const GStrip
   int pn = 0, pi0 = 0;
   bool have_prev = false;
   for (int sidx = s_begin; sidx < s_end; ++sidx) {
-    // the barrier's vmcnt(0) retires this strip's DMA pieces (and the first time the weight staging) of every wave;
-    // it also fences the previous strip's patch reads, so the other buffer may be refilled right behind it
+    // this wave's DMA pieces of the strip (and, the first time, the weight staging) are retired EXPLICITLY before the
+    // barrier: hipcc emits such a wait in front of s_barrier today, but nothing obliges it to (the same omission in
+    // wgrad_strip8_kernel read a strip before its DMA had landed, about one run in twenty).  The barrier also fences
+    // the previous strip's patch reads, so the other buffer may be refilled right behind it.
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
     __syncthreads();
     if (sidx + 1 < s_end) issue_dma(sidx + 1, buf ^ 1);
     if (have_prev && p.epi == 2) prefetch_alpha(pi0);

@@ -37,7 +37,8 @@ def test_config_struct_matches_header_defaults():
     assert list(cfg.filters)[:4] == [32, 64, 128, 256] and list(cfg.kernels)[:4] == [3, 3, 3, 3]
     assert abs(cfg.kl_weight - 0.01) < 1e-9 and cfg.kl_multiplicity == 2
     assert abs(cfg.bn_eps - 1e-3) < 1e-9 and abs(cfg.sigma_floor - 1e-4) < 1e-10 and abs(cfg.diag_shift - 1e-5) < 1e-11
-    assert C.sizeof(_lib.DvConfig) == 4 * (5 + 8 + 8 + 1 + 7)
+    assert cfg.dtype == _lib.DV_DTYPE_F32                       # the reference computes in float32
+    assert C.sizeof(_lib.DvConfig) == 4 * (5 + 8 + 8 + 1 + 7 + 1)
 
 
 def test_arch_queries_match_reference_summary_and_oracle():
