@@ -3062,13 +3062,15 @@ int dv_infer_mc(dv_model* m, const float* x, int64_t N, int32_t nsamples, uint64
                              reps > 1 ? nb : 0));
       DV_TRY(decoder_forward(m, nb * reps, false));
       DV_TRY(head_lane(m, nullptr, nullptr, 0, nb * reps, nb * reps, false, true, 0, &nblk));
+      // normalise=True: the recipe is np.std(deblend(net, [stamp]*100, normalise=True)[0], axis=0), i.e. the statistics
+      // of the DENORMALISED means - each decoded pass goes back through sinh(arctanh(.)) before it is folded in
+      if (m->normalise) DV_TRY(launch_normalise(m->loc, (long)nb * reps * stamp, true, s));
       if (reps > 1)
         DV_TRY(launch_welford_update_multi(m->loc, mean, m2, (long)nb * stamp, reps, k, s));
       else
         DV_TRY(launch_welford_update(m->loc, mean, m2, ((long)(nb * stamp) + 3) & ~3L, k, s));   // buffers carry slack
     }
     DV_TRY(launch_welford_finish(m2, ((long)(nb * stamp) + 3) & ~3L, nsamples, s));
-    if (m->normalise) DV_TRY(launch_normalise(mean, (long)nb * stamp, true, s));   // the mean only, as deblend() does
     if (mean_out)
       DV_HIP(hipMemcpyAsync(mean_out + o * stamp, mean, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
     if (std_out) DV_HIP(hipMemcpyAsync(std_out + o * stamp, m2, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -55,7 +55,7 @@ class _SubModel:
 class _Core:
     """State shared by net / encoder / decoder / z."""
 
-    def __init__(self, input_shape, latent_dim, filters, kernels, max_batch, ctx, **cfg_over):
+    def __init__(self, input_shape, latent_dim, filters, kernels, max_batch, ctx, seed=None, **cfg_over):
         self.input_shape = tuple(int(v) for v in input_shape)
         self.latent_dim = int(latent_dim)
         self.cfg = E.make_config(self.input_shape, latent_dim, tuple(filters), tuple(kernels),
@@ -63,7 +63,22 @@ class _Core:
         self.engine = E.Engine(self.cfg, ctx)
         self.ctx = self.engine.ctx
         self.seed_counter = int.from_bytes(os.urandom(4), "little")
+        self.shuffle_base = 0          # create_model_vae(seed=...) makes shuffling (and the initial weights) reproducible
+        self.upload_keys = {}          # data slot -> identity of the arrays resident in HBM (VAENet._upload_cached)
         self.compiled = False
+        # Keras draws fresh Glorot weights for every model; the engine's dv_model_create always starts from seed 0, so
+        # draw one here (seed=None: from the OS), identical on every rank (rank 0's value travels through the engine's
+        # own all-reduce in exact 16-bit pieces), and keep it for reproducibility (net.init_seed)
+        if seed is None:
+            seed = int.from_bytes(os.urandom(6), "little")
+        seed = int(seed) & ((1 << 48) - 1)
+        if self.ctx.world > 1:
+            parts = [float((seed >> (16 * k)) & 0xFFFF) if self.ctx.rank == 0 else 0.0 for k in range(3)]
+            parts = self.ctx.allreduce(parts)
+            seed = sum(int(round(float(v))) << (16 * k) for k, v in enumerate(parts))
+        self.init_seed = seed
+        self.shuffle_base = seed & 0xFFFFFFFF
+        self.engine.init(seed)
 
     def next_seed(self):
         self.seed_counter += 1
@@ -105,6 +120,7 @@ class VAENet:
     def __init__(self, core: _Core, encoder: Encoder, decoder: Decoder):
         self._core, self.encoder, self.decoder = core, encoder, decoder
         self.losses: List[float] = []
+        self.init_seed = core.init_seed
         self.metrics_names: List[str] = ["loss"]
         self._metrics: List = []
         self.stop_training = False
@@ -171,6 +187,8 @@ class VAENet:
         `net.load_weights(tf.train.latest_checkpoint(dir))` restores (model.py:262-266) - variables, Adam slots and
         step counter included.  A path ending in `.npz` (or save_format="npz") writes a single numpy archive."""
         eng = self._core.engine
+        if self._core.ctx.rank != 0:
+            return            # data-parallel replicas hold identical weights: rank 0 writes, the others must not race it
         if not overwrite and (os.path.exists(filepath + ".index") or os.path.exists(filepath)):
             raise FileExistsError(filepath)
         if save_format in ("h5", "hdf5", "keras") or filepath.endswith((".h5", ".hdf5", ".keras")):
@@ -192,9 +210,14 @@ class VAENet:
             if tr:
                 blob["m/" + name] = eng.get_slot(i, 0)
                 blob["v/" + name] = eng.get_slot(i, 1)
-        np.savez(path, **blob)
-        with open(os.path.join(os.path.dirname(os.path.abspath(path)), "checkpoint"), "w") as f:
-            f.write(f'model_checkpoint_path: "{os.path.basename(path)}"\n')
+        from debvader_amd.model import tf_checkpoint
+        import io
+
+        buf = io.BytesIO()
+        np.savez(buf, **blob)
+        tf_checkpoint.atomic_write(path, buf.getvalue())
+        tf_checkpoint.atomic_write(os.path.join(os.path.dirname(os.path.abspath(path)), "checkpoint"),
+                                   f'model_checkpoint_path: "{os.path.basename(path)}"\n'.encode())
 
     def load_weights(self, filepath):
         """Loads a checkpoint written by save_weights (.npz) or a TensorFlow tensor-bundle checkpoint written by
@@ -248,29 +271,52 @@ class VAENet:
         if not self._core.compiled:
             raise RuntimeError("You must compile your model before training/testing. Use `model.compile(...)`.")
         core, eng = self._core, self._core.engine
+        x_in, y_in = x, y
         x = np.asarray(x, dtype=np.float32)
         y = np.asarray(y, dtype=np.float32)
         n = x.shape[0]
         batch_size = int(batch_size or 32)
         rank, world = core.ctx.rank, core.ctx.world
-        from debvader_amd.parallel import shard_range
+        from debvader_amd.parallel import shard_range, shard_sizes
 
         if shard_range(batch_size, 0, world)[1] > eng.max_batch:
             raise ValueError(f"batch_size {batch_size} over {world} rank(s) exceeds the engine's max_batch "
                              f"{eng.max_batch}; pass max_batch= to create_model_vae")
-        eng.upload(0, x, y)
         nv = 0
+        xv = yv = None
         if validation_data is not None:
             xv = np.asarray(validation_data[0], dtype=np.float32)
             yv = np.asarray(validation_data[1], dtype=np.float32)
             nv = xv.shape[0]
-            eng.upload(1, xv, yv)
+        # Every batch of the epoch - the ragged last ones included - must give every rank at least one stamp: a rank
+        # with an empty shard would skip its collectives while the others have queued theirs.  All ranks see the same
+        # sizes, so all of them raise here, before anything is queued.
+        val_steps = 0
+        if nv:
+            val_steps = int(validation_steps) if validation_steps else -(-nv // batch_size)
+            val_steps = min(val_steps, -(-nv // batch_size))
+        if world > 1:
+            ragged = [n % batch_size] if n % batch_size else []
+            if n >= batch_size:
+                ragged.append(batch_size)
+            ragged += [min(batch_size, nv - s * batch_size) for s in range(val_steps)]
+            small = [b for b in ragged if min(shard_sizes(b, world)) == 0]
+            if small:
+                raise ValueError(f"a batch of {small[0]} stamp(s) cannot be split over {world} ranks: choose a batch size "
+                                 f"(and data-set sizes modulo the batch size) of at least {world}")
+        self._upload_cached(0, x_in, x, y_in, y)
+        if nv:
+            self._upload_cached(1, validation_data[0], xv, validation_data[1], yv)
         hist = History()
         cbs = list(callbacks or [])
         for cb in cbs:
             if hasattr(cb, "set_model"):
                 cb.set_model(self)
-        rng = np.random.default_rng(kwargs.get("shuffle_seed", 0x5EED))   # identical on every rank
+        # Keras reshuffles from the global generator, so every fit() call sees new permutations; here the seed is
+        # (model seed, number of fit calls so far): fresh per call, identical on every rank, reproducible per model
+        self._fit_calls = getattr(self, "_fit_calls", 0) + 1
+        rng = np.random.default_rng(kwargs["shuffle_seed"] if "shuffle_seed" in kwargs
+                                    else [0x5EED, core.shuffle_base, self._fit_calls])
         self.stop_training = False
         for epoch in range(initial_epoch, epochs):
             t0 = time.time()
@@ -291,28 +337,32 @@ class VAENet:
                     sums[k] = sums.get(k, 0.0) + v * count
                 seen += count
 
-            for b0 in range(0, n, batch_size):
-                gidx = order[b0:b0 + batch_size]
-                lo, hi = shard_range(len(gidx), rank, world)
-                if hi <= lo:
-                    raise ValueError("a rank received an empty shard; use batch sizes >= number of ranks")
-                eng.train_step_async(ticket, 0, idx=gidx[lo:hi].astype(np.int32), global_batch=len(gidx),
-                                     seed=core.next_seed())
-                pending.append((ticket, len(gidx)))
-                ticket = (ticket + 1) % 4
-                if len(pending) > 2:
+            try:
+                for b0 in range(0, n, batch_size):
+                    gidx = order[b0:b0 + batch_size]
+                    lo, hi = shard_range(len(gidx), rank, world)
+                    eng.train_step_async(ticket, 0, idx=gidx[lo:hi].astype(np.int32), global_batch=len(gidx),
+                                         seed=core.next_seed())
+                    pending.append((ticket, len(gidx)))
+                    ticket = (ticket + 1) % 4
+                    if len(pending) > 2:
+                        collect(pending.pop(0))
+                while pending:
                     collect(pending.pop(0))
-            while pending:
-                collect(pending.pop(0))
+            finally:
+                # an exception (or Ctrl-C) between queuing and collecting must not leave tickets occupied: the next
+                # fit() would otherwise fail with "ticket has an uncollected result" until the model is recreated
+                for tk, _ in pending:
+                    try:
+                        eng.step_result(tk)
+                    except Exception:
+                        pass
             logs = {k: v / seen for k, v in sums.items()}
             if nv:
-                steps = validation_steps if validation_steps else -(-nv // batch_size)
                 vs: Dict[str, float] = {}
                 vseen = 0
-                for s in range(int(steps)):
+                for s in range(val_steps):
                     b0 = s * batch_size
-                    if b0 >= nv:
-                        break
                     gb = min(batch_size, nv - b0)
                     lo, hi = shard_range(gb, rank, world)
                     scal = eng.eval_step(1, first=b0 + lo, B=hi - lo, global_batch=gb, seed=core.next_seed())
@@ -328,13 +378,32 @@ class VAENet:
             if verbose and rank == 0:
                 msg = " - ".join(f"{k}: {v:.4f}" for k, v in logs.items())
                 print(f"Epoch {epoch + 1}/{epochs} - {time.time() - t0:.1f}s - {msg}")
+            # Callbacks run on every rank (the logs are global, so their decisions - stop_training, "improved" - agree);
+            # what they WRITE goes to disk from rank 0 only (VAENet.save_weights), and the ranks meet again behind it.
             for cb in cbs:
                 if hasattr(cb, "on_epoch_end"):
                     cb.on_epoch_end(epoch, logs)
+            if world > 1 and cbs:
+                core.ctx.allreduce([0.0])
             if self.stop_training:
                 break
         self.history = hist
         return hist
+
+    def _upload_cached(self, slot, x_orig, x32, y_orig, y32):
+        """dv_data_upload once per data set: a later fit() on the SAME arrays (object identity, shape, and a strided
+        content probe, which catches in-place edits of the usual kind) reuses the copy resident in HBM."""
+        def probe(a):
+            flat = a.reshape(-1)
+            step = max(1, flat.size // 4096)
+            return (a.shape, a.__array_interface__["data"][0], float(flat[::step].astype(np.float64).sum()))
+
+        key = (id(x_orig), id(y_orig), probe(x32), probe(y32))
+        cache = self._core.upload_keys
+        if cache.get(slot) == key:
+            return
+        self._core.engine.upload(slot, x32, y32)
+        cache[slot] = key
 
     def evaluate(self, x, y, batch_size=32, verbose=0):
         eng, core = self._core.engine, self._core
@@ -350,10 +419,12 @@ class VAENet:
 
 
 def _build(input_shape, latent_dim, filters, kernels, for_onnx, max_batch, ctx, cfg_over):
+    cfg_over = dict(cfg_over)
+    seed = cfg_over.pop("seed", None)
     if for_onnx:
         raise NotImplementedError("for_onnx=True builds a TF graph for tf2onnx export (model.py:151-152,203-204); "
                                   "ONNX export is outside this engine's scope")
-    core = _Core(input_shape, latent_dim, filters, kernels, max_batch, ctx, **cfg_over)
+    core = _Core(input_shape, latent_dim, filters, kernels, max_batch, ctx, seed=seed, **cfg_over)
     enc, dec = Encoder(core, "encoder"), Decoder(core, "decoder")
     if core.cfg.height != int(np.ceil(core.cfg.height / 2 ** len(filters))) * 2 ** len(filters):
         print("in cropping")                                  # model.py:142
@@ -385,6 +456,8 @@ def create_model_vae(input_shape, latent_dim, filters, kernels, conv_activation=
         kernels: kernels used for the convolutional layers
         conv_activation, dense_activation: accepted and ignored (the reference passes None down, model.py:187-197)
         max_batch: per-GPU stamps per step the engine allocates workspaces for (engine-specific)
+        seed: initial-weight (and shuffle) seed; None draws one from the OS, like Keras' fresh initialisation per model
+              (net.init_seed holds the value used).  dtype=1 selects the bf16 engine (BASELINE configs[2])
         ctx: debvader_amd.engine.Context (GPU / rank); default: GPU 0, single rank
     returns (net, encoder, decoder, z)
     """

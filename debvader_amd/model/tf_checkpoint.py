@@ -417,6 +417,19 @@ def encode_index(entries, num_shards: int = 1, block_size: int = 262144) -> byte
 _DT_OF = {np.dtype(np.float32): DT_FLOAT, np.dtype(np.int64): DT_INT64, np.dtype(np.float64): 2, np.dtype(np.int32): 3}
 
 
+def atomic_write(path: str, payload: bytes) -> None:
+    tmp = f"{path}.tmp-{os.getpid()}"
+    try:
+        with open(tmp, "wb") as f:
+            f.write(payload)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def write_bundle(prefix: str, tensors) -> None:
     """Writes `<prefix>.index` and `<prefix>.data-00000-of-00001`.  tensors: {key: ndarray or bytes (scalar string)}.
     Tensors are laid out in key order, every entry carries its masked crc32c (TensorFlow verifies them on read)."""
@@ -435,17 +448,18 @@ def write_bundle(prefix: str, tensors) -> None:
                                      mask_crc(crc32c(raw)))
         data += raw
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
-    with open(f"{prefix}.data-00000-of-00001", "wb") as f:
-        f.write(data)
-    with open(prefix + ".index", "wb") as f:
-        f.write(encode_index(entries, 1))
+    # data shard first, index next (write_checkpoint_state comes last): each file is written under a temporary name,
+    # flushed to disk and renamed, so a crash mid-save leaves the previous checkpoint - ModelCheckpoint(save_best_only)
+    # keeps overwriting ONE prefix - intact, as TensorFlow's temp-prefix-then-rename does
+    atomic_write(f"{prefix}.data-00000-of-00001", bytes(data))
+    atomic_write(prefix + ".index", encode_index(entries, 1))
 
 
 def write_checkpoint_state(prefix: str) -> None:
     """The `checkpoint` file tf.train.latest_checkpoint reads (relative path, as Keras' ModelCheckpoint writes)."""
     name = os.path.basename(prefix)
-    with open(os.path.join(os.path.dirname(os.path.abspath(prefix)), "checkpoint"), "w") as f:
-        f.write(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
+    atomic_write(os.path.join(os.path.dirname(os.path.abspath(prefix)), "checkpoint"),
+                 f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n'.encode())
 
 
 # ---- Keras object graph -----------------------------------------------------------------------------------------

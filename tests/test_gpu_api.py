@@ -230,6 +230,42 @@ def test_epistemic_monte_carlo_matches_the_reference_loop_statistically():
     assert np.abs(s1).max() == 0 and np.isfinite(m1).all()
 
 
+def test_epistemic_monte_carlo_against_the_oracle_sample_by_sample():
+    """dv_infer_mc draws the noise of (stamp i, sample s) from the engine's Philox stream (seed + s, row i); the oracle
+    reproduces every draw with vo.philox_normal, decodes each sample and takes the mean and the ddof-0 standard deviation
+    over the samples (the reference's np.std(deblend(net, [stamp]*n)[0], axis=0), field_deblender.py:303-313).
+    Tolerance: 2e-4 * max per tensor.  With normalise=True the statistics are those of the DENORMALISED means."""
+    from oracle import vae_oracle as vo
+    from debvader_amd import engine as E
+
+    arch = vo.Arch(input_shape=(13, 13, 4), latent_dim=8, filters=(8, 16), kernels=(3, 3))
+    p = vo.init_params(arch, seed=3, perturb=0.05)
+    p = {k: v.astype(np.float32).astype(np.float64) for k, v in p.items()}
+    rng = np.random.default_rng(17)
+    N, n, seed = 5, 12, 1234
+    x = rng.normal(0, 0.4, size=(N, 13, 13, 4)).astype(np.float32)
+    # max_batch 16 < N * n: the decodes run in several passes of 3 samples each (16 // 5)
+    eng = E.Engine(E.make_config(arch.input_shape, arch.latent_dim, tuple(arch.filters), tuple(arch.kernels), max_batch=16))
+    eng.set_params(p)
+    for normalise in (False, True):
+        xin = np.tanh(np.arcsinh(x.astype(np.float64))) if normalise else x.astype(np.float64)
+        t = vo.encoder_forward(arch, p, xin, training=False)
+        locs = []
+        for s_ in range(n):
+            eps = vo.philox_normal(seed + s_, 0, N, arch.latent_dim).astype(np.float64)
+            _, _, _, z, _ = vo.sampler_forward(arch, t, eps)
+            loc, _ = vo.decoder_forward(arch, p, z)
+            locs.append(np.sinh(np.arctanh(loc)) if normalise else loc)
+        locs = np.stack(locs)
+        eng.set_normalise(normalise)
+        mean, std = eng.infer_mc(x, nsamples=n, seed=seed)
+        eng.set_normalise(False)
+        ref_mean, ref_std = locs.mean(0), locs.std(0)
+        assert np.abs(mean - ref_mean).max() <= 2e-4 * np.abs(ref_mean).max() + 1e-7, normalise
+        assert np.abs(std - ref_std).max() <= 2e-4 * max(np.abs(ref_std).max(), np.abs(ref_mean).max()) + 1e-7, normalise
+    eng.close()
+
+
 def test_pipelined_inference_matches_chunked_calls_bit_for_bit():
     """dv_infer stages long inputs through a pinned three-stage pipeline (engine.hip: infer_pipelined); short inputs
     take the plain path.  Same kernels, same per-stamp noise: the results must be identical, for float32 and for
