@@ -83,6 +83,9 @@ struct BHeadParams {
   float* part;         // [nblocks][2]
   int NB, NBp, Hd, H, nb, crop0;
   float sigma_floor, gscale;
+  int mse_sample;      // see HeadParams (common.h)
+  unsigned mse_stream;
+  unsigned long long mse_seed;
 };
 int launch_bf_head(const BHeadParams& p, hipStream_t s, int* nblocks_out);
 

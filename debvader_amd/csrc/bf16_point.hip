@@ -312,7 +312,12 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
           const float df = ytile[sr][pp * p.nb + c] - loc;
           const float r = df * inv;
           nll += 0.5f * r * r + logf(sig) + 0.91893853320467274178f;
-          se += df * df;
+          if (p.mse_sample) {
+            const float dsm = df - sig * dv_philox_normal((unsigned)b, (unsigned)((h * p.H + w) * p.nb + c), p.mse_stream, p.mse_seed);
+            se += dsm * dsm;
+          } else {
+            se += df * df;
+          }
           const float dl = tl > 0.f ? -(r * inv) * p.gscale : 0.f;
           const float ds = ts > 0.f ? (inv - r * r * inv) * p.gscale : 0.f;
 #pragma unroll

@@ -34,6 +34,35 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef __HIPCC__
+// Philox4x32-10 and the standard normal the engine derives from it (pairs (0,1), (2,3) of a block are one
+// Box-Muller draw): shared by the sampler and the sampled-"mse" metric of the head kernels
+__device__ __forceinline__ void dv_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                                 unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float dv_philox_normal(unsigned row, unsigned col, unsigned stream, unsigned long long seed) {
+  unsigned r[4];
+  dv_philox4x32_10(row, col >> 2, stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+  const int a = col & 3;
+  const float u1 = ((float)r[a & ~1] + 1.0f) * 2.3283064365386963e-10f;
+  const float u2 = ((float)r[(a & ~1) + 1] + 1.0f) * 2.3283064365386963e-10f;
+  const float rad = sqrtf(-2.0f * logf(fminf(u1, 1.0f)));
+  float sn, cs;
+  sincosf(6.283185307179586f * u2, &sn, &cs);
+  return (a & 1) ? rad * sn : rad * cs;
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Gather-GEMM ("gconv"): Y[m, n] = sum_k A[m, k] * B[k, n]  with
 //   m  -> (stamp nb, class-grid row i, class-grid col j),   M = NB*Hc*Wc
@@ -217,7 +246,16 @@ struct HeadParams {
   int ld;              // channels per pixel row of tpre / dt (2*nb, or padded to 16)
   float sigma_floor;
   float gscale;        // 1/(Bglobal*H*H*nb)
+  // Keras' "mse" metric of the reference compares the labels with a SAMPLE of the output distribution (model.py:158
+  // convert_to_tensor_fn = sample, train.py:128): with mse_sample the squared error is taken against
+  // loc + sigma * eps, eps(stamp b, element e) = Philox4x32-10(counter (b, e / 4, mse_stream, 0), key mse_seed), e the
+  // element index inside the [H,H,nb] stamp (oracle: vae_oracle.philox_normal(seed, stream, B, H*H*nb))
+  int mse_sample;
+  int mse_row0;        // index of this launch's first stamp inside the rank's batch (forward lanes)
+  unsigned mse_stream;
+  unsigned long long mse_seed;
 };
+#define DV_MSE_STREAM 0x4D534500u   /* + rank */
 int launch_head(const HeadParams& p, hipStream_t s, int* nblocks_out);
 
 int launch_bn_stats(const float* x, const int* idx, int first, int NB, int HW, int C, float* part, int* nblocks,

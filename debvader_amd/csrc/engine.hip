@@ -440,6 +440,8 @@ struct dv_model {
   std::map<int, hipGraphExec_t> infer_graphs;
   std::map<int, int> infer_seen;
   bool normalise = false;        // dv_model_set_normalise: tanh(arcsinh) on inference inputs, inverse on the mean
+  bool mse_sample = false;       // dv_model_set_mse_sample: DV_S_MSE against a sample of the output distribution
+  unsigned long long cur_seed = 0;   // noise seed of the pass being queued
   bool early_adam = false;       // this step updates finished parameter ranges on the comm stream while the backward runs
   float lr_t_step = 0.f;         // bias-corrected step size of this step
   size_t adam_done_from = 0;     // ranges [adam_done_from, n_train) have been updated already (this step)
@@ -1361,6 +1363,10 @@ static void head_params(dv_model* m, HeadParams& hp, const float* ysrc, const in
   hp.ld = A.C2p;
   hp.sigma_floor = A.cfg.sigma_floor;
   hp.gscale = (float)(1.0 / ((double)Bg * A.H * A.H * A.C));
+  hp.mse_sample = m->mse_sample ? 1 : 0;
+  hp.mse_row0 = m->b0;
+  hp.mse_stream = DV_MSE_STREAM + (unsigned)m->ctx->rank;
+  hp.mse_seed = m->cur_seed;
 }
 
 static int head_lane(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
@@ -1382,6 +1388,7 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
   const Arch& A = m->A;
   dv_ctx* cx = m->ctx;
   hipStream_t s = cx->stream;
+  m->cur_seed = seed;
   if (run_encoder) DV_TRY(bn_prepare(m, xsrc, idx, first, NB, Bg, training, upd_moving));
   if (eps_host)
     DV_HIP(hipMemcpyAsync(m->eps, eps_host, (size_t)NB * A.d * sizeof(float), hipMemcpyHostToDevice, s));
@@ -3015,6 +3022,12 @@ int dv_model_set_keep_outputs(dv_model* m, int32_t on) {
 int dv_model_set_infer_graph(dv_model* m, int32_t on) {
   if (!m) return DV_E_INVALID;
   m->infer_graph = on != 0;
+  return DV_OK;
+}
+
+int dv_model_set_mse_sample(dv_model* m, int32_t on) {
+  if (!m) return DV_E_INVALID;
+  m->mse_sample = on != 0;
   return DV_OK;
 }
 

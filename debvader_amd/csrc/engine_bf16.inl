@@ -223,6 +223,9 @@ static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int firs
   hp.crop0 = A.crop0;
   hp.sigma_floor = A.cfg.sigma_floor;
   hp.gscale = (float)(1.0 / ((double)Bg * A.H * A.H * A.C));
+  hp.mse_sample = m->mse_sample ? 1 : 0;
+  hp.mse_stream = DV_MSE_STREAM + (unsigned)m->ctx->rank;
+  hp.mse_seed = m->cur_seed;
   const long blocks = ((long)A.dec_out * A.dec_out * bf.NBp + 255) / 256;
   if ((size_t)(part_block0 + blocks) * 2 > m->ws3_elems) {
     set_error("head workspace too small");

@@ -402,7 +402,12 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
           const float d = yp[c] - loc;
           const float r = d * inv;
           nll += 0.5f * r * r + logf(sig) + 0.91893853320467274178f;
-          se += d * d;
+          if (p.mse_sample) {
+            const float ds = d - sig * dv_philox_normal((unsigned)(p.mse_row0 + b), (unsigned)((h * p.H + w) * p.nb + c), p.mse_stream, p.mse_seed);
+            se += ds * ds;
+          } else {
+            se += d * d;
+          }
           if (dtp) {
             dtp[c] = tl > 0.f ? -(r * inv) * p.gscale : 0.f;
             dtp[p.nb + c] = ts > 0.f ? (inv - r * r * inv) * p.gscale : 0.f;
@@ -466,7 +471,12 @@ __global__ __launch_bounds__(256) void head6_kernel(const HeadParams p) {
           const float df = yv[c] - loc[c];
           const float r = df * inv;
           nll += 0.5f * r * r + logf(sig[c]) + 0.91893853320467274178f;
-          se += df * df;
+          if (p.mse_sample) {
+            const float dsm = df - sig[c] * dv_philox_normal((unsigned)(p.mse_row0 + b), (unsigned)((h * p.H + w) * 6 + c), p.mse_stream, p.mse_seed);
+            se += dsm * dsm;
+          } else {
+            se += df * df;
+          }
           d[c] = t[c] > 0.f ? -(r * inv) * p.gscale : 0.f;
           d[6 + c] = t[6 + c] > 0.f ? (inv - r * r * inv) * p.gscale : 0.f;
         }

@@ -309,6 +309,11 @@ class Engine:
         """tanh(arcsinh) on inference inputs and the inverse on the predicted mean, on the GPU (deblend(normalise=True))."""
         check(lib.dv_model_set_normalise(self._h, 1 if on else 0))
 
+    def set_mse_sample(self, on: bool):
+        """The "mse" scalar of the step functions against a SAMPLE of the output distribution (Keras semantics of the
+        reference's compile(metrics=["mse"]), model.py:158) instead of its mean."""
+        check(lib.dv_model_set_mse_sample(self._h, 1 if on else 0))
+
     def keep_outputs(self, on: bool):
         """Gradient / train steps also write loc and scale of their forward pass (activation("loc"), activation("scale"));
         off by default - a train step has no reader for them."""

@@ -127,9 +127,12 @@ class VAENet:
         self.history = None
 
     # -- Keras surface -----------------------------------------------------------------------
-    def compile(self, optimizer=None, loss=None, metrics=None, **kwargs):
+    def compile(self, optimizer=None, loss=None, metrics=None, mse_of_mean=False, **kwargs):
         """net.compile(optimizer=legacy.Adam(1e-4), loss=vae_loss, metrics=["mse", kl_metric], ...)
-        (train.py:125-130,178-183; model.py:255-259).  Fresh Adam slots; honours `trainable` flags."""
+        (train.py:125-130,178-183; model.py:255-259).  Fresh Adam slots; honours `trainable` flags.
+        "mse" is Keras' metric on the model OUTPUT, which for this net is a sample of the Normal (model.py:158) - the
+        value that drives the reference's val_mse ModelCheckpoint (train.py:54-62).  mse_of_mean=True (engine
+        extension) reports the squared error of the predicted mean instead."""
         if loss is not None and loss is not vae_loss and getattr(loss, "__name__", "") != "vae_loss":
             raise NotImplementedError("the engine fuses the reference's vae_loss (Normal NLL); other losses are "
                                       "not implemented")
@@ -139,6 +142,7 @@ class VAENet:
         eng.optimizer_reset(lr, b1, b2, eps)
         self.optimizer = Adam(lr, b1, b2, eps)
         self._metrics = list(metrics or [])
+        eng.set_mse_sample(not mse_of_mean)
         self._core.compiled = True
 
     def summary(self, print_fn=print):

@@ -145,6 +145,13 @@ int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t 
  * predicted mean (the scale stays in normalised units) */
 int dv_model_set_normalise(dv_model* m, int32_t on);
 
+/* Keras' "mse" metric of the reference (train.py:128 metrics=["mse", ...]) compares the labels with a SAMPLE of the output
+ * distribution (model.py:158 convert_to_tensor_fn = sample), not with its mean.  While set, DV_S_MSE of the step
+ * functions is mean((y - (loc + sigma * eps))^2) with eps drawn from the engine's Philox stream (seed of the step, stream
+ * 0x4D534500 + rank, counter (stamp, element / 4)); off (default at this level): the squared error against the mean.
+ * The Python surface (debvader_amd.model) switches it on when compile(metrics=[..."mse"...]) asks for the Keras metric. */
+int dv_model_set_mse_sample(dv_model* m, int32_t on);
+
 /* Replay a captured hipGraph for the forward pass of small inference batches (< 64 stamps, one chunk, engine-drawn
  * noise) instead of launching its ~45 kernels one by one: BASELINE configs[4] "hipGraph-captured decode" /
  * SURVEY row A10.  Off by default: on MI355X the replay takes exactly as long as the eager launches (the chain is

@@ -124,6 +124,36 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True):
     return worst
 
 
+def test_keras_mse_metric_is_taken_against_a_sample_of_the_output_distribution():
+    """compile(metrics=["mse"]) of the reference (train.py:128) measures the labels against a SAMPLE of Normal(loc, scale)
+    (model.py:158).  With dv_model_set_mse_sample the engine draws that sample from its Philox stream; the oracle
+    reproduces the draw (vo.philox_normal) - for the fp32 and the bf16 engine, several forward lanes included."""
+    from debvader_amd import engine as E
+
+    for dtype, arch, B in ((0, small_arch(), 7), (0, small_arch(), 96),
+                           (1, vo.Arch(input_shape=(13, 13, 4), latent_dim=8, filters=(16, 32), kernels=(3, 3)), 21)):
+        p, x, y, eps = _case(arch, B, 12)
+        eng = E.Engine(E.make_config(arch.input_shape, arch.latent_dim, tuple(arch.filters), tuple(arch.kernels),
+                                     max_batch=B, dtype=dtype))
+        eng.set_params(p)
+        eng.optimizer_reset(1e-4)
+        eng.upload(0, x, y)
+        eng.keep_outputs(True)
+        seed = 987654321012
+        plain = eng.grad_step(0, first=0, B=B, eps=eps, seed=seed)
+        eng.set_mse_sample(True)
+        out = eng.grad_step(0, first=0, B=B, eps=eps, seed=seed)
+        H, W, C = arch.input_shape
+        loc = eng.activation("loc", (B, H, W, C)).astype(np.float64)
+        scale = eng.activation("scale", (B, H, W, C)).astype(np.float64)
+        e = vo.philox_normal(seed, 0x4D534500, B, H * W * C).astype(np.float64).reshape(B, H, W, C)
+        ref = ((y - (loc + scale * e)) ** 2).mean()
+        assert abs(out["mse"] - ref) <= 1e-4 * ref, (dtype, B, out["mse"], ref)
+        assert abs(plain["mse"] - ((y - loc) ** 2).mean()) <= 1e-4 * plain["mse"]
+        assert out["loss"] == plain["loss"]                     # the metric does not touch the loss
+        eng.close()
+
+
 def test_small_arch_parity():
     _run_parity(small_arch(), B=5, seed=0)
 
