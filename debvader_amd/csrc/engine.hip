@@ -1401,6 +1401,26 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
   int nlanes = (m->split_forward && !m->prof_on && !m->bf.on && cx->aux_stream && NB >= 64) ? std::max(1, std::min(want_lanes, 4)) : 1;
   while (nlanes > 1 && NB / nlanes < 32) --nlanes;
   while (nlanes > 2 && !cx->lane_stream[nlanes - 3]) --nlanes;
+  // The fp32 kernels address a launch's tensors with 32-bit byte offsets (2^30 elements: 8191 stamps of the 59-pixel
+  // net, 2047 of a 128-pixel one).  A forward pass over more stamps - deblend() at BASELINE configs[4]'s batch of 8192 -
+  // runs as lanes of at most that many stamps, each launch addressing its own lane; the backward pass has no lanes, so
+  // training steps stay within the limit (check_step_args).
+  if (!m->bf.on && m->Bc > 0) {
+    const size_t per_stamp = std::max<size_t>(1, m->max_act_elems / (size_t)m->Bc);
+    const long cap = (long)((((size_t)1 << 30) - 1) / per_stamp) & ~31L;
+    if (NB > cap) {
+      if (keep_u || !cx->aux_stream) {
+        set_error("batch %d exceeds the %ld stamps one fp32 launch can address; lower the batch", NB, cap);
+        return E_INVALID;
+      }
+      nlanes = (int)((NB + cap - 1) / cap);
+      if (nlanes > 4 || (nlanes > 2 && !cx->lane_stream[nlanes - 3])) {
+        set_error("batch %d needs %d forward lanes of <= %ld stamps; at most %d are available (DV_FWD_LANES)", NB, nlanes,
+                  cap, cx->lane_stream[1] ? 4 : (cx->lane_stream[0] ? 3 : 2));
+        return E_INVALID;
+      }
+    }
+  }
   const int per = nlanes > 1 ? ((NB / nlanes + 31) / 32) * 32 : NB;   // lane sizes: multiples of 32 stamps
   int blk_done = 0, st = OK;
   // lane 0 runs on the main stream, lane 1 on the aux stream, further lanes on their own streams

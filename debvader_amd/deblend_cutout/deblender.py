@@ -25,6 +25,50 @@ def deblend(net, images, normalise=False):
         eng.set_normalise(False)
     return out.mean().numpy(), out                 # mean in flux units, stddev in normalised units
 
+def deblend_sharded(net, images, normalise=False, dist=None, gather=True, rank=None, world=None):
+    """deblend() over the GPUs of one node (BASELINE configs[4]): the reference calls the network ONCE on all N stamps
+    (deblender.py:18, from field_deblender.py:265-274); stamps are independent, so rank r runs deblend() on the
+    contiguous index range parallel.shard_range(N, r, world) of `images` and no collective touches the data path.
+
+    parameters:
+        net, images, normalise: as deblend().  Every rank passes the same `images` (or at least its own range of it).
+        dist: torch.distributed-like object with gather_object (gloo); only used to bring the pieces to rank 0
+        gather: True - rank 0 returns the full (mean, stddev) arrays in input order, other ranks (None, None);
+                False - every rank returns its own shard (mean, stddev) and (begin, end); nothing is exchanged
+                (the 1M-cutout case: 83 KB of output per stamp does not belong on one host)
+        rank, world: default to the context the network was created on
+    """
+    from debvader_amd.parallel import shard_range
+
+    ctx = getattr(getattr(net, "_core", None), "ctx", None)
+    rank = ctx.rank if rank is None else rank
+    world = ctx.world if world is None else world
+    images = np.asarray(images)
+    lo, hi = shard_range(images.shape[0], rank, world)
+    if hi > lo:
+        mean, out = deblend(net, images[lo:hi], normalise)
+        std = out.stddev().numpy()
+    else:                                              # fewer stamps than ranks
+        mean = np.empty((0,) + images.shape[1:], np.float32)
+        std = np.empty((0,) + images.shape[1:], np.float32)
+    if not gather:
+        return mean, std, (lo, hi)
+    if world == 1:
+        return mean, std
+    if dist is None:
+        raise ValueError("gather=True with more than one rank needs a torch.distributed-like `dist` (gather_object)")
+    pieces = [None] * world if rank == 0 else None
+    dist.gather_object((lo, hi, mean, std), pieces, dst=0)
+    if rank != 0:
+        return None, None
+    full_m = np.empty((images.shape[0],) + mean.shape[1:], np.float32)
+    full_s = np.empty_like(full_m)
+    for b, e, m_, s_ in pieces:
+        full_m[b:e] = m_
+        full_s[b:e] = s_
+    return full_m, full_s
+
+
 def deblend_epistemic(net, images, n_samples=100, normalise=False):
     """Epistemic-uncertainty estimate of the reference's field deblender (deblend/field_deblender.py:303-313:
     `np.std(deblend(net, [stamp] * 100)[0], axis=0)` in a Python loop over objects) as one engine call:

@@ -81,3 +81,84 @@ def test_two_rank_sharded_step_equals_full_batch():
         assert p.exitcode == 0
     loss_rel, grad_rel = q.get(timeout=5)
     assert loss_rel < 1e-12 and grad_rel < 1e-10
+
+
+# ---- deblend_sharded: contiguous index ranges, no collective on the data path, gather on rank 0 -----------------------
+class _StubDist:
+    """Output distribution of the stub network below."""
+
+    def __init__(self, x):
+        self._x = x
+
+    def mean(self):
+        return _Arr(self._x * 2.0 + 1.0)
+
+    def stddev(self):
+        return _Arr(np.abs(self._x) + 0.5)
+
+
+class _Arr:
+    def __init__(self, a):
+        self._a = np.asarray(a, np.float32)
+
+    def numpy(self):
+        return self._a
+
+
+class _StubNet:
+    """Stands in for the engine-backed net (no GPU here): a deterministic per-stamp function of the input."""
+
+    def __init__(self, rank, world):
+        class Ctx:
+            pass
+
+        class Core:
+            pass
+
+        self._core = Core()
+        self._core.ctx = Ctx()
+        self._core.ctx.rank, self._core.ctx.world = rank, world
+        self.calls = []
+
+    def __call__(self, x):
+        self.calls.append(x.shape[0])
+        return _StubDist(np.asarray(x, np.float32))
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from debvader_amd.deblend_cutout.deblender import deblend_sharded
+
+        rng = np.random.default_rng(3)
+        for n in (7, 1, 0, 64):                       # odd split, fewer stamps than ranks, empty, even
+            x = rng.normal(size=(n, 5, 5, 2))
+            net = _StubNet(rank, world)
+            m, s = deblend_sharded(net, x, dist=dist)
+            if rank == 0:
+                np.testing.assert_array_equal(m, (x.astype(np.float32) * 2.0 + 1.0))
+                np.testing.assert_array_equal(s, np.abs(x.astype(np.float32)) + 0.5)
+            else:
+                assert m is None and s is None
+            m2, s2, (lo, hi) = deblend_sharded(net, x, gather=False)
+            assert m2.shape[0] == hi - lo and (hi - lo) in (n // world, n // world + 1)
+            np.testing.assert_array_equal(m2, x[lo:hi].astype(np.float32) * 2.0 + 1.0)
+        q.put((rank, "ok"))
+    except Exception as e:                            # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_deblend_sharded_ranges_and_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: "ok", 1: "ok"}, res

@@ -404,3 +404,54 @@ def test_graph_replayed_small_batch_inference_equals_eager_launches():
             np.testing.assert_array_equal(a[k], b[k])
     assert np.abs(replay[0]["z"] - replay[1]["z"]).max() > 0
     eng.close()
+
+
+def test_deblend_sharded_single_rank_equals_deblend():
+    """One rank: deblend_sharded is deblend() on the whole range (same noise seed -> bit-identical mean and stddev)."""
+    from debvader_amd.deblend_cutout.deblender import deblend, deblend_sharded
+    from debvader_amd.model import model
+
+    net, _, _, _ = model.create_model_vae(**ARCH, max_batch=64, seed=5)
+    x, _ = _data(37, 23)
+    net._core.seed_counter = 1000
+    m0, d0 = deblend(net, x)
+    net._core.seed_counter = 1000
+    m1, s1 = deblend_sharded(net, x)
+    np.testing.assert_array_equal(m0, m1)
+    np.testing.assert_array_equal(d0.stddev().numpy(), s1)
+    net._core.seed_counter = 1000
+    m2, s2, (lo, hi) = deblend_sharded(net, x, gather=False)
+    assert (lo, hi) == (0, 37)
+    np.testing.assert_array_equal(m0, m2)
+
+
+def test_inference_chunk_of_8192_stamps_fp32_lanes_and_bf16():
+    """BASELINE configs[4] quotes batch = 8192.  One fp32 launch addresses 2^30 elements (8191 stamps of the 59-pixel
+    net), so the fp32 engine runs such a chunk as two forward lanes; the bf16 engine's block offsets take it whole.
+    Per-stamp results do not depend on the chunking: a max_batch = 8192 engine must reproduce a max_batch = 256 engine."""
+    from debvader_amd import engine as E
+    from debvader_amd.data import synthetic_stamps
+
+    base, _ = synthetic_stamps(256, seed=77)
+    N = 8192 + 40
+    x = np.tile(base, (N // 256 + 1, 1, 1, 1))[:N]
+    for dtype in (0, 1):
+        small = E.Engine(E.make_config(max_batch=256, dtype=dtype))
+        small.init(3)
+        ref = small.infer(x[:512], seed=9, want=("loc", "z"))
+        tail = small.infer(x[N - 256:], seed=9, want=("loc",))      # rows N-256.. as rows 0.. : different noise rows
+        small.close()
+        big = E.Engine(E.make_config(max_batch=8192, dtype=dtype))
+        big.init(3)
+        out = big.infer(x, seed=9, want=("loc", "z"))
+        big.close()
+        assert np.isfinite(out["loc"]).all()
+        # (the dense layers pick their split-K by the batch size, so fp32 agrees to rounding, not bit for bit)
+        assert np.abs(out["z"][:512] - ref["z"]).max() <= (1e-5 if dtype == 0 else 2e-2) * np.abs(ref["z"]).max()
+        if dtype == 0:
+            assert np.abs(out["loc"][:512] - ref["loc"]).max() <= 1e-4 * np.abs(ref["loc"]).max()
+        else:
+            # the bf16 conv tiles hold 16 stamps of ONE pixel or of several, depending on the chunk's padding: fp32 sums
+            # in another order, bf16 roundings may flip
+            assert np.abs(out["loc"][:512] - ref["loc"]).max() <= 2e-2 * np.abs(ref["loc"]).max()
+        assert tail["loc"].shape == (256, 59, 59, 6)
