@@ -10,12 +10,21 @@ One process per GPU.  The compute path is the HIP engine (libdebvader_hip.so thr
 gradient all-reduce; torch.distributed (gloo) is used only to hand rank 0's RCCL id to the other ranks,
 for the barriers around the timed region and for the max-over-ranks of the elapsed time.
 Inputs are resident in HBM before the timed region (dv_data_upload), synthetic, random-init weights.
+
+The ONE JSON line also carries (rank 0, N = 1 only; --no-secondary / --no-cpu-baseline / --no-roofline switch them off):
+  roofline      per-kernel-family HIP-event timing of the same K steps with the engine's streams serialised
+  cpu_baseline  the same train step restated with torch-CPU ops (tests/torch_ref.py, oneDNN, all host cores), and the
+                numpy oracle as a second entry
+  secondary     the other BASELINE configs, each measured here: bf16 train step (configs[2], HBM roofline), stage-2
+                train step (decoder frozen, train.py:175-183), 128 x 128 x 6 / 6-level net (configs[3]), deblend()
+                inference (configs[4]: cutouts of a tiled scene, 8192 per call)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,14 +34,86 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: ~2.5 PF dense bf16
+HBM_PEAK_GBS = 8000.0           # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
+# minimum materialised activations 836 438 elements per stamp, five passes per train step
+ACT_ELEMS_PER_STAMP = 836438
+TRAIN_PASSES = 5
+PARAM_STEP_BYTES = 5 * 33.27e6  # weights / gradients / Adam slots per step (fp32 in both engines)
 
 
-def cpu_baseline(batch: int, steps: int):
-    """The oracle's train step (numpy float32, BLAS threads = all host cores) on a bounded sample."""
+_T0 = time.perf_counter()
+
+
+def _progress(msg):
+    """stderr only (stdout carries the one JSON line): where a long run is"""
+    print(f"[bench {time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def _cores():
+    """Host cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota (a GPU box shows 256
+    cores in its mask but grants a share of 16 per GPU: 256 threads on that share ran the torch step 500x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                        n = min(n, max(1, q // int(fh.read().split()[0])))
+            break
+        except Exception:
+            continue
+    return min(n, int(os.environ.get("DV_BENCH_MAX_THREADS", "16")))
+
+
+def cpu_baseline_torch(batch: int, steps: int):
+    """The train step (forward + ELBO + autograd backward + Adam) restated with torch CPU ops - conv2d /
+    conv_transpose2d on oneDNN, float32, all host cores.  Not the reference (TensorFlow is not installable here), but
+    the same arithmetic on the kind of CPU backend the reference's Keras fit() uses (train.py:27-37)."""
+    import torch
+
+    from oracle import vae_oracle as vo
+    from tests import torch_ref as tr
+    from debvader_amd.data import synthetic_stamps
+
+    cores = _cores()
+    torch.set_num_threads(cores)
+    arch = vo.Arch()
+    p = {k: torch.tensor(v, dtype=torch.float32, requires_grad="moving" not in k)
+         for k, v in vo.init_params(arch, 0, dtype=np.float32).items()}
+    x, y = synthetic_stamps(batch, seed=7)
+    x, y = torch.tensor(x), torch.tensor(y)
+    eps = torch.randn(batch, arch.latent_dim, generator=torch.Generator().manual_seed(0))
+    opt = torch.optim.Adam([v for v in p.values() if v.requires_grad], lr=1e-4, eps=1e-7)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = tr.net_loss(arch, p, x, y, eps, training=True)
+        out["loss"].backward()
+        opt.step()
+
+    step()                                            # warm-up (thread pool, oneDNN primitive cache)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": batch * steps / dt, "unit": "stamps/s", "cores": cores, "kind": "torch-cpu restatement",
+            "sample": f"{steps} train steps of batch {batch} (torch {torch.__version__} CPU / oneDNN float32 conv2d + "
+                      f"conv_transpose2d, autograd, Adam; tests/torch_ref.py), same model/config"}
+
+
+def cpu_baseline_numpy(batch: int, steps: int):
+    """The oracle's train step (numpy float32, BLAS threads) on a bounded sample."""
     from oracle import vae_oracle as vo
     from debvader_amd.data import synthetic_stamps
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = _cores()
     threads = min(cores, 32)         # numpy's BLAS does not scale past a few tens of threads on these GEMM sizes
     try:
         from threadpoolctl import threadpool_limits
@@ -52,13 +133,135 @@ def cpu_baseline(batch: int, steps: int):
     dt = time.perf_counter() - t0
     if limiter is not None:
         limiter.restore_original_limits()
-    return {
-        "value": batch * steps / dt,
-        "unit": "stamps/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"{steps} train steps of batch {batch} (numpy float32 oracle, BLAS multi-threaded), same model/config",
+    return {"value": batch * steps / dt, "unit": "stamps/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} train steps of batch {batch} (numpy float32 oracle, BLAS multi-threaded), same model/config"}
+
+
+def _git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def _pmc_traffic():
+    """HBM bytes per step and kernel family from the committed rocprofv3 PMC passes of this round (FETCH_SIZE doubled as
+    the micro-architecture guide prescribes for gfx950; tools/pmc_traffic.py spells out the collection)."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic_v13.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as fh:
+                return json.load(fh), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
+def _timed_steps(eng, ctx, B, steps, warmup, seed=100, Bg=None):
+    if warmup > 0:
+        eng.train_steps(0, 0, B, warmup, global_batch=Bg, seed=seed + 1)
+    ctx.sync()
+    t0 = time.perf_counter()
+    scal = eng.train_steps(0, 0, B, steps, global_batch=Bg, seed=seed)
+    ctx.sync()
+    return time.perf_counter() - t0, scal
+
+
+def _family_table(eng, B, steps, peak_tflops, seed):
+    """Per-kernel-family rows from a serialised-stream pass over `steps` train steps."""
+    eng.prof_reset()
+    eng.prof_enable(True)
+    eng.train_steps(0, 0, B, steps, seed=seed)
+    eng.prof_enable(False)
+    fams = eng.prof_families()
+    rows = []
+    for f in fams:
+        ms = f["ms"] / steps
+        tf = f["flops"] / steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        rows.append({"kernel": f["name"], "launches_per_step": f["launches"] / steps, "flops_per_step": f["flops"] / steps,
+                     "ms_per_step": ms, "avg_us": ms * 1e3 / max(1.0, f["launches"] / steps), "tflops": tf,
+                     "frac": tf / peak_tflops})
+    classes = {k: eng.prof_read(i)[1] / steps for i, k in enumerate(("conv", "wgrad", "other"))}
+    return rows, classes
+
+
+def secondary_entries(E, ctx, synthetic_stamps, quick: bool):
+    out = {}
+    enc_macs, dec_macs = E.arch_macs(E.make_config())
+    fwd_flops = 2.0 * (enc_macs + dec_macs + 32 * 33 // 2)
+    # ---- BASELINE configs[2]: the same model with bf16 storage / bf16 MFMA operands (per-GPU batch 256) ----
+    B = 256
+    x, y = synthetic_stamps(4 * B, seed=1000)
+    steps = 20 if quick else 60
+    _progress("secondary: bf16 train step")
+    eng = E.Engine(E.make_config(max_batch=B, dtype=1), ctx)
+    eng.init(seed=0)
+    eng.upload(0, x, y)
+    eng.optimizer_reset(1e-4)
+    dt, scal = _timed_steps(eng, ctx, B, steps, 10)
+    rows, classes = _family_table(eng, B, 10, BF16_MFMA_PEAK_TFLOPS, 300)
+    eng.close()
+    ms = dt / steps * 1e3
+    alg_bytes = ACT_ELEMS_PER_STAMP * 2 * TRAIN_PASSES * B + PARAM_STEP_BYTES
+    pmc, src = _pmc_traffic()
+    out["bf16_train"] = {
+        "workload": "BASELINE configs[2] per GPU: same model, bf16 storage + bf16 MFMA operands, fp32 accumulation / master "
+                    "weights / dense trunk / head, batch 256",
+        "value": B * steps / dt, "unit": "stamps/s", "ms_per_step": ms, "dtype": "bf16", "last_loss": scal["loss"],
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_step": alg_bytes,
+                     "traffic": (pmc or {}).get("bf16_per_step_bytes", {}).get("total"),
+                     "traffic_source": src if (pmc or {}).get("bf16_per_step_bytes") else None,
+                     "mfma_whole_step_tflops": 3.0 * fwd_flops * B / (ms * 1e-3) / 1e12,
+                     "mode": "value: streams overlapped; kernels / classes: streams serialised",
+                     "kernels": rows, "classes_ms_per_step": classes},
     }
+    # ---- stage 2 of train_deblender: decoder frozen, fresh Adam (train.py:175-183); 1.509 GFLOP per stamp ----
+    _progress("secondary: stage-2 train step")
+    eng = E.Engine(E.make_config(max_batch=B), ctx)
+    eng.init(seed=0)
+    eng.upload(0, x, y)
+    eng.set_trainable(True, False)
+    eng.optimizer_reset(1e-4)
+    dt, scal = _timed_steps(eng, ctx, B, steps, 10)
+    ms = dt / steps * 1e3
+    s2_flops = (2.0 * fwd_flops + 2.0 * enc_macs) * B          # fwd + all data gradients + encoder weight gradients
+    out["stage2_train"] = {
+        "workload": "stage 2 of train_deblender (train.py:175-183): decoder frozen, encoder trained, fp32, batch 256",
+        "value": B * steps / dt, "unit": "stamps/s", "ms_per_step": ms, "dtype": "f32", "last_loss": scal["loss"],
+        "whole_step_tflops": s2_flops / (ms * 1e-3) / 1e12,
+        "frac_of_fp32_mfma_peak": s2_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    eng.close()
+    # ---- BASELINE configs[4]: deblend() over cutouts of a field_img_2.npy-style scene, 8192 stamps per call ----
+    from tools.field_cutouts import run as cutouts_run
+
+    _progress("secondary: deblend over field cutouts (fp32, then bf16)")
+    out["deblend_cutouts"] = cutouts_run(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=0)
+    out["deblend_cutouts_bf16"] = cutouts_run(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=1)
+    # ---- BASELINE configs[3]: 128 x 128 x 6 stamps, six levels (per-GPU share of the global batch 512: 64) ----
+    _progress("secondary: 128-pixel architecture")
+    B3 = 64
+    cfg3 = E.make_config((128, 128, 6), 32, (32, 64, 128, 256, 512, 512), (3,) * 6, max_batch=B3)
+    e3, d3 = E.arch_macs(cfg3)
+    rng = np.random.default_rng(5)
+    x3 = rng.normal(0, 0.3, size=(2 * B3, 128, 128, 6)).astype(np.float32)
+    y3 = np.abs(x3) * 0.5
+    eng = E.Engine(cfg3, ctx)
+    eng.init(seed=0)
+    eng.upload(0, x3, y3)
+    eng.optimizer_reset(1e-4)
+    st3 = 6 if quick else 20
+    dt, scal = _timed_steps(eng, ctx, B3, st3, 3)
+    ms = dt / st3 * 1e3
+    fl3 = 3.0 * 2.0 * (e3 + d3) * B3
+    out["arch128_train"] = {
+        "workload": "BASELINE configs[3] per GPU: 128x128x6 stamps, 6 levels, filters [32,64,128,256,512,512], fp32, batch 64",
+        "value": B3 * st3 / dt, "unit": "stamps/s", "ms_per_step": ms, "dtype": "f32", "last_loss": scal["loss"],
+        "whole_step_tflops": fl3 / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": fl3 / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    eng.close()
+    return out
 
 
 def main():
@@ -69,7 +272,13 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="stamps per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="shorter secondary measurements")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        print(json.dumps(cpu_baseline_torch(batch=256, steps=5)), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,47 +334,63 @@ def main():
     fwd_flops = 2.0 * (enc_macs + dec_macs + cfg.latent_dim * (cfg.latent_dim + 1) // 2)
     train_flops = 3.0 * fwd_flops                         # fwd + dgrad + wgrad
 
+    _progress(f"headline: {Bg * args.steps / dt:.0f} stamps/s")
     roofline = None
     if not args.no_roofline:
-        # per-kernel-class HIP-event timing on the engine's stream, over the same K steps (separate pass so the
-        # event records do not perturb `value`)
-        eng.prof_reset()
-        eng.prof_enable(True)
-        eng.train_steps(0, 0, B, args.steps, global_batch=Bg, seed=200)
-        eng.prof_enable(False)
-        n_g, ms_g = eng.prof_read(0)
-        n_w, ms_w = eng.prof_read(1)
-        n_o, ms_o = eng.prof_read(2)
-        # algorithmic FLOPs per step: the gather-GEMM kernel family carries fwd + dgrad (2/3), wgrad 1/3
-        cls = {
-            "gconv_kernel": (2.0 * fwd_flops * B, ms_g / args.steps, n_g // args.steps),
-            "wgrad_kernel": (1.0 * fwd_flops * B, ms_w / args.steps, n_w // args.steps),
-        }
+        # HIP-event timing per kernel family on the stream each launch is queued on, over K steps of the same workload,
+        # with the engine's streams SERIALISED (a separate pass: the records would perturb `value`, and overlapped
+        # kernels cannot be told apart by events)
+        rows, classes = _family_table(eng, B, args.steps, FP32_MFMA_PEAK_TFLOPS, 200)
+        pmc, src = _pmc_traffic()
+        per_step = (pmc or {}).get("per_step_bytes", {})
+        dom = max(rows, key=lambda r: r["ms_per_step"]) if rows else None
+        conv_rows = [r for r in rows if r["kernel"].startswith("gconv")]
+        conv_ms = sum(r["ms_per_step"] for r in conv_rows)
+        conv_fl = sum(r["flops_per_step"] for r in conv_rows)
+        conv_tf = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         traffic = None
-        try:    # HBM bytes per step of the family from the committed PMC passes (profiles/r01_pmc_traffic_v13.json)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v13.json")) as fh:
-                pmc = json.load(fh)["per_step_bytes"]
-            traffic = {"gconv_kernel": next(v for k, v in pmc.items() if k.startswith("gconv"))["hbm_bytes"],
-                       "wgrad_kernel": next(v for k, v in pmc.items() if k.startswith("wgrad"))["hbm_bytes"]}
-        except Exception:
-            traffic = None
-        dom = max(cls, key=lambda k: cls[k][1])
-        fl, ms, nl = cls[dom]
-        achieved = fl / (ms * 1e-3) / 1e12
+        if dom is not None:
+            key = dom["kernel"].split(" ")[0]
+            traffic = next((v.get("hbm_bytes") for k, v in per_step.items() if k.startswith(key)), None)
         roofline = {
-            "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-            "traffic": (traffic or {}).get(dom),
-            "launch": f"one training step's launches of the {dom} family ({nl} launches, batch {B})",
-            "flops_per_step": fl, "ms_per_step_in_kernel": ms,
-            "classes_ms_per_step": {"gconv": ms_g / args.steps, "wgrad": ms_w / args.steps,
-                                    "pointwise": ms_o / args.steps},
+            "bound": "mfma", "kernel": dom["kernel"] if dom else None,
+            "achieved": dom["tflops"] if dom else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["frac"] if dom else None, "traffic": traffic,
+            "traffic_source": {"file": src, "commit": _git_head(),
+                               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed; not "
+                                       "re-measured in this run"} if src else None,
+            "mode": "streams serialised (the per-kernel rows); `value` is measured with the streams overlapped",
+            "launch": (f"one training step's launches of {dom['kernel']} ({dom['launches_per_step']:.0f} launches, "
+                       f"batch {B})") if dom else None,
+            "kernels": rows,
+            "gather_gemm_family": {"ms_per_step": conv_ms, "flops_per_step": conv_fl, "tflops": conv_tf,
+                                   "frac": conv_tf / FP32_MFMA_PEAK_TFLOPS},
+            "classes_ms_per_step": classes,
             "whole_step_tflops": train_flops * B / (dt / args.steps) / 1e12,
+            "whole_step_frac": train_flops * B / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
         }
+    last_loss = scal["loss"]
+    eng.close()
+
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = secondary_entries(E, ctx, synthetic_stamps, args.quick)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(batch=64, steps=3)
+        # in a child process: torch brings its own copy of the HIP runtime, and a process that has loaded both it and
+        # /opt/rocm's (libdebvader_hip.so) aborts in the static destructors at exit ("free(): invalid pointer")
+        _progress("cpu baseline: torch-CPU restatement (child process)")
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"], capture_output=True,
+                               text=True, timeout=900)
+            cpu = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:                    # pragma: no cover
+            cpu = {"value": None, "unit": "stamps/s", "cores": _cores(), "kind": "torch-cpu restatement",
+                   "sample": f"failed: {e!r}"}
+        _progress("cpu baseline: numpy oracle")
+        cpu["also"] = cpu_baseline_numpy(batch=64, steps=3)
+        _progress("done")
 
     if rank == 0:
         value = Bg * args.steps / dt
@@ -177,15 +402,18 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 6-band 59x59 stamps, batch=256 per GPU, latent_dim=32, "
                                    "filters [32,64,128,256], fp32, stage-1 VAE train step",
                        "global_batch": Bg, "per_gpu_batch": B, "parallelism": f"dp{world}"},
-            "last_loss": scal["loss"],
-            "roofline": roofline, "cpu_baseline": cpu,
+            "last_loss": last_loss,
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
-    eng.close()
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        # torch (gloo) and the engine's HIP runtime live in this process: leave without running static destructors
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

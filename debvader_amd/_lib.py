@@ -112,6 +112,8 @@ SIGNATURES = {
     "dv_prof_enable": (C.c_int, [_p, C.c_int32]),
     "dv_prof_read": (C.c_int, [_p, C.c_int32, _i64, C.POINTER(C.c_double)]),
     "dv_prof_reset": (C.c_int, [_p]),
+    "dv_prof_read_family": (C.c_int, [_p, C.c_int32, C.c_char_p, C.c_size_t, _i64, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double)]),
     "dv_debug_gconv": (C.c_int, [_p] + [C.c_int32] * 13 + [_f]),
     "dv_debug_gconv_check": (C.c_int, [_p] + [C.c_int32] * 10 + [_f]),
     "dv_debug_mfma_peak": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),

@@ -314,8 +314,17 @@ struct dv_ctx {
 
 struct ProfRec {
   int klass;
+  int fam;
   hipEvent_t a, b;
 };
+// kernel families of the MFMA work, by the name rocprofv3 prints for them (per-kernel roofline rows of bench.py)
+enum {
+  PF_NONE = -1, PF_GCONV2 = 0, PF_GCONV_S2, PF_GSTRIP, PF_GSTRIP8, PF_GCONV, PF_WGRAD, PF_WSTRIP, PF_BCONV, PF_BWGRAD,
+  PF_COUNT
+};
+static const char* const kProfFamName[PF_COUNT] = {
+    "gconv2_kernel", "gconv_s2_kernel", "gconv_strip_kernel", "gconv_strip8_kernel", "gconv_kernel", "wgrad_kernel",
+    "wgrad_strip_kernel / wgrad_strip8_kernel", "bconv_kernel", "bwgrad_kernel"};
 
 struct DataSlot {
   float* x = nullptr;
@@ -457,6 +466,9 @@ struct dv_model {
   int64_t prof_n[3] = {0, 0, 0};
   int64_t prof_launches[3] = {0, 0, 0};
   bool prof_open = false;
+  int prof_open_fam = -1;
+  int64_t fam_launches[16] = {0};
+  double fam_ms[16] = {0}, fam_flops[16] = {0};
   int prof_open_klass = 0;
   hipStream_t prof_open_stream = nullptr;
   hipEvent_t prof_open_ev = nullptr;
@@ -492,20 +504,26 @@ static void prof_close(dv_model* m) {
   if (!m->prof_open) return;
   hipEvent_t b = prof_event(m);
   (void)hipEventRecord(b, m->prof_open_stream);
-  m->prof.push_back({m->prof_open_klass, m->prof_open_ev, b});
+  m->prof.push_back({m->prof_open_klass, m->prof_open_fam, m->prof_open_ev, b});
   m->prof_open = false;
 }
 struct ProfScope {
-  ProfScope(dv_model* m, int k, hipStream_t s = nullptr) {
+  // fam / flops: kernel family of an MFMA launch and its algorithmic FLOPs (padding taps counted)
+  ProfScope(dv_model* m, int k, hipStream_t s = nullptr, int fam = PF_NONE, double flops = 0.0) {
     if (!m->prof_on) return;
     hipStream_t st = s ? s : (m->cs ? m->cs : m->ctx->stream);
     m->prof_launches[k] += 1;
-    if (m->prof_open && m->prof_open_klass == k && m->prof_open_stream == st) return;   // extend the open run
+    if (fam >= 0) {
+      m->fam_launches[fam] += 1;
+      m->fam_flops[fam] += flops;
+    }
+    if (m->prof_open && m->prof_open_klass == k && m->prof_open_fam == fam && m->prof_open_stream == st) return;   // extend the open run
     prof_close(m);
     m->prof_open_ev = prof_event(m);
     (void)hipEventRecord(m->prof_open_ev, st);
     m->prof_open = true;
     m->prof_open_klass = k;
+    m->prof_open_fam = fam;
     m->prof_open_stream = st;
   }
 };
@@ -518,6 +536,7 @@ static int prof_flush(dv_model* m) {
     float ms = 0.f;
     DV_HIP(hipEventElapsedTime(&ms, r.a, r.b));
     m->prof_ms[r.klass] += ms;
+    if (r.fam >= 0) m->fam_ms[r.fam] += ms;
     m->ev_pool.push_back(r.a);
     m->ev_pool.push_back(r.b);
   }
@@ -671,6 +690,9 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
   Taps one;
   one.add(0, 0, 0);
   const Taps tp = single_tap ? one : taps_fprop(pb);
+  // algorithmic FLOPs of this launch (padding taps counted; the folded first conv and the padded head count their real channels)
+  const double flops = 2.0 * NB * Hout * Hout * tp.n * (double)(W == m->W1p ? m->A.C : Cin) *
+                       (double)(W == m->Whp ? 2 * m->A.C : Cout);
   static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
   if (Cin == 32 && (Cout == 16 || Cout == 32) && s == 1 && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
       !single_tap && !g_force_v1 && !gs_off && !g_no_special && !(fz && !m->no_fuse)) {
@@ -681,7 +703,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     g.tapcode = tp.tapcode; g.wtcode = tp.wtcode; g.epi = epi;
     int r;
     {
-      ProfScope ps(m, 0);
+      ProfScope ps(m, 0, nullptr, PF_GSTRIP, flops);
       r = launch_gconv_strip(g, nmajor, fwd_stream(m));
     }
     if (r <= 0) return r;
@@ -694,7 +716,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     g.NB = NB; g.H = Hout; g.Wd = Hout; g.Cin = Cin; g.Cout = Cout; g.epi = epi;
     int r;
     {
-      ProfScope ps(m, 0);
+      ProfScope ps(m, 0, nullptr, PF_GSTRIP8, flops);
       r = launch_gconv_strip8(g, fwd_stream(m));
     }
     if (r <= 0) return r;
@@ -722,7 +744,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
         q.A = nullptr;
         q.epi = 0;
         {
-          ProfScope ps(m, 0);
+          ProfScope ps(m, 0, nullptr, PF_GCONV2, flops);
           DV_TRY(launch_gconv2(q, fwd_stream(m)));
         }
         ProfScope ps(m, 2);
@@ -733,7 +755,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     long db_rows = 0;
     const bool fuse = fz && !m->no_fuse && fuse_setup(m, q, fz, &db_rows) == OK;
     {
-      ProfScope ps(m, 0);
+      ProfScope ps(m, 0, nullptr, PF_GCONV2, flops);
       DV_TRY(launch_gconv2(q, fwd_stream(m)));
     }
     if (fuse) {
@@ -743,7 +765,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     return OK;
   }
   fill_gconv_common(p, tp, Cin);
-  ProfScope ps(m, 0);
+  ProfScope ps(m, 0, nullptr, PF_GCONV, flops);
   return launch_gconv(p, fwd_stream(m));
 }
 
@@ -753,6 +775,8 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
                        float* U, float* Aout, int epi, int NB, int Hs, int Cs, int Ht, int Ct, int s, int pb,
                        const FuseBwd* fz = nullptr, bool* fused = nullptr) {
   if (fused) *fused = false;
+  // algorithmic FLOPs: every source pixel meets all nine taps; the padded head gradient counts 2*bands channels
+  const double flops = 2.0 * NB * Hs * Hs * 9.0 * (double)(W == m->Whp ? 2 * m->A.C : Cs) * (double)Ct;
   static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
   if (s == 1 && (Cs == 32 || (Cs == 16 && Ct == 32)) && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !gs_off && !g_no_special &&
       !(fz && !m->no_fuse)) {
@@ -765,7 +789,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
       g.tapcode = tp.tapcode; g.wtcode = tp.wtcode; g.epi = epi;
       int r;
       {
-        ProfScope ps(m, 0);
+        ProfScope ps(m, 0, nullptr, PF_GSTRIP, flops);
         r = launch_gconv_strip(g, nmajor, fwd_stream(m));
       }
       if (r <= 0) return r;
@@ -804,7 +828,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
         for (int c = 0; c < 4; ++c)
           if ((e & ~c) == 0) q.wt[e][c] = kk[q.cph[c]][(e & 2) ? 1 : 0] * 3 + kk[q.cpw[c]][(e & 1) ? 1 : 0];
       }
-      ProfScope ps(m, 0);
+      ProfScope ps(m, 0, nullptr, PF_GCONV_S2, flops);
       return launch_gconv_s2(q, fwd_stream(m));
     }
   }
@@ -837,7 +861,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
     long db_rows = 0;
     const bool fuse = fz && !m->no_fuse && fuse_setup(m, q, fz, &db_rows) == OK;
     {
-      ProfScope ps(m, 0);
+      ProfScope ps(m, 0, nullptr, PF_GCONV2, flops);
       DV_TRY(launch_gconv2(q, fwd_stream(m)));
     }
     if (fuse) {
@@ -878,7 +902,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
         return E_INVALID;
       }
       fill_gconv_common(p, t, Cs);
-      ProfScope ps(m, 0);
+      ProfScope ps(m, 0, nullptr, PF_GCONV, flops * t.n / 9.0 / (s * s));
       DV_TRY(launch_gconv(p, fwd_stream(m)));
     }
   return OK;
@@ -911,6 +935,8 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   // slab region and the stream that sums the slabs: with the weight gradients on the aux stream the reduction goes to
   // the reduction stream and the slabs rotate through three regions of ws1
   dv_ctx* cx = m->ctx;
+  const double wflops = 2.0 * NB * Hy * Hy * (single_tap ? 1.0 : 9.0) * (double)(X == m->xn ? m->A.C : Cx) *
+                        (double)(out == m->Ghs ? 2 * m->A.C : Cy);
   // the regions rotate whenever weight-gradient work may be in flight on the aux stream, also for a launch that is
   // itself queued on the main stream (which then reduces its own slabs: no stream hop)
   const bool rot = m->wstream && m->wstream != cx->stream && m->arena_reduce && cx->red_stream && m->ev_wk[0];
@@ -995,7 +1021,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
       sp.groups_out = &groups;
     }
     {
-      ProfScope ps(m, 1, ws);
+      ProfScope ps(m, 1, ws, PF_WSTRIP, wflops);
       st = launch_wgrad_strip(sp, Cx, Cy, sx, ws, &ns);
     }
     if (st < 0) return st;
@@ -1064,7 +1090,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   p.nsplit = (int)ns;
   p.pchunk = pchunk;
   {
-    ProfScope ps(m, 1, ws);
+    ProfScope ps(m, 1, ws, PF_WGRAD, wflops);
     DV_TRY(launch_wgrad(p, ws));
   }
   DV_TRY(hand_over());
@@ -3516,12 +3542,29 @@ int dv_prof_read(dv_model* m, int32_t klass, int64_t* launches, double* total_ms
   if (total_ms) *total_ms = m->prof_ms[klass];
   return DV_OK;
 }
+int dv_prof_read_family(dv_model* m, int32_t fam, char* name, size_t name_len, int64_t* launches, double* total_ms,
+                        double* flops) {
+  if (!m) return DV_E_INVALID;
+  if (fam < 0 || fam >= PF_COUNT) return DV_E_INVALID;
+  DV_TRY(prof_flush(m));
+  if (name && name_len) snprintf(name, name_len, "%s", kProfFamName[fam]);
+  if (launches) *launches = m->fam_launches[fam];
+  if (total_ms) *total_ms = m->fam_ms[fam];
+  if (flops) *flops = m->fam_flops[fam];
+  return DV_OK;
+}
+
 int dv_prof_reset(dv_model* m) {
   if (!m) return DV_E_INVALID;
   DV_TRY(prof_flush(m));
   for (int k = 0; k < 3; ++k) {
     m->prof_n[k] = 0;
     m->prof_ms[k] = 0;
+  }
+  for (int f = 0; f < PF_COUNT; ++f) {
+    m->fam_launches[f] = 0;
+    m->fam_ms[f] = 0;
+    m->fam_flops[f] = 0;
   }
   return DV_OK;
 }

@@ -128,7 +128,13 @@ static int bf_conv(dv_model* m, const void* X, const void* W, int Kpad, int form
   p.dal_part = dalp; p.db_part = dbp;
   p.Hin = Hin; p.Hout = Hout; p.Cin = Cin; p.Cout = Cout; p.NBp = m->bf.NBp;
   p.form = form; p.s = s; p.pb = pb; p.Kpad = Kpad; p.epi = epi;
-  ProfScope ps(m, 0);
+  // algorithmic FLOPs: form 0 meets nine taps per output pixel, form 1 nine per source pixel; the folded
+  // first conv and the padded head count their real channels
+  const BfState& bf = m->bf;
+  const double cin_alg = (W == bf.enc_w[0].f) ? m->A.C : (W == bf.head_w.d ? 2 * m->A.C : Cin);
+  const double cout_alg = (W == bf.head_w.f) ? 2 * m->A.C : Cout;
+  const double px = form == 0 ? (double)Hout * Hout : (double)Hin * Hin;
+  ProfScope ps(m, 0, nullptr, PF_BCONV, 2.0 * bf.NBp * px * 9.0 * cin_alg * cout_alg);
   return launch_bconv(p, fwd_stream(m));
 }
 
@@ -254,7 +260,8 @@ static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, i
     DV_HIP(hipStreamWaitEvent(st, m->ctx->ev_ready, 0));
   }
   {
-    ProfScope ps(m, 1, st);
+    const double cx_alg = X == m->bf.xh ? m->A.C : Cx, cy_alg = out == m->Ghs ? 2 * m->A.C : Cy;
+    ProfScope ps(m, 1, st, PF_BWGRAD, 2.0 * m->bf.NBp * (double)Hy * Hy * 9.0 * cx_alg * cy_alg);
     DV_TRY(launch_bwgrad(p, st, &ns));
   }
   ProfScope ps(m, 2, st);

@@ -394,6 +394,20 @@ class Engine:
     def prof_reset(self):
         check(lib.dv_prof_reset(self._h))
 
+    def prof_families(self) -> List[Dict]:
+        """[{name, launches, ms, flops}] per MFMA kernel family since the last prof_reset (names as rocprofv3 prints them)."""
+        out = []
+        fam = 0
+        while True:
+            name = C.create_string_buffer(96)
+            n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+            if lib.dv_prof_read_family(self._h, fam, name, 96, C.byref(n), C.byref(ms), C.byref(fl)) != 0:
+                break
+            if n.value:
+                out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value))
+            fam += 1
+        return out
+
     def prof_read(self, klass: int) -> Tuple[int, float]:
         n, ms = C.c_int64(), C.c_double()
         check(lib.dv_prof_read(self._h, klass, C.byref(n), C.byref(ms)))

@@ -200,6 +200,10 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
 int dv_prof_enable(dv_model* m, int32_t on);
 int dv_prof_read(dv_model* m, int32_t klass, int64_t* launches, double* total_ms);
 int dv_prof_reset(dv_model* m);
+/* the same timing per MFMA kernel family (fam = 0 .. until DV_E_INVALID): `name` is the kernel name rocprofv3 prints
+ * (without template arguments), flops the algorithmic FLOPs of the timed launches (padding taps counted) */
+int dv_prof_read_family(dv_model* m, int32_t fam, char* name, size_t name_len, int64_t* launches, double* total_ms,
+                        double* flops);
 
 /* kernel micro-benchmarks on random data (tuning aid; average ms per call over `iters`).
  * gconv: source [NB,Hs,Hs,Cs] -> target [NB,Ht,Ht,Ct]; dgrad_form selects the parity-class form; tile -1 = automatic */

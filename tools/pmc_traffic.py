@@ -6,11 +6,13 @@ separately, as the guide prescribes):
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dir>/write -o w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline
   python tools/pmc_traffic.py <dir> > profiles/r01_pmc_traffic_vNN.json
 
-One step = the dispatches between two fold_bn_w1_kernel launches.  FETCH_SIZE is doubled (gfx950 correction for wide
+One step = the dispatches between two adam_kernel launches.  FETCH_SIZE is doubled (gfx950 correction for wide
 coalesced reads, MI355X_MICROARCH.md HBM section); both counters are in KB."""
 import csv, glob, json, sys
 
-FAMILIES = (("gconv family (gconv2, gconv_s2, gconv_strip, gconv_strip8, gconv, splitk_finish)", ("gconv", "splitk_finish")),
+FAMILIES = (("bconv_kernel", ("bconv_kernel",)),
+            ("bwgrad_kernel (+ reduce_partials)", ("bwgrad_kernel",)),
+            ("gconv family (gconv2, gconv_s2, gconv_strip, gconv_strip8, gconv, splitk_finish)", ("gconv", "splitk_finish")),
             ("wgrad family (wgrad, wgrad_strip, wgrad_strip8, reduce_partials)", ("wgrad", "reduce_partials")),
             ("prelu_bwd_kernel", ("prelu_bwd",)))
 
@@ -26,7 +28,7 @@ def one_pass(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    marks = [i for i, r in enumerate(rows) if "fold_bn_w1" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
     lo, hi = marks[-2], marks[-1]                  # the last complete step
     out = {}
     for r in rows[lo:hi]:
@@ -35,14 +37,18 @@ def one_pass(d, counter):
 
 
 root = sys.argv[1]
+label = sys.argv[2] if len(sys.argv) > 2 else "per_step_bytes"     # "bf16_per_step_bytes" for the bf16 engine's passes
 fetch, nf = one_pass(root + "/fetch", "FETCH_SIZE")
 write, nw = one_pass(root + "/write", "WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace on `python bench.py --steps 3 "
-                 "--warmup 1 --no-cpu-baseline --no-roofline`, MI355X; one training step (between two fold_bn_w1_kernel "
+                 "--warmup 1 --no-cpu-baseline --no-roofline`, MI355X; one training step (between two adam_kernel "
                  f"dispatches: {nf} / {nw} dispatches); tools/pmc_traffic.py",
        "correction": "FETCH_SIZE doubled as prescribed for gfx950 wide coalesced reads (MI355X_MICROARCH.md, HBM section); units KB",
-       "per_step_bytes": {}}
+       label: {}}
+tot = 0.0
 for fam in sorted(set(fetch) | set(write)):
     fr, wr = fetch.get(fam, 0.0), write.get(fam, 0.0)
-    res["per_step_bytes"][fam] = {"fetch_raw_kb": fr, "write_kb": wr, "hbm_bytes": (2.0 * fr + wr) * 1024.0}
+    res[label][fam] = {"fetch_raw_kb": fr, "write_kb": wr, "hbm_bytes": (2.0 * fr + wr) * 1024.0}
+    tot += (2.0 * fr + wr) * 1024.0
+res[label]["total"] = tot
 print(json.dumps(res, indent=1))
