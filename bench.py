@@ -292,6 +292,14 @@ def main():
     from debvader_amd.data import synthetic_stamps
     from debvader_amd import parallel
 
+    stub = os.environ.get("DV_BENCH_STUB_ENGINE")        # CPU test of the rank plumbing (tests/test_bench_plumbing.py)
+    if stub:
+        import importlib
+
+        E = importlib.import_module(stub)
+        parallel.E = E
+        args.no_roofline = args.no_secondary = args.no_cpu_baseline = True
+
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
