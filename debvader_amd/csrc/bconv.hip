@@ -478,6 +478,298 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The form the training batches take: stamps padded to a multiple of 256, so a tile is ONE output pixel x 256 stamps.
+// Everything that the general kernel looks up per group is then uniform over the workgroup (one pixel, nine taps that
+// are inside the image or not) and lives in scalar registers; the general kernel's dual paths cost it more
+// instructions than MFMAs (SQ_ACTIVE_INST_ANY 45 %, SQ_VALU_MFMA_BUSY 5-10 %).  Differences:
+//   * DMA sources are  uniform base (scalar) + 32-bit lane offset: no per-instruction vector address arithmetic,
+//     no zero-page select (CINMODE 0: only taps inside the image are walked);
+//   * the accumulators start at the bias; alpha is one row for the whole tile;
+//   * the wave's 64 output rows are consecutive in memory: the LDS tile goes out as plain 16-byte row pieces.
+template <int NBLK, int CINMODE>
+__global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) {
+  constexpr int STAGE = (BC_GT + NBLK) * 1024;
+  constexpr int BN = 16 * NBLK;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  int* stab = reinterpret_cast<int*>(smem + 3 * STAGE);   // [0] valid taps, [1..9] their ids, [10..18] their source pixels
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = p.Cout / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+  const int n0 = tile_n * BN;
+  const int tpp = p.NBp >> 8;                           // tiles per pixel
+  const int vp = tile_m / tpp;
+  const int st0 = (tile_m - vp * tpp) * 256;            // first stamp of the tile
+  const int nbx = (p.Hout + 7) >> 3;
+  const int blk = vp >> 6, by = blk / nbx, bx = blk - by * nbx;
+  const int oh = by * 8 + ((vp >> 3) & 7), ow = bx * 8 + (vp & 7);
+  if (oh >= p.Hout || ow >= p.Hout) return;             // padding of the 8 x 8 pixel blocks
+  const int pix = oh * p.Hout + ow;
+
+  auto src_pixel = [&](int t) -> int {                   // t may be a lane value (CINMODE 1)
+    const int kh = (t * 11) >> 5, kw = t - kh * 3;
+    int ih, iw;
+    bool ok = true;
+    if (p.form == 0) {
+      ih = oh * p.s + kh - p.pb;
+      iw = ow * p.s + kw - p.pb;
+    } else {
+      const int nh = oh + p.pb - kh, nw = ow + p.pb - kw;
+      ok = nh >= 0 && nw >= 0 && (p.s == 1 || ((nh | nw) & 1) == 0);
+      ih = p.s == 1 ? nh : nh >> 1;
+      iw = p.s == 1 ? nw : nw >> 1;
+    }
+    ok = ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Hin;
+    return ok ? ih * p.Hin + iw : -1;
+  };
+  if (CINMODE == 0) {
+    if (tid == 0) {
+      int n = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int sp = src_pixel(t);
+        if (sp >= 0) {
+          stab[1 + n] = t;
+          stab[10 + n] = sp;
+          ++n;
+        }
+      }
+      stab[0] = n;
+    }
+    __syncthreads();
+  }
+  const int cpt = p.Cin >> 5, ppt = p.Cin >> 3;
+  const int nvalid = CINMODE == 0 ? __builtin_amdgcn_readfirstlane(stab[0]) : 9;
+  const int nsteps = CINMODE == 0 ? nvalid * cpt : (9 * ppt + 3) >> 2;
+
+  const int drow = lane >> 2;
+  const int dq = (lane & 3) ^ ((4 - (drow >> 2)) & 3);
+  const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.X);
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
+  const unsigned char* zlane = reinterpret_cast<const unsigned char*>(p.zero) + lane * 16;
+  const int jb = wave % NBLK;
+  // lane parts (bytes) of the DMA sources; the uniform parts are added per instruction as scalars
+  const unsigned a_lane = (unsigned)((((st0 + wave * 64 + drow) * p.Cin) + dq * 8) * 2);
+  const unsigned b_lane = (unsigned)(((NBLK * drow) * p.Kpad + dq * 8) * 2);
+  const size_t pixbytes = (size_t)p.NBp * p.Cin * 2;     // one pixel of the input tensor
+  const unsigned gstride = (unsigned)(16 * p.Cin * 2);   // one 16-stamp group
+  const unsigned char* wbase = Wb + (size_t)(n0 + jb) * p.Kpad * 2;
+
+  // CINMODE 1: the (at most five) steps' lane sources, worked out once
+  const unsigned char* psrc[5] = {zlane, zlane, zlane, zlane, zlane};
+  bool pok[5] = {false, false, false, false, false};
+  if constexpr (CINMODE == 1) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int piece = i * 4 + dq;
+      const int tap = ppt == 1 ? piece : piece >> 1;
+      const int sub = ppt == 1 ? 0 : piece & 1;
+      const int sp = piece < 9 * ppt ? src_pixel(tap) : -1;
+      pok[i] = sp >= 0;
+      psrc[i] = Xb + (size_t)(sp >= 0 ? sp : 0) * pixbytes +
+                (unsigned)((((st0 + wave * 64 + drow) * p.Cin) + sub * 8) * 2);
+    }
+  }
+
+  int is_ti = -1, is_cc = 0, is_tap = 0;
+  const unsigned char* tsrc = Xb;                          // uniform: input pixel of the current tap
+  auto issue = [&](int step, int buf) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + BC_GT * 1024;
+    if constexpr (CINMODE == 0) {
+      if (is_ti < 0 || is_cc + 1 == cpt) {
+        ++is_ti;
+        is_cc = 0;
+        is_tap = __builtin_amdgcn_readfirstlane(stab[1 + is_ti]);
+        tsrc = Xb + (size_t)__builtin_amdgcn_readfirstlane(stab[10 + is_ti]) * pixbytes;
+      } else {
+        ++is_cc;
+      }
+      const unsigned char* cs = tsrc + is_cc * 64;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+        __builtin_amdgcn_global_load_lds((bc_gptr_t)(cs + gi * gstride + a_lane), (bc_lptr_t)(sA + (wave * 4 + gi) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((bc_gptr_t)(wbase + (is_tap * p.Cin + is_cc * 32) * 2 + b_lane),
+                                       (bc_lptr_t)(sB + jb * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        if (i == step) {
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) {
+            const void* src = pok[i] ? (const void*)(psrc[i] + gi * gstride) : (const void*)zlane;
+            __builtin_amdgcn_global_load_lds((bc_gptr_t)src, (bc_lptr_t)(sA + (wave * 4 + gi) * 1024), 16, 0, 0);
+          }
+        }
+      __builtin_amdgcn_global_load_lds((bc_gptr_t)(wbase + step * 64 + b_lane), (bc_lptr_t)(sB + jb * 1024), 16, 0, 0);
+    }
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int fragoff = (fr * 4 + (fq ^ ((4 - (fr >> 2)) & 3))) * 16;
+  const int c = lane & 15, g4 = lane >> 4;
+  const int ch0 = n0 + NBLK * c;
+
+  // fused PReLU backward: the wave's [64 rows][BN] tile of the pre-activation, parked in registers
+  constexpr int NPC = BN / 8;                             // 16-byte pieces per lane of a [64][BN] bf16 tile
+  const size_t rb0 = (size_t)pix * p.NBp + st0 + wave * 64;   // first output row of this wave
+  f32x4 uin[NPC];
+  if (p.epi == BEPI_BWD) {
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+      const int byte = (k * 64 + lane) * 16;
+      const int row = byte / (BN * 2), colb = byte - row * (BN * 2);
+      uin[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.Uin) +
+                                               ((rb0 + row) * p.Cout + n0) * 2 + colb);
+    }
+  }
+  float bias[NBLK];
+#pragma unroll
+  for (int j = 0; j < NBLK; ++j) bias[j] = 0.f;
+  if (p.bias && (p.epi == BEPI_FWD || p.epi == BEPI_RAW32)) load_f32<NBLK>(p.bias + ch0, bias);
+  f32x4 acc[4][NBLK];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) acc[gi][j] = (f32x4){bias[j], bias[j], bias[j], bias[j]};
+
+  if (nsteps > 0) issue(0, 0);
+  if (nsteps > 1) issue(1, 1);
+  int buf = 0;
+  for (int i = 0; i < nsteps; ++i) {
+    if (i + 1 < nsteps)
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (i + 2 < nsteps) issue(i + 2, buf >= 1 ? buf - 1 : 2);
+    const unsigned char* sA = smem + buf * STAGE + wave * 4096 + fragoff;
+    const unsigned char* sB = smem + buf * STAGE + BC_GT * 1024 + fragoff;
+    bc_bf16x8 a[4], b[NBLK];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) a[gi] = *reinterpret_cast<const bc_bf16x8*>(sA + gi * 1024);
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) b[j] = *reinterpret_cast<const bc_bf16x8*>(sB + j * 1024);
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j)
+        acc[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gi], b[j], acc[gi][j], 0, 0, 0);
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+
+  // ---- epilogue: per-wave LDS tile [64 rows][BN]; the 64 rows are consecutive rows of the output tensor ----
+  __builtin_amdgcn_s_barrier();
+  constexpr int WREG = 64 * BN * (NBLK == 1 ? 4 : 2);
+  unsigned char* wreg = smem + wave * WREG;
+  auto flush = [&](void* dst, int esz) {
+    const int rowb = BN * esz;
+    unsigned char* out = reinterpret_cast<unsigned char*>(dst) + (rb0 * p.Cout + n0) * esz;
+    const size_t rstride = (size_t)p.Cout * esz;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k >= 64 * rowb / 1024) break;
+      const int byte = (k * 64 + lane) * 16;
+      const int row = byte / rowb, colb = byte - row * rowb;
+      *reinterpret_cast<f32x4*>(out + row * rstride + colb) = *reinterpret_cast<const f32x4*>(wreg + byte);
+    }
+  };
+  if (p.epi == BEPI_RAW32) {
+    if constexpr (NBLK == 1) {
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) reinterpret_cast<float*>(wreg)[(gi * 16 + 4 * g4 + r) * BN + c] = acc[gi][0][r];
+      flush(p.Uf, 4);
+    } else {
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j) p.Uf[(rb0 + gi * 16 + 4 * g4 + r) * p.Cout + ch0 + j] = acc[gi][j][r];
+    }
+    return;
+  }
+  bc_bf16* wt = reinterpret_cast<bc_bf16*>(wreg);
+  if (p.epi == BEPI_RAWBF || (p.epi == BEPI_FWD && p.U)) {
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v[NBLK];
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) v[j] = acc[gi][j][r];
+        store_bf<NBLK>(wt + (gi * 16 + 4 * g4 + r) * BN + NBLK * c, v);
+      }
+    flush(p.U, 2);
+    if (p.epi == BEPI_RAWBF) return;
+  }
+  float al[NBLK];
+  load_f32<NBLK>(p.alpha + (size_t)pix * p.Cout + ch0, al);
+  if (p.epi == BEPI_FWD) {
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a[NBLK];
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) a[j] = fmaxf(acc[gi][j][r], 0.f) + al[j] * fminf(acc[gi][j][r], 0.f);
+        store_bf<NBLK>(wt + (gi * 16 + 4 * g4 + r) * BN + NBLK * c, a);
+      }
+    flush(p.A, 2);
+    return;
+  }
+  // BEPI_BWD
+#pragma unroll
+  for (int k = 0; k < NPC; ++k) *reinterpret_cast<f32x4*>(wreg + (k * 64 + lane) * 16) = uin[k];
+  float dal[NBLK], db[NBLK];
+#pragma unroll
+  for (int j = 0; j < NBLK; ++j) dal[j] = db[j] = 0.f;
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bc_bf16* q = wt + (gi * 16 + 4 * g4 + r) * BN + NBLK * c;
+      float u[NBLK], du[NBLK];
+      load_bf<NBLK>(q, u);
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) {
+        const float v = acc[gi][j][r];
+        du[j] = v * (u[j] > 0.f ? 1.f : al[j]);
+        dal[j] += v * fminf(u[j], 0.f);
+        db[j] += du[j];
+      }
+      store_bf<NBLK>(q, du);
+    }
+  flush(p.U, 2);
+  if (p.dal_part) {
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+      dal[j] += __shfl_xor(dal[j], 16);
+      dal[j] += __shfl_xor(dal[j], 32);
+      db[j] += __shfl_xor(db[j], 16);
+      db[j] += __shfl_xor(db[j], 32);
+    }
+    if (g4 == 0) {
+      const int part = (st0 >> 6) + wave;
+      const size_t o = ((size_t)part * p.Hout * p.Hout + pix) * p.Cout + ch0;
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) {
+        p.dal_part[o + j] = dal[j];
+        p.db_part[o + j] = db[j];
+      }
+    }
+  }
+}
+
 int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   BConvParams p = p_in;
   static const int dbg = getenv("DV_BCONV_DBG") ? atoi(getenv("DV_BCONV_DBG")) : 0;
@@ -506,19 +798,26 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   // deep layers have few row tiles and a long K loop that one workgroup walks alone: narrower column tiles put a
   // workgroup on every CU (their input is re-read from L2 once more per halving, which these latency-bound launches
   // do not notice)
-  static const long want_tiles = getenv("DV_BCONV_MIN_TILES") ? atol(getenv("DV_BCONV_MIN_TILES")) : 512;
+  const long want_tiles = getenv("DV_BCONV_MIN_TILES") ? atol(getenv("DV_BCONV_MIN_TILES")) : 512;   // (read per call: the tests toggle it)
   while (nblk > 1 && ((M16 + BC_GT - 1) / BC_GT) * (p.Cout / (16 * nblk)) < want_tiles) nblk >>= 1;
   const long tiles = ((M16 + BC_GT - 1) / BC_GT) * (p.Cout / (16 * nblk));
   const size_t lds = (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;
+  static const bool no_uni = getenv("DV_BCONV_NO_UNI") != nullptr;
+  const bool uni = (p.NBp & 255) == 0 && !no_uni && p.dbg == 0;
 #define BC_LAUNCH(NB_, MODE_)                                                                          \
   do {                                                                                                 \
     static bool attr_done = false;                                                                     \
     if (!attr_done) {                                                                                  \
       DV_HIP(hipFuncSetAttribute((const void*)bconv_kernel<NB_, MODE_>,                                \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+      DV_HIP(hipFuncSetAttribute((const void*)bconv_uni_kernel<NB_, MODE_>,                            \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
       attr_done = true;                                                                                \
     }                                                                                                  \
-    hipLaunchKernelGGL((bconv_kernel<NB_, MODE_>), dim3((unsigned)tiles), dim3(256), lds, s, p);       \
+    if (uni)                                                                                           \
+      hipLaunchKernelGGL((bconv_uni_kernel<NB_, MODE_>), dim3((unsigned)tiles), dim3(256), lds, s, p); \
+    else                                                                                               \
+      hipLaunchKernelGGL((bconv_kernel<NB_, MODE_>), dim3((unsigned)tiles), dim3(256), lds, s, p);     \
   } while (0)
   if (mode == 0) {
     if (nblk == 4) BC_LAUNCH(4, 0);

@@ -261,10 +261,14 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
   const int chunks = (p.Hd * p.Hd) >> 4;
   const int pc = blockIdx.x % chunks, sc = blockIdx.x / chunks;
   const int pix0 = pc * 16, b0 = sc * 16;
-  const int oh = pix0 / p.Hd, ow0 = pix0 - oh * p.Hd;       // Hd is a multiple of 16: a chunk never wraps a row
+  // grids that are a multiple of 16 wide (the reference's 64): a chunk is a run of ONE row and its labels go through
+  // LDS; other widths (multiples of 4 / 8 for shallow nets) read their labels per thread
+  const bool tiled = (p.Hd & 15) == 0;
+  const int lin = pix0 + (threadIdx.x >> 4);
+  const int oh = tiled ? pix0 / p.Hd : lin / p.Hd, ow0 = tiled ? pix0 - oh * p.Hd : 0;
   const int h = oh - p.crop0;
   const bool rowin = (unsigned)h < (unsigned)p.H;
-  if (p.y && rowin) {
+  if (p.y && rowin && tiled) {
     // label run of stamp b: pixels w in [w_lo, w_hi) of row h
     const int w_lo = max(ow0 - p.crop0, 0), w_hi = min(ow0 + 16 - p.crop0, p.H);
     const int nf = (w_hi - w_lo) * p.nb;
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
   __syncthreads();
   const int sr = threadIdx.x & 15, pp = threadIdx.x >> 4;
   const int b = b0 + sr;
-  const int ow = ow0 + pp, w = ow - p.crop0;
+  const int ow = tiled ? ow0 + pp : lin - oh * p.Hd, w = ow - p.crop0;
   const long e = (long)(pix0 + pp) * p.NBp + b;
   float nll = 0.f, se = 0.f;
   {
@@ -309,7 +313,9 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
         if (p.scale) p.scale[opix * p.nb + c] = sig;
         if (p.y) {
           const float inv = 1.0f / sig;
-          const float df = ytile[sr][pp * p.nb + c] - loc;
+          const float yv = tiled ? ytile[sr][pp * p.nb + c]
+                                 : p.y[(((p.idx ? (long)p.idx[b] : (long)p.first + b) * p.H + h) * p.H + w) * p.nb + c];
+          const float df = yv - loc;
           const float r = df * inv;
           nll += 0.5f * r * r + logf(sig) + 0.91893853320467274178f;
           if (p.mse_sample) {
@@ -349,8 +355,8 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
 }
 
 int launch_bf_head(const BHeadParams& p, hipStream_t s, int* nblocks_out) {
-  if (p.nb > 8 || (p.Hd & 15) || (p.NBp & 15)) {
-    set_error("bf_head: at most 8 bands, grid size and stamp padding multiples of 16");
+  if (p.nb > 8 || ((p.Hd * p.Hd) & 15) || (p.NBp & 15)) {
+    set_error("bf_head: at most 8 bands, pixel count and stamp padding multiples of 16");
     return E_INVALID;
   }
   const int nb = ((p.Hd * p.Hd) >> 4) * (p.NBp >> 4);

@@ -138,6 +138,34 @@ def test_toy_arch_ragged_batch_with_fused_epilogues():
     _run(toy_arch(), B=50, seed=2, tol_grad_b=5e-2)
 
 
+def test_toy_arch_256_and_512_stamps_uniform_tile_kernel():
+    """Stamps padded to a multiple of 256 take bconv_uni_kernel (one output pixel x 256 stamps per tile, scalar tap
+    bookkeeping, accumulators preloaded with the bias): one and two tiles per pixel."""
+    _run(toy_arch(), B=256, seed=7, tol_grad_b=5e-2)
+    _run(toy_arch(), B=500, seed=8, tol_grad_b=5e-2)
+
+
+def test_wide_channel_arch_all_column_tile_widths():
+    """Three levels up to 128 channels on 20 x 20 stamps: K loops of several 32-channel chunks per tap, 64-wide column
+    tiles (DV_BCONV_MIN_TILES=1 keeps the launcher from narrowing them for these few-pixel layers) and the narrowed
+    ones, in the uniform-tile kernel (256 stamps) and in the general one (48 stamps: a tile spans several pixels)."""
+    import os
+
+    arch = vo.Arch(input_shape=(20, 20, 4), latent_dim=8, filters=(32, 64, 128), kernels=(3, 3, 3))
+    for min_tiles in ("1", None):
+        if min_tiles is None:
+            os.environ.pop("DV_BCONV_MIN_TILES", None)
+        else:
+            os.environ["DV_BCONV_MIN_TILES"] = min_tiles
+        try:
+            # (d(gamma) / d(beta) of the input BatchNorm are four numbers each, sums over every pixel with heavy
+            # cancellation: they carry the loosest agreement, 0.1-0.2 of their maximum between any two bf16 evaluations)
+            _run(arch, B=256, seed=11, tol_grad_b=0.25, min_cos=0.95, tol_grad_64=0.35)
+            _run(arch, B=48, seed=12, tol_grad_b=0.25, min_cos=0.95, tol_grad_64=0.35)
+        finally:
+            os.environ.pop("DV_BCONV_MIN_TILES", None)
+
+
 def test_full_arch_dc2_stamps():
     """The reference's 59 x 59 x 6 / [32,64,128,256] net on its own sample stamps (tests/golden, the first 4 DC2 stamps)."""
     import os
