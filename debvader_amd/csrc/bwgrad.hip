@@ -35,7 +35,7 @@ typedef __attribute__((address_space(3))) bw_bf16x4* bw_l4ptr_t;
 namespace {
 constexpr int BW_NCS = 8;                              // column slots of the X window
 constexpr int BW_NYS = 8;                              // Y slots
-constexpr int BW_WAVE_LDS = (3 * BW_NCS + BW_NYS + 1) * 1024;   // + 1 KiB of zeros
+constexpr int BW_WAVE_LDS = (3 * BW_NCS + BW_NYS) * 1024;
 constexpr int BW_RED_BYTES = 9 * 16 * 64 * 4;          // one wave's accumulators
 
 struct BWGeom {
@@ -49,9 +49,10 @@ struct BWGeom {
 // statement is invisible to that pass, and the counted vmcnt / lgkmcnt waits below are placed by hand
 // (cdna_hip_programming.md 5.7: hipcc neither counts nor orders what is inside asm).
 typedef unsigned bw_u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
 __device__ __forceinline__ bw_u32x2 tr_read(unsigned lds_addr) {
   bw_u32x2 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(OFF));
   return v;
 }
 __device__ __forceinline__ bw_bf16x8 tr_join(bw_u32x2 lo, bw_u32x2 hi) {
@@ -85,8 +86,6 @@ __global__ __launch_bounds__(256, 1) void bwgrad_kernel(const BWgradParams p, co
   unsigned char* wl = smem + wave * BW_WAVE_LDS;
   unsigned char* xwin = wl;                            // [3][BW_NCS] KiB
   unsigned char* ywin = wl + 3 * BW_NCS * 1024;        // [BW_NYS] KiB
-  unsigned char* zreg = ywin + BW_NYS * 1024;          // 1 KiB of zeros
-  reinterpret_cast<f32x4*>(zreg)[lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bw_bf16* Xb = reinterpret_cast<const bw_bf16*>(p.X);
   const bw_bf16* Yb = reinterpret_cast<const bw_bf16*>(p.Y);
@@ -100,23 +99,23 @@ __global__ __launch_bounds__(256, 1) void bwgrad_kernel(const BWgradParams p, co
                                     : reinterpret_cast<const unsigned char*>(Yb + ((size_t)st0 + (lane >> 2)) * p.Cy + cy0 + (lane & 3) * 8);
   const size_t xps = (size_t)p.NBp * p.Cx * 2, yps = (size_t)p.NBp * p.Cy * 2;   // bytes per pixel
   const size_t xps_l = (XC16 && lane >= 32) ? 0 : xps, yps_l = (YC16 && lane >= 32) ? 0 : yps;
+  // A block that lies outside the image (or past the end of the row) is never multiplied - its taps are skipped - so
+  // its DMA needs no zero page and no select: the indices are clamped to some valid pixel and whatever lands is ignored.
   auto dma = [&](bool isx, int pix, unsigned char* dst) {
-    const void* src = zlane;
-    if (pix >= 0) src = isx ? (const void*)(xlane + (size_t)pix * xps_l) : (const void*)(ylane + (size_t)pix * yps_l);
+    const void* src = isx ? (const void*)(xlane + (size_t)pix * xps_l) : (const void*)(ylane + (size_t)pix * yps_l);
     __builtin_amdgcn_global_load_lds((bw_gptr_t)src, (bw_lptr_t)dst, 16, 0, 0);
   };
   // column xc of the three window rows of Y row r (image rows r*s - pb + {0,1,2})
   auto load_col = [&](int r, int xc) {
-    const bool cok = xc >= 0 && xc < p.Hx;
+    const int xcc = min(max(xc, 0), p.Hx - 1);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-      const int xr = r * p.s - p.pb + kh;
-      const int pix = (cok && xr >= 0 && xr < p.Hx) ? xr * p.Hx + xc : -1;
-      dma(true, pix, xwin + (kh * BW_NCS + (xc & (BW_NCS - 1))) * 1024);
+      const int xr = min(max(r * p.s - p.pb + kh, 0), p.Hx - 1);
+      dma(true, xr * p.Hx + xcc, xwin + (kh * BW_NCS + (xc & (BW_NCS - 1))) * 1024);
     }
   };
   auto load_y = [&](int r, int w) {
-    dma(false, w < p.Hy ? r * p.Hy + w : -1, ywin + (w & (BW_NYS - 1)) * 1024);
+    dma(false, r * p.Hy + min(w, p.Hy - 1), ywin + (w & (BW_NYS - 1)) * 1024);
   };
 
   // transposed-read lane roles for a [16 stamps][32 ch] block: 16-lane group g = (channel half g & 1, stamp half g >> 1)
@@ -127,17 +126,12 @@ __global__ __launch_bounds__(256, 1) void bwgrad_kernel(const BWgradParams p, co
   const int o32 = (khalf * 8 + tq) * 64 + chalf * 32 + tp * 8;
   const int o16 = (khalf * 8 + tq) * 32 + tp * 8;
   const unsigned wl_addr = (unsigned)(size_t)(bw_lptr_t)wl;   // LDS byte address of the wave region
-  const unsigned zaddr = wl_addr + (unsigned)(zreg - wl) + 128 + li * 8;
-  // addresses of the two transposed reads of a block at wave-relative byte offset `boff`
-  auto fa0 = [&](unsigned boff, bool c16) -> unsigned {
-    if (c16) return chalf ? zaddr : wl_addr + boff + o16;
-    return wl_addr + boff + o32;
-  };
-  auto fa1 = [&](unsigned boff, bool c16) -> unsigned {
-    if (c16) return chalf ? zaddr : wl_addr + boff + o16 + 4 * 32;
-    return wl_addr + boff + o32 + 4 * 64;
-  };
-  const unsigned xwin_off = 0, ywin_off = 3 * BW_NCS * 1024;
+  // lane part of the transposed-read addresses; a block adds its (scalar) slot offset, the window row and the second
+  // read are immediates
+  const unsigned xl_addr = XC16 ? wl_addr + o16 : wl_addr + o32;
+  const unsigned yl_addr = (YC16 ? wl_addr + o16 : wl_addr + o32) + 3 * BW_NCS * 1024;
+  constexpr int XSECOND = XC16 ? 4 * 32 : 4 * 64, YSECOND = YC16 ? 4 * 32 : 4 * 64;
+  const bool xzero = XC16 && chalf, yzero = YC16 && chalf;
 
   bw_f32x16 acc[9];
 #pragma unroll
@@ -170,22 +164,37 @@ __global__ __launch_bounds__(256, 1) void bwgrad_kernel(const BWgradParams p, co
           asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         else
           asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        // all twenty transposed reads of the step are issued back to back (taps outside the image read stale
-        // blocks that no MFMA consumes), then one wait
-        const unsigned yb = ywin_off + (w & (BW_NYS - 1)) * 1024;
-        const bw_u32x2 b0 = tr_read(fa0(yb, YC16)), b1 = tr_read(fa1(yb, YC16));
+        // all twenty transposed reads of the step are issued back to back (taps outside the image read blocks that no
+        // MFMA consumes), then one wait.  One vector add per window column; rows and second reads are immediates.
+        const unsigned ya = yl_addr + (w & (BW_NYS - 1)) * 1024;
+        bw_u32x2 b0 = tr_read<0>(ya), b1 = tr_read<YSECOND>(ya);
         const int xc0 = w * p.s - p.pb;
         bw_u32x2 a0[9], a1[9];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const unsigned xb = xwin_off + (kh * BW_NCS + ((xc0 + kw) & (BW_NCS - 1))) * 1024;
-            a0[kh * 3 + kw] = tr_read(fa0(xb, XC16));
-            a1[kh * 3 + kw] = tr_read(fa1(xb, XC16));
-          }
+        for (int kw = 0; kw < 3; ++kw) {
+          const unsigned xa = xl_addr + ((xc0 + kw) & (BW_NCS - 1)) * 1024;
+          a0[0 + kw] = tr_read<0>(xa);
+          a1[0 + kw] = tr_read<XSECOND>(xa);
+          a0[3 + kw] = tr_read<BW_NCS * 1024>(xa);
+          a1[3 + kw] = tr_read<BW_NCS * 1024 + XSECOND>(xa);
+          a0[6 + kw] = tr_read<2 * BW_NCS * 1024>(xa);
+          a1[6 + kw] = tr_read<2 * BW_NCS * 1024 + XSECOND>(xa);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        // 16-channel operands: the lanes of the absent channel half read the present half's rows (the transposed read
+        // wants every lane active with an address of its own) and are zeroed here, by a select, not a branch
+        if (YC16) {
+          b0 = yzero ? (bw_u32x2){0u, 0u} : b0;
+          b1 = yzero ? (bw_u32x2){0u, 0u} : b1;
+        }
+        if (XC16) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            a0[t] = xzero ? (bw_u32x2){0u, 0u} : a0[t];
+            a1[t] = xzero ? (bw_u32x2){0u, 0u} : a1[t];
+          }
+        }
         const bw_bf16x8 b = tr_join(b0, b1);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
