@@ -367,35 +367,57 @@ int launch_bf_head(const BHeadParams& p, hipStream_t s, int* nblocks_out) {
   return OK;
 }
 
-// ---- batched partial-slab sums (grid.y = entry) and the column sums behind them ------------------------------------
+// ---- batched partial-slab sums (grid.y = entry) ---------------------------------------------------------------------
+// entries without columns: out[e] = sum_p src[p][e] (d(alpha)).  Entries with columns (d(bias)): a block takes a range of
+// rows of the [rows][cols] image, sums the slabs and its rows per column and leaves ONE partial row in `out`
+// ([gridDim.x][cols]); bf_colsum_final_kernel adds those few rows in block order.  Fixed orders throughout.
+constexpr int BR_BLOCKS = 64;
 __global__ __launch_bounds__(256) void bf_reduce_batch_kernel(const BRedBatch b) {
+  __shared__ float sh[256 * 4];
   const BRedEntry d = b.e[blockIdx.y];
-  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < d.n; e += (long)gridDim.x * 1024) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(d.src + e);
-    for (int p = 1; p < d.nparts; ++p) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(d.src + (size_t)p * d.n + e);
-      a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+  if (d.cols <= 0) {
+    for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < d.n; e += (long)gridDim.x * 1024) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(d.src + e);
+      for (int p = 1; p < d.nparts; ++p) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(d.src + (size_t)p * d.n + e);
+        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+      }
+      *reinterpret_cast<f32x4*>(d.out + e) = a;
     }
-    *reinterpret_cast<f32x4*>(d.out + e) = a;
+    return;
+  }
+  const int cq = d.cols >> 2;                          // column quads (cols is a multiple of 4)
+  const int rows = d.n / d.cols;
+  const int rpb = (rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
+  for (int q0 = 0; q0 < cq; q0 += 256) {               // (cols <= 1024: one pass)
+    const int nl = max(1, 256 / min(cq - q0, 256));    // row lanes
+    const int q = q0 + threadIdx.x % min(cq - q0, 256), rl = threadIdx.x / min(cq - q0, 256);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (rl < nl)
+      for (int r = r0 + rl; r < r1; r += nl)
+        for (int p = 0; p < d.nparts; ++p) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(d.src + (size_t)p * d.n + (size_t)r * d.cols + q * 4);
+          a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        }
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(sh + threadIdx.x * 4) = a;
+    __syncthreads();
+    if (rl == 0) {
+      for (int l = 1; l < nl; ++l) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sh + (threadIdx.x + l * min(cq - q0, 256)) * 4);
+        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+      }
+      *reinterpret_cast<f32x4*>(d.out + (size_t)blockIdx.x * d.cols + q * 4) = a;
+    }
   }
 }
-// one workgroup per (32-column group, entry): 8 row lanes x 32 columns, fixed summation order
-__global__ __launch_bounds__(256) void bf_colsum_batch_kernel(const BRedBatch b) {
-  __shared__ float sh[8][33];
-  const BRedEntry d = b.e[blockIdx.y];
+__global__ __launch_bounds__(256) void bf_colsum_final_kernel(const BRedBatch b, int nblocks) {
+  const BRedEntry d = b.e[blockIdx.x];
   if (!d.final_out || d.cols <= 0) return;
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
-  if (blockIdx.x * 32 >= d.cols) return;
-  const int rows = d.n / d.cols;
-  float a = 0.f;
-  if (c < d.cols)
-    for (int r = rl; r < rows; r += 8) a += d.out[(size_t)r * d.cols + c];
-  sh[rl][threadIdx.x & 31] = a;
-  __syncthreads();
-  if (rl == 0 && c < d.cols) {
+  for (int c = threadIdx.x; c < d.cols; c += 256) {
     float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t += sh[i][threadIdx.x & 31];
+    for (int r = 0; r < nblocks; ++r) t += d.out[(size_t)r * d.cols + c];
     d.final_out[c] = t;
   }
 }
@@ -406,19 +428,16 @@ int launch_bf_reduce_batch(const BRedBatch& b, hipStream_t s) {
     set_error("bf_reduce_batch: too many entries");
     return E_INVALID;
   }
-  int maxn = 0, maxc = 0;
+  bool anyc = false;
   for (int i = 0; i < b.count; ++i) {
-    if (b.e[i].n & 3) {
-      set_error("bf_reduce_batch: slab sizes must be multiples of 4");
+    if ((b.e[i].n & 3) || (b.e[i].cols & 3)) {       // (`out` of a column entry holds max(n, BR_BLOCKS * cols) floats)
+      set_error("bf_reduce_batch: slab sizes / column counts must be multiples of 4");
       return E_INVALID;
     }
-    maxn = std::max(maxn, b.e[i].n);
-    if (b.e[i].final_out) maxc = std::max(maxc, b.e[i].cols);
+    anyc = anyc || (b.e[i].cols > 0 && b.e[i].final_out);
   }
-  const unsigned gx = (unsigned)std::min(64, std::max(1, (maxn + 1023) / 1024));
-  hipLaunchKernelGGL(bf_reduce_batch_kernel, dim3(gx, (unsigned)b.count), dim3(256), 0, s, b);
-  if (maxc > 0)
-    hipLaunchKernelGGL(bf_colsum_batch_kernel, dim3((unsigned)((maxc + 31) / 32), (unsigned)b.count), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(bf_reduce_batch_kernel, dim3(BR_BLOCKS, (unsigned)b.count), dim3(256), 0, s, b);
+  if (anyc) hipLaunchKernelGGL(bf_colsum_final_kernel, dim3((unsigned)b.count), dim3(256), 0, s, b, BR_BLOCKS);
   DV_HIP(hipGetLastError());
   return OK;
 }

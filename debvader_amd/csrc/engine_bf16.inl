@@ -283,14 +283,15 @@ static int bf_dgrad_prelu(dv_model* m, const void* X, const void* W, int Kpad, i
     float *dal = nullptr, *db = nullptr;
     if (want_grads) {
       // partial slabs + the [pixels][Cout] image the d(bias) column sum reads
-      if (m->arena_off + (size_t)(2 * nparts + 1) * E > m->arena_elems || bf.red.count + 2 > DV_BF_MAX_RED) {
+      const size_t img = std::max<size_t>((size_t)E, (size_t)64 * Cout);    // partial rows of the d(bias) column sum
+      if (m->arena_off + (size_t)2 * nparts * E + img > m->arena_elems || bf.red.count + 2 > DV_BF_MAX_RED) {
         set_error("gradient-partial arena exhausted");
         return E_STATE;
       }
       dal = m->arena + m->arena_off;
       db = dal + (size_t)nparts * E;
       float* dbimg = db + (size_t)nparts * E;
-      m->arena_off += (size_t)(2 * nparts + 1) * E;
+      m->arena_off += (size_t)2 * nparts * E + img;
       BRedEntry& a = bf.red.e[bf.red.count++];
       a.src = dal; a.out = m->G + A.specs[alpha_spec].off; a.final_out = nullptr; a.nparts = nparts; a.n = (int)E; a.cols = 0;
       BRedEntry& b = bf.red.e[bf.red.count++];

@@ -6,12 +6,12 @@ separately, as the guide prescribes):
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dir>/write -o w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline
   python tools/pmc_traffic.py <dir> > profiles/r01_pmc_traffic_vNN.json
 
-One step = the dispatches between two adam_kernel launches.  FETCH_SIZE is doubled (gfx950 correction for wide
+One step = the dispatches between two fold_bn_w1_kernel launches (one per step in both engines).  FETCH_SIZE is doubled (gfx950 correction for wide
 coalesced reads, MI355X_MICROARCH.md HBM section); both counters are in KB."""
 import csv, glob, json, sys
 
-FAMILIES = (("bconv_kernel", ("bconv_kernel",)),
-            ("bwgrad_kernel (+ reduce_partials)", ("bwgrad_kernel",)),
+FAMILIES = (("bconv_kernel / bconv_uni_kernel", ("bconv_",)),
+            ("bwgrad_kernel", ("bwgrad_kernel",)),
             ("gconv family (gconv2, gconv_s2, gconv_strip, gconv_strip8, gconv, splitk_finish)", ("gconv", "splitk_finish")),
             ("wgrad family (wgrad, wgrad_strip, wgrad_strip8, reduce_partials)", ("wgrad", "reduce_partials")),
             ("prelu_bwd_kernel", ("prelu_bwd",)))
@@ -28,7 +28,7 @@ def one_pass(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    marks = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "fold_bn_w1" in r["Kernel_Name"]]
     lo, hi = marks[-2], marks[-1]                  # the last complete step
     out = {}
     for r in rows[lo:hi]:
@@ -41,7 +41,7 @@ label = sys.argv[2] if len(sys.argv) > 2 else "per_step_bytes"     # "bf16_per_s
 fetch, nf = one_pass(root + "/fetch", "FETCH_SIZE")
 write, nw = one_pass(root + "/write", "WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace on `python bench.py --steps 3 "
-                 "--warmup 1 --no-cpu-baseline --no-roofline`, MI355X; one training step (between two adam_kernel "
+                 "--warmup 1 --no-cpu-baseline --no-roofline`, MI355X; one training step (between two fold_bn_w1_kernel "
                  f"dispatches: {nf} / {nw} dispatches); tools/pmc_traffic.py",
        "correction": "FETCH_SIZE doubled as prescribed for gfx950 wide coalesced reads (MI355X_MICROARCH.md, HBM section); units KB",
        label: {}}
