@@ -350,7 +350,7 @@ def main():
         # kernels cannot be told apart by events)
         rows, classes = _family_table(eng, B, args.steps, FP32_MFMA_PEAK_TFLOPS, 200)
         pmc, src = _pmc_traffic()
-        per_step = (pmc or {}).get("per_step_bytes", {})
+        per_kernel = (pmc or {}).get("per_kernel_bytes", {})
         dom = max(rows, key=lambda r: r["ms_per_step"]) if rows else None
         conv_rows = [r for r in rows if r["kernel"].startswith("gconv")]
         conv_ms = sum(r["ms_per_step"] for r in conv_rows)
@@ -358,8 +358,8 @@ def main():
         conv_tf = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         traffic = None
         if dom is not None:
-            key = dom["kernel"].split(" ")[0]
-            traffic = next((v.get("hbm_bytes") for k, v in per_step.items() if k.startswith(key)), None)
+            # HBM bytes of the same launches (one step's launches of the dominant kernel), from the PMC passes
+            traffic = (per_kernel.get(dom["kernel"].split(" ")[0]) or {}).get("hbm_bytes")
         roofline = {
             "bound": "mfma", "kernel": dom["kernel"] if dom else None,
             "achieved": dom["tflops"] if dom else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -209,3 +209,33 @@ def test_bf16_rejects_unsupported_filters():
 
     with pytest.raises(DvError):
         E.Engine(E.make_config((13, 13, 4), 8, (8, 16), (3, 3), max_batch=4, dtype=1))
+
+
+def test_bf16_training_tracks_fp32():
+    """What the format costs a training run: 40 legacy-Adam steps (train.py:104-107) of the bf16 and of the fp32 engine
+    from the same initialisation on the same batches; the loss curves must stay within 3 % of each other."""
+    from debvader_amd.data import synthetic_stamps
+
+    arch = vo.Arch()
+    B = 64
+    x, y = synthetic_stamps(2 * B, seed=21)
+    curves = []
+    for dtype in (0, 1):
+        eng = _engine(arch, B, dtype=dtype)
+        eng.init(seed=5)
+        hb = eng.get_param("dec/head/bias")
+        hb[arch.nb:] += 0.3                                  # sigma off its floor, see the module docstring
+        eng.set_param("dec/head/bias", hb)
+        eng.optimizer_reset(1e-4)
+        eng.upload(0, x, y)
+        losses = []
+        for step in range(40):
+            out = eng.train_step(0, first=(step % 2) * B, B=B, seed=100 + step)
+            losses.append(out["loss"])
+        eng.close()
+        curves.append(np.asarray(losses, np.float64))
+    f32, bf = curves
+    assert np.all(np.isfinite(bf))
+    assert f32[-1] < f32[0]                                  # the run does train
+    assert np.abs(bf - f32).max() <= 3e-2 * np.abs(f32).max(), (f32[-5:], bf[-5:])
+    assert abs(bf[-1] - f32[-1]) <= 3e-2 * abs(f32[-1])

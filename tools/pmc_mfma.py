@@ -9,7 +9,8 @@ mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel
 (MI355X_MICROARCH.md, DVFS section); v_mfma_f32_16x16x4_f32 holds the pipe for 32 cycles."""
 import csv, glob, json, sys
 
-FAMILIES = (("gconv_strip (incl. first-layer form)", ("gconv_strip",)), ("gconv_s2", ("gconv_s2",)),
+FAMILIES = (("bconv_uni_kernel / bconv_kernel (bf16)", ("bconv_",)), ("bwgrad_kernel (bf16)", ("bwgrad_kernel",)),
+            ("gconv_strip (incl. first-layer form)", ("gconv_strip",)), ("gconv_s2", ("gconv_s2",)),
             ("gconv2 / gconv", ("gconv2_kernel", "gconv_kernel")), ("wgrad_strip (incl. first-layer form)", ("wgrad_strip",)),
             ("wgrad (tiled)", ("wgrad_kernel",)))
 
@@ -42,8 +43,14 @@ for i in ids:
     e["launches"] += 1
     e["mfma_busy_cycles"] += d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
     e["kernel_cycles"] += d.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    for extra in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):      # optional wave-level counters
+        if extra in d:
+            e[extra] = e.get(extra, 0.0) + d[extra]
 for e in fams.values():
     e["mfma_pipe_busy"] = round(e["mfma_busy_cycles"] / (1024.0 * e["kernel_cycles"]), 4)
+    if e.get("SQ_WAVE_CYCLES"):
+        e["wait_any_of_wave_cycles"] = round(e.get("SQ_WAIT_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 4)
+        e["active_inst_of_wave_cycles"] = round(e.get("SQ_ACTIVE_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 4)
     tot_b += e["mfma_busy_cycles"]
     tot_c += e["kernel_cycles"]
 print(json.dumps({

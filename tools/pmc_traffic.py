@@ -30,16 +30,27 @@ def one_pass(d, counter):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     marks = [i for i, r in enumerate(rows) if "fold_bn_w1" in r["Kernel_Name"]]
     lo, hi = marks[-2], marks[-1]                  # the last complete step
-    out = {}
+    out, per = {}, {}
     for r in rows[lo:hi]:
         out[family(r["Kernel_Name"])] = out.get(family(r["Kernel_Name"]), 0.0) + float(r["Counter_Value"])
-    return out, hi - lo
+        base = short_name(r["Kernel_Name"])
+        e = per.setdefault(base, [0, 0.0])
+        e[0] += 1
+        e[1] += float(r["Counter_Value"])
+    return out, hi - lo, per
+
+
+def short_name(name):
+    """rocprof kernel name without the namespace, template arguments and signature: `gconv2_kernel`"""
+    n = name.split("(")[0].split("<")[0].strip()
+    n = n.split(" ")[-1]
+    return n.split("::")[-1]
 
 
 root = sys.argv[1]
 label = sys.argv[2] if len(sys.argv) > 2 else "per_step_bytes"     # "bf16_per_step_bytes" for the bf16 engine's passes
-fetch, nf = one_pass(root + "/fetch", "FETCH_SIZE")
-write, nw = one_pass(root + "/write", "WRITE_SIZE")
+fetch, nf, kfetch = one_pass(root + "/fetch", "FETCH_SIZE")
+write, nw, kwrite = one_pass(root + "/write", "WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace on `python bench.py --steps 3 "
                  "--warmup 1 --no-cpu-baseline --no-roofline`, MI355X; one training step (between two fold_bn_w1_kernel "
                  f"dispatches: {nf} / {nw} dispatches); tools/pmc_traffic.py",
@@ -51,4 +62,11 @@ for fam in sorted(set(fetch) | set(write)):
     res[label][fam] = {"fetch_raw_kb": fr, "write_kb": wr, "hbm_bytes": (2.0 * fr + wr) * 1024.0}
     tot += (2.0 * fr + wr) * 1024.0
 res[label]["total"] = tot
+# the same per rocprof kernel name (launches of one step)
+kl = label.replace("per_step_bytes", "per_kernel_bytes")
+res[kl] = {}
+for k in sorted(set(kfetch) | set(kwrite)):
+    n, fr = kfetch.get(k, [0, 0.0])
+    n2, wr = kwrite.get(k, [0, 0.0])
+    res[kl][k] = {"launches": max(n, n2), "fetch_raw_kb": fr, "write_kb": wr, "hbm_bytes": (2.0 * fr + wr) * 1024.0}
 print(json.dumps(res, indent=1))
