@@ -425,6 +425,11 @@ class VAENet:
 def _build(input_shape, latent_dim, filters, kernels, for_onnx, max_batch, ctx, cfg_over):
     cfg_over = dict(cfg_over)
     seed = cfg_over.pop("seed", None)
+    if isinstance(cfg_over.get("dtype"), str):                 # "float32" / "bf16" as well as the DV_DTYPE_* codes
+        names = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+        if cfg_over["dtype"].lower() not in names:
+            raise ValueError(f"dtype {cfg_over['dtype']!r}: the engine stores activations as float32 or bf16")
+        cfg_over["dtype"] = names[cfg_over["dtype"].lower()]
     if for_onnx:
         raise NotImplementedError("for_onnx=True builds a TF graph for tf2onnx export (model.py:151-152,203-204); "
                                   "ONNX export is outside this engine's scope")
@@ -461,7 +466,8 @@ def create_model_vae(input_shape, latent_dim, filters, kernels, conv_activation=
         conv_activation, dense_activation: accepted and ignored (the reference passes None down, model.py:187-197)
         max_batch: per-GPU stamps per step the engine allocates workspaces for (engine-specific)
         seed: initial-weight (and shuffle) seed; None draws one from the OS, like Keras' fresh initialisation per model
-              (net.init_seed holds the value used).  dtype=1 selects the bf16 engine (BASELINE configs[2])
+              (net.init_seed holds the value used)
+        dtype (keyword): "float32" (default) or "bf16": bf16 activations / MFMA operands (BASELINE configs[2])
         ctx: debvader_amd.engine.Context (GPU / rank); default: GPU 0, single rank
     returns (net, encoder, decoder, z)
     """
