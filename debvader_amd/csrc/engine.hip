@@ -445,6 +445,11 @@ struct dv_model {
   unsigned long long* seed_dev = nullptr;
   bool use_seed_dev = false;
   bool infer_graph = false;
+  // small-batch forward (small_fwd.hip): batches of at most small_max stamps run the encoder and the decoder stack as
+  // one cooperative launch each; small_grid = workgroups such a launch may use (-1: not queried yet, 0: unavailable).
+  // Opt-in (0 = off): measured SLOWER than the per-layer launches on MI355X
+  int small_max = 0;
+  int small_grid = -1;
   bool keep_outputs = false;     // gradient / train steps also write loc and scale (introspection)
   std::map<int, hipGraphExec_t> infer_graphs;
   std::map<int, int> infer_seen;
@@ -1279,6 +1284,37 @@ static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int firs
 static int bf_backward(dv_model* m, int NB, int Bg);
 
 // encoder: dataset rows (idx / first) of the lane -> t
+// Inference batches of a few stamps are bound by kernel-to-kernel dispatch latency: they take the cooperative
+// layer-stack kernel (small_fwd.hip) instead of one launch per layer.  Not for passes that keep pre-activations
+// (training), not while a hipGraph capture / replay is in use, not under the profiler's per-launch events.
+static bool small_forward_ok(dv_model* m, int NB, bool keep_u) {
+  static const int env_max = getenv("DV_SMALL_FWD_MAX") ? atoi(getenv("DV_SMALL_FWD_MAX")) : -1;
+  const int lim = env_max >= 0 ? env_max : m->small_max;
+  if (keep_u || NB > lim || m->bf.on || m->prof_on || m->use_seed_dev || m->infer_graph || m->lane_id != 0 || m->b0 != 0)
+    return false;
+  const Arch& A = m->A;
+  if (2 * A.L + 3 > DV_SM_MAX_LAYERS) return false;
+  for (int i = 0; i < A.L; ++i)
+    if (A.cfg.filters[i] & 3) return false;
+  if ((size_t)16 * NB * A.tw > m->ws4_elems) return false;
+  if (m->small_grid < 0) m->small_grid = small_stack_max_grid(m->ctx->device);
+  return m->small_grid > 0;
+}
+
+static void sm_conv(SmLayer& L, const float* in, float* out, const float* W, bool nmajor, const float* bias,
+                    const float* alpha, int form, int hin, int cin, int hout, int cout, int st, int pb) {
+  memset(&L, 0, sizeof L);
+  L.kind = SM_CONV; L.in = in; L.out = out; L.W = W; L.nmajor = nmajor ? 1 : 0; L.bias = bias; L.alpha = alpha;
+  L.form = form; L.hin = hin; L.cin = cin; L.hout = hout; L.cout = cout; L.s = st; L.pb = pb;
+}
+
+static void sm_dense(SmLayer& L, const float* in, const float* in_alpha, float* out, const float* W, const float* bias,
+                     const float* alpha, int K, int N, int ksplit, float* part) {
+  memset(&L, 0, sizeof L);
+  L.kind = SM_DENSE; L.in = in; L.in_alpha = in_alpha; L.out = out; L.W = W; L.bias = bias; L.alpha = alpha;
+  L.cin = K; L.cout = N; L.ksplit = ksplit; L.part = part;
+}
+
 static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u) {
   if (m->bf.on) return bf_encoder_forward(m, xsrc, idx, first, NB, keep_u);
   const Arch& A = m->A;
@@ -1289,6 +1325,28 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
   {
     ProfScope ps(m, 2);
     DV_TRY(launch_bn_apply(xsrc, idx ? idx + m->b0 : nullptr, first + m->b0, NB, HW, A.C, 8, m->bnstate, xn, s));
+  }
+  if (small_forward_ok(m, NB, keep_u)) {
+    SmStack st;
+    memset(&st, 0, sizeof st);
+    st.NB = NB;
+    const float* in = xn;
+    for (int j = 0; j < 2 * A.L; ++j) {
+      int hin, cin, hout, cout, sd;
+      A.enc_layer(j, &hin, &cin, &hout, &cout, &sd);
+      sm_conv(st.L[st.n++], in, m->enc_a[j], j == 0 ? m->W1p : P + A.specs[A.enc_k(j)].off, false,
+              P + A.specs[A.enc_b(j)].off, P + A.specs[A.enc_al(j)].off, 0, hin, j == 0 ? 8 : cin, hout, cout, sd,
+              same_pad_before(hin, 3, sd, nullptr));
+      in = m->enc_a[j];
+    }
+    // flatten -> PReLU (on load) -> Dense(params_size), K split 8 x 4 ways, partials summed in order
+    const int ks = 8;
+    sm_dense(st.L[st.n++], in, P + A.specs[A.enc_flat_al()].off, nullptr, P + A.specs[A.enc_dk()].off, nullptr, nullptr,
+             A.flat, A.tw, ks, m->ws4);
+    SmLayer& R = st.L[st.n++];
+    memset(&R, 0, sizeof R);
+    R.kind = SM_REDUCE; R.part = m->ws4; R.out = m->t; R.bias = P + A.specs[A.enc_db()].off; R.cout = A.tw; R.ksplit = ks;
+    return launch_small_stack(st, m->small_grid, s);
   }
   const float* in = xn;
   for (int j = 0; j < 2 * A.L; ++j) {
@@ -1316,6 +1374,27 @@ static int decoder_forward(dv_model* m, int NB, bool keep_u) {
   const Arch& A = m->A;
   hipStream_t s = fwd_stream(m);
   float* P = m->P;
+  if (small_forward_ok(m, NB, keep_u)) {
+    SmStack st;
+    memset(&st, 0, sizeof st);
+    st.NB = NB;
+    const int r = A.w0 * A.w0 * A.cfg.filters[A.L - 1];
+    sm_dense(st.L[st.n++], m->z, P + A.specs[A.D0].off, m->dec_ah, P + A.specs[A.D0 + 1].off, P + A.specs[A.D0 + 2].off,
+             P + A.specs[A.D0 + 3].off, A.d, A.dec_hidden, 1, nullptr);
+    sm_dense(st.L[st.n++], m->dec_ah, nullptr, m->dec_ar, P + A.specs[A.D0 + 4].off, P + A.specs[A.D0 + 5].off,
+             P + A.specs[A.D0 + 6].off, A.dec_hidden, r, 1, nullptr);
+    const float* in = m->dec_ar;
+    for (int j = 0; j < 2 * A.L; ++j) {
+      int hin, cin, hout, cout, sd;
+      A.dec_layer(j, &hin, &cin, &hout, &cout, &sd);
+      sm_conv(st.L[st.n++], in, m->dec_a[j], P + A.specs[A.dec_k(j)].off, true, P + A.specs[A.dec_b(j)].off,
+              P + A.specs[A.dec_al(j)].off, 1, hin, cin, hout, cout, sd, same_pad_before(hout, 3, sd, nullptr));
+      in = m->dec_a[j];
+    }
+    sm_conv(st.L[st.n++], in, m->tpre, m->Whp, false, m->bhp, nullptr, 0, A.dec_out, A.cfg.filters[0], A.dec_out, A.C2p,
+            1, 1);
+    return launch_small_stack(st, m->small_grid, s);
+  }
   {
     ProfScope ps(m, 2);
     DV_TRY(launch_prelu_fwd(LANE(m->z, A.d), P + A.specs[A.D0].off, LANE(m->dec_ain, A.d), NB, A.d, s));
@@ -3068,6 +3147,12 @@ int dv_model_set_keep_outputs(dv_model* m, int32_t on) {
 int dv_model_set_infer_graph(dv_model* m, int32_t on) {
   if (!m) return DV_E_INVALID;
   m->infer_graph = on != 0;
+  return DV_OK;
+}
+
+int dv_model_set_small_forward(dv_model* m, int32_t max_stamps) {
+  if (!m || max_stamps < 0) return DV_E_INVALID;
+  m->small_max = max_stamps;
   return DV_OK;
 }
 

@@ -324,6 +324,12 @@ class Engine:
         measured no faster than the eager launches on MI355X, hence off by default."""
         check(lib.dv_model_set_infer_graph(self._h, 1 if on else 0))
 
+    def set_small_forward(self, max_stamps: int):
+        """Inference batches of at most `max_stamps` stamps (0 = off, the default) take the cooperative layer-stack
+        kernels: two launches instead of ~25 for the conv / dense stacks.  Measured slower than the per-layer launches on
+        MI355X, kept as an opt-in."""
+        check(lib.dv_model_set_small_forward(self._h, int(max_stamps)))
+
     def infer(self, x, eps=None, seed=0, want=("loc", "scale"), out=None) -> Dict[str, np.ndarray]:
         """One stochastic forward pass over all stamps.  float64 arrays (numpy's default, what the reference's callers
         pass) go to the engine as they are: the float32 cast of deblender.py:18 happens while the library stages them."""

@@ -158,6 +158,15 @@ int dv_model_set_mse_sample(dv_model* m, int32_t on);
  * bound by dispatch latency on the GPU, not by host submission).  Same results either way. */
 int dv_model_set_infer_graph(dv_model* m, int32_t on);
 
+/* Small-batch forward: inference batches of at most `max_stamps` stamps (0 = off, the default) run the encoder stack
+ * and the decoder stack as ONE cooperative kernel each (grid-wide barriers between layers) instead of one launch per
+ * layer - the per-object calls of deblend (deblend_cutout/deblender.py:18, deblend/field_deblender.py:265-274).
+ * fp32 engine only; same arithmetic up to the order of the K sums (agreement with the batched path <= 2e-5 of a
+ * tensor's maximum).  Off by default: on MI355X a grid-wide barrier costs 8 us with one workgroup per CU (cross-XCD L2
+ * write-back + invalidate) and the per-layer vector loops are latency-bound, 1.4 ms against 0.61 ms per one-stamp
+ * call. */
+int dv_model_set_small_forward(dv_model* m, int32_t max_stamps);
+
 /* Gradient / train steps also write the output distribution (loc, scale) of their forward pass, for
  * dv_model_get_activation("loc" / "scale") - what the parity tests compare with the oracle.  Off by default: the
  * train step of the reference (train.py:27) has no reader for them (42 MB of stores per 256-stamp step). */

@@ -1,4 +1,6 @@
-"""deblend() latency for small numbers of stamps (the per-field use of the reference's DeblendField)."""
+"""deblend() latency for small numbers of stamps (the per-object use of the reference's DeblendField,
+deblend/field_deblender.py:265-274): cooperative layer-stack kernels (batches of <= 8 stamps, small_fwd.hip) against the
+per-layer launches of the batched engine."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,11 +9,22 @@ from debvader_amd.deblend_cutout.deblender import deblend
 from debvader_amd.data import synthetic_stamps
 net, _, _, _ = model.create_model_vae((59, 59, 6), 32, [32, 64, 128, 256], [3, 3, 3, 3], max_batch=256)
 x, _ = synthetic_stamps(256, seed=1)
-for n in (1, 8, 32, 64, 128, 256):
-    for _ in range(3):
+eng = net._core.engine
+
+
+def timed(n, reps=50):
+    for _ in range(5):
         deblend(net, x[:n])
     t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(reps):
         deblend(net, x[:n])
-    dt = (time.perf_counter() - t0) / 20
-    print(f"N={n:4d}: {dt*1e3:7.3f} ms per call = {n/dt:8.0f} stamps/s")
+    return (time.perf_counter() - t0) / reps
+
+
+for n in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+    eng.set_small_forward(8)
+    a = timed(n)
+    eng.set_small_forward(0)
+    b = timed(n)
+    tag = "cooperative stack" if n <= 8 else "batched (same path)"
+    print(f"N={n:4d}: {a*1e3:7.3f} ms per call ({tag}) | per-layer launches {b*1e3:7.3f} ms | {n/a:8.0f} stamps/s", flush=True)
