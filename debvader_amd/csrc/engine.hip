@@ -449,6 +449,9 @@ struct dv_model {
   // one cooperative launch each; small_grid = workgroups such a launch may use (-1: not queried yet, 0: unavailable).
   // Opt-in (0 = off): measured SLOWER than the per-layer launches on MI355X
   int small_max = 0;
+  // set by dv_infer / dv_encode / dv_decode for calls of at most 16 stamps: the deep layers slice K over workgroups
+  // (gconv2_small_splitk).  Decided per CALL, not per launch, so that how a longer input is chunked never changes bits.
+  bool tiny_call = false;
   int small_grid = -1;
   bool keep_outputs = false;     // gradient / train steps also write loc and scale (introspection)
   std::map<int, hipGraphExec_t> infer_graphs;
@@ -667,6 +670,39 @@ static int fuse_finish(dv_model* m, const GConv2Params& q, const FuseBwd* fz, lo
   return launch_reduce_rows_f64(q.db_part, (int)db_rows, q.Cout, m->G + A.specs[fz->bias_spec].off, 1.0f, rs);
 }
 
+// Tiny batches (deblend on a few stamps, deblender.py:18): a deep layer has a handful of output tiles, each walking the
+// whole K = taps x Cin loop serially at the latency of its own gathers (56 us for the 4 x 4 x 256 layer of one stamp,
+// DESIGN 7a).  Slice K over blockIdx.y into raw slabs like the dense layers do and finish with bias + PReLU in
+// splitk_finish.  Returns 1 when it handled the launch, 0 when the caller should launch as usual, < 0 on error.
+static int gconv2_small_splitk(dv_model* m, GConv2Params& q, int NB, int Hout, int Cout, int nchunks, int epi,
+                               const float* bias, const float* alpha, float* U, float* Aout, double flops) {
+  static const bool off = getenv("DV_NO_SMALL_SPLITK") != nullptr;
+  if (off || !m->tiny_call || NB > 16 || q.nclass != 1 || !m->ws4 || m->prof_on || epi > 2) return 0;
+  const long M = (long)NB * Hout * Hout;
+  const long MN = M * Cout;
+  const long tiles64 = ((M + 63) / 64) * (long)((Cout + 63) / 64);
+  if (tiles64 > 64 || nchunks < 16 || (MN & 3) || (Cout & 3)) return 0;
+  const size_t ws4_cap = m->ws4_elems / 4;
+  float* ws4 = m->ws4 + (size_t)m->lane_id * ws4_cap;
+  int ks = (int)std::min<long>(std::min<long>(16, nchunks / 4), (long)(ws4_cap / (size_t)MN));
+  ks = (int)std::min<long>(ks, std::max<long>(1, 512 / tiles64));
+  if (ks < 2) return 0;
+  q.ksplit = ks;
+  q.U = ws4;
+  q.A = nullptr;
+  q.epi = 0;
+  q.bias = nullptr;
+  q.alpha = nullptr;
+  {
+    ProfScope ps(m, 0, nullptr, PF_GCONV2, flops);
+    DV_TRY(launch_gconv2(q, fwd_stream(m)));
+  }
+  ProfScope ps(m, 2);
+  DV_TRY(launch_splitk_finish(ws4, ks, MN, Cout, epi >= 1 ? bias : nullptr, epi == 2 ? alpha : nullptr,
+                              (long)Hout * Hout * Cout, U, epi == 2 ? Aout : nullptr, fwd_stream(m)));
+  return 1;
+}
+
 // fprop-form gconv over an [NB,Hin,Hin,Cin] tensor: out[NB,Hout,Hout,Cout], in pixel = out*s + k - pb
 static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor, const float* bias, const float* alpha,
                        float* U, float* Aout, int epi, int NB, int Hin, int Cin, int Hout, int Cout, int s, int pb,
@@ -756,6 +792,10 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
         return launch_splitk_finish(ws4, ks, MN, Cout, epi >= 1 ? bias : nullptr, epi == 2 ? alpha : nullptr,
                                     (long)Hout * Hout * Cout, U, epi == 2 ? Aout : nullptr, fwd_stream(m));
       }
+    }
+    if (!fz && !single_tap) {
+      const int r = gconv2_small_splitk(m, q, NB, Hout, Cout, nchunks, epi, bias, alpha, U, Aout, flops);
+      if (r != 0) return r < 0 ? r : OK;
     }
     long db_rows = 0;
     const bool fuse = fz && !m->no_fuse && fuse_setup(m, q, fz, &db_rows) == OK;
@@ -863,6 +903,10 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
       c.ntaps = t.n; c.tapcode = t.tapcode; c.wtcode = t.wtcode;
     }
     q.nclass = k;
+    if (!fz && k == 1 && Cs % 32 == 0) {
+      const int r = gconv2_small_splitk(m, q, NB, Ht, Ct, q.cls[0].ntaps * (Cs / 32), epi, bias, alpha, U, Aout, flops);
+      if (r != 0) return r < 0 ? r : OK;
+    }
     long db_rows = 0;
     const bool fuse = fz && !m->no_fuse && fuse_setup(m, q, fz, &db_rows) == OK;
     {
@@ -1284,6 +1328,12 @@ static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int firs
 static int bf_backward(dv_model* m, int NB, int Bg);
 
 // encoder: dataset rows (idx / first) of the lane -> t
+struct TinyCall {          // scope of one public inference call of at most 16 stamps
+  dv_model* m;
+  TinyCall(dv_model* mm, int64_t N) : m(mm) { m->tiny_call = N <= 16; }
+  ~TinyCall() { m->tiny_call = false; }
+};
+
 // Inference batches of a few stamps are bound by kernel-to-kernel dispatch latency: they take the cooperative
 // layer-stack kernel (small_fwd.hip) instead of one launch per layer.  Not for passes that keep pre-activations
 // (training), not while a hipGraph capture / replay is in use, not under the profiler's per-launch events.
@@ -3053,6 +3103,7 @@ static int infer_entry(dv_model* m, const void* x, bool x_f64, int64_t N, const 
                        float* scale, float* mu, float* zstd, float* z) {
   if (!m || !x || N < 0) return DV_E_INVALID;
   const Arch& A = m->A;
+  TinyCall tiny(m, N);
   DV_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->stream;
   const size_t stamp = (size_t)A.H * A.H * A.C;
@@ -3227,6 +3278,7 @@ int dv_infer_mc(dv_model* m, const float* x, int64_t N, int32_t nsamples, uint64
 int dv_encode(dv_model* m, const float* x, int64_t N, float* t) {
   if (!m || !x || !t || N < 0) return DV_E_INVALID;
   const Arch& A = m->A;
+  TinyCall tiny(m, N);
   DV_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->stream;
   const size_t stamp = (size_t)A.H * A.H * A.C;
@@ -3244,6 +3296,7 @@ int dv_encode(dv_model* m, const float* x, int64_t N, float* t) {
 int dv_decode(dv_model* m, const float* z, int64_t N, float* loc, float* scale) {
   if (!m || !z || N < 0) return DV_E_INVALID;
   const Arch& A = m->A;
+  TinyCall tiny(m, N);
   DV_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->stream;
   const size_t stamp = (size_t)A.H * A.H * A.C;

@@ -212,8 +212,12 @@ def test_bf16_rejects_unsupported_filters():
 
 
 def test_bf16_training_tracks_fp32():
-    """What the format costs a training run: 40 legacy-Adam steps (train.py:104-107) of the bf16 and of the fp32 engine
-    from the same initialisation on the same batches; the loss curves must stay within 3 % of each other."""
+    """What the format costs a training run: 16 legacy-Adam steps (train.py:104-107) of the bf16 and of the fp32 engine
+    from the same initialisation on the same batches.  The loss curves must coincide to 2 % of the loss scale step by
+    step (measured: 4 digits).  Not longer: around step 20 a first pixel's sigma reaches its 1e-4 floor (relu of the
+    scale pre-activation, model.py:154-159), the NLL spikes by orders of magnitude in whichever run gets there first,
+    and from there on two fp32 runs with different summation orders do not track each other either
+    (tools/bf16_vs_f32_grads.py prints the gradients per tensor - norm ratio 0.96-1.08, cosine >= 0.985 - and the curves)."""
     from debvader_amd.data import synthetic_stamps
 
     arch = vo.Arch()
@@ -229,13 +233,13 @@ def test_bf16_training_tracks_fp32():
         eng.optimizer_reset(1e-4)
         eng.upload(0, x, y)
         losses = []
-        for step in range(40):
+        for step in range(16):
             out = eng.train_step(0, first=(step % 2) * B, B=B, seed=100 + step)
             losses.append(out["loss"])
         eng.close()
         curves.append(np.asarray(losses, np.float64))
     f32, bf = curves
     assert np.all(np.isfinite(bf))
-    assert f32[-1] < f32[0]                                  # the run does train
-    assert np.abs(bf - f32).max() <= 3e-2 * np.abs(f32).max(), (f32[-5:], bf[-5:])
-    assert abs(bf[-1] - f32[-1]) <= 3e-2 * abs(f32[-1])
+    assert f32[-2:].mean() < f32[:2].mean()                  # the run does train
+    scale = np.abs(f32).max()
+    assert np.abs(bf - f32).max() <= 2e-2 * scale, (f32, bf)
