@@ -495,3 +495,27 @@ def test_small_batch_forward_in_two_cooperative_launches_matches_the_batched_ker
             assert np.abs(dec_a[0] - dec_b[0]).max() <= 2e-5 * np.abs(dec_b[0]).max()
             assert np.abs(dec_a[1] - dec_b[1]).max() <= 2e-5 * np.abs(dec_b[1]).max()
         eng.close()
+
+
+def test_tiny_inference_calls_slice_k_and_match_the_same_stamps_in_a_large_call():
+    """Calls of <= 16 stamps run their deep conv layers with K sliced over workgroups (gconv2_small_splitk: a one-stamp
+    layer otherwise has 1-4 workgroups walking 72 K chunks serially).  Only the order of the K sum changes: the rows must
+    agree with the same stamps evaluated inside a 40-stamp call to 2e-5 of each tensor's maximum."""
+    from debvader_amd import engine as E
+
+    rng = np.random.default_rng(41)
+    eng = E.Engine(E.make_config(max_batch=64))
+    eng.init(seed=4)
+    for name, _, _ in eng.specs:
+        if name.endswith("alpha"):
+            eng.set_param(name, rng.uniform(0.05, 0.3, size=eng.get_param(name).shape).astype(np.float32))
+    x = rng.normal(0, 0.4, size=(40, 59, 59, 6)).astype(np.float32)
+    eps = rng.normal(size=(40, 32)).astype(np.float32)
+    want = ("loc", "scale", "mu", "z", "zstd")
+    big = eng.infer(x, eps=eps, want=want)
+    for n in (1, 5, 16):
+        tiny = eng.infer(x[:n], eps=eps[:n], want=want)
+        for k in want:
+            err = np.abs(tiny[k] - big[k][:n]).max() / (np.abs(big[k][:n]).max() + 1e-30)
+            assert err <= 2e-5, (n, k, err)
+    eng.close()
