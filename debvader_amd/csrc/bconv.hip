@@ -487,10 +487,16 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
 //     no zero-page select (CINMODE 0: only taps inside the image are walked);
 //   * the accumulators start at the bias; alpha is one row for the whole tile;
 //   * the wave's 64 output rows are consecutive in memory: the LDS tile goes out as plain 16-byte row pieces.
-template <int NBLK, int CINMODE>
-__global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) {
-  constexpr int STAGE = (BC_GT + NBLK) * 1024;
+// GT = 16-stamp groups per tile (16, 8 or 4: 256, 128 or 64 stamps per workgroup; a wave owns GW = GT/4 of them).  The
+// deep layers (16 x 16 pixels and below) have only a few hundred 256-stamp tiles, each walking 36-72 K steps at the
+// latency of its own three-stage ring; smaller stamp tiles put 4-8 independent pipelines on a CU.
+template <int NBLK, int CINMODE, int GT>
+__global__ __launch_bounds__(256, GT == 16 ? 2 : 4) void bconv_uni_kernel(const BConvParams p) {
+  constexpr int GW = GT / 4;                              // groups per wave
+  constexpr int RW = GW * 16;                             // output rows (stamps) per wave
+  constexpr int STAGE = (GT + NBLK) * 1024;
   constexpr int BN = 16 * NBLK;
+  static_assert(RW * BN * 2 >= 1024, "a wave's bf16 tile must be at least one 1-KiB row piece");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   int* stab = reinterpret_cast<int*>(smem + 3 * STAGE);   // [0] valid taps, [1..9] their ids, [10..18] their source pixels
 
@@ -504,9 +510,9 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
   }
   const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
   const int n0 = tile_n * BN;
-  const int tpp = p.NBp >> 8;                           // tiles per pixel
+  const int tpp = p.NBp / (GT * 16);                    // tiles per pixel
   const int vp = tile_m / tpp;
-  const int st0 = (tile_m - vp * tpp) * 256;            // first stamp of the tile
+  const int st0 = (tile_m - vp * tpp) * (GT * 16);      // first stamp of the tile
   const int nbx = (p.Hout + 7) >> 3;
   const int blk = vp >> 6, by = blk / nbx, bx = blk - by * nbx;
   const int oh = by * 8 + ((vp >> 3) & 7), ow = bx * 8 + (vp & 7);
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
   const unsigned char* zlane = reinterpret_cast<const unsigned char*>(p.zero) + lane * 16;
   const int jb = wave % NBLK;
   // lane parts (bytes) of the DMA sources; the uniform parts are added per instruction as scalars
-  const unsigned a_lane = (unsigned)((((st0 + wave * 64 + drow) * p.Cin) + dq * 8) * 2);
+  const unsigned a_lane = (unsigned)((((st0 + wave * RW + drow) * p.Cin) + dq * 8) * 2);
   const unsigned b_lane = (unsigned)(((NBLK * drow) * p.Kpad + dq * 8) * 2);
   const size_t pixbytes = (size_t)p.NBp * p.Cin * 2;     // one pixel of the input tensor
   const unsigned gstride = (unsigned)(16 * p.Cin * 2);   // one 16-stamp group
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
       const int sp = piece < 9 * ppt ? src_pixel(tap) : -1;
       pok[i] = sp >= 0;
       psrc[i] = Xb + (size_t)(sp >= 0 ? sp : 0) * pixbytes +
-                (unsigned)((((st0 + wave * 64 + drow) * p.Cin) + sub * 8) * 2);
+                (unsigned)((((st0 + wave * RW + drow) * p.Cin) + sub * 8) * 2);
     }
   }
 
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
   const unsigned char* tsrc = Xb;                          // uniform: input pixel of the current tap
   auto issue = [&](int step, int buf) {
     unsigned char* sA = smem + buf * STAGE;
-    unsigned char* sB = sA + BC_GT * 1024;
+    unsigned char* sB = sA + GT * 1024;
     if constexpr (CINMODE == 0) {
       if (is_ti < 0 || is_cc + 1 == cpt) {
         ++is_ti;
@@ -594,8 +600,8 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
       }
       const unsigned char* cs = tsrc + is_cc * 64;
 #pragma unroll
-      for (int gi = 0; gi < 4; ++gi)
-        __builtin_amdgcn_global_load_lds((bc_gptr_t)(cs + gi * gstride + a_lane), (bc_lptr_t)(sA + (wave * 4 + gi) * 1024), 16, 0, 0);
+      for (int gi = 0; gi < GW; ++gi)
+        __builtin_amdgcn_global_load_lds((bc_gptr_t)(cs + gi * gstride + a_lane), (bc_lptr_t)(sA + (wave * GW + gi) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((bc_gptr_t)(wbase + (is_tap * p.Cin + is_cc * 32) * 2 + b_lane),
                                        (bc_lptr_t)(sB + jb * 1024), 16, 0, 0);
     } else {
@@ -603,9 +609,9 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
       for (int i = 0; i < 5; ++i)
         if (i == step) {
 #pragma unroll
-          for (int gi = 0; gi < 4; ++gi) {
+          for (int gi = 0; gi < GW; ++gi) {
             const void* src = pok[i] ? (const void*)(psrc[i] + gi * gstride) : (const void*)zlane;
-            __builtin_amdgcn_global_load_lds((bc_gptr_t)src, (bc_lptr_t)(sA + (wave * 4 + gi) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((bc_gptr_t)src, (bc_lptr_t)(sA + (wave * GW + gi) * 1024), 16, 0, 0);
           }
         }
       __builtin_amdgcn_global_load_lds((bc_gptr_t)(wbase + step * 64 + b_lane), (bc_lptr_t)(sB + jb * 1024), 16, 0, 0);
@@ -618,8 +624,8 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
   const int ch0 = n0 + NBLK * c;
 
   // fused PReLU backward: the wave's [64 rows][BN] tile of the pre-activation, parked in registers
-  constexpr int NPC = BN / 8;                             // 16-byte pieces per lane of a [64][BN] bf16 tile
-  const size_t rb0 = (size_t)pix * p.NBp + st0 + wave * 64;   // first output row of this wave
+  constexpr int NPC = RW * BN / 512;                      // 16-byte pieces per lane of the wave's [RW][BN] bf16 tile
+  const size_t rb0 = (size_t)pix * p.NBp + st0 + wave * RW;   // first output row of this wave
   f32x4 uin[NPC];
   if (p.epi == BEPI_BWD) {
 #pragma unroll
@@ -634,9 +640,9 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
 #pragma unroll
   for (int j = 0; j < NBLK; ++j) bias[j] = 0.f;
   if (p.bias && (p.epi == BEPI_FWD || p.epi == BEPI_RAW32)) load_f32<NBLK>(p.bias + ch0, bias);
-  f32x4 acc[4][NBLK];
+  f32x4 acc[GW][NBLK];
 #pragma unroll
-  for (int gi = 0; gi < 4; ++gi)
+  for (int gi = 0; gi < GW; ++gi)
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) acc[gi][j] = (f32x4){bias[j], bias[j], bias[j], bias[j]};
 
@@ -645,29 +651,29 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
   int buf = 0;
   for (int i = 0; i < nsteps; ++i) {
     if (i + 1 < nsteps)
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + 1) : "memory");     // the newest stage: GW + 1 instructions per wave
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (i + 2 < nsteps) issue(i + 2, buf >= 1 ? buf - 1 : 2);
-    const unsigned char* sA = smem + buf * STAGE + wave * 4096 + fragoff;
-    const unsigned char* sB = smem + buf * STAGE + BC_GT * 1024 + fragoff;
-    bc_bf16x8 a[4], b[NBLK];
+    const unsigned char* sA = smem + buf * STAGE + wave * (GW * 1024) + fragoff;
+    const unsigned char* sB = smem + buf * STAGE + GT * 1024 + fragoff;
+    bc_bf16x8 a[GW], b[NBLK];
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi) a[gi] = *reinterpret_cast<const bc_bf16x8*>(sA + gi * 1024);
+    for (int gi = 0; gi < GW; ++gi) a[gi] = *reinterpret_cast<const bc_bf16x8*>(sA + gi * 1024);
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) b[j] = *reinterpret_cast<const bc_bf16x8*>(sB + j * 1024);
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi)
+    for (int gi = 0; gi < GW; ++gi)
 #pragma unroll
       for (int j = 0; j < NBLK; ++j)
         acc[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gi], b[j], acc[gi][j], 0, 0, 0);
     buf = buf == 2 ? 0 : buf + 1;
   }
 
-  // ---- epilogue: per-wave LDS tile [64 rows][BN]; the 64 rows are consecutive rows of the output tensor ----
+  // ---- epilogue: per-wave LDS tile [RW rows][BN]; the rows are consecutive rows of the output tensor ----
   __builtin_amdgcn_s_barrier();
-  constexpr int WREG = 64 * BN * (NBLK == 1 ? 4 : 2);
+  constexpr int WREG = RW * BN * (NBLK == 1 ? 4 : 2);
   unsigned char* wreg = smem + wave * WREG;
   auto flush = [&](void* dst, int esz) {
     const int rowb = BN * esz;
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
     const size_t rstride = (size_t)p.Cout * esz;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      if (k >= 64 * rowb / 1024) break;
+      if (k >= RW * rowb / 1024) break;
       const int byte = (k * 64 + lane) * 16;
       const int row = byte / rowb, colb = byte - row * rowb;
       *reinterpret_cast<f32x4*>(out + row * rstride + colb) = *reinterpret_cast<const f32x4*>(wreg + byte);
@@ -684,13 +690,13 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
   if (p.epi == BEPI_RAW32) {
     if constexpr (NBLK == 1) {
 #pragma unroll
-      for (int gi = 0; gi < 4; ++gi)
+      for (int gi = 0; gi < GW; ++gi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) reinterpret_cast<float*>(wreg)[(gi * 16 + 4 * g4 + r) * BN + c] = acc[gi][0][r];
       flush(p.Uf, 4);
     } else {
 #pragma unroll
-      for (int gi = 0; gi < 4; ++gi)
+      for (int gi = 0; gi < GW; ++gi)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
   bc_bf16* wt = reinterpret_cast<bc_bf16*>(wreg);
   if (p.epi == BEPI_RAWBF || (p.epi == BEPI_FWD && p.U)) {
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi)
+    for (int gi = 0; gi < GW; ++gi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v[NBLK];
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
   load_f32<NBLK>(p.alpha + (size_t)pix * p.Cout + ch0, al);
   if (p.epi == BEPI_FWD) {
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi)
+    for (int gi = 0; gi < GW; ++gi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float a[NBLK];
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
 #pragma unroll
   for (int j = 0; j < NBLK; ++j) dal[j] = db[j] = 0.f;
 #pragma unroll
-  for (int gi = 0; gi < 4; ++gi)
+  for (int gi = 0; gi < GW; ++gi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       bc_bf16* q = wt + (gi * 16 + 4 * g4 + r) * BN + NBLK * c;
@@ -758,8 +764,36 @@ __global__ __launch_bounds__(256, 2) void bconv_uni_kernel(const BConvParams p) 
       db[j] += __shfl_xor(db[j], 16);
       db[j] += __shfl_xor(db[j], 32);
     }
+    if constexpr (GW < 4) {
+      // a partial slab row covers 64 stamps = 4 / GW waves: sum them through LDS in wave order (p.dal_part is the same for
+      // every wave, so all of them reach the barrier)
+      float* pbuf = reinterpret_cast<float*>(smem + 3 * STAGE + 1024);   // [4 waves][2][BN]
+      if (g4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
+          pbuf[(wave * 2 + 0) * BN + NBLK * c + j] = dal[j];
+          pbuf[(wave * 2 + 1) * BN + NBLK * c + j] = db[j];
+        }
+      }
+      __syncthreads();
+      constexpr int WPP = 4 / GW;                           // waves per partial row
+      if (wave % WPP == 0 && g4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int w = 0; w < WPP; ++w) {
+            a += pbuf[((wave + w) * 2 + 0) * BN + NBLK * c + j];
+            b += pbuf[((wave + w) * 2 + 1) * BN + NBLK * c + j];
+          }
+          dal[j] = a;
+          db[j] = b;
+        }
+      }
+      if (wave % WPP != 0) return;
+    }
     if (g4 == 0) {
-      const int part = (st0 >> 6) + wave;
+      const int part = (st0 + wave * RW) >> 6;
       const size_t o = ((size_t)part * p.Hout * p.Hout + pix) * p.Cout + ch0;
 #pragma unroll
       for (int j = 0; j < NBLK; ++j) {
@@ -795,29 +829,38 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   int nblk = p.Cout % 64 == 0 ? 4 : (p.Cout % 32 == 0 ? 2 : 1);
   const long nbx = (p.Hout + 7) / 8;
   const long M16 = nbx * nbx * 64 * (p.NBp >> 4);   // 8 x 8 pixel blocks, see the kernel
-  // deep layers have few row tiles and a long K loop that one workgroup walks alone: narrower column tiles put a
-  // workgroup on every CU (their input is re-read from L2 once more per halving, which these latency-bound launches
-  // do not notice)
-  const long want_tiles = getenv("DV_BCONV_MIN_TILES") ? atol(getenv("DV_BCONV_MIN_TILES")) : 512;   // (read per call: the tests toggle it)
-  while (nblk > 1 && ((M16 + BC_GT - 1) / BC_GT) * (p.Cout / (16 * nblk)) < want_tiles) nblk >>= 1;
-  const long tiles = ((M16 + BC_GT - 1) / BC_GT) * (p.Cout / (16 * nblk));
-  const size_t lds = (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;
   static const bool no_uni = getenv("DV_BCONV_NO_UNI") != nullptr;
   const bool uni = (p.NBp & 255) == 0 && !no_uni && p.dbg == 0;
+  // Deep layers have few row tiles and a long K loop that one workgroup walks alone.  First smaller stamp tiles (uniform
+  // kernel: 128 or 64 stamps per workgroup, 4-8 independent pipelines per CU; the weights are re-read from L2 once more
+  // per halving), then narrower column tiles (the input is re-read once more per halving) put enough workgroups on the
+  // chip; these launches are latency-bound and do not notice the extra L2 traffic.
+  const long want_tiles = getenv("DV_BCONV_MIN_TILES") ? atol(getenv("DV_BCONV_MIN_TILES")) : 512;   // (read per call: the tests toggle it)
+  const long gt_tiles = getenv("DV_BCONV_GT_TILES") ? atol(getenv("DV_BCONV_GT_TILES")) : 1024;
+  int gt = BC_GT;
+  auto ntiles = [&](int g, int nb) { return ((M16 + g - 1) / g) * (long)(p.Cout / (16 * nb)); };
+  if (uni && mode == 0)
+    while (gt > 4 && ntiles(gt, nblk) < gt_tiles && (gt / 2) * nblk >= 8) gt >>= 1;
+  while (nblk > 1 && ntiles(gt, nblk) < want_tiles && gt * (nblk / 2) >= 8) nblk >>= 1;
+  const long tiles = ntiles(gt, nblk);
+  const size_t lds = uni ? (size_t)3 * (gt + nblk) * 1024 + 4096 : (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;
+#define BC_LAUNCH_K(KERNEL_)                                                                           \
+  do {                                                                                                 \
+    static size_t attr_lds = 0;                                                                        \
+    if (attr_lds < lds) {                                                                              \
+      DV_HIP(hipFuncSetAttribute((const void*)KERNEL_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      attr_lds = lds;                                                                                  \
+    }                                                                                                  \
+    hipLaunchKernelGGL(KERNEL_, dim3((unsigned)tiles), dim3(256), lds, s, p);                          \
+  } while (0)
 #define BC_LAUNCH(NB_, MODE_)                                                                          \
   do {                                                                                                 \
-    static bool attr_done = false;                                                                     \
-    if (!attr_done) {                                                                                  \
-      DV_HIP(hipFuncSetAttribute((const void*)bconv_kernel<NB_, MODE_>,                                \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-      DV_HIP(hipFuncSetAttribute((const void*)bconv_uni_kernel<NB_, MODE_>,                            \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-      attr_done = true;                                                                                \
+    if (!uni) BC_LAUNCH_K((bconv_kernel<NB_, MODE_>));                                                 \
+    else if (gt == 16) BC_LAUNCH_K((bconv_uni_kernel<NB_, MODE_, 16>));                                \
+    else if constexpr (MODE_ == 0 && NB_ >= 1) {                                                       \
+      if (gt == 8) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 8>));                                         \
+      else if constexpr (NB_ >= 2) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 4>));                         \
     }                                                                                                  \
-    if (uni)                                                                                           \
-      hipLaunchKernelGGL((bconv_uni_kernel<NB_, MODE_>), dim3((unsigned)tiles), dim3(256), lds, s, p); \
-    else                                                                                               \
-      hipLaunchKernelGGL((bconv_kernel<NB_, MODE_>), dim3((unsigned)tiles), dim3(256), lds, s, p);     \
   } while (0)
   if (mode == 0) {
     if (nblk == 4) BC_LAUNCH(4, 0);
@@ -828,6 +871,7 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
     else if (nblk == 2) BC_LAUNCH(2, 1);
     else BC_LAUNCH(1, 1);
   }
+#undef BC_LAUNCH_K
 #undef BC_LAUNCH
   DV_HIP(hipGetLastError());
   return OK;
