@@ -61,6 +61,9 @@ _i32 = C.POINTER(C.c_int32)
 _i64 = C.POINTER(C.c_int64)
 
 # name -> (restype, argtypes); every symbol declared in include/debvader_hip.h
+# dv_chunk_fn of dv_infer_cutouts_stream: int (*)(void* user, int64 first, int32 count, const float* mean, const float* stddev)
+CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+
 SIGNATURES = {
     "dv_version": (C.c_int, []),
     "dv_crc32c": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
@@ -104,6 +107,9 @@ SIGNATURES = {
     "dv_model_set_keep_outputs": (C.c_int, [_p, C.c_int32]),
     "dv_infer": (C.c_int, [_p, _f, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
     "dv_infer_f64": (C.c_int, [_p, _d, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
+    "dv_infer_cutouts": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_uint64, _f, _f, _f, _f, _f]),
+    "dv_infer_cutouts_stream": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_uint64,
+                                          C.c_void_p, C.c_void_p]),
     "dv_scene_extract": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _d]),
     "dv_scene_composite": (C.c_int, [_p, _d, C.c_int32, C.c_int32, _d, _d, C.c_int32, C.c_int32, C.c_double]),
     "dv_infer_mc": (C.c_int, [_p, _f, C.c_int64, C.c_int32, C.c_uint64, _f, _f]),

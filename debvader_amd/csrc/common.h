@@ -138,6 +138,9 @@ void gconv2_tile_geometry(const GConv2Params& p, int* bm, int* wgm, long* mtiles
 void debug_set_gconv2_tile(int code);
 
 // Scene compositing (scene.hip): host float64 buffers in, host float64 buffers out
+// device-resident gather + float32 cast (dv_infer_cutouts): starts_dev points at the first cutout of the chunk
+int launch_scene_extract_f32(const double* field_dev, int F, int nb, const int* starts_dev, long count, int cs,
+                             float* out_dev, hipStream_t s);
 int scene_extract(const double* field_h, int F, int nb, const int32_t* starts_h, int N, int cs, double* out_h,
                   hipStream_t s);
 int scene_composite(double* field_h, int F, int nb, const double* stamps_h, const double* pos_h, int N, int cs,

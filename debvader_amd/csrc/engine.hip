@@ -2210,8 +2210,16 @@ static void host_copy(float* dst, const void* src, size_t n, bool src_f64, int t
   for (auto& th : pool) th.join();
 }
 
+// input of the pipeline when the stamps are cutouts of a field that already sits in HBM (dv_infer_cutouts)
+struct CutoutSrc {
+  const double* field;   // device, [F][F][nb]
+  const int* starts;     // device, [N][2]
+  int F, nb, cs;
+};
+
 static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, const float* eps, uint64_t seed,
-                           float* loc, float* scale, float* mu, float* zstd, float* z) {
+                           float* loc, float* scale, float* mu, float* zstd, float* z, const CutoutSrc* cut = nullptr,
+                           dv_chunk_fn sink = nullptr, void* sink_user = nullptr) {
   const Arch& A = m->A;
   hipStream_t s = m->ctx->stream;
   const size_t stamp = (size_t)A.H * A.H * A.C;
@@ -2227,6 +2235,14 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
     const int64_t o = k * chunk;
     const int nb = (int)std::min<int64_t>(chunk, N - o);
     DV_HIP(hipEventSynchronize(p->ev_d2h[b]));
+    if (sink) {
+      // streaming consumer: it reads the pinned transfer buffers in place (valid until it returns), nothing is copied
+      if (sink(sink_user, o, nb, p->hloc[b], p->hscale[b]) != 0) {
+        set_error("the chunk consumer of dv_infer_cutouts_stream asked to stop at stamp %ld", (long)o);
+        return E_STATE;
+      }
+      return OK;
+    }
     if (loc) host_copy(loc + o * stamp, p->hloc[b], nb * stamp, false, p->threads);
     if (scale) host_copy(scale + o * stamp, p->hscale[b], nb * stamp, false, p->threads);
     if (mu) memcpy(mu + o * d, p->hsmall[b], (size_t)nb * d * sizeof(float));
@@ -2235,6 +2251,7 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
     return OK;
   };
   auto stage_in = [&](int64_t k) -> int {     // stage A, host part: caller's array -> pinned (float64 cast here)
+    if (cut) return OK;                       // cutouts are gathered on the GPU, no host staging
     const int b = (int)(k & 1);
     const int64_t o = k * chunk;
     const int nb = (int)std::min<int64_t>(chunk, N - o);
@@ -2254,7 +2271,10 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
     const int nb = (int)std::min<int64_t>(chunk, N - k * chunk);
     if (k >= 2) DV_HIP(hipStreamWaitEvent(p->s_in, p->ev_comp[b], 0));   // forward of chunk k-2 has read din[b]
     if (trace) DV_HIP(hipEventRecord(tev[6 * k + 0], p->s_in));
-    DV_HIP(hipMemcpyAsync(p->din[b], p->hin[b], nb * stamp * sizeof(float), hipMemcpyHostToDevice, p->s_in));
+    if (cut)
+      DV_TRY(launch_scene_extract_f32(cut->field, cut->F, cut->nb, cut->starts + 2 * k * chunk, nb, cut->cs, p->din[b], p->s_in));
+    else
+      DV_HIP(hipMemcpyAsync(p->din[b], p->hin[b], nb * stamp * sizeof(float), hipMemcpyHostToDevice, p->s_in));
     if (trace) DV_HIP(hipEventRecord(tev[6 * k + 1], p->s_in));
     DV_HIP(hipEventRecord(p->ev_h2d[b], p->s_in));
     return OK;
@@ -2291,7 +2311,7 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
       m->scale = keep_scale;
       DV_TRY(st);
     }
-    if (m->normalise && loc) DV_TRY(launch_normalise(p->dloc[b], (long)nb * stamp, true, s));
+    if (m->normalise && (loc || sink)) DV_TRY(launch_normalise(p->dloc[b], (long)nb * stamp, true, s));
     if (mu)
       DV_HIP(hipMemcpy2DAsync(p->dsmall[b], d * sizeof(float), m->t, A.tw * sizeof(float), d * sizeof(float), nb,
                               hipMemcpyDeviceToDevice, s));
@@ -2305,8 +2325,8 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
     const int h = (int)(k % 3);
     DV_HIP(hipStreamWaitEvent(p->s_out, p->ev_comp[b], 0));
     if (trace) DV_HIP(hipEventRecord(tev[6 * k + 4], p->s_out));
-    if (loc) DV_HIP(hipMemcpyAsync(p->hloc[h], p->dloc[b], nb * stamp * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
-    if (scale) DV_HIP(hipMemcpyAsync(p->hscale[h], p->dscale[b], nb * stamp * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
+    if (loc || sink) DV_HIP(hipMemcpyAsync(p->hloc[h], p->dloc[b], nb * stamp * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
+    if (scale || sink) DV_HIP(hipMemcpyAsync(p->hscale[h], p->dscale[b], nb * stamp * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
     if (mu || zstd || z)
       DV_HIP(hipMemcpyAsync(p->hsmall[h], p->dsmall[b], (size_t)chunk * 3 * d * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
     if (trace) DV_HIP(hipEventRecord(tev[6 * k + 5], p->s_out));
@@ -3227,6 +3247,63 @@ int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t 
 int dv_infer_f64(dv_model* m, const double* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
                  float* mu, float* zstd, float* z) {
   return infer_entry(m, x, true, N, eps, seed, loc, scale, mu, zstd, z);
+}
+
+static int infer_cutouts_impl(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
+                              uint64_t seed, float* loc, float* scale, float* mu, float* zstd, float* z, dv_chunk_fn sink,
+                              void* sink_user) {
+  if (!m || !field || !starts || N < 0 || F < 1) return DV_E_INVALID;
+  const Arch& A = m->A;
+  const int cs = A.H;
+  if (nb != A.C || cs > F) {
+    set_error("dv_infer_cutouts: the field has %d bands and %d pixels, the network takes %d x %d x %d stamps", nb, F, cs, cs,
+              A.C);
+    return DV_E_INVALID;
+  }
+  for (int64_t i = 0; i < N; ++i) {
+    const int x = starts[2 * i], y = starts[2 * i + 1];
+    if (x < 0 || y < 0 || x + cs > F || y + cs > F) {
+      set_error("dv_infer_cutouts: cutout %ld (start %d,%d size %d) leaves the %d-pixel field", (long)i, x, y, cs, F);
+      return DV_E_INVALID;
+    }
+  }
+  if (N == 0) return DV_OK;
+  TinyCall tiny(m, N);
+  DV_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  double* fdev = nullptr;
+  int* sdev = nullptr;
+  const size_t fb = (size_t)F * F * nb * sizeof(double), sb = (size_t)N * 2 * sizeof(int);
+  if (hipMalloc((void**)&fdev, fb) != hipSuccess || hipMalloc((void**)&sdev, sb) != hipSuccess) {
+    (void)hipFree(fdev);
+    set_error("dv_infer_cutouts: out of device memory for the field (%zu bytes)", fb);
+    return DV_E_NOMEM;
+  }
+  int st = OK;
+  if (hipMemcpyAsync(fdev, field, fb, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(sdev, starts, sb, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)      // the gather runs on the pipeline's copy stream
+    st = E_HIP;
+  if (st == OK) {
+    CutoutSrc cut{fdev, sdev, F, nb, cs};
+    st = infer_pipelined(m, nullptr, false, N, nullptr, seed, loc, scale, mu, zstd, z, &cut, sink, sink_user);
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(fdev);
+  (void)hipFree(sdev);
+  if (st != OK) return st;
+  return prof_flush(m);
+}
+
+int dv_infer_cutouts(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
+                     uint64_t seed, float* loc, float* scale, float* mu, float* zstd, float* z) {
+  return infer_cutouts_impl(m, field, F, nb, starts, N, seed, loc, scale, mu, zstd, z, nullptr, nullptr);
+}
+
+int dv_infer_cutouts_stream(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
+                            uint64_t seed, dv_chunk_fn consumer, void* user) {
+  if (!consumer) return DV_E_INVALID;
+  return infer_cutouts_impl(m, field, F, nb, starts, N, seed, nullptr, nullptr, nullptr, nullptr, nullptr, consumer, user);
 }
 
 int dv_infer_mc(dv_model* m, const float* x, int64_t N, int32_t nsamples, uint64_t seed, float* mean_out,

@@ -43,6 +43,23 @@ __global__ __launch_bounds__(256) void scene_extract_kernel(const double* __rest
   out[e] = field[((long)x * F + y) * nb + b];
 }
 
+// the same gather on device-resident operands, cast to float32 as deblend() does (tf.cast, deblender.py:18): cutouts
+// [first, first + count) of `starts` straight into the network's input buffer
+__global__ __launch_bounds__(256) void scene_extract_f32_kernel(const double* __restrict__ field, int F, int nb,
+                                                                const int* __restrict__ starts, long total, int cs,
+                                                                float* __restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int b = (int)(e % nb);
+  long r = e / nb;
+  const int j = (int)(r % cs);
+  r /= cs;
+  const int i = (int)(r % cs);
+  const int n = (int)(r / cs);
+  const int x = starts[2 * n] + i, y = starts[2 * n + 1] + j;
+  out[e] = (float)field[((long)x * F + y) * nb + b];
+}
+
 // cubic B-spline coefficients of stamp `objs[o]` zero-extended by T on every side: coef[k][P][P][nb]
 __global__ __launch_bounds__(256) void scene_prefilter_kernel(const double* __restrict__ stamps,
                                                               const int* __restrict__ which, int cs, int nb,
@@ -189,6 +206,16 @@ int scene_extract(const double* field_h, int F, int nb, const int32_t* starts_h,
   SC_HIP(hipMemcpyAsync(out_h, out, ob, hipMemcpyDeviceToHost, s));
   SC_HIP(hipStreamSynchronize(s));
   cleanup();
+  return OK;
+}
+
+int launch_scene_extract_f32(const double* field_dev, int F, int nb, const int* starts_dev, long count, int cs,
+                             float* out_dev, hipStream_t s) {
+  const long total = count * cs * cs * nb;
+  if (total <= 0) return OK;
+  hipLaunchKernelGGL(scene_extract_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, field_dev, F, nb,
+                     starts_dev, total, cs, out_dev);
+  DV_HIP(hipGetLastError());
   return OK;
 }
 

@@ -25,6 +25,35 @@ def deblend(net, images, normalise=False):
         eng.set_normalise(False)
     return out.mean().numpy(), out                 # mean in flux units, stddev in normalised units
 
+def deblend_field_cutouts(net, field, starts, normalise=False, on_chunk=None):
+    """deblend(net, cutouts) for cutouts[i] = field[starts[i,0]:+size, starts[i,1]:+size, :] without materialising the
+    cutouts on the host: what DeblendField.deblend_field does with extract_cutouts followed by deblend
+    (deblend/field_deblender.py:260-274, extract/extraction.py:4-43, deblender.py:18) as ONE engine call - the float64
+    field goes to the GPU once, every chunk's cutouts are gathered and cast to float32 there, only mean and stddev come
+    back.  Same numbers, bit for bit, as deblend(net, field cutouts) with the same noise seed.
+
+    parameters:
+        field: (F, F, bands) float array;  starts: (N, 2) integer top-left corners, windows inside the field
+        on_chunk: None, or a function (first, mean, stddev) that consumes the results chunk by chunk (max_batch stamps,
+            float32 views of the transfer buffers, valid during the call) instead of two N-stamp arrays - BASELINE
+            configs[4]'s million cutouts are 167 GB of mean and stddev; then the function returns None
+    returns (mean ndarray (N,size,size,bands), distribution)
+    """
+    from debvader_amd.distributions import Normal
+
+    eng, core = net._core.engine, net._core
+    eng.set_normalise(bool(normalise))
+    try:
+        if on_chunk is not None:
+            eng.infer_cutouts_stream(field, starts, on_chunk, seed=core.next_seed())
+            return None
+        r = eng.infer_cutouts(field, starts, seed=core.next_seed(), want=("loc", "scale"))
+    finally:
+        eng.set_normalise(False)
+    out = Normal(r["loc"], r["scale"])
+    return out.mean().numpy(), out
+
+
 def deblend_sharded(net, images, normalise=False, dist=None, gather=True, rank=None, world=None):
     """deblend() over the GPUs of one node (BASELINE configs[4]): the reference calls the network ONCE on all N stamps
     (deblender.py:18, from field_deblender.py:265-274); stamps are independent, so rank r runs deblend() on the

@@ -361,6 +361,59 @@ class Engine:
                                _fp(bufs["mu"]), _fp(bufs["zstd"]), _fp(bufs["z"])))
         return {k: v for k, v in bufs.items() if v is not None}
 
+    def infer_cutouts(self, field, starts, seed=0, want=("loc", "scale"), out=None) -> Dict[str, np.ndarray]:
+        """infer() on the cutouts field[x:x+H, y:y+H, :] of a float64 field (F, F, bands) for every row (x, y) of `starts`,
+        gathered and cast on the GPU (dv_infer_cutouts): the stamps never visit the host.  Bit-identical to
+        infer(ctx.scene_extract(field, starts, H)) with the same seed."""
+        field = np.ascontiguousarray(field, dtype=np.float64)
+        starts = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, 2)
+        if field.ndim != 3 or field.shape[0] != field.shape[1]:
+            raise ValueError(f"expected a square field (F, F, bands), got {field.shape}")
+        N = starts.shape[0]
+        bufs = {}
+        for k in ("loc", "scale", "mu", "zstd", "z"):
+            shape = (N,) + self.stamp_shape if k in ("loc", "scale") else (N, self.latent)
+            if k not in want:
+                bufs[k] = None
+            elif out is not None and k in out:
+                if out[k].shape != shape or out[k].dtype != np.float32 or not out[k].flags.c_contiguous:
+                    raise ValueError(f"out[{k!r}] must be a C-contiguous float32 array of shape {shape}")
+                bufs[k] = out[k]
+            else:
+                bufs[k] = np.empty(shape, np.float32)
+        check(lib.dv_infer_cutouts(self._h, field.ctypes.data_as(C.POINTER(C.c_double)), field.shape[0], field.shape[2],
+                                   starts.ctypes.data_as(C.POINTER(C.c_int32)), N, int(seed), _fp(bufs["loc"]),
+                                   _fp(bufs["scale"]), _fp(bufs["mu"]), _fp(bufs["zstd"]), _fp(bufs["z"])))
+        return {k: v for k, v in bufs.items() if v is not None}
+
+    def infer_cutouts_stream(self, field, starts, consumer, seed=0):
+        """infer_cutouts() for inputs whose outputs do not belong on one host (a million cutouts: 167 GB): every finished
+        chunk is handed to consumer(first, mean, stddev) - float32 views (count, H, H, bands) of the pinned transfer
+        buffers, valid until the consumer returns, stamps [first, first + count) in input order.  Nothing is copied on
+        the host; the GPU works on the next chunks meanwhile."""
+        field = np.ascontiguousarray(field, dtype=np.float64)
+        starts = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, 2)
+        if field.ndim != 3 or field.shape[0] != field.shape[1]:
+            raise ValueError(f"expected a square field (F, F, bands), got {field.shape}")
+        failure = []
+
+        def trampoline(_user, first, count, mean_p, std_p):
+            try:
+                shape = (int(count),) + self.stamp_shape
+                consumer(int(first), np.ctypeslib.as_array(mean_p, shape=shape), np.ctypeslib.as_array(std_p, shape=shape))
+                return 0
+            except BaseException as e:          # never let an exception cross the C frames
+                failure.append(e)
+                return 1
+
+        cb = _lib.CHUNK_FN(trampoline)
+        rc = lib.dv_infer_cutouts_stream(self._h, field.ctypes.data_as(C.POINTER(C.c_double)), field.shape[0],
+                                         field.shape[2], starts.ctypes.data_as(C.POINTER(C.c_int32)), starts.shape[0],
+                                         int(seed), C.cast(cb, C.c_void_p), None)
+        if failure:
+            raise failure[0]
+        check(rc)
+
     def infer_mc(self, x, nsamples=100, seed=0):
         """(mean, std) over `nsamples` stochastic decodes of every stamp (encoder runs once per stamp)."""
         x = _f32c(x)

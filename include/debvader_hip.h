@@ -179,6 +179,26 @@ int dv_infer(dv_model* m, const float* x, int64_t N, const float* eps, uint64_t 
  * library stages the array */
 int dv_infer_f64(dv_model* m, const double* x, int64_t N, const float* eps, uint64_t seed, float* loc, float* scale,
              float* mu, float* zstd, float* z);
+/* deblend() on cutouts of a field without the host round trip: out = net(float32(field[x:x+H, y:y+H, :])) for every
+ * start (x, y), H = the network's stamp size.  Replaces the pair extract_cutouts(field, ...) -> deblend(net, cutouts)
+ * of DeblendField.deblend_field (deblend/field_deblender.py:260-274 with extract/extraction.py:4-43 and
+ * deblend_cutout/deblender.py:18): the float64 field is uploaded once, each chunk's cutouts are gathered and cast on the
+ * GPU straight into the network's input buffer, and only mean / stddev travel back.  Results are bit-identical to
+ * dv_infer_f64 on the cutouts dv_scene_extract returns (same cast, same kernels, same noise numbering).  Every window
+ * must lie inside the field (DV_E_INVALID otherwise); engine-drawn noise only. */
+int dv_infer_cutouts(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
+                     uint64_t seed, float* loc, float* scale, float* mu, float* zstd, float* z);
+
+/* The same, streaming: instead of filling N-stamp result arrays (167 KB per stamp - a million cutouts do not belong on one
+ * host) the library hands every finished chunk to `consumer(user, first, count, mean, stddev)`, stamps
+ * [first, first + count) in input order, `mean` / `stddev` pointing into the pinned transfer ring (valid until the
+ * consumer returns; nothing is copied on the host).  The consumer runs on the calling thread while the GPU works on the
+ * next chunks; a non-zero return value stops the call (DV_E_STATE).  Chunks are max_batch stamps (BASELINE configs[4]:
+ * 8192). */
+typedef int (*dv_chunk_fn)(void* user, int64_t first, int32_t count, const float* mean, const float* stddev);
+int dv_infer_cutouts_stream(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
+                            uint64_t seed, dv_chunk_fn consumer, void* user);
+
 /* Monte-Carlo epistemic uncertainty: encode each stamp once, decode it `nsamples` times with fresh eps, return the
  * mean and the standard deviation (ddof 0) of the predicted means over the samples.  Replaces the per-object loop
  * `np.std(deblend(net, [stamp]*100)[0], axis=0)` of deblend/field_deblender.py:303-313. */

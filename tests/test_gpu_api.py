@@ -519,3 +519,51 @@ def test_tiny_inference_calls_slice_k_and_match_the_same_stamps_in_a_large_call(
             err = np.abs(tiny[k] - big[k][:n]).max() / (np.abs(big[k][:n]).max() + 1e-30)
             assert err <= 2e-5, (n, k, err)
     eng.close()
+
+
+def test_deblend_field_cutouts_equals_extract_then_deblend_bit_for_bit():
+    """DeblendField's extract_cutouts -> deblend pair (field_deblender.py:260-274) as one engine call with the gather and
+    the float32 cast on the GPU (dv_infer_cutouts): same cast, same kernels, same noise numbering - identical results,
+    on both sides of the pipelined path's size threshold and for a tiny call; windows leaving the field are refused."""
+    from debvader_amd._lib import DvError
+    from debvader_amd.deblend_cutout.deblender import deblend, deblend_field_cutouts
+    from debvader_amd.model import model
+
+    net, _, _, _ = model.create_model_vae(**ARCH, max_batch=128, seed=3)
+    ctx = net._core.ctx
+    rng = np.random.default_rng(17)
+    F = 300
+    field = rng.normal(0, 0.4, size=(F, F, 6))
+    for n in (5, 200, 128 * 3 + 11):
+        starts = rng.integers(0, F - 59 + 1, size=(n, 2)).astype(np.int32)
+        cut = ctx.scene_extract(field, starts, 59)
+        np.testing.assert_array_equal(cut[0], field[starts[0, 0]:starts[0, 0] + 59, starts[0, 1]:starts[0, 1] + 59])
+        net._core.seed_counter = 500
+        m0, d0 = deblend(net, cut)
+        net._core.seed_counter = 500
+        m1, d1 = deblend_field_cutouts(net, field, starts)
+        np.testing.assert_array_equal(m1, m0)
+        np.testing.assert_array_equal(d1.stddev().numpy(), d0.stddev().numpy())
+    with pytest.raises(DvError):
+        deblend_field_cutouts(net, field, np.array([[F - 58, 0]], np.int32))
+    # streaming consumer: the same numbers chunk by chunk, in order, nothing copied by the library
+    got_m, got_s, firsts = [], [], []
+
+    def consume(first, mean, std):
+        firsts.append(first)
+        got_m.append(mean.copy())
+        got_s.append(std.copy())
+
+    net._core.seed_counter = 500
+    assert deblend_field_cutouts(net, field, starts, on_chunk=consume) is None
+    assert firsts == sorted(firsts) and firsts[0] == 0 and len(firsts) == 4
+    np.testing.assert_array_equal(np.concatenate(got_m), m0)
+    np.testing.assert_array_equal(np.concatenate(got_s), d0.stddev().numpy())
+
+    def broken(first, mean, std):
+        raise RuntimeError("consumer failed")
+
+    with pytest.raises(RuntimeError):
+        deblend_field_cutouts(net, field, starts, on_chunk=broken)
+    m2, _ = deblend_field_cutouts(net, field, starts[:3])          # the engine is usable afterwards
+    assert np.isfinite(m2).all()
