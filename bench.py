@@ -237,15 +237,15 @@ def secondary_entries(E, ctx, synthetic_stamps, quick: bool):
     # ---- BASELINE configs[4]: deblend() over cutouts of a field_img_2.npy-style scene, 8192 stamps per call ----
     from tools.field_cutouts import run as cutouts_run
 
-    _progress("secondary: deblend over field cutouts (fp32, then bf16)")
-    out["deblend_cutouts"] = cutouts_run(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=0)
-    out["deblend_cutouts_bf16"] = cutouts_run(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=1)
     # the same work as ONE engine call: gather + float32 cast on the GPU, results consumed chunk by chunk from the pinned
     # transfer ring (deblend_field_cutouts(on_chunk=...)); `python tools/field_cutouts.py --stream` runs the full million
     _progress("secondary: deblend_field_cutouts, streaming (fp32, then bf16)")
     out["deblend_field_cutouts_stream"] = cutouts_run(ctx, n_cutouts=65536 if quick else 262144, chunk=8192, dtype=0, stream=True)
     out["deblend_field_cutouts_stream_bf16"] = cutouts_run(ctx, n_cutouts=65536 if quick else 262144, chunk=8192, dtype=1,
                                                            stream=True)
+    _progress("secondary: deblend over field cutouts (fp32, then bf16)")
+    out["deblend_cutouts"] = cutouts_run(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=0)
+    out["deblend_cutouts_bf16"] = cutouts_run(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=1)
     # ---- BASELINE configs[3]: 128 x 128 x 6 stamps, six levels (per-GPU share of the global batch 512: 64) ----
     _progress("secondary: 128-pixel architecture")
     B3 = 64

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/debvader_hip.h"
+#include <chrono>
 #include "common.h"
 #include "bf16.h"
 
@@ -3279,18 +3280,26 @@ static int infer_cutouts_impl(dv_model* m, const double* field, int32_t F, int32
     set_error("dv_infer_cutouts: out of device memory for the field (%zu bytes)", fb);
     return DV_E_NOMEM;
   }
+  static const bool trace = getenv("DV_PIPE_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   int st = OK;
   if (hipMemcpyAsync(fdev, field, fb, hipMemcpyHostToDevice, s) != hipSuccess ||
       hipMemcpyAsync(sdev, starts, sb, hipMemcpyHostToDevice, s) != hipSuccess ||
       hipStreamSynchronize(s) != hipSuccess)      // the gather runs on the pipeline's copy stream
     st = E_HIP;
+  const double t_up = since();
   if (st == OK) {
     CutoutSrc cut{fdev, sdev, F, nb, cs};
     st = infer_pipelined(m, nullptr, false, N, nullptr, seed, loc, scale, mu, zstd, z, &cut, sink, sink_user);
   }
   (void)hipStreamSynchronize(s);
+  const double t_pipe = since();
   (void)hipFree(fdev);
   (void)hipFree(sdev);
+  if (trace)
+    fprintf(stderr, "cutouts call: field + starts upload %.1f ms, pipeline %.1f ms, free %.1f ms (%ld stamps)\n", t_up,
+            t_pipe - t_up, since() - t_pipe, (long)N);
   if (st != OK) return st;
   return prof_flush(m);
 }

@@ -567,3 +567,34 @@ def test_deblend_field_cutouts_equals_extract_then_deblend_bit_for_bit():
         deblend_field_cutouts(net, field, starts, on_chunk=broken)
     m2, _ = deblend_field_cutouts(net, field, starts[:3])          # the engine is usable afterwards
     assert np.isfinite(m2).all()
+
+
+def test_config0_plumbing_1000_stamps_batch_5_and_256():
+    """BASELINE configs[0] / SURVEY 8(d) "Config 1 (plumbing)": 1000 synthetic stamps of the survey's generator, latent 32,
+    one epoch of net.fit at the reference's default batch 5 (train.py:88) and at 256, through the same surface
+    train_network uses (train.py:27-37).  Step counts, History keys and the ELBO of the trained weights against the
+    oracle (same weights, same eps) are checked; the oracle's CPU run of this configuration is bench.py's cpu_baseline."""
+    from debvader_amd.model import model
+    from debvader_amd.training.metrics import vae_loss
+    from oracle import vae_oracle as vo
+
+    x, y = _data(1000, 0)
+    xv, yv = _data(64, 7)
+    for batch, steps in ((5, 200), (256, 4)):
+        net, _, _, _ = model.create_model_vae(**ARCH, max_batch=256, seed=11)
+        net.compile(optimizer=model.Adam(learning_rate=1e-4), loss=vae_loss, metrics=["mse"])
+        hist = net.fit(x, y, epochs=1, batch_size=batch, verbose=0, shuffle=True, validation_data=(xv, yv))
+        eng = net._core.engine
+        assert eng.iterations == steps                      # 1000 / 256: three full batches and one of 232
+        assert sorted(hist.history) == ["loss", "mse", "val_loss", "val_mse"]
+        assert all(len(v) == 1 and np.isfinite(v).all() for v in hist.history.values())
+        # the trained weights, evaluated by the engine and by the oracle on the same 5 stamps with the same noise
+        p = {k: v.astype(np.float64) for k, v in eng.get_params().items()}
+        eps = np.random.default_rng(3).normal(size=(5, 32)).astype(np.float32)
+        eng.upload(1, x[:5], y[:5])
+        out = eng.eval_step(1, first=0, B=5, eps=eps)
+        arch = vo.Arch()
+        c = vo.forward(arch, p, x[:5].astype(np.float64), eps.astype(np.float64), training=False)
+        r = vo.losses(arch, c, y[:5].astype(np.float64))
+        for k in ("loss", "nll_mean", "kl_reg"):
+            assert abs(out[k] - r[k]) <= 1e-4 * abs(r[k]) + 1e-7, (batch, k, out[k], r[k])
