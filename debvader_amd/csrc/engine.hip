@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/debvader_hip.h"
+#include "../../include/debvader_hip_debug.h"
 #include <chrono>
 #include "common.h"
 #include "bf16.h"

@@ -11,9 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "debvader_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(dv_[a-z0-9_]+)\s*\(", txt)))
+    """every function include/*.h declares: the drop-in boundary (debvader_hip.h) and the development entry points the
+    tools use (debvader_hip_debug.h)"""
+    names = set()
+    for header in ("debvader_hip.h", "debvader_hip_debug.h"):
+        txt = open(os.path.join(ROOT, "include", header)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(dv_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
