@@ -259,7 +259,12 @@ int launch_bwgrad(const BWgradParams& p, hipStream_t s, int* nsplit_out) {
     set_error("bwgrad: slab workspace too small");
     return E_STATE;
   }
-  int nrseg = (int)std::min<long>(p.Hy, copies / gm.nsc4);
+  // ... and no more row segments than fill the chip once: a workgroup's fixed costs (window fill, the LDS reduction of
+  // its four waves, a 9 x 32 x 32 slab written and reduced again) are paid per segment
+  static const long want_wgs = getenv("DV_BWGRAD_WGS") ? atol(getenv("DV_BWGRAD_WGS")) : 256;
+  const long per_seg = (long)gm.nsc4 * gm.ntx * gm.nty;
+  long nseg_want = std::max<long>(1, (want_wgs + per_seg - 1) / per_seg);
+  int nrseg = (int)std::min<long>(std::min<long>(p.Hy, copies / gm.nsc4), nseg_want);
   gm.rows_per = (p.Hy + nrseg - 1) / nrseg;
   gm.nrseg = (p.Hy + gm.rows_per - 1) / gm.rows_per;
   if (nsplit_out) *nsplit_out = gm.nrseg * gm.nsc4;
