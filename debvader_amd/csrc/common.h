@@ -232,6 +232,19 @@ bool wgrad_strip_supported(int Cx, int Cy, int sx, int ntaps);
 int launch_wgrad_strip(const WStripParams& p, int Cx, int Cy, int sx, hipStream_t s, int* nsplit_out);
 
 // out[(r/Cpad)*Creal + r%Cpad][c] = scale * sum_s part[s][r][c]   for r%Cpad < Creal
+// the slab reductions of a whole backward pass in one launch: entry i sums nsplit slabs of slab4 float4 elements
+// ([rows][ncols4] each) into out, rows compacted from cpad to creal channels like launch_reduce_partials
+#define DV_WRED_MAX 24
+struct WRedEntry {
+  const float* part;
+  float* out;
+  int nsplit, slab4, ncols4, cpad, creal;
+};
+struct WRedBatch {
+  WRedEntry e[DV_WRED_MAX];
+  int count;
+};
+int launch_reduce_partials_batch(const WRedBatch& b, hipStream_t s);
 int launch_reduce_partials(const float* part, float* out, int nsplit, long slab_elems, int ncols, int cpad,
                            int creal, hipStream_t s);
 

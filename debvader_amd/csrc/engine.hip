@@ -354,8 +354,10 @@ struct BfState {
   std::vector<void*> gpool;      // one activation-gradient buffer per data-gradient launch of a step (bf16): the
                                  // weight gradients run on the aux stream and nothing ever waits for a buffer
   dv::BRedBatch red;             // fused-epilogue partials of the backward pass being queued (summed in two launches)
-  float* slab = nullptr;         // weight-gradient partial slabs (aux stream)
+  float* slab = nullptr;         // weight-gradient partial slabs (aux stream): a per-pass pool, every launch its region
   size_t slab_elems = 0;
+  size_t slab_off = 0;
+  dv::WRedBatch wred;            // their reductions, all in one launch at the end of the pass (bf_flush_wred)
   std::vector<BfW> enc_w, dec_w;
   BfW head_w;
   std::vector<dv::BCastDesc> descs;

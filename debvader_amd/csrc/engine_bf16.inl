@@ -59,9 +59,11 @@ static int bf_alloc(dv_model* m) {
   DV_TRY(balloc((void**)&bf.flat_in, (size_t)m->Bc * A.flat * 4));
   bf.gpool.resize(4 * A.L + 4);
   for (auto& g : bf.gpool) DV_TRY(balloc(&g, max_e * Bp * 2));
-  bf.slab_elems = (size_t)8 << 20;
+  // slab pool of one backward pass: ~9.4 MB per launch with the launcher's 256-workgroup rule (bwgrad.hip), 17 launches
+  // for the 59-pixel net; a pass that needs more flushes its reductions early (bf_flush_wred) and starts over
+  bf.slab_elems = (size_t)64 << 20;
   for (auto& sp : A.specs)
-    if (sp.ndim == 4) bf.slab_elems = std::max(bf.slab_elems, sp.count * 4);
+    if (sp.ndim == 4) bf.slab_elems = std::max(bf.slab_elems, sp.count * 8);
   DV_TRY(balloc((void**)&bf.slab, bf.slab_elems * 4));
 
   // bf16 weight matrices and the descriptors the cast kernel walks
@@ -247,12 +249,32 @@ static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int firs
 static hipStream_t bf_wstream(dv_model* m) {
   return (m->overlap_wgrad && !m->prof_on && m->ctx->aux_stream) ? m->ctx->aux_stream : m->ctx->stream;
 }
+// queues the reductions registered so far (one launch) on the weight-gradient stream and empties the slab pool
+static int bf_flush_wred(dv_model* m) {
+  BfState& bf = m->bf;
+  if (bf.wred.count > 0) {
+    hipStream_t st = bf_wstream(m);
+    ProfScope ps(m, 2, st);
+    DV_TRY(launch_reduce_partials_batch(bf.wred, st));
+  }
+  bf.wred.count = 0;
+  bf.slab_off = 0;
+  return OK;
+}
+
+// weight gradient of one layer: partial slabs into this launch's region of the pool; the fixed-order sum over the slabs
+// is registered and runs with all the others of the pass in one launch (17 five-microsecond reductions otherwise sit
+// between the weight-gradient kernels of the aux stream, which is the tail of the step)
 static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, int Hy, int Cy, int s, int pb, float* out,
                     int cpad, int creal) {
+  BfState& bf = m->bf;
+  const size_t slab = (size_t)9 * Cx * Cy;
+  if (bf.wred.count >= DV_WRED_MAX || bf.slab_off + 4 * ((size_t)(bf.NBp + 63) / 64) * slab > bf.slab_elems)
+    DV_TRY(bf_flush_wred(m));
   BWgradParams p;
   memset(&p, 0, sizeof p);
-  p.X = X; p.Y = Y; p.zero = m->bf.zero; p.part = m->bf.slab; p.part_capacity = m->bf.slab_elems;
-  p.Hx = Hx; p.Cx = Cx; p.Hy = Hy; p.Cy = Cy; p.NBp = m->bf.NBp; p.s = s; p.pb = pb;
+  p.X = X; p.Y = Y; p.zero = bf.zero; p.part = bf.slab + bf.slab_off; p.part_capacity = bf.slab_elems - bf.slab_off;
+  p.Hx = Hx; p.Cx = Cx; p.Hy = Hy; p.Cy = Cy; p.NBp = bf.NBp; p.s = s; p.pb = pb;
   int ns = 0;
   hipStream_t st = bf_wstream(m);
   if (st != m->ctx->stream) {
@@ -260,12 +282,18 @@ static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, i
     DV_HIP(hipStreamWaitEvent(st, m->ctx->ev_ready, 0));
   }
   {
-    const double cx_alg = X == m->bf.xh ? m->A.C : Cx, cy_alg = out == m->Ghs ? 2 * m->A.C : Cy;
-    ProfScope ps(m, 1, st, PF_BWGRAD, 2.0 * m->bf.NBp * (double)Hy * Hy * 9.0 * cx_alg * cy_alg);
+    const double cx_alg = X == bf.xh ? m->A.C : Cx, cy_alg = out == m->Ghs ? 2 * m->A.C : Cy;
+    ProfScope ps(m, 1, st, PF_BWGRAD, 2.0 * bf.NBp * (double)Hy * Hy * 9.0 * cx_alg * cy_alg);
     DV_TRY(launch_bwgrad(p, st, &ns));
   }
-  ProfScope ps(m, 2, st);
-  return launch_reduce_partials(m->bf.slab, out, ns, 9L * Cx * Cy, Cy, cpad, creal, st);
+  if ((slab & 3) || (Cy & 3)) {
+    set_error("bf_wgrad: slab sizes must be multiples of 4 floats");
+    return E_INVALID;
+  }
+  WRedEntry& e = bf.wred.e[bf.wred.count++];
+  e.part = p.part; e.out = out; e.nsplit = ns; e.slab4 = (int)(slab / 4); e.ncols4 = Cy / 4; e.cpad = cpad; e.creal = creal;
+  bf.slab_off += (((size_t)ns * slab + 63) / 64) * 64;
+  return OK;
 }
 
 // data gradient into `out` with the PReLU backward of the target layer (pre-activation u, slopes / bias specs) applied:
@@ -328,6 +356,8 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   m->wstream = s;
   m->arena_off = 0;
   bf.red.count = 0;
+  bf.wred.count = 0;
+  bf.slab_off = 0;
   m->ws_count = 0;
   m->main_marked = false;
   const int Hd = A.dec_out, f0 = A.cfg.filters[0], C2 = 2 * A.C;
@@ -338,11 +368,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   hipStream_t ws = bf_wstream(m);
   // ---- head conv ----
   if (dg) {
-    DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, 1, 1, m->Ghs, f0, f0));
-    {
-      ProfScope ps(m, 2, ws);
-      DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, ws));
-    }
+    DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, 1, 1, m->Ghs, f0, f0));   // (columns taken at the end)
     ProfScope ps(m, 2, s);
     int nr = 0;
     DV_TRY(launch_bf_colsum(bf.dt, (long)Hd * Hd * bf.NBp, 16, m->ws3, &nr, s));
@@ -429,7 +455,10 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       // first conv with the folded input BatchNorm: the gradient w.r.t. the 16-channel folded kernel (channels
       // 0..C-1 = bands, C = the constant one) yields d(kernel), d(gamma), d(beta); no data gradient
       DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8));
+      // every slab reduction of the pass, then what reads the two scratch gradients (padded head kernel, folded first conv)
+      DV_TRY(bf_flush_wred(m));
       ProfScope ps(m, 2, ws);
+      if (dg) DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, ws));
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
                                    G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, 9, A.C, 8, cout,
                                    ws));

@@ -302,6 +302,69 @@ __global__ __launch_bounds__(256) void reduce_partials_scalar_kernel(const float
   out[e] = (a0 + a1) + (a2 + a3);
 }
 
+// All slab reductions of a backward pass in one launch (grid.y = entry): the same two fixed-order strategies as above,
+// chosen per entry (many small slabs: 16 split lanes per column group; few large ones: one thread per float4 column).
+__global__ __launch_bounds__(256) void reduce_partials_batch_kernel(const WRedBatch b) {
+  __shared__ f32x4 sh[16][17];
+  const WRedEntry d = b.e[blockIdx.y];
+  const f32x4* part = reinterpret_cast<const f32x4*>(d.part);
+  f32x4* out = reinterpret_cast<f32x4*>(d.out);
+  if (d.nsplit >= 16) {
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    for (int e0 = blockIdx.x * 16; e0 < d.slab4; e0 += gridDim.x * 16) {      // (uniform trip count per block)
+      const int e = e0 + cl;
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+      if (e < d.slab4) {
+        const f32x4* p = part + e;
+        int s = sl;
+        for (; s + 48 < d.nsplit; s += 64) {
+          a0 += p[(size_t)(s + 0) * d.slab4];
+          a1 += p[(size_t)(s + 16) * d.slab4];
+          a2 += p[(size_t)(s + 32) * d.slab4];
+          a3 += p[(size_t)(s + 48) * d.slab4];
+        }
+        for (; s < d.nsplit; s += 16) a0 += p[(size_t)s * d.slab4];
+      }
+      __syncthreads();
+      sh[sl][cl] = (a0 + a1) + (a2 + a3);
+      __syncthreads();
+      if (sl == 0 && e < d.slab4) {
+        f32x4 v = sh[0][cl];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v += sh[k][cl];
+        const int r = e / d.ncols4, c4 = e - r * d.ncols4, ci = r % d.cpad;
+        if (ci < d.creal) out[(size_t)((r / d.cpad) * d.creal + ci) * d.ncols4 + c4] = v;
+      }
+    }
+    return;
+  }
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < d.slab4; e += gridDim.x * 256) {
+    const int r = e / d.ncols4, c4 = e - r * d.ncols4, ci = r % d.cpad;
+    if (ci >= d.creal) continue;
+    const f32x4* p = part + e;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    int s = 0;
+    for (; s + 4 <= d.nsplit; s += 4) {
+      a0 += p[(size_t)(s + 0) * d.slab4];
+      a1 += p[(size_t)(s + 1) * d.slab4];
+      a2 += p[(size_t)(s + 2) * d.slab4];
+      a3 += p[(size_t)(s + 3) * d.slab4];
+    }
+    for (; s < d.nsplit; ++s) a0 += p[(size_t)s * d.slab4];
+    out[(size_t)((r / d.cpad) * d.creal + ci) * d.ncols4 + c4] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+int launch_reduce_partials_batch(const WRedBatch& b, hipStream_t s) {
+  if (b.count <= 0) return OK;
+  if (b.count > DV_WRED_MAX) return E_INVALID;
+  for (int i = 0; i < b.count; ++i)
+    if (b.e[i].slab4 <= 0 || b.e[i].ncols4 <= 0 || b.e[i].cpad < b.e[i].creal || b.e[i].nsplit < 1) return E_INVALID;
+  hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3(128, (unsigned)b.count), dim3(256), 0, s, b);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
 int launch_reduce_partials(const float* part, float* out, int nsplit, long slab_elems, int ncols, int cpad, int creal,
                            hipStream_t s) {
   if (slab_elems <= 0) return OK;
