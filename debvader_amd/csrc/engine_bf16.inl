@@ -366,6 +366,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   void* cur = next_buf();
   void* oth = nullptr;
   hipStream_t ws = bf_wstream(m);
+  bool head_cols_taken = false, dec_bucket_done = false;
   // ---- head conv ----
   if (dg) {
     DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, 1, 1, m->Ghs, f0, f0));   // (columns taken at the end)
@@ -416,6 +417,44 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
                      A.d, 1, 0, true));
   std::swap(c32, o32);
   DV_TRY(prelu_bwd(m, c32, m->z, A.D0, -1, NB, A.d, A.d, dg));
+  // Every decoder gradient has been queued and no later kernel of the step reads a decoder parameter: finish the
+  // decoder's reductions now (slab sums and d(alpha) / d(bias) partials, one launch each, on the weight-gradient
+  // stream), all-reduce the bucket on the comm stream while the encoder backward runs and - early_adam - update it there
+  // (18.3 of the 33.3 MB; SURVEY 8(e): buckets in reverse layer order).
+  {
+    dv_ctx* cx = m->ctx;
+    const bool ovl = ws != s;
+    const bool early = m->early_adam && ovl;
+    if ((cx->comm || early) && dg && A.n_train > A.n_enc_train) {
+      if (ovl) {                                         // the partials of the fused epilogues come from the main stream
+        DV_HIP(hipEventRecord(cx->ev_ready, s));
+        DV_HIP(hipStreamWaitEvent(ws, cx->ev_ready, 0));
+      }
+      DV_TRY(bf_flush_wred(m));
+      {
+        ProfScope ps(m, 2, ws);
+        DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, ws));
+        DV_TRY(launch_bf_reduce_batch(bf.red, ws));
+      }
+      bf.red.count = 0;
+      head_cols_taken = true;
+      DV_HIP(hipEventRecord(cx->ev_dec, s));             // the main stream has finished reading decoder parameters
+      DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_dec, 0));
+      if (ovl) {
+        DV_HIP(hipEventRecord(cx->ev_join, ws));
+        DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_join, 0));
+      }
+      if (cx->comm)
+        DV_NCCL(ncclAllReduce(G + A.n_enc_train, G + A.n_enc_train, A.n_train - A.n_enc_train, ncclFloat, ncclSum, cx->comm,
+                              cx->comm_stream));
+      if (early && m->opt_dec) {
+        DV_TRY(adam_range(m, A.n_enc_train, A.n_train, cx->comm_stream));
+        DV_TRY(refresh_head_pad(m, cx->comm_stream));
+        m->adam_done_from = A.n_enc_train;
+      }
+      dec_bucket_done = true;
+    }
+  }
   const float kls = (float)((double)A.cfg.kl_multiplicity * A.cfg.kl_weight / ((double)Bg * (double)Bg));
   {
     ProfScope ps(m, 2);
@@ -458,7 +497,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       // every slab reduction of the pass, then what reads the two scratch gradients (padded head kernel, folded first conv)
       DV_TRY(bf_flush_wred(m));
       ProfScope ps(m, 2, ws);
-      if (dg) DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, ws));
+      if (dg && !head_cols_taken) DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, ws));
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
                                    G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, 9, A.C, 8, cout,
                                    ws));
@@ -478,15 +517,9 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     DV_HIP(hipEventRecord(m->ctx->ev_join, ws));
     DV_HIP(hipStreamWaitEvent(s, m->ctx->ev_join, 0));
   }
+  // data parallelism: the decoder bucket went out above; the encoder bucket [0, n_enc_train) is all-reduced by
+  // enqueue_step behind this pass (with a frozen decoder it is the only one)
+  (void)dec_bucket_done;
   m->enc_reduced_from = A.n_enc_train;
-  // data parallelism: one all-reduce of the whole gradient (the step is ~1 ms; bucketing it buys little)
-  if (m->ctx->comm) {
-    dv_ctx* cx = m->ctx;
-    DV_HIP(hipEventRecord(cx->ev_dec, s));
-    DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_dec, 0));
-    const size_t n = dg ? A.n_train : A.n_enc_train;
-    DV_NCCL(ncclAllReduce(G, G, n, ncclFloat, ncclSum, cx->comm, cx->comm_stream));
-    m->enc_reduced_from = 0;
-  }
   return OK;
 }

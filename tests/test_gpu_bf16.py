@@ -269,3 +269,38 @@ def test_bf16_gradients_are_bit_reproducible_at_full_batch():
         assert out == ref[0], rep
         for name, g in grads.items():
             assert np.array_equal(g, ref[1][name]), (rep, name)
+
+
+def test_bf16_decoder_bucket_on_the_comm_stream_changes_no_bit():
+    """The bf16 backward finishes the decoder's reductions at the decoder / encoder boundary, all-reduces that bucket on
+    the comm stream while the encoder is differentiated and (early Adam) updates it there; the encoder bucket follows at
+    the end.  DV_FORCE_COMM=1 runs this with a 1-rank RCCL communicator on one GPU, DV_NO_EARLY_ADAM=1 and DV_NO_OVERLAP=1
+    take the single-stream orders: all four must produce bit-identical parameters after three steps."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from debvader_amd import engine as E
+from debvader_amd.data import synthetic_stamps
+x, y = synthetic_stamps(128, seed=3)
+eng = E.Engine(E.make_config(max_batch=64, dtype=1))
+eng.init(seed=4); eng.optimizer_reset(1e-4); eng.upload(0, x, y)
+out = eng.train_steps(0, 0, 64, 3, seed=7)
+names = ("dec/convt5/kernel", "dec/head/kernel", "dec/prelut3/alpha", "dec/convt0/bias", "dec/dense1/kernel",
+         "enc/conv0/kernel", "enc/conv5/kernel", "enc/dense/kernel", "enc/bn/gamma")
+print(repr(out["loss"]), " ".join(repr(float(np.abs(eng.get_param(n).astype(np.float64)).sum())) for n in names))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ({}, {"DV_FORCE_COMM": "1"}, {"DV_NO_EARLY_ADAM": "1"}, {"DV_NO_OVERLAP": "1"}):
+        env = dict(os.environ)
+        for k in ("DV_FORCE_COMM", "DV_NO_EARLY_ADAM", "DV_NO_OVERLAP"):
+            env.pop(k, None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code % root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2] == outs[3], outs
