@@ -276,6 +276,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="stamps per GPU per step")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32: BASELINE configs[1] (the headline, reference precision); bf16: BASELINE configs[2] - the same "
+                         "step on the bf16 engine, e.g. `--gpus 8 --dtype bf16` for its 8-GPU data-parallel form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -315,7 +318,8 @@ def main():
     ctx = parallel.make_context(rank, world, local_rank, dist)
 
     B = args.batch
-    cfg = E.make_config(max_batch=B)
+    bf16 = args.dtype == "bf16"
+    cfg = E.make_config(max_batch=B, dtype=1) if bf16 else E.make_config(max_batch=B)
     eng = E.Engine(cfg, ctx)
     eng.init(seed=0)                                     # same weights on every rank
     pool = 4 * B                                         # per-rank shard of the synthetic set, resident in HBM
@@ -354,7 +358,7 @@ def main():
         # HIP-event timing per kernel family on the stream each launch is queued on, over K steps of the same workload,
         # with the engine's streams SERIALISED (a separate pass: the records would perturb `value`, and overlapped
         # kernels cannot be told apart by events)
-        rows, classes = _family_table(eng, B, args.steps, FP32_MFMA_PEAK_TFLOPS, 200)
+        rows, classes = _family_table(eng, B, args.steps, BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS, 200)
         pmc, src = _pmc_traffic()
         per_kernel = (pmc or {}).get("per_kernel_bytes", {})
         dom = max(rows, key=lambda r: r["ms_per_step"]) if rows else None
@@ -366,23 +370,38 @@ def main():
         if dom is not None:
             # HBM bytes of the same launches (one step's launches of the dominant kernel), from the PMC passes
             traffic = (per_kernel.get(dom["kernel"].split(" ")[0]) or {}).get("hbm_bytes")
-        roofline = {
-            "bound": "mfma", "kernel": dom["kernel"] if dom else None,
-            "achieved": dom["tflops"] if dom else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom["frac"] if dom else None, "traffic": traffic,
-            "traffic_source": {"file": src, "commit": _git_head(),
-                               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed; not "
-                                       "re-measured in this run"} if src else None,
-            "mode": "streams serialised (the per-kernel rows); `value` is measured with the streams overlapped",
-            "launch": (f"one training step's launches of {dom['kernel']} ({dom['launches_per_step']:.0f} launches, "
-                       f"batch {B})") if dom else None,
-            "kernels": rows,
-            "gather_gemm_family": {"ms_per_step": conv_ms, "flops_per_step": conv_fl, "tflops": conv_tf,
-                                   "frac": conv_tf / FP32_MFMA_PEAK_TFLOPS},
-            "classes_ms_per_step": classes,
-            "whole_step_tflops": train_flops * B / (dt / args.steps) / 1e12,
-            "whole_step_frac": train_flops * B / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-        }
+        if bf16:
+            alg_bytes = ACT_ELEMS_PER_STAMP * 2 * TRAIN_PASSES * B + PARAM_STEP_BYTES
+            ms_step = dt / args.steps * 1e3
+            roofline = {
+                "bound": "hbm", "kernel": dom["kernel"] if dom else None,
+                "achieved": alg_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": (pmc or {}).get("bf16_per_step_bytes", {}).get("total"),
+                "traffic_source": src if (pmc or {}).get("bf16_per_step_bytes") else None,
+                "launch": "one training step per GPU (all launches), algorithmic bytes 8.36 MB per stamp + 5 x 33.3 MB",
+                "mode": "streams serialised (the per-kernel rows); `value` is measured with the streams overlapped",
+                "kernels": rows, "classes_ms_per_step": classes,
+                "mfma_whole_step_tflops": train_flops * B / (dt / args.steps) / 1e12,
+            }
+        else:
+            roofline = {
+                "bound": "mfma", "kernel": dom["kernel"] if dom else None,
+                "achieved": dom["tflops"] if dom else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": dom["frac"] if dom else None, "traffic": traffic,
+                "traffic_source": {"file": src, "commit": _git_head(),
+                                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed; not "
+                                           "re-measured in this run"} if src else None,
+                "mode": "streams serialised (the per-kernel rows); `value` is measured with the streams overlapped",
+                "launch": (f"one training step's launches of {dom['kernel']} ({dom['launches_per_step']:.0f} launches, "
+                           f"batch {B})") if dom else None,
+                "kernels": rows,
+                "gather_gemm_family": {"ms_per_step": conv_ms, "flops_per_step": conv_fl, "tflops": conv_tf,
+                                       "frac": conv_tf / FP32_MFMA_PEAK_TFLOPS},
+                "classes_ms_per_step": classes,
+                "whole_step_tflops": train_flops * B / (dt / args.steps) / 1e12,
+                "whole_step_frac": train_flops * B / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            }
     last_loss = scal["loss"]
     eng.close()
 
@@ -412,9 +431,11 @@ def main():
             "metric": "galaxy stamps/sec (train fwd+bwd+Adam) 59x59x6",
             "value": value, "unit": "stamps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 6-band 59x59 stamps, batch=256 per GPU, latent_dim=32, "
-                                   "filters [32,64,128,256], fp32, stage-1 VAE train step",
+            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[2]: same model and step, bf16 storage + bf16 MFMA operands, fp32 "
+                                    "accumulation / master weights / head, batch=256 per GPU" if bf16 else
+                                    "BASELINE configs[1]: 6-band 59x59 stamps, batch=256 per GPU, latent_dim=32, "
+                                    "filters [32,64,128,256], fp32, stage-1 VAE train step"),
                        "global_batch": Bg, "per_gpu_batch": B, "parallelism": f"dp{world}"},
             "last_loss": last_loss,
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
