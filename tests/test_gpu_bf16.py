@@ -304,3 +304,32 @@ print(repr(out["loss"]), " ".join(repr(float(np.abs(eng.get_param(n).astype(np.f
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] == outs[2] == outs[3], outs
+
+
+def test_python_surface_with_the_bf16_engine(tmp_path):
+    """create_model_vae(..., dtype="bf16") behind the reference's call surface (train.py:27-37,118-130,
+    deblender.py:6-24): compile / fit with validation / History, deblend on float64 stamps, TF-format checkpoint round trip
+    (the checkpoint holds the fp32 master weights, so an fp32 net can load what a bf16 net saved)."""
+    from debvader_amd.data import synthetic_stamps
+    from debvader_amd.deblend_cutout.deblender import deblend
+    from debvader_amd.model import model
+    from debvader_amd.training.metrics import vae_loss
+
+    arch = dict(input_shape=(59, 59, 6), latent_dim=32, filters=[32, 64, 128, 256], kernels=[3, 3, 3, 3])
+    net, enc, dec, z = model.create_model_vae(**arch, max_batch=64, dtype="bf16", seed=2)
+    net.compile(optimizer=model.Adam(learning_rate=1e-4), loss=vae_loss, metrics=["mse"])
+    x, y = synthetic_stamps(96, seed=1)
+    xv, yv = synthetic_stamps(20, seed=2)
+    hist = net.fit(x, y, epochs=2, batch_size=64, verbose=0, validation_data=(xv, yv))
+    assert sorted(hist.history) == ["loss", "mse", "val_loss", "val_mse"]
+    assert all(np.isfinite(v).all() and len(v) == 2 for v in hist.history.values())
+    mean, dist = deblend(net, x[:5].astype(np.float64))
+    assert mean.shape == (5, 59, 59, 6) and np.isfinite(mean).all() and dist.stddev().numpy().min() >= 1e-4 * (1 - 1e-6)
+    net.save_weights(str(tmp_path / "w" / "weights_noisy_v4.ckpt"))
+    ref, _, _, _ = model.create_model_vae(**arch, max_batch=64, seed=3)          # fp32 engine
+    ref.load_weights(model.latest_checkpoint(str(tmp_path / "w")))
+    for a, b in zip(net.get_weights(), ref.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    m32, _ = deblend(ref, x[:5])
+    t_bf, t_32 = enc(x[:5]).numpy(), ref.encoder(x[:5]).numpy()
+    assert np.abs(t_bf - t_32).max() <= 2e-2 * np.abs(t_32).max()              # the format's cost on the encoder output
