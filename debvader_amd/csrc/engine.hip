@@ -681,7 +681,7 @@ static int fuse_finish(dv_model* m, const GConv2Params& q, const FuseBwd* fz, lo
 static int gconv2_small_splitk(dv_model* m, GConv2Params& q, int NB, int Hout, int Cout, int nchunks, int epi,
                                const float* bias, const float* alpha, float* U, float* Aout, double flops) {
   static const bool off = getenv("DV_NO_SMALL_SPLITK") != nullptr;
-  if (off || !m->tiny_call || NB > 16 || q.nclass != 1 || !m->ws4 || m->prof_on || epi > 2) return 0;
+  if (off || !m->tiny_call || NB > 16 || q.nclass < 1 || !m->ws4 || m->prof_on || epi > 2) return 0;
   const long M = (long)NB * Hout * Hout;
   const long MN = M * Cout;
   const long tiles64 = ((M + 63) / 64) * (long)((Cout + 63) / 64);
@@ -845,7 +845,10 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
     }
   }
   static const bool no_s2f = getenv("DV_NO_S2F") != nullptr;
-  if (s == 2 && Cs % 32 == 0 && Ct % 4 == 0 && nmajor && !g_force_v1 && !no_s2f && !g_no_special && !(fz && !m->no_fuse)) {
+  // (tiny inference calls take the parity-class form below instead: it can slice K over workgroups, the fused kernel cannot)
+  const bool tiny_splitk = m->tiny_call && NB <= 16 && !fz && !getenv("DV_NO_SMALL_SPLITK");
+  if (s == 2 && Cs % 32 == 0 && Ct % 4 == 0 && nmajor && !g_force_v1 && !no_s2f && !g_no_special && !(fz && !m->no_fuse) &&
+      !tiny_splitk) {
     // all four parity classes in one workgroup (gconv_s2.hip)
     GConvS2Params q;
     memset(&q, 0, sizeof q);
@@ -907,8 +910,10 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
       c.ntaps = t.n; c.tapcode = t.tapcode; c.wtcode = t.wtcode;
     }
     q.nclass = k;
-    if (!fz && k == 1 && Cs % 32 == 0) {
-      const int r = gconv2_small_splitk(m, q, NB, Ht, Ct, q.cls[0].ntaps * (Cs / 32), epi, bias, alpha, U, Aout, flops);
+    if (!fz && k >= 1 && Cs % 32 == 0) {
+      int maxtaps = 0;                                 // (classes with fewer chunks write zero slabs for the rest)
+      for (int i = 0; i < k; ++i) maxtaps = std::max(maxtaps, q.cls[i].ntaps);
+      const int r = gconv2_small_splitk(m, q, NB, Ht, Ct, maxtaps * (Cs / 32), epi, bias, alpha, U, Aout, flops);
       if (r != 0) return r < 0 ? r : OK;
     }
     long db_rows = 0;

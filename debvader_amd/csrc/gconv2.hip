@@ -601,8 +601,8 @@ int launch_gconv2(const GConv2Params& p0, hipStream_t s) {
     set_error("gconv2: the fused PReLU-backward epilogue needs batch-major tiles, u, alpha and an output");
     return E_INVALID;
   }
-  if (p.ksplit > 1 && (p.nclass != 1 || p.epi != 0)) {
-    set_error("gconv2: split-K launches write raw partial slabs (one class, epi 0)");
+  if (p.ksplit > 1 && p.epi != 0) {
+    set_error("gconv2: split-K launches write raw partial slabs (epi 0)");
     return E_INVALID;
   }
   return p.w_nmajor ? dispatch2<true>(p, s) : dispatch2<false>(p, s);
