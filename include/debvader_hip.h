@@ -163,8 +163,8 @@ int dv_model_set_infer_graph(dv_model* m, int32_t on);
  * layer - the per-object calls of deblend (deblend_cutout/deblender.py:18, deblend/field_deblender.py:265-274).
  * fp32 engine only; same arithmetic up to the order of the K sums (agreement with the batched path <= 2e-5 of a
  * tensor's maximum).  Off by default: on MI355X a grid-wide barrier costs 8 us with one workgroup per CU (cross-XCD L2
- * write-back + invalidate) and the per-layer vector loops are latency-bound, 1.4 ms against 0.61 ms per one-stamp
- * call. */
+ * write-back + invalidate) and the per-layer vector loops are latency-bound, 1.4 ms per one-stamp call against 0.36 ms
+ * for the per-layer launches with K slicing. */
 int dv_model_set_small_forward(dv_model* m, int32_t max_stamps);
 
 /* Gradient / train steps also write the output distribution (loc, scale) of their forward pass, for
