@@ -490,11 +490,18 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
 // GT = 16-stamp groups per tile (16, 8 or 4: 256, 128 or 64 stamps per workgroup; a wave owns GW = GT/4 of them).  The
 // deep layers (16 x 16 pixels and below) have only a few hundred 256-stamp tiles, each walking 36-72 K steps at the
 // latency of its own three-stage ring; smaller stamp tiles put 4-8 independent pipelines on a CU.
-template <int NBLK, int CINMODE, int GT>
-__global__ __launch_bounds__(256, GT == 16 ? 2 : 4) void bconv_uni_kernel(const BConvParams p) {
+// CH = 32-channel chunks per K step.  With Cin >= 64 a row of an operand block is 64 bytes out of a >= 128-byte row
+// of the tensor, i.e. HALF of a 128-byte cache line per row: an LDS-DMA instruction then costs the L2 / Infinity Cache /
+// HBM path 16 line requests for 1 KiB of use, and measured operand bandwidth halves (tools/probes/dma_probe.hip:
+// 17 vs 33 TB/s out of L2, 4.2 vs 8.4 out of the Infinity Cache, 3.5 vs 7.0 out of HBM).  CH = 2 issues the two halves
+// of the same lines back to back (chunks 2i and 2i+1 of a tap), so the second request merges with the first in L1.
+template <int NBLK, int CINMODE, int GT, int CH = 1>
+__global__ __launch_bounds__(256, GT == 16 ? (CH == 1 ? 2 : 1) : (CH == 1 ? 4 : 2)) void bconv_uni_kernel(const BConvParams p) {
   constexpr int GW = GT / 4;                              // groups per wave
   constexpr int RW = GW * 16;                             // output rows (stamps) per wave
-  constexpr int STAGE = (GT + NBLK) * 1024;
+  constexpr int SUB = (GT + NBLK) * 1024;                 // one chunk of a stage: GT A blocks, NBLK B blocks
+  constexpr int STAGE = CH * SUB;
+  static_assert(CH == 1 || CINMODE == 0, "paired chunks only for Cin % 32 == 0");
   constexpr int BN = 16 * NBLK;
   static_assert(RW * BN * 2 >= 1024, "a wave's bf16 tile must be at least one 1-KiB row piece");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(256, GT == 16 ? 2 : 4) void bconv_uni_kernel(const 
   }
   const int cpt = p.Cin >> 5, ppt = p.Cin >> 3;
   const int nvalid = CINMODE == 0 ? __builtin_amdgcn_readfirstlane(stab[0]) : 9;
-  const int nsteps = CINMODE == 0 ? nvalid * cpt : (9 * ppt + 3) >> 2;
+  const int nsteps = CINMODE == 0 ? nvalid * (cpt / CH) : (9 * ppt + 3) >> 2;      // (CH == 2: cpt is even)
 
   const int drow = lane >> 2;
   const int dq = (lane & 3) ^ ((4 - (drow >> 2)) & 3);
@@ -590,20 +597,25 @@ __global__ __launch_bounds__(256, GT == 16 ? 2 : 4) void bconv_uni_kernel(const 
     unsigned char* sA = smem + buf * STAGE;
     unsigned char* sB = sA + GT * 1024;
     if constexpr (CINMODE == 0) {
-      if (is_ti < 0 || is_cc + 1 == cpt) {
+      if (is_ti < 0 || is_cc + CH == cpt) {
         ++is_ti;
         is_cc = 0;
         is_tap = __builtin_amdgcn_readfirstlane(stab[1 + is_ti]);
         tsrc = Xb + (size_t)__builtin_amdgcn_readfirstlane(stab[10 + is_ti]) * pixbytes;
       } else {
-        ++is_cc;
+        is_cc += CH;
       }
       const unsigned char* cs = tsrc + is_cc * 64;
 #pragma unroll
       for (int gi = 0; gi < GW; ++gi)
-        __builtin_amdgcn_global_load_lds((bc_gptr_t)(cs + gi * gstride + a_lane), (bc_lptr_t)(sA + (wave * GW + gi) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((bc_gptr_t)(wbase + (is_tap * p.Cin + is_cc * 32) * 2 + b_lane),
-                                       (bc_lptr_t)(sB + jb * 1024), 16, 0, 0);
+#pragma unroll
+        for (int h = 0; h < CH; ++h)       // both halves of the same cache lines back to back
+          __builtin_amdgcn_global_load_lds((bc_gptr_t)(cs + h * 64 + gi * gstride + a_lane),
+                                           (bc_lptr_t)(sA + h * SUB + (wave * GW + gi) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int h = 0; h < CH; ++h)
+        __builtin_amdgcn_global_load_lds((bc_gptr_t)(wbase + (is_tap * p.Cin + (is_cc + h) * 32) * 2 + b_lane),
+                                         (bc_lptr_t)(sB + h * SUB + jb * 1024), 16, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < 5; ++i)
@@ -651,23 +663,26 @@ __global__ __launch_bounds__(256, GT == 16 ? 2 : 4) void bconv_uni_kernel(const 
   int buf = 0;
   for (int i = 0; i < nsteps; ++i) {
     if (i + 1 < nsteps)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + 1) : "memory");     // the newest stage: GW + 1 instructions per wave
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH * (GW + 1)) : "memory");     // the newest stage: CH * (GW + 1) instructions per wave
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (i + 2 < nsteps) issue(i + 2, buf >= 1 ? buf - 1 : 2);
-    const unsigned char* sA = smem + buf * STAGE + wave * (GW * 1024) + fragoff;
-    const unsigned char* sB = smem + buf * STAGE + GT * 1024 + fragoff;
-    bc_bf16x8 a[GW], b[NBLK];
 #pragma unroll
-    for (int gi = 0; gi < GW; ++gi) a[gi] = *reinterpret_cast<const bc_bf16x8*>(sA + gi * 1024);
+    for (int h = 0; h < CH; ++h) {
+      const unsigned char* sA = smem + buf * STAGE + h * SUB + wave * (GW * 1024) + fragoff;
+      const unsigned char* sB = smem + buf * STAGE + h * SUB + GT * 1024 + fragoff;
+      bc_bf16x8 a[GW], b[NBLK];
 #pragma unroll
-    for (int j = 0; j < NBLK; ++j) b[j] = *reinterpret_cast<const bc_bf16x8*>(sB + j * 1024);
+      for (int gi = 0; gi < GW; ++gi) a[gi] = *reinterpret_cast<const bc_bf16x8*>(sA + gi * 1024);
 #pragma unroll
-    for (int gi = 0; gi < GW; ++gi)
+      for (int j = 0; j < NBLK; ++j) b[j] = *reinterpret_cast<const bc_bf16x8*>(sB + j * 1024);
 #pragma unroll
-      for (int j = 0; j < NBLK; ++j)
-        acc[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gi], b[j], acc[gi][j], 0, 0, 0);
+      for (int gi = 0; gi < GW; ++gi)
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j)
+          acc[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gi], b[j], acc[gi][j], 0, 0, 0);
+    }
     buf = buf == 2 ? 0 : buf + 1;
   }
 
@@ -842,8 +857,14 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   if (uni && mode == 0)
     while (gt > 4 && ntiles(gt, nblk) < gt_tiles && (gt / 2) * nblk >= 8) gt >>= 1;
   while (nblk > 1 && ntiles(gt, nblk) < want_tiles && gt * (nblk / 2) >= 8) nblk >>= 1;
+  // paired chunks (K step = 64 channels) where an operand row is half a cache line per chunk (Cin >= 64) AND the launch
+  // is one of the deep, L2-resident ones that the tile rule above gave small stamp tiles: -10..20 % there; the large
+  // launches (256-stamp tiles) are bound elsewhere and lose with the doubled stage (measured, tools/bconv_launches.py)
+  static const bool no_pair = getenv("DV_BCONV_NO_PAIR") != nullptr;
+  const bool pair = uni && mode == 0 && !no_pair && p.Cin % 64 == 0 && gt <= 8;
+  const int ch = pair ? 2 : 1;
   const long tiles = ntiles(gt, nblk);
-  const size_t lds = uni ? (size_t)3 * (gt + nblk) * 1024 + 4096 : (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;
+  const size_t lds = uni ? (size_t)3 * ch * (gt + nblk) * 1024 + 4096 : (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;
 #define BC_LAUNCH_K(KERNEL_)                                                                           \
   do {                                                                                                 \
     static size_t attr_lds = 0;                                                                        \
@@ -856,10 +877,15 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
 #define BC_LAUNCH(NB_, MODE_)                                                                          \
   do {                                                                                                 \
     if (!uni) BC_LAUNCH_K((bconv_kernel<NB_, MODE_>));                                                 \
-    else if (gt == 16) BC_LAUNCH_K((bconv_uni_kernel<NB_, MODE_, 16>));                                \
-    else if constexpr (MODE_ == 0 && NB_ >= 1) {                                                       \
-      if (gt == 8) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 8>));                                         \
-      else if constexpr (NB_ >= 2) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 4>));                         \
+    else if constexpr (MODE_ == 1) BC_LAUNCH_K((bconv_uni_kernel<NB_, 1, 16, 1>));                     \
+    else if (gt == 16) {                                                                               \
+      BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 16, 1>));                                                  \
+    } else if (gt == 8) {                                                                              \
+      if (pair) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 8, 2>));                                         \
+      else BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 8, 1>));                                              \
+    } else if constexpr (NB_ >= 2) {                                                                   \
+      if (pair) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 4, 2>));                                         \
+      else BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 4, 1>));                                              \
     }                                                                                                  \
   } while (0)
   if (mode == 0) {

@@ -16,6 +16,28 @@ __device__ __forceinline__ unsigned mix(unsigned x) {
   return x;
 }
 
+// the conv kernels' real gather for Cin >= 64: one instruction = 16 rows x 64 B at a 512-byte row stride (half of 16
+// 128-byte lines); PAIR issues the other halves of the same lines right behind it
+template <bool PAIR>
+__global__ __launch_bounds__(256) void probe_rows(const unsigned char* __restrict__ src, unsigned nblocks, int iters, float* sink) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned wid = blockIdx.x * 4 + wave;
+  const size_t lane_off = (size_t)(lane >> 2) * 512 + (lane & 3) * 16;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < (PAIR ? 4 : 8); ++k) {
+      const size_t base = (size_t)(mix(wid * 7919u + (unsigned)(it * 8 + k)) % nblocks) * 8192 + lane_off;   // 16 rows of 512 B
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + base), (lptr_t)(lds + (wave * 8 + k) * 1024), 16, 0, 0);
+      if (PAIR)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + base + 64), (lptr_t)(lds + (wave * 8 + 4 + k) * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  f32x4 acc = *reinterpret_cast<const f32x4*>(lds + threadIdx.x * 16);
+  if (acc[0] == 123.456f) sink[0] = acc[1];
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void probe(const unsigned char* __restrict__ src, unsigned nblocks, int iters, float* sink) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -74,6 +96,28 @@ int main() {
         const double bytes = (double)grid * 4 * iters * 8 * 1024;
         printf("region %5zu MB  %d WG/CU (8 KiB in flight per wave)  %-8s %7.2f TB/s\n", region >> 20, wgs_per_cu,
                mode == 0 ? "lds-dma" : "regs", bytes / (ms * 1e-3) / 1e12);
+      }
+  // half-line rows (useful bytes counted: 1 KiB per instruction either way)
+  for (size_t region : regions)
+    for (int wgs_per_cu : {2, 4})
+      for (int pair = 0; pair < 2; ++pair) {
+        const int grid = 256 * wgs_per_cu;
+        const unsigned nblocks = (unsigned)(region / 8192);
+        auto launch = [&]() {
+          if (pair) hipLaunchKernelGGL(probe_rows<true>, dim3(grid), dim3(256), 32768, 0, buf, nblocks, iters, sink);
+          else hipLaunchKernelGGL(probe_rows<false>, dim3(grid), dim3(256), 32768, 0, buf, nblocks, iters, sink);
+        };
+        launch();
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(a, 0);
+        launch();
+        (void)hipEventRecord(b, 0);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        const double bytes = (double)grid * 4 * iters * 8 * 1024;
+        printf("region %5zu MB  %d WG/CU  16 rows x 64 B @ 512 B stride, %s  %7.2f TB/s useful\n", region >> 20, wgs_per_cu,
+               pair ? "both halves back to back" : "one half per instruction ", bytes / (ms * 1e-3) / 1e12);
       }
   return 0;
 }
