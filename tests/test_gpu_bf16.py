@@ -333,3 +333,10 @@ def test_python_surface_with_the_bf16_engine(tmp_path):
     m32, _ = deblend(ref, x[:5])
     t_bf, t_32 = enc(x[:5]).numpy(), ref.encoder(x[:5]).numpy()
     assert np.abs(t_bf - t_32).max() <= 2e-2 * np.abs(t_32).max()              # the format's cost on the encoder output
+
+
+def test_deep_arch_128px_six_levels():
+    """BASELINE configs[3] on the bf16 engine: 128 x 128 x 6 stamps, six levels up to 512 channels (no crop: 128 = 2^7),
+    two stamps against both oracles (the loose 17-layer tolerances of the golden-stamp test: 23 bf16 layers here)."""
+    arch = vo.Arch(input_shape=(128, 128, 6), latent_dim=32, filters=(32, 64, 128, 256, 512, 512), kernels=(3,) * 6)
+    _run(arch, B=2, seed=5, tol_out=3e-2, tol_grad_b=0.5, min_cos=0.85, tol_grad_64=0.6)
