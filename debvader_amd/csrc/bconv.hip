@@ -845,14 +845,19 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   const long nbx = (p.Hout + 7) / 8;
   const long M16 = nbx * nbx * 64 * (p.NBp >> 4);   // 8 x 8 pixel blocks, see the kernel
   static const bool no_uni = getenv("DV_BCONV_NO_UNI") != nullptr;
-  const bool uni = (p.NBp & 255) == 0 && !no_uni && p.dbg == 0;
+  // uniform-tile kernel: the stamp count must be a multiple of its stamp tile (256, 128 or 64 stamps); the first-layer
+  // form (CINMODE 1) exists for 256-stamp tiles only, and a 64-stamp tile needs at least 32 output columns
+  int gt0 = (p.NBp & 255) == 0 ? 16 : ((p.NBp & 127) == 0 ? 8 : ((p.NBp & 63) == 0 ? 4 : 0));
+  if (mode == 1 && gt0 != 16) gt0 = 0;
+  if (gt0 == 4 && nblk < 2) gt0 = 0;
+  const bool uni = gt0 != 0 && !no_uni && p.dbg == 0;
   // Deep layers have few row tiles and a long K loop that one workgroup walks alone.  First smaller stamp tiles (uniform
   // kernel: 128 or 64 stamps per workgroup, 4-8 independent pipelines per CU; the weights are re-read from L2 once more
   // per halving), then narrower column tiles (the input is re-read once more per halving) put enough workgroups on the
   // chip; these launches are latency-bound and do not notice the extra L2 traffic.
   const long want_tiles = getenv("DV_BCONV_MIN_TILES") ? atol(getenv("DV_BCONV_MIN_TILES")) : 512;   // (read per call: the tests toggle it)
   const long gt_tiles = getenv("DV_BCONV_GT_TILES") ? atol(getenv("DV_BCONV_GT_TILES")) : 1024;
-  int gt = BC_GT;
+  int gt = uni ? gt0 : BC_GT;
   auto ntiles = [&](int g, int nb) { return ((M16 + g - 1) / g) * (long)(p.Cout / (16 * nb)); };
   if (uni && mode == 0)
     while (gt > 4 && ntiles(gt, nblk) < gt_tiles && (gt / 2) * nblk >= 8) gt >>= 1;
