@@ -253,7 +253,7 @@ int launch_bwgrad(const BWgradParams& p, hipStream_t s, int* nsplit_out) {
   // Y rows per workgroup: as few as the slab budget allows (more workgroups), never fewer than what keeps the slabs of
   // one launch under ~24 MB
   static const long budget = getenv("DV_BWGRAD_SLAB_MB") ? atol(getenv("DV_BWGRAD_SLAB_MB")) << 20 : 24L << 20;
-  long copies = std::max<long>(1, budget / (long)(slab * sizeof(float)));
+  long copies = std::max<long>(gm.nsc4, budget / (long)(slab * sizeof(float)));   // (one slab per 64-stamp chunk at least)
   copies = std::min<long>(copies, (long)(p.part_capacity / slab));
   if (copies < gm.nsc4) {
     set_error("bwgrad: slab workspace too small");

@@ -340,3 +340,31 @@ def test_deep_arch_128px_six_levels():
     two stamps against both oracles (the loose 17-layer tolerances of the golden-stamp test: 23 bf16 layers here)."""
     arch = vo.Arch(input_shape=(128, 128, 6), latent_dim=32, filters=(32, 64, 128, 256, 512, 512), kernels=(3,) * 6)
     _run(arch, B=2, seed=5, tol_out=3e-2, tol_grad_b=0.5, min_cos=0.85, tol_grad_64=0.6)
+
+
+def test_thousand_stamp_batches_on_the_bf16_engine():
+    """Per-GPU batches of 1024 stamps (16 slab rows per weight-gradient launch, more than the 24 MB slab budget holds for
+    the 256-channel layers: the budget is a target, one slab per 64-stamp chunk the floor): the step runs, and its loss
+    and gradients agree with the fp32 engine on the same batch as the 256-stamp case does."""
+    from debvader_amd.data import synthetic_stamps
+
+    arch = vo.Arch()
+    B = 1024
+    x, y = synthetic_stamps(B, seed=41)
+    res = []
+    for dtype in (0, 1):
+        eng = _engine(arch, B, dtype=dtype)
+        eng.init(seed=6)
+        hb = eng.get_param("dec/head/bias")
+        hb[arch.nb:] += 0.3
+        eng.set_param("dec/head/bias", hb)
+        eng.optimizer_reset(1e-4)
+        eng.upload(0, x, y)
+        out = eng.grad_step(0, first=0, B=B, seed=13)
+        res.append((out, {n: eng.get_grad(n) for n in ("dec/convt0/kernel", "enc/conv7/kernel", "enc/conv0/kernel", "dec/head/bias")}))
+        eng.close()
+    (o32, g32), (obf, gbf) = res
+    assert abs(obf["loss"] - o32["loss"]) <= 1e-2 * abs(o32["loss"])
+    for n in g32:
+        assert np.isfinite(gbf[n]).all()
+        assert _cos(gbf[n], g32[n].astype(np.float64)) >= 0.97, (n, _cos(gbf[n], g32[n].astype(np.float64)))
