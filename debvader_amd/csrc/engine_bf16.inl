@@ -62,8 +62,8 @@ static int bf_alloc(dv_model* m) {
   // slab pool of one backward pass: ~9.4 MB per launch with the launcher's 256-workgroup rule (bwgrad.hip), 17 launches
   // for the 59-pixel net; a pass that needs more flushes its reductions early (bf_flush_wred) and starts over
   bf.slab_elems = (size_t)64 << 20;
-  for (auto& sp : A.specs)
-    if (sp.ndim == 4) bf.slab_elems = std::max(bf.slab_elems, sp.count * 8);
+  for (auto& sp : A.specs)          // a launch needs one slab per 64-stamp chunk at least: room for two such launches
+    if (sp.ndim == 4) bf.slab_elems = std::max(bf.slab_elems, sp.count * 2 * std::max<size_t>(4, (Bp + 63) / 64));
   DV_TRY(balloc((void**)&bf.slab, bf.slab_elems * 4));
 
   // bf16 weight matrices and the descriptors the cast kernel walks
