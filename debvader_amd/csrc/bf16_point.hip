@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void bf_prelu_bwd_kernel(const bp_bf16* __rest
   extern __shared__ float sh[];                       // [2][lanes][C]
   const int pix = blockIdx.x;
   const int c8n = C >> 3;
-  const int nl = 256 / c8n;                            // stamp lanes (c8n divides 256: C in {16,32,64,...,2048})
+  const int nl = 256 / c8n;                            // stamp lanes (threads past nl * c8n idle when c8n does not divide 256)
   const int c8 = threadIdx.x % c8n, sl = threadIdx.x / c8n;
   float al[8], sa[8], sb[8];
 #pragma unroll
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void bf_prelu_bwd_kernel(const bp_bf16* __rest
 int launch_bf_prelu_bwd(const void* da, const void* u, const float* alpha, void* du, float* dalpha, float* db_rows,
                         int NBp, int P, int C, hipStream_t s) {
   const int c8n = C >> 3;
-  if ((C & 7) || c8n > 256 || 256 % c8n) {
+  if ((C & 7) || c8n < 1 || c8n > 256) {
     set_error("bf_prelu_bwd: unsupported channel count %d", C);
     return E_INVALID;
   }

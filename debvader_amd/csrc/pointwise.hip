@@ -256,7 +256,7 @@ int launch_prelu_fwd(const float* u, const float* alpha, float* a, long NB, int 
 
 // du = da * (u>0 ? 1 : alpha) in place; d(alpha)[e] = sum_n da*min(u,0); d(bias)[c] = sum_{n,hw} du.
 // grid (ceil(E/1024), nsplit): thread owns 4 consecutive elements e, loops over its slice of the batch.
-// dbias_mode 0: none; 1: E == C (dense), partial [nsplit][E]; 2: 1024 % C == 0, partial [nsplit*gridDim.x][C]
+// dbias_mode 0: none; 1: E == C (dense), partial [nsplit][E]; 2: C % 4 == 0 and C <= 1024, partial [nsplit*gridDim.x][C]
 __global__ __launch_bounds__(256) void prelu_bwd_kernel(float* __restrict__ da, const float* __restrict__ u,
                                                         const float* __restrict__ alpha, int NB, int E, int C,
                                                         int nper, float* __restrict__ dalpha_part,
@@ -291,8 +291,11 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(float* __restrict__ da, 
     __syncthreads();
     const int cq = C / 4;
     if ((int)threadIdx.x < cq) {
+      // thread t of the block holds channel quad (blockIdx.x * 256 + t) % cq (the block starts anywhere in a row when C
+      // does not divide 1024): the threads of quad threadIdx.x, in order
+      const int t0 = (int)(((long)threadIdx.x - (long)blockIdx.x * 256 % cq + cq) % cq);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int t = threadIdx.x; t < 256; t += cq) acc += shv[t];
+      for (int t = t0; t < 256; t += cq) acc += shv[t];
       size_t row = (size_t)split * gridDim.x + blockIdx.x;
       *reinterpret_cast<f32x4*>(dbias_part + row * C + threadIdx.x * 4) = acc;
     }
@@ -308,7 +311,7 @@ int launch_prelu_bwd(float* da, const float* u, const float* alpha, int NB, int 
     if (E == C) {
       mode = 1;
       *dbias_rows = nsplit;
-    } else if (C <= 1024 && (1024 % C) == 0) {
+    } else if (C <= 1024 && (C & 3) == 0 && (E % C) == 0) {
       mode = 2;
       *dbias_rows = nsplit * gx;
     } else {

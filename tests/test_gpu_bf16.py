@@ -62,7 +62,7 @@ def toy_arch():
 
 
 def _run(arch, B, seed, data=None, train_decoder=True, tol_out=1e-2, tol_grad_b=5e-3, check_fp64_grads=True,
-         min_cos=0.97, tol_grad_64=0.25):
+         min_cos=0.97, tol_grad_64=0.25, tol_scal_64=5e-3):
     p, x, y, eps = _case(arch, B, seed, data)
     eng = _engine(arch, B)
     eng.set_params(p)
@@ -90,7 +90,7 @@ def _run(arch, B, seed, data=None, train_decoder=True, tol_out=1e-2, tol_grad_b=
         assert _relmax(v, c[k]) <= 2e-2, ("fp64 oracle", k, _relmax(v, c[k]))
     for k in ("loss", "nll_mean", "kl_reg", "mse"):
         assert abs(out[k] - rb[k]) <= 5e-4 * abs(rb[k]) + 1e-9, ("bf16 oracle", k, out[k], rb[k])
-        assert abs(out[k] - r[k]) <= 5e-3 * abs(r[k]) + 1e-9, ("fp64 oracle", k, out[k], r[k])
+        assert abs(out[k] - r[k]) <= tol_scal_64 * abs(r[k]) + 1e-9, ("fp64 oracle", k, out[k], r[k])
     assert set(gb) == set(g)
     for name in g:
         gg = eng.get_grad(name)
@@ -368,3 +368,12 @@ def test_thousand_stamp_batches_on_the_bf16_engine():
     for n in g32:
         assert np.isfinite(gbf[n]).all()
         assert _cos(gbf[n], g32[n].astype(np.float64)) >= 0.97, (n, _cos(gbf[n], g32[n].astype(np.float64)))
+
+
+def test_channel_counts_that_are_not_powers_of_two():
+    """filters (32, 96) on the bf16 engine: 12 eight-channel pieces per row do not divide the 256 threads of the unfused
+    PReLU-backward kernel (ragged batch), three 32-channel column tiles in the fused one (64 stamps)."""
+    arch = vo.Arch(input_shape=(20, 20, 4), latent_dim=8, filters=(32, 96), kernels=(3, 3))
+    # (the KL regulariser of this tiny net is ~1e-3: its bf16 cost is 0.55 % of itself, the stated 1 % here)
+    _run(arch, B=5, seed=21, tol_grad_b=5e-2, tol_scal_64=1e-2)
+    _run(arch, B=64, seed=22, tol_grad_b=0.1, min_cos=0.95, tol_grad_64=0.35, tol_scal_64=1e-2)

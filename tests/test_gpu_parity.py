@@ -295,3 +295,12 @@ def test_specialised_kernels_match_the_general_gather_gemm():
         check(lib.dv_debug_gconv_check(ctx._h, *c, out))
         assert out[1] > 0.1, c
         assert out[0] <= 2e-5 * out[1], (c, out[0], out[1])
+
+
+def test_channel_counts_that_are_not_powers_of_two():
+    """filters (32, 96): 96 divides neither 1024 (the block size of the PReLU-backward bias sums) nor a column-tile width;
+    such architectures used to be accepted and then fail in the first training step (found by tools/fuzz_configs.py).
+    Full parity at the usual fp32 tolerances, 3 and 40 stamps."""
+    arch = vo.Arch(input_shape=(20, 20, 4), latent_dim=8, filters=(32, 96), kernels=(3, 3))
+    _run_parity(arch, B=3, seed=21)
+    _run_parity(arch, B=40, seed=22)

@@ -1,0 +1,47 @@
+"""Corner-case sweep of both engines: architectures / batch sizes the tests do not pin, one train step + one inference
+each; prints what is refused (with the library's message) and fails on anything that is accepted but not finite."""
+import itertools, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from debvader_amd import engine as E
+from debvader_amd._lib import DvError
+
+rng = np.random.default_rng(0)
+cases = []
+for size, bands, filters, latent in [(32, 2, (16, 32), 8), (45, 4, (32, 64, 128), 16), (59, 6, (32, 32, 32, 32), 32),
+                                     (64, 6, (16, 32, 64), 8), (20, 4, (32, 64), 8), (59, 6, (32, 64, 128, 256), 16),
+                                     (16, 2, (32,), 8), (59, 6, (64, 64, 64, 64), 32), (40, 4, (32, 96), 16),
+                                     (33, 6, (32, 64, 64), 32), (24, 2, (8, 16), 8), (59, 6, (16, 16, 16, 16), 8)]:
+    for B in (1, 7, 64, 100, 256, 300):
+        cases.append((size, bands, filters, latent, B))
+bad = 0
+for dtype in (0, 1):
+    for size, bands, filters, latent, B in cases:
+        tag = f"dtype {dtype} size {size} bands {bands} filters {filters} latent {latent} B {B}"
+        try:
+            cfg = E.make_config((size, size, bands), latent, filters, (3,) * len(filters), max_batch=B, dtype=dtype)
+            eng = E.Engine(cfg)
+        except (DvError, ValueError) as e:
+            if B == 1:
+                print("refused:", tag, "|", str(e)[:110])
+            continue
+        try:
+            eng.init(seed=1)
+            eng.optimizer_reset(1e-4)
+            x = rng.normal(0, 0.4, size=(B, size, size, bands)).astype(np.float32)
+            y = np.abs(x) * 0.5
+            eng.upload(0, x, y)
+            o1 = eng.train_step(0, first=0, B=B, seed=1)
+            o2 = eng.train_step(0, first=0, B=B, seed=2)
+            r = eng.infer(x[: min(B, 9)], seed=3)
+            ok = np.isfinite([o1["loss"], o2["loss"]]).all() and np.isfinite(r["loc"]).all() and (r["scale"] > 0).all()
+            if not ok:
+                bad += 1
+                print("NOT FINITE:", tag, o1, o2)
+        except DvError as e:
+            bad += 1
+            print("FAILED:", tag, "|", str(e)[:160])
+        finally:
+            eng.close()
+print("done,", bad, "problem(s)")
+sys.exit(1 if bad else 0)
