@@ -2810,7 +2810,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   for (auto& s : A.specs)
     if (s.ndim >= 2) max_w = std::max(max_w, s.count);
   max_w = std::max(max_w, (size_t)9 * 8 * cfg->filters[0]);
-  m->ws1_elems = std::max((size_t)32 << 20, max_w * 2);
+  m->ws1_elems = std::max((size_t)32 << 20, (max_w + 1024) * 3);   // three rotating regions, each at least one slab
   ALLOC(m->ws1, m->ws1_elems);
   m->ws4_elems = (size_t)4 * 16 * Bc * std::max((size_t)A.flat, (size_t)A.tw);
   ALLOC(m->ws4, m->ws4_elems);

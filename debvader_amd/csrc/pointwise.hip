@@ -326,12 +326,13 @@ int launch_prelu_bwd(float* da, const float* u, const float* alpha, int NB, int 
   return OK;
 }
 
-// column sums of x[rows][C] (C multiple of 4, C/4 <= 256) -> part[block][C]
+// column sums of x[rows][C] (C multiple of 4) -> part[block][C]; blockIdx.y walks column tiles of 1024
 constexpr int COLSUM_ROWS = 2048;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long rows, int C,
                                                      float* __restrict__ part, int rows_per_block) {
   __shared__ f32x4 shv[256];
-  const int cq = C / 4;
+  const int q0 = blockIdx.y * 256;
+  const int cq = min(256, C / 4 - q0);             // column quads of this tile
   const int rpb = 256 / cq;
   const int t = threadIdx.x;
   const int q = t % cq, rr = t / cq;
@@ -339,18 +340,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = min(rows, r0 + rows_per_block);
   if (rr < rpb)
-    for (long r = r0 + rr; r < r1; r += rpb) acc += *reinterpret_cast<const f32x4*>(x + r * C + q * 4);
+    for (long r = r0 + rr; r < r1; r += rpb) acc += *reinterpret_cast<const f32x4*>(x + r * C + (q0 + q) * 4);
   shv[t] = acc;
   __syncthreads();
   if (t < cq) {
     f32x4 tot = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < rpb; ++k) tot += shv[k * cq + t];
-    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + t * 4) = tot;
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + (q0 + t) * 4) = tot;
   }
 }
 
 int launch_colsum(const float* x, long rows, int C, float* part, int* nrows_part, hipStream_t s) {
-  if ((C & 3) || C / 4 > 256) {
+  if ((C & 3) || C < 4) {
     set_error("colsum: unsupported C=%d", C);
     return E_INVALID;
   }
@@ -358,7 +359,7 @@ int launch_colsum(const float* x, long rows, int C, float* part, int* nrows_part
   int rpb = (int)std::min<long>(COLSUM_ROWS, std::max<long>(4, (rows + 63) / 64));
   int nb = (int)((rows + rpb - 1) / rpb);
   *nrows_part = nb;
-  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, s, x, rows, C, part, rpb);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb, (C / 4 + 255) / 256), dim3(256), 0, s, x, rows, C, part, rpb);
   DV_HIP(hipGetLastError());
   return OK;
 }

@@ -304,3 +304,10 @@ def test_channel_counts_that_are_not_powers_of_two():
     arch = vo.Arch(input_shape=(20, 20, 4), latent_dim=8, filters=(32, 96), kernels=(3, 3))
     _run_parity(arch, B=3, seed=21)
     _run_parity(arch, B=40, seed=22)
+
+
+def test_wide_latent_space_and_odd_filter_counts():
+    """latent_dim 64 (params_size 2144 columns: more than one 1024-column tile of the bias-gradient column sums) and
+    filters (24, 48) on 27-pixel stamps with 2 bands - configurations the sweep tool found failing or never exercised."""
+    _run_parity(vo.Arch(input_shape=(20, 20, 2), latent_dim=64, filters=(32, 64), kernels=(3, 3)), B=5, seed=31)
+    _run_parity(vo.Arch(input_shape=(27, 27, 4), latent_dim=8, filters=(24, 48), kernels=(3, 3)), B=6, seed=32)

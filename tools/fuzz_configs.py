@@ -11,7 +11,9 @@ cases = []
 for size, bands, filters, latent in [(32, 2, (16, 32), 8), (45, 4, (32, 64, 128), 16), (59, 6, (32, 32, 32, 32), 32),
                                      (64, 6, (16, 32, 64), 8), (20, 4, (32, 64), 8), (59, 6, (32, 64, 128, 256), 16),
                                      (16, 2, (32,), 8), (59, 6, (64, 64, 64, 64), 32), (40, 4, (32, 96), 16),
-                                     (33, 6, (32, 64, 64), 32), (24, 2, (8, 16), 8), (59, 6, (16, 16, 16, 16), 8)]:
+                                     (33, 6, (32, 64, 64), 32), (24, 2, (8, 16), 8), (59, 6, (16, 16, 16, 16), 8),
+                                     (27, 4, (24, 48), 8), (30, 2, (12, 20), 8), (36, 6, (16, 96), 16),
+                                     (48, 6, (32, 160, 224), 32), (100, 2, (32, 64, 96, 128), 64), (21, 6, (32, 64), 32)]:
     for B in (1, 7, 64, 100, 256, 300):
         cases.append((size, bands, filters, latent, B))
 bad = 0
