@@ -19,6 +19,11 @@ static int bf_alloc(dv_model* m) {
       return E_INVALID;
     }
   }
+  if ((A.dec_out * A.dec_out) & 15) {
+    // (only a one-level net on stamps whose half size is odd: the head kernel walks the decoder output 16 pixels at a time)
+    set_error("bf16 engine: the decoder output (%d x %d pixels) must be a multiple of 16 pixels", A.dec_out, A.dec_out);
+    return E_INVALID;
+  }
   if (A.cfg.filters[A.L - 1] & 7 || A.C2p != 16) {
     set_error("bf16 engine: unsupported head / trunk geometry");
     return E_INVALID;

@@ -13,7 +13,9 @@ for size, bands, filters, latent in [(32, 2, (16, 32), 8), (45, 4, (32, 64, 128)
                                      (16, 2, (32,), 8), (59, 6, (64, 64, 64, 64), 32), (40, 4, (32, 96), 16),
                                      (33, 6, (32, 64, 64), 32), (24, 2, (8, 16), 8), (59, 6, (16, 16, 16, 16), 8),
                                      (27, 4, (24, 48), 8), (30, 2, (12, 20), 8), (36, 6, (16, 96), 16),
-                                     (48, 6, (32, 160, 224), 32), (100, 2, (32, 64, 96, 128), 64), (21, 6, (32, 64), 32)]:
+                                     (48, 6, (32, 160, 224), 32), (100, 2, (32, 64, 96, 128), 64), (21, 6, (32, 64), 32),
+                                     (10, 6, (16, 32), 8), (8, 2, (32, 32, 32), 8), (59, 6, (32, 64, 128, 256, 256), 32),
+                                     (9, 4, (32,), 8)]:
     for B in (1, 7, 64, 100, 256, 300):
         cases.append((size, bands, filters, latent, B))
 bad = 0
@@ -37,6 +39,17 @@ for dtype in (0, 1):
             o2 = eng.train_step(0, first=0, B=B, seed=2)
             r = eng.infer(x[: min(B, 9)], seed=3)
             ok = np.isfinite([o1["loss"], o2["loss"]]).all() and np.isfinite(r["loc"]).all() and (r["scale"] > 0).all()
+            # stage 2 (decoder frozen), evaluation, chunked inference beyond max_batch, Monte-Carlo statistics
+            eng.set_trainable(True, False)
+            eng.optimizer_reset(1e-4)
+            o3 = eng.train_step(0, first=0, B=B, seed=4)
+            eng.upload(1, x[: max(1, B // 2)], y[: max(1, B // 2)])
+            o4 = eng.eval_step(1, first=0, B=max(1, B // 2), seed=5)
+            big = np.concatenate([x, x, x[:3]]) if B <= 64 else x
+            r2 = eng.infer(big, seed=6, want=("loc", "mu", "zstd"))
+            mean, std = eng.infer_mc(x[: min(B, 5)], nsamples=3, seed=7)
+            ok = ok and np.isfinite([o3["loss"], o4["loss"]]).all() and np.isfinite(r2["loc"]).all() and \
+                np.isfinite(r2["zstd"]).all() and np.isfinite(mean).all() and np.isfinite(std).all()
             if not ok:
                 bad += 1
                 print("NOT FINITE:", tag, o1, o2)
