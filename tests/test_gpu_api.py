@@ -339,15 +339,16 @@ def test_training_reduces_the_loss_on_a_small_set():
     assert all(np.isfinite(w).all() for w in net.get_weights())
 
 
-def test_edge_cases_empty_and_ragged_inputs():
+@pytest.mark.parametrize("dtype", ["float32", "bf16"])
+def test_edge_cases_empty_and_ragged_inputs(dtype):
     """Empty inputs, a single stamp, a data set smaller than the batch, the largest batch the workspace takes and one
-    more (which must be refused with a message, not crash)."""
+    more (which must be refused with a message, not crash) - on both engines."""
     from debvader_amd._lib import DvError
     from debvader_amd.deblend_cutout.deblender import deblend
     from debvader_amd.model import model
     from debvader_amd.training.metrics import vae_loss
 
-    net, enc, dec, z = model.create_model_vae(**ARCH, max_batch=8)
+    net, enc, dec, z = model.create_model_vae(**ARCH, max_batch=8, dtype=dtype)
     x, y = _data(11, 51)
     mean, dist = deblend(net, x[:0])
     assert mean.shape == (0, 59, 59, 6) and dist.stddev().numpy().shape == (0, 59, 59, 6)
