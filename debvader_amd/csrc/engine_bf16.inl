@@ -372,6 +372,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   void* oth = nullptr;
   hipStream_t ws = bf_wstream(m);
   bool head_cols_taken = false, dec_bucket_done = false;
+  size_t enc_reduced = A.n_enc_train;                    // [enc_reduced, n_enc_train) all-reduced inside this pass
   // ---- head conv ----
   if (dg) {
     DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, 1, 1, m->Ghs, f0, f0));   // (columns taken at the end)
@@ -513,6 +514,40 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     DV_TRY(bf_dgrad_prelu(m, cur, bf.enc_w[j].d, bf.enc_w[j].Kd, 1, hout, cout, hin, cin, st, pb, oth, bf.enc_u[j - 1],
                           A.enc_al(j - 1), A.enc_b(j - 1), true));
     cur = oth;
+    if (j == A.L && A.L >= 2) {
+      // Middle bucket, as in the fp32 backward: the deep half of the encoder (conv L .. conv 2L-1, their PReLUs, the
+      // flatten PReLU, the dense layer: 13.8 of 15 MB) is final once this layer's weight gradient has been queued, and
+      // the data-gradient kernel just queued was the last reader of those layers.  Its reductions are flushed, the
+      // bucket all-reduced on the comm stream and (early Adam) updated there while the shallow half is differentiated.
+      dv_ctx* cx = m->ctx;
+      const bool ovl = ws != s;
+      const bool early = m->early_adam && ovl;
+      const size_t split = enc_bucket_split(A);
+      if ((cx->comm || early) && split < A.n_enc_train) {
+        if (ovl) {
+          DV_HIP(hipEventRecord(cx->ev_ready, s));
+          DV_HIP(hipStreamWaitEvent(ws, cx->ev_ready, 0));
+        }
+        DV_TRY(bf_flush_wred(m));
+        {
+          ProfScope ps(m, 2, ws);
+          DV_TRY(launch_bf_reduce_batch(bf.red, ws));
+        }
+        bf.red.count = 0;
+        DV_HIP(hipEventRecord(cx->ev_mid, ws));
+        DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_mid, 0));
+        DV_HIP(hipEventRecord(cx->ev_dec, s));           // the main stream has finished reading those parameters
+        DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_dec, 0));
+        if (cx->comm) {
+          DV_NCCL(ncclAllReduce(G + split, G + split, A.n_enc_train - split, ncclFloat, ncclSum, cx->comm, cx->comm_stream));
+          enc_reduced = split;
+        }
+        if (early && m->opt_enc) {
+          DV_TRY(adam_range(m, split, A.n_enc_train, cx->comm_stream));
+          m->adam_done_from = std::min(m->adam_done_from, split);
+        }
+      }
+    }
   }
   {
     ProfScope ps(m, 2, s);
@@ -525,6 +560,6 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   // data parallelism: the decoder bucket went out above; the encoder bucket [0, n_enc_train) is all-reduced by
   // enqueue_step behind this pass (with a frozen decoder it is the only one)
   (void)dec_bucket_done;
-  m->enc_reduced_from = A.n_enc_train;
+  m->enc_reduced_from = enc_reduced;
   return OK;
 }
