@@ -92,7 +92,7 @@ int launch_bf_head(const BHeadParams& p, hipStream_t s, int* nblocks_out);
 // Batched fixed-order reductions of the fused PReLU-backward partials of a whole backward pass (two launches instead of
 // two per layer): entry i sums nparts slabs of n floats, out[e] = sum_p src[p*n + e]; entries with cols > 0 are then
 // column-summed, final[c] = sum_r out[r*cols + c] (d(bias): out is a scratch [pixels][cols] image).
-#define DV_BF_MAX_RED 48
+#define DV_BF_MAX_RED 64   /* 8 L - 2 entries per backward pass: covers DV_MAX_LEVELS = 8; bf_dgrad_prelu flushes when full */
 struct BRedEntry {
   const float* src;
   float* out;

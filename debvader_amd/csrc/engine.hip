@@ -351,6 +351,8 @@ struct BfState {
   float* tpre32 = nullptr;       // head conv output, fp32 [Hd*Hd][NBp][16]
   void* dt = nullptr;            // d(loss)/d(tpre), bf16
   float* flat_in = nullptr;      // encoder output as fp32 rows [NB][flat] (input of the flatten PReLU)
+  std::vector<void*> du_enc, du_dec;   // where the last backward pass left d(pre-activation) of every conv layer, and
+  void* d_dec_in = nullptr;            // d(decoder trunk output) (introspection: dv_model_get_activation "enc_du3" ...)
   std::vector<void*> gpool;      // one activation-gradient buffer per data-gradient launch of a step (bf16): the
                                  // weight gradients run on the aux stream and nothing ever waits for a buffer
   dv::BRedBatch red;             // fused-epilogue partials of the backward pass being queued (summed in two launches)
@@ -1039,7 +1041,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
     m->ws_last = reg;
     return OK;
   };
-  if (!single_tap && !g_force_v1 && cpad == creal && wgrad_strip_supported(Cx, Cy, sx, 9)) {
+  if (!single_tap && !g_force_v1 && !(g_no_special && !fz) && cpad == creal && wgrad_strip_supported(Cx, Cy, sx, 9)) {
     WStripParams sp;
     memset(&sp, 0, sizeof sp);
     sp.X = X; sp.Y = Y; sp.part = part; sp.part_capacity = part_cap;
@@ -3447,6 +3449,18 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
     const void* bsrc = nullptr;
     size_t Pn = 0, Cn = 0;
     if (n == "xn") { bsrc = m->bf.xh; Pn = (size_t)A.H * A.H; Cn = 16; }
+    else if (n == "dec_in") { bsrc = m->bf.dec_in; Pn = (size_t)A.w0 * A.w0; Cn = A.cfg.filters[A.L - 1]; }
+    else if (n == "d_dec_in") { bsrc = m->bf.d_dec_in; Pn = (size_t)A.w0 * A.w0; Cn = A.cfg.filters[A.L - 1]; }
+    else if (n == "d_head_pre") { bsrc = m->bf.dt; Pn = (size_t)A.dec_out * A.dec_out; Cn = 16; }
+    else if (n.size() > 6 && (n.rfind("enc_du", 0) == 0 || n.rfind("dec_du", 0) == 0)) {
+      // d(pre-activation) of conv layer j as the last backward pass left it (bf16; tests/test_gpu_bf16_layers.py)
+      const int j = atoi(n.c_str() + 6);
+      if (j < 0 || j >= 2 * A.L || (int)m->bf.du_enc.size() != 2 * A.L) return DV_E_INVALID;
+      int hin, cin, hout, cout, s;
+      if (n[0] == 'e') A.enc_layer(j, &hin, &cin, &hout, &cout, &s); else A.dec_layer(j, &hin, &cin, &hout, &cout, &s);
+      Pn = (size_t)hout * hout; Cn = cout;
+      bsrc = n[0] == 'e' ? m->bf.du_enc[j] : m->bf.du_dec[j];
+    }
     else if (n.size() > 5 && (n.rfind("enc_u", 0) == 0 || n.rfind("enc_a", 0) == 0 || n.rfind("dec_u", 0) == 0 || n.rfind("dec_a", 0) == 0)) {
       int j = atoi(n.c_str() + 5);
       if (j < 0 || j >= 2 * A.L) return DV_E_INVALID;
@@ -3462,6 +3476,10 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
     if (nbytes != elems * sizeof(float)) {
       set_error("activation %s holds %zu bytes, caller passed %zu", name, elems * sizeof(float), nbytes);
       return DV_E_INVALID;
+    }
+    if (!bsrc) {
+      set_error("activation %s has not been computed yet", name);
+      return DV_E_STATE;
     }
     const size_t NBp = (size_t)m->bf.NBp;
     std::vector<uint16_t> tmp(Pn * NBp * Cn);
@@ -3667,6 +3685,11 @@ int dv_debug_gconv_check(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_
   (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(m.ws1); (void)hipFree(m.zero_page);
   for (auto& b : bufs) (void)hipFree(b);
   return st;
+}
+
+int dv_debug_general_kernels(int32_t on) {
+  g_no_special = on != 0;
+  return DV_OK;
 }
 
 int dv_debug_mfma_peak(dv_ctx* ctx, int32_t blocks, int32_t iters, int32_t nacc, int32_t randomize, float* out3) {

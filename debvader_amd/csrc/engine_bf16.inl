@@ -317,7 +317,14 @@ static int bf_dgrad_prelu(dv_model* m, const void* X, const void* W, int Kpad, i
     if (want_grads) {
       // partial slabs + the [pixels][Cout] image the d(bias) column sum reads
       const size_t img = std::max<size_t>((size_t)E, (size_t)64 * Cout);    // partial rows of the d(bias) column sum
-      if (m->arena_off + (size_t)2 * nparts * E + img > m->arena_elems || bf.red.count + 2 > DV_BF_MAX_RED) {
+      if (bf.red.count + 2 > DV_BF_MAX_RED) {
+        // the batch is full (deep nets without a bucket flush in between): sum what has been registered so far.  The
+        // partials were written by main-stream kernels, so the reduction is ordered behind them on the same stream.
+        ProfScope ps(m, 2, st);
+        DV_TRY(launch_bf_reduce_batch(bf.red, st));
+        bf.red.count = 0;
+      }
+      if (m->arena_off + (size_t)2 * nparts * E + img > m->arena_elems) {
         set_error("gradient-partial arena exhausted");
         return E_STATE;
       }
@@ -370,6 +377,8 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   auto next_buf = [&]() -> void* { return bf.gpool[gnext++ % bf.gpool.size()]; };
   void* cur = next_buf();
   void* oth = nullptr;
+  bf.du_enc.assign(2 * A.L, nullptr);
+  bf.du_dec.assign(2 * A.L, nullptr);
   hipStream_t ws = bf_wstream(m);
   bool head_cols_taken = false, dec_bucket_done = false;
   size_t enc_reduced = A.n_enc_train;                    // [enc_reduced, n_enc_train) all-reduced inside this pass
@@ -392,6 +401,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
     const int pb = same_pad_before(hout, 3, st, nullptr);
     const void* xin = j == 0 ? bf.dec_in : bf.dec_a[j - 1];
+    bf.du_dec[j] = cur;
     if (dg) DV_TRY(bf_wgrad(m, cur, hout, cout, xin, hin, cin, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout));
     oth = next_buf();
     if (j > 0) {
@@ -403,6 +413,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     }
     cur = oth;
   }
+  bf.d_dec_in = cur;
   // ---- dense trunk of the decoder, sampler, encoder dense: fp32 rows in m->gA / m->gB ----
   const int fl = A.cfg.filters[A.L - 1];
   const int r = A.w0 * A.w0 * fl;
@@ -496,6 +507,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     int hin, cin, hout, cout, st;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
     const int pb = same_pad_before(hin, 3, st, nullptr);
+    bf.du_enc[j] = cur;
     if (j == 0) {
       // first conv with the folded input BatchNorm: the gradient w.r.t. the 16-channel folded kernel (channels
       // 0..C-1 = bands, C = the constant one) yields d(kernel), d(gamma), d(beta); no data gradient

@@ -20,6 +20,10 @@ int dv_debug_gconv_check(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_
 /* issue-rate probe of v_mfma_f32_16x16x4_f32 (no memory traffic), nacc = 16 or 36 independent accumulators,
  * trivial or pseudo-random operands: out3 = {TFLOP/s, in-kernel clock MHz, shader cycles per MFMA} */
 int dv_debug_mfma_peak(dv_ctx* ctx, int32_t blocks, int32_t iters, int32_t nacc, int32_t randomize, float* out3);
+/* process-wide: the fp32 engine routes every conv / conv-transpose / weight-gradient launch through the general
+ * gather-GEMM and tiled weight-gradient kernels (no strip or fused stride-2 forms): the same arithmetic in another
+ * summation order.  The control of tests/test_gpu_bf16.py (two fp32 summation orders against the bf16 engine). */
+int dv_debug_general_kernels(int32_t on);
 int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, int32_t Cy, int32_t sx,
                    int32_t pad_before, int32_t single_tap, int32_t iters, float* ms_out);
 

@@ -211,38 +211,101 @@ def test_bf16_rejects_unsupported_filters():
         E.Engine(E.make_config((13, 13, 4), 8, (8, 16), (3, 3), max_batch=4, dtype=1))
 
 
-def test_bf16_training_tracks_fp32():
-    """What the format costs a training run: 16 legacy-Adam steps (train.py:104-107) of the bf16 and of the fp32 engine
-    from the same initialisation on the same batches.  The loss curves must coincide to 2 % of the loss scale step by
-    step (measured: 4 digits).  Not longer: around step 20 a first pixel's sigma reaches its 1e-4 floor (relu of the
-    scale pre-activation, model.py:154-159), the NLL spikes by orders of magnitude in whichever run gets there first,
-    and from there on two fp32 runs with different summation orders do not track each other either
-    (tools/bf16_vs_f32_grads.py prints the gradients per tensor - norm ratio 0.96-1.08, cosine >= 0.985 - and the curves)."""
+def _training_run(kind, steps, sigma_floor, shift, data, val, B=64, lr=1e-4):
+    """`steps` legacy-Adam steps (train.py:104-107,125-130) of one engine from a fixed initialisation on fixed batches.
+    kind: "f32" (the fp32 engine as shipped), "f32alt" (the fp32 engine with the general gather-GEMM / tiled
+    weight-gradient kernels instead of the strip and fused stride-2 forms: the SAME arithmetic in another summation
+    order) or "bf16".  Returns per-step losses, per-step count of pixels on the sigma floor, final validation loss."""
+    from debvader_amd import engine as E
+    from debvader_amd._lib import check, lib
+
+    x, y = data
+    xv, yv = val
+    check(lib.dv_debug_general_kernels(1 if kind == "f32alt" else 0))
+    try:
+        eng = E.Engine(E.make_config(max_batch=B, dtype=1 if kind == "bf16" else 0, sigma_floor=sigma_floor))
+        eng.init(seed=5)
+        if shift:
+            hb = eng.get_param("dec/head/bias")
+            hb[6:] += shift
+            eng.set_param("dec/head/bias", hb)
+        eng.optimizer_reset(lr)
+        eng.upload(0, x, y)
+        eng.upload(1, xv, yv)
+        eng.keep_outputs(True)
+        nb = x.shape[0] // B
+        losses, floor_px = [], []
+        for s in range(steps):
+            out = eng.train_step(0, first=(s % nb) * B, B=B, seed=100 + s)
+            losses.append(out["loss"])
+            floor_px.append(int((eng.activation("scale", (B, 59, 59, 6)) <= sigma_floor * (1 + 1e-5)).sum()))
+        v = np.mean([eng.eval_step(1, first=k * B, B=B, seed=7000 + k)["loss"] for k in range(xv.shape[0] // B)])
+        eng.close()
+    finally:
+        check(lib.dv_debug_general_kernels(0))
+    return np.asarray(losses, np.float64), np.asarray(floor_px), float(v)
+
+
+@pytest.fixture(scope="module")
+def training_data():
     from debvader_amd.data import synthetic_stamps
 
-    arch = vo.Arch()
-    B = 64
-    x, y = synthetic_stamps(2 * B, seed=21)
-    curves = []
-    for dtype in (0, 1):
-        eng = _engine(arch, B, dtype=dtype)
-        eng.init(seed=5)
-        hb = eng.get_param("dec/head/bias")
-        hb[arch.nb:] += 0.3                                  # sigma off its floor, see the module docstring
-        eng.set_param("dec/head/bias", hb)
-        eng.optimizer_reset(1e-4)
-        eng.upload(0, x, y)
-        losses = []
-        for step in range(16):
-            out = eng.train_step(0, first=(step % 2) * B, B=B, seed=100 + step)
-            losses.append(out["loss"])
-        eng.close()
-        curves.append(np.asarray(losses, np.float64))
-    f32, bf = curves
+    x, y = synthetic_stamps(512 + 128, seed=21)
+    return (x[:512], y[:512]), (x[512:], y[512:])
+
+
+def test_bf16_training_quality_over_200_steps_against_two_fp32_summation_orders(training_data):
+    """What the bf16 FORMAT costs a training run, measured where a measurement is possible: 200 Adam steps of the three
+    engines configurations from the same initialisation on the same batches, with the head's sigma floor at 0.05
+    instead of the reference's 1e-4 (model.py:154-159; the floor is a dv_config field).  With the floor at 1e-4 the loss
+    is chaotic - see the next test - and no two runs can be compared; at 0.05 its curvature is bounded (1 / sigma^2 <=
+    400), the fp32 engine under another summation order tracks itself to a few 1e-2 per step and 1e-3 in the final
+    validation loss, and the bf16 engine must stay within a stated band of both:
+    per step |bf16 - f32| <= 0.1 (measured 0.05; the loss falls from +2.2e3 to -1.9 over the run), median <= 5e-3
+    (measured 1.7e-3), final validation loss within 1e-2 (measured 2.5e-3 = 0.13 %; the fp32 control: 6e-4)."""
+    data, val = training_data
+    runs = {k: _training_run(k, 200, 0.05, 0.0, data, val) for k in ("f32", "f32alt", "bf16")}
+    f32, falt, bf = (runs[k][0] for k in ("f32", "f32alt", "bf16"))
     assert np.all(np.isfinite(bf))
-    assert f32[-2:].mean() < f32[:2].mean()                  # the run does train
-    scale = np.abs(f32).max()
-    assert np.abs(bf - f32).max() <= 2e-2 * scale, (f32, bf)
+    assert f32[-20:].mean() < -1.5 < 0.0 < f32[:3].mean()         # the run trains (the loss starts at ~2e3)
+    late = slice(20, None)                                         # (the first steps fall through three decades)
+    d_ctl, d_bf = np.abs(falt - f32)[late], np.abs(bf - f32)[late]
+    print(f"\nper-step |f32alt-f32| max {d_ctl.max():.4f} median {np.median(d_ctl):.5f}; |bf16-f32| max {d_bf.max():.4f} "
+          f"median {np.median(d_bf):.5f}; validation f32 {runs['f32'][2]:.5f} f32alt {runs['f32alt'][2]:.5f} "
+          f"bf16 {runs['bf16'][2]:.5f}")
+    assert d_ctl.max() <= 0.1 and abs(runs["f32alt"][2] - runs["f32"][2]) <= 5e-3            # the control holds
+    assert d_bf.max() <= 0.1 and np.median(d_bf) <= 5e-3
+    assert abs(runs["bf16"][2] - runs["f32"][2]) <= 1e-2
+
+
+def test_at_the_reference_sigma_floor_two_fp32_summation_orders_separate_like_bf16_does(training_data):
+    """Round 2's 40-step comparison of the bf16 and the fp32 engine failed after ~20 steps; this is the evidence for why
+    (tools/bf16_drift.py, profiles/r03_bf16_drift_*.txt).  With the reference's floor of 1e-4 under sigma the first
+    pixel reaches the floor at the SAME step in every run (a property of the data and the optimiser, not of a kernel);
+    there (y - mu)^2 / sigma^2 is ~1e8 (y - mu)^2, the loss jumps by orders of magnitude for a step and Adam turns the
+    spike into a full-size update, after which any two runs decorrelate - the fp32 engine under a different SUMMATION
+    ORDER just as much as the bf16 engine.  Asserted: (i) until that step the fp32 control agrees with fp32 to 1e-3 of
+    the loss scale and bf16 to 2e-2; (ii) the first floor pixel arrives at the same step in all three runs; (iii) past
+    it the fp32 control is further from fp32 than 20x its distance before (it has separated, with identical arithmetic)
+    and the bf16 run is no further from fp32 than 4x the control is (median over the remaining steps)."""
+    data, val = training_data
+    steps = 120
+    runs = {k: _training_run(k, steps, 1e-4, 0.3, data, val) for k in ("f32", "f32alt", "bf16")}
+    f32, falt, bf = (runs[k][0] for k in ("f32", "f32alt", "bf16"))
+    first = {k: int(np.argmax(runs[k][1] > 0)) if (runs[k][1] > 0).any() else -1 for k in runs}
+    print(f"\nfirst floor pixel at steps {first}")
+    assert first["f32"] == first["f32alt"] == first["bf16"] and 5 <= first["f32"] < steps - 60, first
+    t0 = first["f32"]
+    scale = np.abs(f32[:t0]).max()
+    pre_ctl, pre_bf = np.abs(falt - f32)[:t0].max(), np.abs(bf - f32)[:t0].max()
+    assert pre_ctl <= 1e-3 * scale and pre_bf <= 2e-2 * scale, (pre_ctl, pre_bf, scale)
+    post = slice(t0 + 10, None)
+    m_ctl, m_bf = np.median(np.abs(falt - f32)[post]), np.median(np.abs(bf - f32)[post])
+    print(f"before step {t0}: |f32alt-f32| <= {pre_ctl:.2e}, |bf16-f32| <= {pre_bf:.2e} (loss scale {scale:.3f}); after: "
+          f"median |f32alt-f32| {m_ctl:.4f}, median |bf16-f32| {m_bf:.4f}; validation f32 {runs['f32'][2]:.4f} "
+          f"f32alt {runs['f32alt'][2]:.4f} bf16 {runs['bf16'][2]:.4f}")
+    assert m_ctl >= 20 * max(pre_ctl, 1e-6), (m_ctl, pre_ctl)
+    assert m_bf <= 4 * m_ctl, (m_bf, m_ctl)
 
 
 def test_bf16_gradients_are_bit_reproducible_at_full_batch():
