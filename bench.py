@@ -7,8 +7,8 @@
         bench.py --gpus N --steps K --warmup W
 
 One process per GPU.  The compute path is the HIP engine (libdebvader_hip.so through ctypes) with RCCL
-gradient all-reduce; torch.distributed (gloo) is used only to hand rank 0's RCCL id to the other ranks,
-for the barriers around the timed region and for the max-over-ranks of the elapsed time.
+gradient all-reduce.  Rank 0's RCCL id, the barriers around the timed region and the max-over-ranks of the
+elapsed time travel over debvader_amd.parallel.HostGroup (a TCP star on MASTER_ADDR): no torch in a GPU process.
 Inputs are resident in HBM before the timed region (dv_data_upload), synthetic, random-init weights.
 
 The ONE JSON line also carries (rank 0, N = 1 only; --no-secondary / --no-cpu-baseline / --no-roofline switch them off):
@@ -309,13 +309,8 @@ def main():
         parallel.E = E
         args.no_roofline = args.no_secondary = args.no_cpu_baseline = True
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        dist.init_process_group("gloo")
-    ctx = parallel.make_context(rank, world, local_rank, dist)
+    ctx = parallel.make_context(rank, world, local_rank)     # world > 1: the ranks meet in a parallel.HostGroup
+    group = ctx.group
 
     B = args.batch
     bf16 = args.dtype == "bf16"
@@ -330,8 +325,8 @@ def main():
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            dist.barrier()
+        if group is not None:
+            group.barrier()
 
     if args.warmup > 0:
         eng.train_steps(0, 0, B, args.warmup, global_batch=Bg, seed=1)
@@ -341,12 +336,8 @@ def main():
     ctx.sync()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    if group is not None:
+        dt = group.max(dt)
 
     enc_macs, dec_macs = E.arch_macs(cfg)
     fwd_flops = 2.0 * (enc_macs + dec_macs + cfg.latent_dim * (cfg.latent_dim + 1) // 2)
@@ -441,14 +432,11 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
+    if group is not None:
+        group.barrier()          # nobody tears its communicator down while another rank is still inside a collective
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-        # torch (gloo) and the engine's HIP runtime live in this process: leave without running static destructors
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+    if group is not None:
+        group.close()
 
 
 if __name__ == "__main__":

@@ -103,7 +103,6 @@ SIGNATURES = {
     "dv_model_set_normalise": (C.c_int, [_p, C.c_int32]),
     "dv_model_set_mse_sample": (C.c_int, [_p, C.c_int32]),
     "dv_model_set_infer_graph": (C.c_int, [_p, C.c_int32]),
-    "dv_model_set_small_forward": (C.c_int, [_p, C.c_int32]),
     "dv_model_set_keep_outputs": (C.c_int, [_p, C.c_int32]),
     "dv_infer": (C.c_int, [_p, _f, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
     "dv_infer_f64": (C.c_int, [_p, _d, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),

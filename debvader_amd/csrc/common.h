@@ -294,28 +294,6 @@ int launch_prelu_bwd(float* da, const float* u, const float* alpha, int NB, int 
                      float* dalpha_part, float* dbias_part, int* dbias_rows, hipStream_t s);
 int launch_colsum(const float* x, long rows, int C, float* part, int* nrows_part, hipStream_t s);
 
-// ---- small-batch forward: a conv / dense layer stack in one cooperative launch (small_fwd.hip) ----------------
-enum { SM_CONV = 0, SM_DENSE = 1, SM_REDUCE = 2 };
-struct SmLayer {
-  const float* in;        // conv: [NB][hin][hin][cin] (cin = physical channels, multiple of 4); dense: [NB][cin]
-  float* out;             // conv: [NB][hout][hout][cout]; dense / reduce: [NB][cout]
-  const float* W;         // conv: [tap][cin][cout], or [tap][cout][cin] when nmajor; dense: [cin][cout]
-  const float* bias;      // [cout] or null
-  const float* alpha;     // PReLU slopes of the output ([hout*hout*cout] for a conv, [cout] for a dense layer) or null
-  const float* in_alpha;  // dense: PReLU applied to the input on load ([cin]) or null
-  float* part;            // dense with ksplit > 1 / reduce: partial sums [ksplit][NB][cout]
-  int kind, form, nmajor, ksplit;
-  int hin, cin, hout, cout, s, pb;
-};
-#define DV_SM_MAX_LAYERS 16
-struct SmStack {
-  SmLayer L[DV_SM_MAX_LAYERS];
-  int n, NB;
-  int dbg;                // timing ablations (wrong results): 1 barriers only, 2 no barriers
-};
-// workgroups a cooperative launch of the stack kernel may use on this device (0: cooperative launches unavailable)
-int small_stack_max_grid(int device);
-int launch_small_stack(const SmStack& p, int grid, hipStream_t s);
 
 struct SamplerParams {
   const float* t;      // [NB, d + d(d+1)/2]

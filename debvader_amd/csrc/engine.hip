@@ -312,6 +312,7 @@ struct dv_ctx {
   hipEvent_t ev_mid = nullptr;
   ncclComm_t comm = nullptr;
   float* red_dev = nullptr;  // small device buffer for host all-reduce
+  std::vector<dv_model*> models;   // live models of this context: dv_ctx_destroy destroys them first
 };
 
 struct ProfRec {
@@ -451,14 +452,9 @@ struct dv_model {
   unsigned long long* seed_dev = nullptr;
   bool use_seed_dev = false;
   bool infer_graph = false;
-  // small-batch forward (small_fwd.hip): batches of at most small_max stamps run the encoder and the decoder stack as
-  // one cooperative launch each; small_grid = workgroups such a launch may use (-1: not queried yet, 0: unavailable).
-  // Opt-in (0 = off): measured SLOWER than the per-layer launches on MI355X
-  int small_max = 0;
   // set by dv_infer / dv_encode / dv_decode for calls of at most 16 stamps: the deep layers slice K over workgroups
   // (gconv2_small_splitk).  Decided per CALL, not per launch, so that how a longer input is chunked never changes bits.
   bool tiny_call = false;
-  int small_grid = -1;
   bool keep_outputs = false;     // gradient / train steps also write loc and scale (introspection)
   std::map<int, hipGraphExec_t> infer_graphs;
   std::map<int, int> infer_seen;
@@ -590,29 +586,30 @@ static void fill_gconv_common(GConvParams& p, const Taps& t, int cin) {
   p.cin_shift = ilog2_exact(cin);
 }
 
-// Flags of the events that only order streams of this GPU against each other.  By default a HIP event record carries
-// a system-scope release (cache write-back so that the host and peer GPUs see the data); these events have no such
-// readers behind them - results reach the host through copies and the events of the result ring, peers through
-// RCCL's own fences - so the fence is switched off (+0.7 % steps/s; tools/determinism_probe.py stays bit-identical
-// over repeated gradient and train steps).  DV_EVENT_SCOPE=system restores the default, =device asks for an explicit
-// device-scope release.
+// Flags of the engine's ordering events.  By default a HIP event record carries a system-scope release (cache write-back
+// so that the host and peer GPUs see the data).
+//  * One rank (the headline configuration): every event orders streams of ONE GPU - main / aux / reduction / comm
+//    stream, forward lanes, buffer hand-overs - whose waiters read through the same L2; results reach the host through
+//    copies and the events of the result ring.  The fence is switched off (+0.7 % steps/s; tools/determinism_probe.py
+//    stays bit-identical over repeated gradient and train steps).
+//  * Several ranks: EVERY event keeps HIP's default system-scope release.  RCCL kernels read the gradient buckets through
+//    peer mappings over xGMI and hand results back to the main stream (ev_comm, ev_small2, ev_bnpre); which of those
+//    hand-overs could do without the fence has never been measured on more than one GPU (no multi-GPU box is reachable
+//    from a build session), so nothing is relaxed there.  DV_EVENT_SCOPE=relaxed opts a multi-rank job into the
+//    single-rank flags for exactly that experiment (compare parameters bit for bit against the default).
+//  * DV_EVENT_SCOPE=system / device force system scope / an explicit device-scope release everywhere.
 static bool g_multi_rank = false;      // set by dv_ctx_create (one context per process) before any event exists
 static unsigned sync_event_flags() {
   const char* e = getenv("DV_EVENT_SCOPE");
   if (e && !strcmp(e, "system")) return (unsigned)hipEventDisableTiming;
   if (e && !strcmp(e, "device")) return (unsigned)(hipEventDisableTiming | hipEventReleaseToDevice);
-  // Default: no fence.  These events order streams of ONE GPU (main / aux / reduction stream, forward lanes, buffer
-  // hand-overs): the waiter runs on the same device and reads through the same L2, with one rank or with eight.
+  if (g_multi_rank && !(e && !strcmp(e, "relaxed"))) return (unsigned)hipEventDisableTiming;
   return (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
 }
-// Events the COMM stream waits on in front of an RCCL launch (gradient buckets, BN sums, loss sums).  With peers in the
-// job what is recorded behind them is read by OTHER GPUs over xGMI, so the record keeps HIP's default system-scope
-// release; with one rank (or the one-rank test communicator) nothing leaves the device and the fence is dropped like
-// everywhere else.  Results come BACK from the comm stream through ev_comm / ev_small2 / ev_bnpre: RCCL's kernels
-// complete their own peer traffic before they retire, the waiter is a local stream - no fence.
+// Events the COMM stream waits on in front of an RCCL launch (gradient buckets, BN sums, loss sums): what is recorded
+// behind them is read by OTHER GPUs, so with several ranks they keep the system-scope release even under
+// DV_EVENT_SCOPE=relaxed.
 static unsigned comm_gate_event_flags() {
-  const char* e = getenv("DV_EVENT_SCOPE");
-  if (e && !strcmp(e, "none")) return (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
   if (g_multi_rank) return (unsigned)hipEventDisableTiming;
   return sync_event_flags();
 }
@@ -1345,37 +1342,6 @@ struct TinyCall {          // scope of one public inference call of at most 16 s
   ~TinyCall() { m->tiny_call = false; }
 };
 
-// Inference batches of a few stamps are bound by kernel-to-kernel dispatch latency: they take the cooperative
-// layer-stack kernel (small_fwd.hip) instead of one launch per layer.  Not for passes that keep pre-activations
-// (training), not while a hipGraph capture / replay is in use, not under the profiler's per-launch events.
-static bool small_forward_ok(dv_model* m, int NB, bool keep_u) {
-  static const int env_max = getenv("DV_SMALL_FWD_MAX") ? atoi(getenv("DV_SMALL_FWD_MAX")) : -1;
-  const int lim = env_max >= 0 ? env_max : m->small_max;
-  if (keep_u || NB > lim || m->bf.on || m->prof_on || m->use_seed_dev || m->infer_graph || m->lane_id != 0 || m->b0 != 0)
-    return false;
-  const Arch& A = m->A;
-  if (2 * A.L + 3 > DV_SM_MAX_LAYERS) return false;
-  for (int i = 0; i < A.L; ++i)
-    if (A.cfg.filters[i] & 3) return false;
-  if ((size_t)16 * NB * A.tw > m->ws4_elems) return false;
-  if (m->small_grid < 0) m->small_grid = small_stack_max_grid(m->ctx->device);
-  return m->small_grid > 0;
-}
-
-static void sm_conv(SmLayer& L, const float* in, float* out, const float* W, bool nmajor, const float* bias,
-                    const float* alpha, int form, int hin, int cin, int hout, int cout, int st, int pb) {
-  memset(&L, 0, sizeof L);
-  L.kind = SM_CONV; L.in = in; L.out = out; L.W = W; L.nmajor = nmajor ? 1 : 0; L.bias = bias; L.alpha = alpha;
-  L.form = form; L.hin = hin; L.cin = cin; L.hout = hout; L.cout = cout; L.s = st; L.pb = pb;
-}
-
-static void sm_dense(SmLayer& L, const float* in, const float* in_alpha, float* out, const float* W, const float* bias,
-                     const float* alpha, int K, int N, int ksplit, float* part) {
-  memset(&L, 0, sizeof L);
-  L.kind = SM_DENSE; L.in = in; L.in_alpha = in_alpha; L.out = out; L.W = W; L.bias = bias; L.alpha = alpha;
-  L.cin = K; L.cout = N; L.ksplit = ksplit; L.part = part;
-}
-
 static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u) {
   if (m->bf.on) return bf_encoder_forward(m, xsrc, idx, first, NB, keep_u);
   const Arch& A = m->A;
@@ -1386,28 +1352,6 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
   {
     ProfScope ps(m, 2);
     DV_TRY(launch_bn_apply(xsrc, idx ? idx + m->b0 : nullptr, first + m->b0, NB, HW, A.C, 8, m->bnstate, xn, s));
-  }
-  if (small_forward_ok(m, NB, keep_u)) {
-    SmStack st;
-    memset(&st, 0, sizeof st);
-    st.NB = NB;
-    const float* in = xn;
-    for (int j = 0; j < 2 * A.L; ++j) {
-      int hin, cin, hout, cout, sd;
-      A.enc_layer(j, &hin, &cin, &hout, &cout, &sd);
-      sm_conv(st.L[st.n++], in, m->enc_a[j], j == 0 ? m->W1p : P + A.specs[A.enc_k(j)].off, false,
-              P + A.specs[A.enc_b(j)].off, P + A.specs[A.enc_al(j)].off, 0, hin, j == 0 ? 8 : cin, hout, cout, sd,
-              same_pad_before(hin, 3, sd, nullptr));
-      in = m->enc_a[j];
-    }
-    // flatten -> PReLU (on load) -> Dense(params_size), K split 8 x 4 ways, partials summed in order
-    const int ks = 8;
-    sm_dense(st.L[st.n++], in, P + A.specs[A.enc_flat_al()].off, nullptr, P + A.specs[A.enc_dk()].off, nullptr, nullptr,
-             A.flat, A.tw, ks, m->ws4);
-    SmLayer& R = st.L[st.n++];
-    memset(&R, 0, sizeof R);
-    R.kind = SM_REDUCE; R.part = m->ws4; R.out = m->t; R.bias = P + A.specs[A.enc_db()].off; R.cout = A.tw; R.ksplit = ks;
-    return launch_small_stack(st, m->small_grid, s);
   }
   const float* in = xn;
   for (int j = 0; j < 2 * A.L; ++j) {
@@ -1435,27 +1379,6 @@ static int decoder_forward(dv_model* m, int NB, bool keep_u) {
   const Arch& A = m->A;
   hipStream_t s = fwd_stream(m);
   float* P = m->P;
-  if (small_forward_ok(m, NB, keep_u)) {
-    SmStack st;
-    memset(&st, 0, sizeof st);
-    st.NB = NB;
-    const int r = A.w0 * A.w0 * A.cfg.filters[A.L - 1];
-    sm_dense(st.L[st.n++], m->z, P + A.specs[A.D0].off, m->dec_ah, P + A.specs[A.D0 + 1].off, P + A.specs[A.D0 + 2].off,
-             P + A.specs[A.D0 + 3].off, A.d, A.dec_hidden, 1, nullptr);
-    sm_dense(st.L[st.n++], m->dec_ah, nullptr, m->dec_ar, P + A.specs[A.D0 + 4].off, P + A.specs[A.D0 + 5].off,
-             P + A.specs[A.D0 + 6].off, A.dec_hidden, r, 1, nullptr);
-    const float* in = m->dec_ar;
-    for (int j = 0; j < 2 * A.L; ++j) {
-      int hin, cin, hout, cout, sd;
-      A.dec_layer(j, &hin, &cin, &hout, &cout, &sd);
-      sm_conv(st.L[st.n++], in, m->dec_a[j], P + A.specs[A.dec_k(j)].off, true, P + A.specs[A.dec_b(j)].off,
-              P + A.specs[A.dec_al(j)].off, 1, hin, cin, hout, cout, sd, same_pad_before(hout, 3, sd, nullptr));
-      in = m->dec_a[j];
-    }
-    sm_conv(st.L[st.n++], in, m->tpre, m->Whp, false, m->bhp, nullptr, 0, A.dec_out, A.cfg.filters[0], A.dec_out, A.C2p,
-            1, 1);
-    return launch_small_stack(st, m->small_grid, s);
-  }
   {
     ProfScope ps(m, 2);
     DV_TRY(launch_prelu_fwd(LANE(m->z, A.d), P + A.specs[A.D0].off, LANE(m->dec_ain, A.d), NB, A.d, s));
@@ -2542,6 +2465,12 @@ int dv_comm_unique_id(void* out_id) {
   return DV_OK;
 }
 
+// Set by an exit handler that is registered at the first dv_ctx_create, i.e. AFTER the HIP runtime registered its own:
+// exit() runs handlers in reverse order, so from the moment this flag is up the runtime may already be gone and the
+// destroy calls only release host memory (the process is going away; the driver reclaims the rest).
+static bool g_process_exiting = false;
+static void mark_process_exiting() { g_process_exiting = true; }
+
 int dv_ctx_destroy(dv_ctx* c);
 static int ctx_build(dv_ctx* c, int world, int rank, const void* unique_id) {
   DV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -2605,6 +2534,11 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
     return DV_E_INVALID;
   }
   DV_HIP(hipSetDevice(device));
+  static bool exit_hook = false;
+  if (!exit_hook) {
+    (void)hipFree(nullptr);                 // the runtime is fully initialised (and has its exit handlers) before ours
+    exit_hook = atexit(mark_process_exiting) == 0;
+  }
   dv_ctx* c = new dv_ctx();
   c->device = device;
   c->rank = rank;
@@ -2622,7 +2556,15 @@ int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* uniqu
 
 int dv_ctx_destroy(dv_ctx* c) {
   if (!c) return DV_OK;
+  // models first: their buffers, events and pinned memory belong to this context's device and streams
+  while (!c->models.empty()) dv_model_destroy(c->models.back());
+  if (g_process_exiting) {
+    delete c;
+    return DV_OK;
+  }
   (void)hipSetDevice(c->device);
+  for (hipStream_t st : {c->stream, c->comm_stream, c->aux_stream, c->red_stream})
+    if (st) (void)hipStreamSynchronize(st);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->red_dev) (void)hipFree(c->red_dev);
   if (c->ev_dec) (void)hipEventDestroy(c->ev_dec);
@@ -2680,8 +2622,21 @@ int dv_ctx_allreduce_host(dv_ctx* c, float* buf, int32_t n) {
 
 int dv_model_destroy(dv_model* m) {
   if (!m) return DV_OK;
+  if (m->ctx) {
+    auto& v = m->ctx->models;
+    v.erase(std::remove(v.begin(), v.end(), m), v.end());
+  }
+  if (g_process_exiting) {                   // see mark_process_exiting: host memory only
+    delete m->pipe;
+    delete m;
+    return DV_OK;
+  }
   (void)hipSetDevice(m->ctx->device);
-  (void)hipStreamSynchronize(m->ctx->stream);
+  // every stream a step or an inference call may have queued work on (weight gradients, reductions, collectives)
+  for (hipStream_t st : {m->ctx->stream, m->ctx->aux_stream, m->ctx->red_stream, m->ctx->comm_stream})
+    if (st) (void)hipStreamSynchronize(st);
+  for (hipStream_t st : m->ctx->lane_stream)
+    if (st) (void)hipStreamSynchronize(st);
   for (void* p : m->allocs) (void)hipFree(p);
   for (int s = 0; s < 2; ++s) {
     if (m->slots[s].x) (void)hipFree(m->slots[s].x);
@@ -2722,13 +2677,13 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
     delete m;
     return st;
   }
+  ctx->models.push_back(m);
   const Arch& A = m->A;
   const size_t Bc = (size_t)cfg->max_batch;
   m->Bc = cfg->max_batch;
   if (cfg->dtype != DV_DTYPE_F32 && cfg->dtype != DV_DTYPE_BF16) {
     set_error("unknown dtype %d", cfg->dtype);
-    delete m;
-    return DV_E_INVALID;
+    return dv_model_destroy(m), DV_E_INVALID;
   }
   const bool bf16 = cfg->dtype == DV_DTYPE_BF16;
   const size_t Ba = bf16 ? 0 : Bc;   // fp32 activations of the conv stacks: not allocated by the bf16 engine
@@ -3232,11 +3187,6 @@ int dv_model_set_infer_graph(dv_model* m, int32_t on) {
   return DV_OK;
 }
 
-int dv_model_set_small_forward(dv_model* m, int32_t max_stamps) {
-  if (!m || max_stamps < 0) return DV_E_INVALID;
-  m->small_max = max_stamps;
-  return DV_OK;
-}
 
 int dv_model_set_mse_sample(dv_model* m, int32_t on) {
   if (!m) return DV_E_INVALID;
@@ -3273,7 +3223,7 @@ static int infer_cutouts_impl(dv_model* m, const double* field, int32_t F, int32
   }
   for (int64_t i = 0; i < N; ++i) {
     const int x = starts[2 * i], y = starts[2 * i + 1];
-    if (x < 0 || y < 0 || x + cs > F || y + cs > F) {
+    if (x < 0 || y < 0 || x > F - cs || y > F - cs) {   // (cs <= F holds; no x + cs: it overflows near INT_MAX)
       set_error("dv_infer_cutouts: cutout %ld (start %d,%d size %d) leaves the %d-pixel field", (long)i, x, y, cs, F);
       return DV_E_INVALID;
     }

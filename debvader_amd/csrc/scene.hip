@@ -183,7 +183,7 @@ int scene_extract(const double* field_h, int F, int nb, const int32_t* starts_h,
   if (N == 0) return OK;
   for (int i = 0; i < N; ++i) {
     const int x = starts_h[2 * i], y = starts_h[2 * i + 1];
-    if (x < 0 || y < 0 || x + cs > F || y + cs > F) {
+    if (x < 0 || y < 0 || x > F - cs || y > F - cs) {   // (cs <= F holds; no x + cs: it overflows near INT_MAX)
       set_error("scene_extract: cutout %d (start %d,%d size %d) leaves the %d-pixel field", i, x, y, cs, F);
       return E_INVALID;
     }

@@ -5,7 +5,9 @@ sit on top of it.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -75,6 +77,20 @@ def _fp(a: Optional[np.ndarray]):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+def _i32_rows(a, what: str) -> np.ndarray:
+    """Integer (x, y) rows for the C-ABI's int32 arrays.  A plain astype would wrap 64-bit values into range silently -
+    a start of 2**32 + 5 would fetch the cutout at 5 - so the range is checked before the cast."""
+    a = np.asarray(a)
+    if a.dtype.kind not in "iu":
+        r = np.rint(np.asarray(a, dtype=np.float64))
+        if a.size and not np.array_equal(r, np.asarray(a, dtype=np.float64)):
+            raise ValueError(f"{what} must be integers")
+        a = r
+    if a.size and (a.min() < -2 ** 31 or a.max() > 2 ** 31 - 1):
+        raise ValueError(f"{what} outside the int32 range")
+    return np.ascontiguousarray(a, dtype=np.int32).reshape(-1, 2)
+
+
 def _f32c(a, shape=None) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.float32)
     if shape is not None and tuple(a.shape) != tuple(shape):
@@ -83,10 +99,21 @@ def _f32c(a, shape=None) -> np.ndarray:
 
 
 class Context:
-    """One per process: selects the GPU, owns the HIP stream and the RCCL communicator."""
+    """One per process: selects the GPU, owns the HIP streams and the RCCL communicator.
+
+    Lifetime: every Engine registers with its Context; close() destroys the live engines first (their buffers, events
+    and pinned memory hang off the context's device and streams), then the communicator and the streams.  Contexts still
+    open when the interpreter exits are closed by an atexit hook, i.e. BEFORE Python finalises modules in arbitrary
+    order and before the C runtime runs the HIP runtime's own exit handlers - relying on __del__ there left models
+    alive behind their context (SIGSEGV inside exit() under rocprofv3)."""
+
+    _live: "weakref.WeakSet[Context]" = weakref.WeakSet()
 
     def __init__(self, device: int = 0, rank: int = 0, world: int = 1, unique_id: Optional[bytes] = None):
         self._h = C.c_void_p()
+        self._engines: "weakref.WeakSet[Engine]" = weakref.WeakSet()
+        self.group = None                 # host-side rendezvous of the job (debvader_amd.parallel.make_context)
+        self._owns_group = False
         self.rank, self.world, self.device = rank, world, device
         idbuf = None
         if world > 1:
@@ -94,6 +121,7 @@ class Context:
                 raise ValueError("world > 1 needs rank 0's unique id (Context.unique_id())")
             idbuf = C.create_string_buffer(unique_id, _lib.DV_UNIQUE_ID_BYTES)
         check(lib.dv_ctx_create(device, rank, world, idbuf, C.byref(self._h)))
+        Context._live.add(self)
 
     @staticmethod
     def unique_id() -> bytes:
@@ -113,7 +141,7 @@ class Context:
     def scene_extract(self, field, starts, cutout_size: int) -> np.ndarray:
         """cutouts[i] = field[starts[i,0]:+cs, starts[i,1]:+cs, :] for a field (F, F, bands)."""
         field = np.ascontiguousarray(field, dtype=np.float64)
-        starts = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, 2)
+        starts = _i32_rows(starts, "cutout starts")
         if field.ndim != 3 or field.shape[0] != field.shape[1]:
             raise ValueError(f"expected a square field (F, F, bands), got {field.shape}")
         out = np.empty((starts.shape[0], cutout_size, cutout_size, field.shape[2]), np.float64)
@@ -142,15 +170,36 @@ class Context:
         return out
 
     def close(self):
+        """Destroys the engines created on this context, then the context.  Idempotent."""
+        for eng in list(self._engines):
+            eng.close()
         if self._h:
             lib.dv_ctx_destroy(self._h)
             self._h = C.c_void_p()
+        if self.group is not None and self._owns_group:
+            try:
+                self.group.close()
+            except Exception:
+                pass
+        self.group = None
+        Context._live.discard(self)
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+
+@atexit.register
+def _close_all_contexts():
+    global _default_ctx
+    for ctx in list(Context._live):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+    _default_ctx = None
 
 
 _default_ctx: Optional[Context] = None
@@ -175,7 +224,10 @@ class Engine:
         self.ctx = ctx or default_context()
         self.cfg = cfg
         self._h = C.c_void_p()
+        if not self.ctx._h:
+            raise RuntimeError("the Context of this Engine has been closed")
         check(lib.dv_model_create(self.ctx._h, C.byref(cfg), C.byref(self._h)))
+        self.ctx._engines.add(self)
         self.specs = arch_specs(cfg)
         self.index = {n: i for i, (n, _, _) in enumerate(self.specs)}
         self.latent = cfg.latent_dim
@@ -188,6 +240,10 @@ class Engine:
         if self._h:
             lib.dv_model_destroy(self._h)
             self._h = C.c_void_p()
+        try:
+            self.ctx._engines.discard(self)
+        except Exception:
+            pass
 
     def __del__(self):
         try:
@@ -324,12 +380,6 @@ class Engine:
         measured no faster than the eager launches on MI355X, hence off by default."""
         check(lib.dv_model_set_infer_graph(self._h, 1 if on else 0))
 
-    def set_small_forward(self, max_stamps: int):
-        """Inference batches of at most `max_stamps` stamps (0 = off, the default) take the cooperative layer-stack
-        kernels: two launches instead of ~25 for the conv / dense stacks.  Measured slower than the per-layer launches on
-        MI355X, kept as an opt-in."""
-        check(lib.dv_model_set_small_forward(self._h, int(max_stamps)))
-
     def infer(self, x, eps=None, seed=0, want=("loc", "scale"), out=None) -> Dict[str, np.ndarray]:
         """One stochastic forward pass over all stamps.  float64 arrays (numpy's default, what the reference's callers
         pass) go to the engine as they are: the float32 cast of deblender.py:18 happens while the library stages them."""
@@ -366,7 +416,7 @@ class Engine:
         gathered and cast on the GPU (dv_infer_cutouts): the stamps never visit the host.  Bit-identical to
         infer(ctx.scene_extract(field, starts, H)) with the same seed."""
         field = np.ascontiguousarray(field, dtype=np.float64)
-        starts = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, 2)
+        starts = _i32_rows(starts, "cutout starts")
         if field.ndim != 3 or field.shape[0] != field.shape[1]:
             raise ValueError(f"expected a square field (F, F, bands), got {field.shape}")
         N = starts.shape[0]
@@ -392,7 +442,7 @@ class Engine:
         buffers, valid until the consumer returns, stamps [first, first + count) in input order.  Nothing is copied on
         the host; the GPU works on the next chunks meanwhile."""
         field = np.ascontiguousarray(field, dtype=np.float64)
-        starts = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, 2)
+        starts = _i32_rows(starts, "cutout starts")
         if field.ndim != 3 or field.shape[0] != field.shape[1]:
             raise ValueError(f"expected a square field (F, F, bands), got {field.shape}")
         failure = []

@@ -267,17 +267,28 @@ class VAENet:
         self.losses = [scal["kl_reg"] / k] * k
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, shuffle=True,
-            validation_data=None, validation_steps=None, initial_epoch=0, **kwargs):
+            validation_data=None, validation_steps=None, initial_epoch=0, reuse_device_data=False, **kwargs):
         """Keras Model.fit for in-memory arrays (train.py:27-37): per-epoch shuffle, last partial batch used,
         validation in inference mode, returns History with loss / mse / <metric fn names> / val_*.
-        With several ranks (debvader_amd.parallel) `batch_size` is the GLOBAL batch; each rank runs its
-        contiguous slice of every batch and gradients are all-reduced inside the engine."""
+
+        Several ranks (debvader_amd.parallel): `batch_size` is the GLOBAL batch; rank r runs the r-th contiguous slice
+        of every global batch and gradients are all-reduced inside the engine.  Every rank passes the same arrays and
+        keeps only ITS rows in HBM: the rows the unshuffled batch sequence gives it (`_home_rows`), 1/world of the set.
+        Shuffling then permutes each rank's rows among themselves, so a global batch is the union of one random piece
+        per rank - every stamp once per epoch, batches stratified over the ranks' shards instead of drawn from one
+        global permutation; with one rank it is Keras' global shuffle, and shuffle=False reproduces the sequential
+        batches exactly for any number of ranks.
+
+        reuse_device_data: Keras re-reads the arrays on every call, and so does this method (the upload is PCIe-bound,
+        faster than any content hash of the arrays would be).  reuse_device_data=True skips the upload when the same
+        array OBJECTS (identity, shape, batch geometry) are still resident from the previous fit() - the caller's
+        promise that their contents have not changed in between."""
         if not self._core.compiled:
             raise RuntimeError("You must compile your model before training/testing. Use `model.compile(...)`.")
         core, eng = self._core, self._core.engine
         x_in, y_in = x, y
-        x = np.asarray(x, dtype=np.float32)
-        y = np.asarray(y, dtype=np.float32)
+        x = np.asarray(x)
+        y = np.asarray(y)
         n = x.shape[0]
         batch_size = int(batch_size or 32)
         rank, world = core.ctx.rank, core.ctx.world
@@ -289,8 +300,8 @@ class VAENet:
         nv = 0
         xv = yv = None
         if validation_data is not None:
-            xv = np.asarray(validation_data[0], dtype=np.float32)
-            yv = np.asarray(validation_data[1], dtype=np.float32)
+            xv = np.asarray(validation_data[0])
+            yv = np.asarray(validation_data[1])
             nv = xv.shape[0]
         # Every batch of the epoch - the ragged last ones included - must give every rank at least one stamp: a rank
         # with an empty shard would skip its collectives while the others have queued theirs.  All ranks see the same
@@ -308,9 +319,14 @@ class VAENet:
             if small:
                 raise ValueError(f"a batch of {small[0]} stamp(s) cannot be split over {world} ranks: choose a batch size "
                                  f"(and data-set sizes modulo the batch size) of at least {world}")
-        self._upload_cached(0, x_in, x, y_in, y)
+        # this rank's rows of the training set, per step; resident rows are addressed by their position in `home`
+        home, pieces = self._home_rows(n, batch_size, rank, world)
+        self._upload(0, x_in, x, y_in, y, home, (n, batch_size, rank, world), reuse_device_data)
+        vpieces = []
         if nv:
-            self._upload_cached(1, validation_data[0], xv, validation_data[1], yv)
+            vhome, vpieces = self._home_rows(min(nv, val_steps * batch_size), batch_size, rank, world)
+            self._upload(1, validation_data[0], xv, validation_data[1], yv, vhome, (nv, batch_size, val_steps, rank, world),
+                         reuse_device_data)
         hist = History()
         cbs = list(callbacks or [])
         for cb in cbs:
@@ -321,10 +337,17 @@ class VAENet:
         self._fit_calls = getattr(self, "_fit_calls", 0) + 1
         rng = np.random.default_rng(kwargs["shuffle_seed"] if "shuffle_seed" in kwargs
                                     else [0x5EED, core.shuffle_base, self._fit_calls])
+        all_sizes = [self._home_rows(n, batch_size, r, world)[0].size for r in range(world)] if world > 1 else [n]
         self.stop_training = False
         for epoch in range(initial_epoch, epochs):
             t0 = time.time()
-            order = rng.permutation(n) if shuffle else np.arange(n)
+            # one permutation per rank from the SHARED generator (its state stays identical on all ranks); this rank
+            # applies its own to its resident rows
+            order = None
+            for r, sz in enumerate(all_sizes):
+                perm = rng.permutation(sz) if shuffle else np.arange(sz)
+                if r == rank:
+                    order = perm
             sums: Dict[str, float] = {}
             seen = 0
             # Steps are queued two ahead of the one whose loss the host is reading (deferred results), so the GPU
@@ -342,12 +365,10 @@ class VAENet:
                 seen += count
 
             try:
-                for b0 in range(0, n, batch_size):
-                    gidx = order[b0:b0 + batch_size]
-                    lo, hi = shard_range(len(gidx), rank, world)
-                    eng.train_step_async(ticket, 0, idx=gidx[lo:hi].astype(np.int32), global_batch=len(gidx),
+                for (c0, c1, gb) in pieces:
+                    eng.train_step_async(ticket, 0, idx=order[c0:c1].astype(np.int32), global_batch=gb,
                                          seed=core.next_seed())
-                    pending.append((ticket, len(gidx)))
+                    pending.append((ticket, gb))
                     ticket = (ticket + 1) % 4
                     if len(pending) > 2:
                         collect(pending.pop(0))
@@ -365,11 +386,8 @@ class VAENet:
             if nv:
                 vs: Dict[str, float] = {}
                 vseen = 0
-                for s in range(val_steps):
-                    b0 = s * batch_size
-                    gb = min(batch_size, nv - b0)
-                    lo, hi = shard_range(gb, rank, world)
-                    scal = eng.eval_step(1, first=b0 + lo, B=hi - lo, global_batch=gb, seed=core.next_seed())
+                for (c0, c1, gb) in vpieces:
+                    scal = eng.eval_step(1, first=c0, B=c1 - c0, global_batch=gb, seed=core.next_seed())
                     self._set_losses(scal)
                     for k, v in self._metric_values(scal).items():
                         vs[k] = vs.get(k, 0.0) + v * gb
@@ -394,23 +412,42 @@ class VAENet:
         self.history = hist
         return hist
 
-    def _upload_cached(self, slot, x_orig, x32, y_orig, y32):
-        """dv_data_upload once per data set: a later fit() on the SAME arrays (object identity, shape, and a strided
-        content probe, which catches in-place edits of the usual kind) reuses the copy resident in HBM."""
-        def probe(a):
-            flat = a.reshape(-1)
-            step = max(1, flat.size // 4096)
-            return (a.shape, a.__array_interface__["data"][0], float(flat[::step].astype(np.float64).sum()))
+    @staticmethod
+    def _home_rows(n, batch_size, rank, world):
+        """Rows of an n-stamp set that `rank` owns, and its slice of every step.  Global batch k of the unshuffled
+        sequence is rows [k*batch_size, ...) and rank r takes its r-th contiguous slice (contiguous equal
+        shards of the global batch by index); the union over k is what the rank keeps resident - a partition of the
+        set over the ranks, sizes equal up to one stamp per step.
+        returns (home, pieces): global row numbers in resident order; per step (begin, end, global_batch) with begin /
+        end positions in `home`."""
+        from debvader_amd.parallel import shard_range
 
-        key = (id(x_orig), id(y_orig), probe(x32), probe(y32))
+        rows, pieces, c = [], [], 0
+        for b0 in range(0, n, batch_size):
+            gb = min(batch_size, n - b0)
+            lo, hi = shard_range(gb, rank, world)
+            rows.append(np.arange(b0 + lo, b0 + hi, dtype=np.int64))
+            pieces.append((c, c + hi - lo, gb))
+            c += hi - lo
+        return (np.concatenate(rows) if rows else np.zeros(0, np.int64)), pieces
+
+    def _upload(self, slot, x_orig, x, y_orig, y, home, geometry, reuse):
+        """dv_data_upload of this rank's rows (float32, as Keras casts them in fit).  With reuse=True a later fit() on the
+        same array objects and the same batch geometry keeps the resident copy (see fit's reuse_device_data)."""
+        key = (id(x_orig), id(y_orig), np.shape(x), np.shape(y), geometry)
         cache = self._core.upload_keys
-        if cache.get(slot) == key:
+        if reuse and cache.get(slot) == key:
             return
-        self._core.engine.upload(slot, x32, y32)
+        cache.pop(slot, None)
+        whole = home.size == np.shape(x)[0]                          # one rank: no gather, the cast is the only copy
+        xs = np.asarray(x if whole else x[home], dtype=np.float32)
+        ys = np.asarray(y if whole else y[home], dtype=np.float32)
+        self._core.engine.upload(slot, xs, ys)
         cache[slot] = key
 
     def evaluate(self, x, y, batch_size=32, verbose=0):
         eng, core = self._core.engine, self._core
+        core.upload_keys.pop(1, None)        # slot 1 no longer holds fit()'s validation set (reuse_device_data)
         n = eng.upload(1, x, y)
         tot: Dict[str, float] = {}
         for b0 in range(0, n, batch_size):

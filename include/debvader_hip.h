@@ -86,6 +86,9 @@ int dv_device_count(int32_t* n);
 int dv_comm_unique_id(void* out_id /* DV_UNIQUE_ID_BYTES */);
 /* world == 1: id may be NULL.  world > 1: every rank passes rank 0's id (exchanged by the host). */
 int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* unique_id, dv_ctx** out);
+/* Destroys the models still alive on the context first (their handles become invalid), then the communicator, events
+ * and streams.  Once the process is inside exit() (the HIP runtime's own exit handlers may have run) both destroy calls
+ * only release host memory. */
 int dv_ctx_destroy(dv_ctx* ctx);
 int dv_ctx_sync(dv_ctx* ctx);
 /* sum `n` floats over ranks in place (host buffer); used by the host loop for History scalars */
@@ -119,7 +122,8 @@ int dv_data_free(dv_model* m, int32_t slot);
 /* ---- steps: replace one Keras train_function / test_function call inside net.fit (train.py:27-37) ---- */
 /* Batch = rows idx[0..B) of `slot` (idx == NULL: rows first..first+B).  eps == NULL: the engine draws
  * eps ~ N(0,I) from Philox(seed); else eps[B,latent] is used (parity tests).  global_batch = sum of B over ranks
- * (0: B).  out[DV_N_SCALARS] are the GLOBAL loss, nll mean, kl regulariser and mse-vs-mean. */
+ * (0: B).  out[DV_N_SCALARS] are the GLOBAL loss, nll mean, kl regulariser and mse (against the predicted mean, or
+ * against a sample of the output distribution - Keras' metric - while dv_model_set_mse_sample is on). */
 int dv_train_step(dv_model* m, int32_t slot, const int32_t* idx, int64_t first, int32_t B, int32_t global_batch,
                   const float* eps, uint64_t seed, float* out);
 /* forward + losses in inference mode (moving BN statistics), no update: Keras validation step */
@@ -154,18 +158,10 @@ int dv_model_set_mse_sample(dv_model* m, int32_t on);
 
 /* Replay a captured hipGraph for the forward pass of small inference batches (< 64 stamps, one chunk, engine-drawn
  * noise) instead of launching its ~45 kernels one by one: BASELINE configs[4] "hipGraph-captured decode" /
- * SURVEY row A10.  Off by default: on MI355X the replay takes exactly as long as the eager launches (the chain is
- * bound by dispatch latency on the GPU, not by host submission).  Same results either way. */
+ * SURVEY row A10.  Off by default: on MI355X the replay takes exactly as long as the eager launches - a one-stamp forward
+ * is bound by the DURATION of its kernels (a handful of workgroups per layer walking K serially: 27 kernels, 520 us of
+ * kernel time inside a 668 us span), not by host submission or dispatch.  Same results either way. */
 int dv_model_set_infer_graph(dv_model* m, int32_t on);
-
-/* Small-batch forward: inference batches of at most `max_stamps` stamps (0 = off, the default) run the encoder stack
- * and the decoder stack as ONE cooperative kernel each (grid-wide barriers between layers) instead of one launch per
- * layer - the per-object calls of deblend (deblend_cutout/deblender.py:18, deblend/field_deblender.py:265-274).
- * fp32 engine only; same arithmetic up to the order of the K sums (agreement with the batched path <= 2e-5 of a
- * tensor's maximum).  Off by default: on MI355X a grid-wide barrier costs 8 us with one workgroup per CU (cross-XCD L2
- * write-back + invalidate) and the per-layer vector loops are latency-bound, 1.4 ms per one-stamp call against 0.36 ms
- * for the per-layer launches with K slicing. */
-int dv_model_set_small_forward(dv_model* m, int32_t max_stamps);
 
 /* Gradient / train steps also write the output distribution (loc, scale) of their forward pass, for
  * dv_model_get_activation("loc" / "scale") - what the parity tests compare with the oracle.  Off by default: the

@@ -3,6 +3,7 @@ no HIP.  It records what every rank did in $DV_STUB_LOG.<rank> so that the test 
 barriers around the timed region and the MAX over ranks of the elapsed time."""
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -33,7 +34,7 @@ class Context:
         _log(self.rank, event="sync", t=time.time())
 
     def close(self):
-        _log(self.rank, event="close")
+        _log(self.rank, event="close", torch_loaded="torch" in sys.modules)
 
 
 class Engine:
@@ -53,7 +54,8 @@ class Engine:
     def train_steps(self, slot, first, B, steps, global_batch=None, seed=0):
         # rank r is slower by 20 ms per step: the reported time must be the slowest rank's
         time.sleep(steps * (0.005 + 0.02 * self.ctx.rank))
-        _log(self.ctx.rank, event="train_steps", B=B, steps=steps, global_batch=global_batch, t=time.time())
+        _log(self.ctx.rank, event="train_steps", B=B, steps=steps, global_batch=global_batch, t=time.time(),
+             torch_loaded="torch" in sys.modules)
         return {"loss": 1.0, "nll_mean": 1.0, "kl_reg": 0.0, "mse": 0.0}
 
     def close(self):

@@ -1,7 +1,9 @@
 """bench.py's N > 1 plumbing on CPU: launched exactly as the driver launches it (torch.distributed.run, one rank per GPU)
 with a stub engine in place of the HIP library.  Checked: rank 0's RCCL id reaches every rank, the barriers bracket the
-timed region, the elapsed time is the MAX over ranks, ONE JSON line comes out, on rank 0's stdout only, and `value` is the
-whole-job aggregate."""
+timed region, the elapsed time is the MAX over ranks, ONE JSON line comes out, on rank 0's stdout only, `value` is the
+whole-job aggregate, the rank processes exit 0 on their own (no os._exit) and never import torch (the launcher is the
+only torch process: the ranks meet through debvader_amd.parallel.HostGroup).  A second launch without torch.distributed.run
+(two plain processes with RANK / WORLD_SIZE / MASTER_* set, MASTER_PORT free) covers HostGroup's direct-port mode."""
 import glob
 import json
 import os
@@ -51,3 +53,26 @@ def test_two_rank_bench_launch_with_a_stub_engine(tmp_path):
         assert [t["steps"] for t in ts] == [warmup, steps]
         assert all(t["global_batch"] == 256 * world and t["B"] == 256 for t in ts)
         assert sum(e["event"] == "sync" for e in ev) >= 3      # before the timed region, inside it and at its end
+        assert not any(e.get("torch_loaded") for e in ev), "torch was imported into a rank process"
+        assert ev[-1]["event"] == "close"                      # the context was closed, the process left normally
+
+
+def test_two_plain_processes_meet_on_master_port(tmp_path):
+    """The same bench without a launcher: RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT by hand, the port free, so rank 0
+    listens on it directly."""
+    log = str(tmp_path / "stub")
+    port, world, steps = _free_port(), 2, 3
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, DV_BENCH_STUB_ENGINE="tests.stub_engine", DV_STUB_LOG=log, PYTHONPATH=ROOT, RANK=str(rank),
+                   LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps),
+                                       "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                                      cwd=ROOT))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], [o[1][-1500:] for o in outs]
+    lines0 = [ln for ln in outs[0][0].splitlines() if ln.strip().startswith("{")]
+    assert len(lines0) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.strip().startswith("{")]
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == world and d["ms_per_step"] >= 24.0

@@ -1,6 +1,5 @@
 """deblend() latency for small numbers of stamps (the per-object use of the reference's DeblendField,
-deblend/field_deblender.py:265-274): cooperative layer-stack kernels (batches of <= 8 stamps, small_fwd.hip) against the
-per-layer launches of the batched engine."""
+deblend/field_deblender.py:265-274): per call, host copies included."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,9 +21,5 @@ def timed(n, reps=50):
 
 
 for n in (1, 2, 4, 8, 16, 32, 64, 128, 256):
-    eng.set_small_forward(8)
     a = timed(n)
-    eng.set_small_forward(0)
-    b = timed(n)
-    tag = "cooperative stack" if n <= 8 else "batched (same path)"
-    print(f"N={n:4d}: {a*1e3:7.3f} ms per call ({tag}) | per-layer launches {b*1e3:7.3f} ms | {n/a:8.0f} stamps/s", flush=True)
+    print(f"N={n:4d}: {a*1e3:7.3f} ms per call | {n/a:8.0f} stamps/s", flush=True)
