@@ -163,6 +163,33 @@ struct GStripParams {
 int launch_gconv_strip(GStripParams p, bool nmajor, hipStream_t s);   // 1 = not taken (use gconv2)
 int launch_gconv_strip8(GStripParams p, hipStream_t s);               // first layer (Cin 8 -> 32, k-major); 1 = not taken
 
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 layers (wino.hip): X [NB,H,H,Cin] -> [NB,H,H,Cout], pad 1
+struct WinoParams {
+  const float* X;
+  const float* Ut;     // transformed weights [column tile][K chunk][16 pos][32 n][16 k] (wino_weights_kernel)
+  float* U;
+  float* A;
+  const float* bias;
+  const float* alpha;
+  const float* zero;   // >= 16 bytes of zeros (source of the out-of-image patch slots)
+  int NB, H, Cin, Cout;
+  int epi;             // 0 raw, 1 +bias, 2 +bias then PReLU
+  int nbh, nct, NC, groups, items, items_per_wg;   // filled by the launcher
+  int dbg;             // timing ablations (wrong results): 1 no epilogue, 2 no input transform, 4 no MFMA, 8 no stagger,
+                       // 16 no DMA, 64 phase stamps
+  float* dbg_out;
+};
+struct WinoWDesc {
+  const float* W;      // nine taps, [wt][k][n] or (nmajor) [wt][n][k]
+  float* Ut;
+  int Cin, Cout, nmajor;
+  int wtmap[9];        // weight tap index of the input offset (r - 1, s - 1), r * 3 + s
+};
+bool wino_supported(int NB, int H, int Cin, int Cout);
+size_t wino_weight_floats(int Cin, int Cout);
+int launch_wino_weights(const WinoWDesc* descs_dev, const WinoWDesc* descs_host, int n, hipStream_t s);
+int launch_wino_conv(WinoParams p, hipStream_t s);   // 1 = not taken
+
 // Stride-2 data-gradient form with the four parity classes fused per workgroup (gconv_s2.hip).
 // Class c = 2*[row parity has two taps] + [column parity has two taps]; neighbour e = 2*[dh == x] + [dw == x].
 struct GConvS2Params {

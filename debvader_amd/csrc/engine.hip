@@ -323,11 +323,11 @@ struct ProfRec {
 // kernel families of the MFMA work, by the name rocprofv3 prints for them (per-kernel roofline rows of bench.py)
 enum {
   PF_NONE = -1, PF_GCONV2 = 0, PF_GCONV_S2, PF_GSTRIP, PF_GSTRIP8, PF_GCONV, PF_WGRAD, PF_WSTRIP, PF_BCONV, PF_BWGRAD,
-  PF_COUNT
+  PF_WINO, PF_COUNT
 };
 static const char* const kProfFamName[PF_COUNT] = {
     "gconv2_kernel", "gconv_s2_kernel", "gconv_strip_kernel", "gconv_strip8_kernel", "gconv_kernel", "wgrad_kernel",
-    "wgrad_strip_kernel / wgrad_strip8_kernel", "bconv_kernel", "bwgrad_kernel"};
+    "wgrad_strip_kernel / wgrad_strip8_kernel", "bconv_kernel", "bwgrad_kernel", "wino_conv_kernel"};
 
 struct DataSlot {
   float* x = nullptr;
@@ -369,9 +369,20 @@ struct BfState {
   void* zero = nullptr;          // 1 KiB of zeros
 };
 
+// Winograd-domain weights of one stride-1 3x3 layer in one form (forward or data gradient), see wino.hip
+struct WinoEntry {
+  dv::WinoWDesc d;
+  uint64_t epoch = ~(uint64_t)0;   // parameter epoch the transform was computed at
+};
+
 struct dv_model {
   dv_ctx* ctx = nullptr;
   dv::Arch A;
+  std::vector<WinoEntry> wino;     // (W, nmajor, tap map) -> transformed weights
+  dv::WinoWDesc* wino_descs_dev = nullptr;
+  size_t wino_descs_cap = 0;
+  uint64_t param_epoch = 0;        // bumped whenever a parameter changes (Winograd weights are re-derived lazily)
+  bool use_wino = true;
   int Bc = 0;
   BfState bf;
   // flat parameter-shaped buffers
@@ -561,6 +572,7 @@ static int prof_flush(dv_model* m) {
 
 static bool g_force_v1 = false;  // tuning aid: route everything through the first-generation kernel
 static bool g_no_special = false; // cross-check aid: skip the strip / fused stride-2 kernels (general gconv2 path only)
+static bool g_no_wino = false;    // cross-check aid: stride-1 layers take the direct (strip / gather-GEMM) kernels
 
 // Every collective of a context is issued on ONE stream (comm_stream), the usual single-stream-per-communicator
 // pattern; the main stream hands data over and takes it back through events.
@@ -706,6 +718,86 @@ static int gconv2_small_splitk(dv_model* m, GConv2Params& q, int NB, int Hout, i
   return 1;
 }
 
+// ---- Winograd-domain weights (wino.hip) -----------------------------------------------------------------------------
+// One entry per (weight tensor, orientation, tap map).  The transform U = G g G^T is re-derived when the parameter
+// epoch has moved: for every registered entry in ONE launch at the head of a forward pass (wino_refresh_all, before
+// the forward lanes split), or for a single entry at its first use (the debug harness, layers registered late).
+static WinoEntry* wino_find(dv_model* m, const float* W, bool nmajor, const Taps& tp) {
+  int wtmap[9];
+  for (int t = 0; t < 9; ++t) {
+    const int dh = (int)((tp.tapcode >> (4 * t)) & 3) - 1, dw = (int)((tp.tapcode >> (4 * t + 2)) & 3) - 1;
+    wtmap[(dh + 1) * 3 + (dw + 1)] = (int)((tp.wtcode >> (4 * t)) & 15);
+  }
+  for (auto& e : m->wino)
+    if (e.d.W == W && e.d.nmajor == (nmajor ? 1 : 0) && !memcmp(e.d.wtmap, wtmap, sizeof wtmap)) return &e;
+  return nullptr;
+}
+static int wino_register(dv_model* m, const float* W, bool nmajor, const Taps& tp, int Cin, int Cout, WinoEntry** out) {
+  WinoEntry e;
+  memset(&e.d, 0, sizeof e.d);
+  e.d.W = W; e.d.Cin = Cin; e.d.Cout = Cout; e.d.nmajor = nmajor ? 1 : 0;
+  for (int t = 0; t < 9; ++t) {
+    const int dh = (int)((tp.tapcode >> (4 * t)) & 3) - 1, dw = (int)((tp.tapcode >> (4 * t + 2)) & 3) - 1;
+    e.d.wtmap[(dh + 1) * 3 + (dw + 1)] = (int)((tp.wtcode >> (4 * t)) & 15);
+  }
+  DV_TRY(dalloc(m, &e.d.Ut, wino_weight_floats(Cin, Cout)));
+  m->wino.push_back(e);
+  if (out) *out = &m->wino.back();
+  return OK;
+}
+static int wino_upload_descs(dv_model* m, hipStream_t st) {
+  if (m->wino_descs_cap < m->wino.size()) {
+    float* q = nullptr;
+    const size_t cap = m->wino.size() + 16;
+    DV_TRY(dalloc(m, &q, (cap * sizeof(WinoWDesc) + 3) / 4));
+    m->wino_descs_dev = reinterpret_cast<WinoWDesc*>(q);
+    m->wino_descs_cap = cap;
+  }
+  std::vector<WinoWDesc> h(m->wino.size());
+  for (size_t i = 0; i < h.size(); ++i) h[i] = m->wino[i].d;
+  DV_HIP(hipMemcpyAsync(m->wino_descs_dev, h.data(), h.size() * sizeof(WinoWDesc), hipMemcpyHostToDevice, st));
+  DV_HIP(hipStreamSynchronize(st));          // (h goes out of scope; registration time only)
+  return OK;
+}
+static int wino_refresh_all(dv_model* m, hipStream_t st) {
+  if (m->wino.empty()) return OK;
+  bool stale = false;
+  for (auto& e : m->wino) stale = stale || e.epoch != m->param_epoch;
+  if (!stale) return OK;
+  std::vector<WinoWDesc> h(m->wino.size());
+  for (size_t i = 0; i < h.size(); ++i) h[i] = m->wino[i].d;
+  ProfScope ps(m, 2, st);
+  DV_TRY(launch_wino_weights(m->wino_descs_dev, h.data(), (int)h.size(), st));
+  for (auto& e : m->wino) e.epoch = m->param_epoch;
+  return OK;
+}
+// stride-1, pad-1, nine-tap layer through the Winograd kernel; returns 1 when the layer is not taken
+static int wino_conv(dv_model* m, const float* X, const float* W, bool nmajor, const Taps& tp, const float* bias,
+                     const float* alpha, float* U, float* Aout, int epi, int NB, int H, int Cin, int Cout, double flops) {
+  if (!m->use_wino || g_no_wino || m->tiny_call || m->bf.on || !m->zero_page || !wino_supported(NB, H, Cin, Cout)) return 1;
+  // the head conv (16 output columns, or 16 input channels in its data gradient) is faster in strip form: half of the
+  // kernel's 32-column tile / 16-channel chunk pipeline would be padding (tools/wino_check.py: 163 vs 114 us)
+  if (Cin < 32 || Cout < 32) return 1;
+  WinoEntry* e = wino_find(m, W, nmajor, tp);
+  hipStream_t st = fwd_stream(m);
+  if (!e) {
+    DV_TRY(wino_register(m, W, nmajor, tp, Cin, Cout, &e));
+    DV_TRY(wino_upload_descs(m, st));
+  }
+  if (e->epoch != m->param_epoch) {            // not covered by the refresh at the head of the pass
+    const size_t i = (size_t)(e - m->wino.data());
+    ProfScope ps(m, 2, st);
+    DV_TRY(launch_wino_weights(m->wino_descs_dev + i, &e->d, 1, st));
+    e->epoch = m->param_epoch;
+  }
+  WinoParams p;
+  memset(&p, 0, sizeof p);
+  p.X = X; p.Ut = e->d.Ut; p.U = U; p.A = Aout; p.bias = bias; p.alpha = alpha; p.zero = m->zero_page;
+  p.NB = NB; p.H = H; p.Cin = Cin; p.Cout = Cout; p.epi = epi;
+  ProfScope ps(m, 0, nullptr, PF_WINO, flops);
+  return launch_wino_conv(p, st);
+}
+
 // fprop-form gconv over an [NB,Hin,Hin,Cin] tensor: out[NB,Hout,Hout,Cout], in pixel = out*s + k - pb
 static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor, const float* bias, const float* alpha,
                        float* U, float* Aout, int epi, int NB, int Hin, int Cin, int Hout, int Cout, int s, int pb,
@@ -738,6 +830,10 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
   const double flops = 2.0 * NB * Hout * Hout * tp.n * (double)(W == m->W1p ? m->A.C : Cin) *
                        (double)(W == m->Whp ? 2 * m->A.C : Cout);
   static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
+  if (s == 1 && pb == 1 && Hin == Hout && tp.n == 9 && !single_tap && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse)) {
+    const int r = wino_conv(m, X, W, nmajor, tp, bias, alpha, U, Aout, epi, NB, Hout, Cin, Cout, flops);
+    if (r <= 0) return r;
+  }
   if (Cin == 32 && (Cout == 16 || Cout == 32) && s == 1 && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
       !single_tap && !g_force_v1 && !gs_off && !g_no_special && !(fz && !m->no_fuse)) {
     GStripParams g;
@@ -826,6 +922,13 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
   // algorithmic FLOPs: every source pixel meets all nine taps; the padded head gradient counts 2*bands channels
   const double flops = 2.0 * NB * Hs * Hs * 9.0 * (double)(W == m->Whp ? 2 * m->A.C : Cs) * (double)Ct;
   static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
+  if (s == 1 && pb == 1 && Hs == Ht && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse)) {
+    const Taps tp = taps_dgrad(1, pb, 0, 0);
+    if (tp.n == 9) {
+      const int r = wino_conv(m, X, W, nmajor, tp, bias, alpha, U, Aout, epi, NB, Ht, Cs, Ct, flops);
+      if (r <= 0) return r;
+    }
+  }
   if (s == 1 && (Cs == 32 || (Cs == 16 && Ct == 32)) && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !gs_off && !g_no_special &&
       !(fz && !m->no_fuse)) {
     const Taps tp = taps_dgrad(1, pb, 0, 0);
@@ -1277,6 +1380,7 @@ static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int 
 static int refresh_head_pad(dv_model* m, hipStream_t st = nullptr) {
   const Arch& A = m->A;
   m->bf.dirty = true;
+  m->param_epoch++;
   if (!st) st = m->ctx->stream;
   DV_TRY(launch_pad_cols(m->P + A.specs[A.head_k()].off, m->Whp, 9 * A.cfg.filters[0], 2 * A.C, A.C2p, st));
   return launch_pad_cols(m->P + A.specs[A.head_b()].off, m->bhp, 1, 2 * A.C, A.C2p, st);
@@ -1285,6 +1389,7 @@ static int refresh_head_pad(dv_model* m, hipStream_t st = nullptr) {
 static int refresh_w1p(dv_model* m) {
   const Arch& A = m->A;
   m->bf.dirty = true;
+  m->param_epoch++;
   return launch_pad_w1(m->P + A.specs[A.enc_k(0)].off, m->P + A.specs[0].off, m->P + A.specs[1].off, m->W1p, 9, A.C, 8,
                        A.cfg.filters[0], m->ctx->stream);
 }
@@ -1478,6 +1583,7 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
   dv_ctx* cx = m->ctx;
   hipStream_t s = cx->stream;
   m->cur_seed = seed;
+  if (!m->bf.on) DV_TRY(wino_refresh_all(m, s));   // before the lanes split: both read the same transformed weights
   if (run_encoder) DV_TRY(bn_prepare(m, xsrc, idx, first, NB, Bg, training, upd_moving));
   if (eps_host)
     DV_HIP(hipMemcpyAsync(m->eps, eps_host, (size_t)NB * A.d * sizeof(float), hipMemcpyHostToDevice, s));
@@ -1879,6 +1985,7 @@ static int optimizer_step(dv_model* m) {
   const Arch& A = m->A;
   DV_TRY(adam_range(m, 0, std::min(m->adam_done_from, A.n_train), m->ctx->stream));
   m->bf.dirty = true;
+  m->param_epoch++;
   if (m->opt_enc) DV_TRY(refresh_w1p(m));
   if (m->opt_dec && m->adam_done_from > A.n_enc_train) DV_TRY(refresh_head_pad(m));
   return OK;
@@ -2777,6 +2884,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   if (getenv("DV_NO_FWD_SPLIT")) m->split_forward = false;
   if (getenv("DV_FUSE_PRELU_BWD")) m->no_fuse = false;
   if (getenv("DV_NO_FUSE_FIRST")) m->fuse_first = false;
+  if (getenv("DV_NO_WINO")) m->use_wino = false;
   m->arena_elems = 0;
   for (auto& sp : A.specs)
     if (sp.name.size() > 6 && sp.name.compare(sp.name.size() - 6, 6, "/alpha") == 0)
@@ -2826,6 +2934,30 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
     return fail(E_HIP);
   if (bf16) {
     st = bf_alloc(m);
+    if (st != OK) return fail(st);
+  } else if (m->use_wino) {
+    // Winograd-domain weights of every stride-1 3x3 layer, forward and data-gradient form (wino.hip)
+    auto reg = [&](const float* W, bool nmajor, const Taps& tp, int cin, int cout) -> int {
+      if (!wino_supported(1, 8, cin, cout) || tp.n != 9) return OK;
+      return wino_register(m, W, nmajor, tp, cin, cout, nullptr);
+    };
+    const Taps tf = taps_fprop(1), td = taps_dgrad(1, 1, 0, 0);
+    for (int j = 0; j < 2 * A.L && st == OK; ++j) {
+      int hin, cin, hout, cout, sd;
+      A.enc_layer(j, &hin, &cin, &hout, &cout, &sd);
+      if (sd == 1 && j > 0) {
+        st = reg(m->P + A.specs[A.enc_k(j)].off, false, tf, cin, cout);
+        if (st == OK) st = reg(m->P + A.specs[A.enc_k(j)].off, true, td, cout, cin);
+      }
+      A.dec_layer(j, &hin, &cin, &hout, &cout, &sd);
+      if (sd == 1 && st == OK) {
+        st = reg(m->P + A.specs[A.dec_k(j)].off, true, td, cin, cout);
+        if (st == OK) st = reg(m->P + A.specs[A.dec_k(j)].off, false, tf, cout, cin);
+      }
+    }
+    if (st == OK) st = reg(m->Whp, false, tf, cfg->filters[0], A.C2p);
+    if (st == OK) st = reg(m->Whp, true, td, A.C2p, cfg->filters[0]);
+    if (st == OK && !m->wino.empty()) st = wino_upload_descs(m, ctx->stream);
     if (st != OK) return fail(st);
   }
   st = dv_model_init(m, 0);
@@ -2916,6 +3048,7 @@ int dv_model_get_param(dv_model* m, int32_t i, float* host, size_t nbytes) {
 int dv_model_set_param(dv_model* m, int32_t i, const float* host, size_t nbytes) {
   DV_TRY(tensor_io(m, m ? m->P : nullptr, i, const_cast<float*>(host), nbytes, false));
   m->bf.dirty = true;
+  m->param_epoch++;
   if (i == m->A.head_k() || i == m->A.head_b()) {
     DV_TRY(refresh_head_pad(m));
     DV_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -3581,6 +3714,7 @@ int dv_debug_gconv(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_t Ht, 
   DV_HIP(hipEventElapsedTime(&ms, a, b));
   *ms_out = ms / iters;
   (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(Y2); (void)hipFree(m.ws1); (void)hipFree(m.zero_page);
+  for (void* q : m.allocs) (void)hipFree(q);      // Winograd weights registered on the fly
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   return st;
 }
@@ -3634,7 +3768,13 @@ int dv_debug_gconv_check(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_
   }
   (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(m.ws1); (void)hipFree(m.zero_page);
   for (auto& b : bufs) (void)hipFree(b);
+  for (void* q : m.allocs) (void)hipFree(q);      // Winograd weights registered on the fly
   return st;
+}
+
+int dv_debug_winograd(int32_t on) {
+  g_no_wino = on == 0;
+  return DV_OK;
 }
 
 int dv_debug_general_kernels(int32_t on) {

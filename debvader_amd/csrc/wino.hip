@@ -1,0 +1,401 @@
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 layers in fp32: the four stride-1 Conv2D layers of the encoder
+// (model.py:81-83), the four stride-1 Conv2DTranspose layers of the decoder (model.py:128-134), the head conv
+// (model.py:137) and the data gradients of all of them - 62 % of the network's multiply-adds.
+//
+// A 3x3 stride-1 layer is  Y = A^T [ sum_c (G g_c G^T) . (B^T d_c B) ] A  per 4x4 input tile d / 2x2 output tile Y:
+// 16 element-wise positions, each an independent [tiles x Cin] x [Cin x Cout] contraction, 4 multiply-adds per output
+// pixel and channel pair instead of 9.  fp32 MFMA runs at the vector rate on gfx950 (157 TFLOP/s), so the 2.25x fewer
+// MFMA cycles are worth having; the transforms are adds on the (otherwise idle) vector pipe.  Everything is fused:
+// a workgroup DMAs raw input patches and pre-transformed weight chunks (wino_weights_kernel: U = G g G^T, once per
+// weight update) into LDS, every wave transforms the 4x4 input tiles of ITS 16 tiles in registers (B^T d B on float4
+// channel quads), runs the 16 position GEMMs on v_mfma_f32_16x16x4_f32 with 16 x 2 accumulator blocks, applies the
+// output transform to its accumulators and writes bias / PReLU outputs through a per-wave LDS staging tile.
+//
+// Geometry: an M block is 4 x 4 tiles = 8 x 8 output pixels of one stamp (its input patch: 10 x 10 pixels); a
+// workgroup (4 waves) owns 4 consecutive M blocks x 32 output channels and walks K in chunks of 16 input channels
+// through a double-buffered LDS ring (patch chunk 4 x 6.25 KiB wave-private, weight chunk 32 KiB shared), persistent
+// over (block group, column tile) items with the ring running across item boundaries.
+// MFMA roles: A = transformed input V[tile][k], B = transformed weights U[k][n]; lane (l15, lg): A row l15 = tile
+// (ty, tx) = (l15 >> 2, l15 & 3), k = lg; C rows 4 lg + r = tile (lg, r), column l15.
+// Numerics: exact fp32 arithmetic in another association (sums of up to four inputs before the product, 0.5 factors
+// in G); agreement with the direct kernels 2e-6 of a layer's largest output (dv_debug_gconv_check, tests/test_gpu_parity).
+#include "common.h"
+#include <algorithm>
+#include <stdlib.h>
+#include <stdio.h>
+
+namespace dv {
+
+typedef const __attribute__((address_space(1))) void* wn_gptr_t;
+typedef __attribute__((address_space(3))) void* wn_lptr_t;
+
+namespace {
+constexpr int WN_MB = 4;                              // M blocks (16 tiles = 8 x 8 output pixels each) per workgroup
+constexpr int WN_WAVES = 8;                           // wave w: M block w & 3, column half w >> 2 (16 of the 32 columns)
+constexpr int WN_THREADS = 64 * WN_WAVES;
+constexpr int WN_PATCH_PIECES = 7;                    // 100 pixels x 4 quads = 400 16-byte slots -> 7 x 64
+constexpr int WN_PATCH_FLOATS = WN_PATCH_PIECES * 256;
+constexpr int WN_UCH_FLOATS = 16 * 32 * 16;           // [pos][n][k]
+constexpr int WN_LDS_STAGE = 20;                      // floats per staged pixel row (16 columns + pad)
+}  // namespace
+
+__global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                                            // [2][4 blocks][WN_PATCH_FLOATS]
+  float* uch = smem + 2 * WN_MB * WN_PATCH_FLOATS;                // [2][WN_UCH_FLOATS]
+  float* stage = uch + 2 * WN_UCH_FLOATS;                         // [8 waves][32][WN_LDS_STAGE]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mb = wave & 3, nh = wave >> 2;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int H = p.H, Cin = p.Cin, Cout = p.Cout, NC = p.NC;
+  const int nb2 = p.nbh * p.nbh;
+
+  // ---- item-invariant DMA addressing: the two waves of an M block share its patch pieces (4 + 3); slot e = 64 k + lane
+  // -> (patch pixel L, channel quad) ----
+  constexpr int NPP = 4;
+  const int k0 = nh * 4;
+  int prow[NPP], pcol[NPP], prel[NPP];
+#pragma unroll
+  for (int k = 0; k < NPP; ++k) {
+    const int e = 64 * (k0 + k) + lane;
+    const int L = e >> 2;
+    const int pr = L / 10, pc = L - pr * 10;
+    const int q = (e & 3) ^ (pr & 3);                      // LDS slot e & 3 of a pixel in patch row pr holds channel quad q
+    prow[k] = (L < 100 && k0 + k < WN_PATCH_PIECES) ? pr - 1 : -100000;
+    pcol[k] = pc - 1;
+    prel[k] = ((pr - 1) * H + (pc - 1)) * Cin + q * 4;
+  }
+
+  const int item0 = blockIdx.x * p.items_per_wg;
+  const int nitems = min(p.items, item0 + p.items_per_wg) - item0;
+  if (nitems <= 0) return;
+  const int qtotal = nitems * NC;
+
+  // DMA of chunk q (item item0 + q / NC, K chunk q % NC) into ring buffer b: dma_setup works out the wave-uniform
+  // parts once per chunk, dma_piece(k) issues piece k of this wave's eight (0-3: its share of the M block's patch,
+  // 4-7: its share of the weight chunk).  The pieces are issued one at a time BETWEEN the MFMA groups of the previous
+  // chunk: issued back to back in front of them they hold the wave (in-order issue, the memory pipeline accepts a
+  // 1-KiB gather every ~150 cycles under load) while the matrix pipe idles.
+  const float* dm_base = p.zero;
+  const float* dm_usrc = p.zero;
+  float *dm_dstp = patch, *dm_dstu = uch;
+  bool dm_live = false;
+  int dm_by = 0, dm_bx = 0;
+  auto dma_setup = [&](int q, int b) {
+    const int it = q / NC, c = q - it * NC;
+    const int item = item0 + it;
+    const int ct = item / p.groups, g = item - ct * p.groups;   // column tile outermost: one weight slice hot in every L2
+    const int mblock = g * WN_MB + mb;
+    dm_live = mblock < p.NB * nb2;
+    const int n = dm_live ? mblock / nb2 : 0;
+    const int rem = dm_live ? mblock - n * nb2 : 0;
+    dm_by = rem / p.nbh;
+    dm_bx = rem - dm_by * p.nbh;
+    dm_base = p.X + ((size_t)(n * H + dm_by * 8) * H + dm_bx * 8) * Cin + c * 16;
+    dm_dstp = patch + (b * WN_MB + mb) * WN_PATCH_FLOATS + k0 * 256;
+    dm_usrc = p.Ut + ((size_t)(ct * NC + c) * WN_UCH_FLOATS) + wave * 1024 + lane * 4;
+    dm_dstu = uch + b * WN_UCH_FLOATS + wave * 1024;
+  };
+  auto dma_piece = [&](int k) {                       // k is a compile-time constant at every call site
+    if (p.dbg & 16) return;
+    if (k < NPP) {
+      if (k0 + k < WN_PATCH_PIECES) {                 // wave-uniform
+        const bool ok = dm_live && (unsigned)(dm_by * 8 + prow[k]) < (unsigned)H && (unsigned)(dm_bx * 8 + pcol[k]) < (unsigned)H;
+        const float* src = ok ? dm_base + prel[k] : p.zero;
+        __builtin_amdgcn_global_load_lds((wn_gptr_t)src, (wn_lptr_t)(dm_dstp + k * 256), 16, 0, 0);
+      }
+    } else {
+      __builtin_amdgcn_global_load_lds((wn_gptr_t)(dm_usrc + (k - NPP) * 256), (wn_lptr_t)(dm_dstu + (k - NPP) * 256), 16, 0, 0);
+    }
+  };
+  auto issue = [&](int q, int b) {
+    dma_setup(q, b);
+#pragma unroll
+    for (int k = 0; k < 2 * NPP; ++k) dma_piece(k);
+  };
+
+  // ---- per-lane fragment addressing ----
+  const int ty = l15 >> 2, tx = l15 & 3;
+  // LDS images are swizzled so that the ds_read_b128 fragment reads spread over the banks (lane groups of
+  // MI355X_MICROARCH.md, LDS): a pixel of patch row r keeps channel quad q in slot q ^ (r & 3) - tiles step by two
+  // pixels, so 2-way is the floor for 64-byte pixel rows, and this reaches it (unswizzled: 4-way) -; weight row n keeps
+  // quad q in slot q ^ {0,2,3,1}[(n >> 2) & 3] (conflict-free; unswizzled 2-way).  Both swizzles are applied on the
+  // global side: by the DMA's per-lane source address and by wino_weights_kernel.
+  int a_off[4];                                                      // float offset of d[i][0] in the block's patch
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = ((2 * ty + i) * 10 + 2 * tx) * 16 + ((lg ^ ((2 * ty + i) & 3)) << 2);
+  const int b_off = (nh * 16 + l15) * 16 + ((lg ^ ((0x78 >> (2 * ((l15 >> 2) & 3))) & 3)) << 2);   // + pos * 32 * 16
+  float* stg = stage + wave * (32 * WN_LDS_STAGE);
+
+  // One barrier per chunk: every wave waits for its own DMA pieces of chunk q, meets the others (all pieces landed, all
+  // reads of the other ring buffer done), issues the DMA of chunk q + 1 into that buffer and computes chunk q.  Raw
+  // s_barrier with explicit counters: the epilogue's plain loads and stores share vmcnt with the DMA.
+  // (Tried and measured slower on MI355X, kept out: a half-chunk stagger of waves 4-7 against their SIMD partners with
+  // two barriers per chunk - 126 -> 147 us on the 256-channel layer; see DESIGN.md.)
+  auto sync_point = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // diagnostic build (dbg & 64): s_memtime stamps per phase, summed per wave, written by workgroup 0
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define STAMP(k)                                                        \
+  if (p.dbg & 64) {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memtime();        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
+    if (tprev) tsum[k] += tn_ - tprev;                                  \
+    tprev = tn_;                                                        \
+  }
+  f32x4 acc[16];
+  issue(0, 0);
+  int buf = 0;
+  for (int q = 0; q < qtotal; ++q) {
+    const int it = q / NC, c = q - it * NC;
+    sync_point();
+    const bool more = q + 1 < qtotal;
+    if (more) {
+      if (p.dbg & 32) issue(q + 1, buf ^ 1);          // (ablation: all eight pieces up front)
+      else dma_setup(q + 1, buf ^ 1);
+    }
+    if (c == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    STAMP(0);
+    const float* P = patch + (buf * WN_MB + mb) * WN_PATCH_FLOATS;
+    const float* Uc = uch + buf * WN_UCH_FLOATS + b_off;
+    // A phase: the 4 x 4 input tile of this lane's tile and channel quad, then its transform
+    STAMP(1);
+    // All LDS reads of the chunk go out first - the 16 weight fragments (one per position) and the 4 x 4 input tile - so
+    // that the MFMA stream below never waits for one (left to itself hipcc sinks every fragment read to just in front
+    // of its four MFMAs: read latency + a dependent accumulator chain per position).
+    f32x4 bfr[16];
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) bfr[pos] = *reinterpret_cast<const f32x4*>(Uc + (pos * 32) * 16);
+    f32x4 V[16];
+    if (p.dbg & 2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) V[i] = *reinterpret_cast<const f32x4*>(P + a_off[i >> 2] + (i & 3) * 16);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // input transform V = B^T d B on the float4 channel quad of this lane's tile
+      f32x4 d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(P + a_off[i] + j * 16);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 t[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[0][j] - d[2][j];
+        t[1][j] = d[1][j] + d[2][j];
+        t[2][j] = d[2][j] - d[1][j];
+        t[3][j] = d[1][j] - d[3][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        V[i * 4 + 0] = t[i][0] - t[i][2];
+        V[i * 4 + 1] = t[i][1] + t[i][2];
+        V[i * 4 + 2] = t[i][2] - t[i][1];
+        V[i * 4 + 3] = t[i][1] - t[i][3];
+      }
+    }
+    STAMP(2);
+    STAMP(3);
+    // 16 position GEMMs, two accumulator chains interleaved (a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles,
+    // an independent one every 32)
+    if (!(p.dbg & 4)) {
+#pragma unroll
+      for (int pos = 0; pos < 16; pos += 2) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[pos][jj], bfr[pos][jj], acc[pos], 0, 0, 0);
+          acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[pos + 1][jj], bfr[pos + 1][jj], acc[pos + 1], 0, 0, 0);
+        }
+        if (more && !(p.dbg & 32)) {
+          __builtin_amdgcn_sched_barrier(0);
+          dma_piece(pos / 2);                         // one DMA piece of the next chunk behind every eighth MFMA
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else if (more && !(p.dbg & 32)) {
+#pragma unroll
+      for (int k = 0; k < 2 * NPP; ++k) dma_piece(k);
+    }
+    STAMP(4);
+    if (c == NC - 1 && !(p.dbg & 1)) {
+      // ---- output transform Y = A^T M A on the accumulators, then bias / PReLU / stores through the staging tile ----
+      const int item = item0 + it;
+      const int ct = item / p.groups, g = item - ct * p.groups;   // column tile outermost: one weight slice hot in every L2
+      const int mblock = g * WN_MB + mb;
+      const bool live = mblock < p.NB * nb2;
+      const int n = live ? mblock / nb2 : 0;
+      const int rem = live ? mblock - n * nb2 : 0;
+      const int by = rem / p.nbh, bx = rem - by * p.nbh;
+      const int col0 = ct * 32 + nh * 16;
+      if (col0 < Cout) {                                // wave-uniform
+        float y[2][4][2];                               // [a][r][b]: pixel (2 lg + a, 2 r + b) of the 8 x 8 block
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float tt[2][4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float m0 = acc[0 + j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
+            tt[0][j] = m0 + m1 + m2;
+            tt[1][j] = m1 - m2 - m3;
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            y[a][r][0] = tt[a][0] + tt[a][1] + tt[a][2];
+            y[a][r][1] = tt[a][1] - tt[a][2] - tt[a][3];
+          }
+        }
+        const int f4 = lane & 3, col = col0 + f4 * 4;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.epi >= 1) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {                   // two passes of 32 pixels: block rows 2 lg + a
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            stg[(lg * 8 + 2 * r) * WN_LDS_STAGE + l15] = y[a][r][0];
+            stg[(lg * 8 + 2 * r + 1) * WN_LDS_STAGE + l15] = y[a][r][1];
+          }
+          __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): wave-private region
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int s = k * 16 + (lane >> 2);
+            const int row = by * 8 + 2 * (s >> 3) + a, cl = bx * 8 + (s & 7);
+            if (!live || row >= H || cl >= H) continue;
+            const size_t aoff = ((size_t)row * H + cl) * Cout + col;
+            const size_t ooff = (size_t)n * H * H * Cout + aoff;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + s * WN_LDS_STAGE + f4 * 4);
+            v += bias4;
+            if (p.U) *reinterpret_cast<f32x4*>(p.U + ooff) = v;
+            if (p.epi == 2) {
+              const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + aoff);
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : al[e] * v[e];
+              *reinterpret_cast<f32x4*>(p.A + ooff) = o;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    STAMP(5);
+    buf ^= 1;
+  }
+  if ((p.dbg & 64) && blockIdx.x == 0 && lane == 0 && p.dbg_out)
+    for (int k = 0; k < 8; ++k) p.dbg_out[wave * 8 + k] = (float)tsum[k] / (float)qtotal;
+#undef STAMP
+}
+
+// ---- weight transform U = G g G^T, laid out [column tile][K chunk][pos][n 32][k 16] ----------------------------
+// one thread per (n, k) of the padded [nct * 32][NC * 16] matrix; grid.y = descriptor
+__global__ __launch_bounds__(256) void wino_weights_kernel(const WinoWDesc* __restrict__ descs) {
+  const WinoWDesc d = descs[blockIdx.y];
+  const int NC = d.Cin / 16, nct = (d.Cout + 31) / 32;
+  const long total = (long)nct * NC * 512;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int kk = (int)(e & 15), nn = (int)((e >> 4) & 31);
+    const long blk = e >> 9;                            // ct * NC + kc
+    const int kc = (int)(blk % NC), ct = (int)(blk / NC);
+    const int k = kc * 16 + kk, n = ct * 32 + nn;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wt = d.wtmap[r * 3 + s];
+        g[r][s] = n < d.Cout ? (d.nmajor ? d.W[((size_t)wt * d.Cout + n) * d.Cin + k] : d.W[((size_t)wt * d.Cin + k) * d.Cout + n])
+                             : 0.f;
+      }
+    // rows: G g
+    float t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      t[0][s] = g[0][s];
+      t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+      t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+      t[3][s] = g[2][s];
+    }
+    float* out = d.Ut + (size_t)blk * (16 * 512) + nn * 16 + ((((kk >> 2) ^ ((0x78 >> (2 * ((nn >> 2) & 3))) & 3)) << 2) | (kk & 3));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      out[(i * 4 + 0) * 512] = t[i][0];
+      out[(i * 4 + 1) * 512] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+      out[(i * 4 + 2) * 512] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+      out[(i * 4 + 3) * 512] = t[i][2];
+    }
+  }
+}
+
+size_t wino_weight_floats(int Cin, int Cout) { return (size_t)((Cout + 31) / 32) * (Cin / 16) * WN_UCH_FLOATS; }
+
+bool wino_supported(int NB, int H, int Cin, int Cout) {
+  return Cin >= 16 && Cin % 16 == 0 && Cout >= 16 && Cout % 16 == 0 && H >= 5 && H <= 1024 && NB >= 1 &&
+         (size_t)H * H * (size_t)std::max(Cin, Cout) < ((size_t)1 << 31);
+}
+
+int launch_wino_weights(const WinoWDesc* descs_dev, const WinoWDesc* descs_host, int n, hipStream_t s) {
+  if (n <= 0) return OK;
+  long most = 0;
+  for (int i = 0; i < n; ++i) most = std::max(most, (long)wino_weight_floats(descs_host[i].Cin, descs_host[i].Cout) / 16);
+  const int gx = (int)std::min<long>(256, (most + 255) / 256);
+  hipLaunchKernelGGL(wino_weights_kernel, dim3(gx, n), dim3(256), 0, s, descs_dev);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+int launch_wino_conv(WinoParams p, hipStream_t s) {
+  if (!wino_supported(p.NB, p.H, p.Cin, p.Cout) || !p.zero || !p.Ut || p.epi < 0 || p.epi > 2) return 1;
+  if (p.epi == 2 && (!p.alpha || !p.A)) return 1;
+  p.nbh = (p.H + 7) / 8;
+  p.nct = (p.Cout + 31) / 32;
+  p.NC = p.Cin / 16;
+  const long blocks = (long)p.NB * p.nbh * p.nbh;
+  p.groups = (int)((blocks + WN_MB - 1) / WN_MB);
+  p.items = p.groups * p.nct;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  p.items_per_wg = (p.items + cus - 1) / cus;
+  const int grid = (p.items + p.items_per_wg - 1) / p.items_per_wg;
+  const size_t smem = ((size_t)2 * WN_MB * WN_PATCH_FLOATS + 2 * WN_UCH_FLOATS + (size_t)WN_WAVES * 32 * WN_LDS_STAGE) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    attr_set = true;
+  }
+  static const int dbg = getenv("DV_WINO_DBG") ? atoi(getenv("DV_WINO_DBG")) : 0;
+  p.dbg = dbg;
+  static float* dbg_buf = nullptr;
+  if ((dbg & 64) && !dbg_buf) DV_HIP(hipMalloc((void**)&dbg_buf, 64 * sizeof(float)));
+  p.dbg_out = dbg_buf;
+  hipLaunchKernelGGL(wino_conv_kernel, dim3(grid), dim3(WN_THREADS), smem, s, p);
+  DV_HIP(hipGetLastError());
+  if (dbg & 64) {
+    float h[64];
+    DV_HIP(hipStreamSynchronize(s));
+    DV_HIP(hipMemcpy(h, dbg_buf, sizeof h, hipMemcpyDeviceToHost));
+    static int shown = 0;
+    if (shown++ % 52 == 51)
+      for (int w = 0; w < 8; ++w)
+        fprintf(stderr, "  wave %d cycles/chunk: sync+issue %.0f | (stamp) %.0f | reads+transform %.0f | mid sync %.0f | mfma %.0f | epilogue %.0f\n", w,
+                h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
+  }
+  return OK;
+}
+
+}  // namespace dv

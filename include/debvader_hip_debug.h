@@ -24,6 +24,9 @@ int dv_debug_mfma_peak(dv_ctx* ctx, int32_t blocks, int32_t iters, int32_t nacc,
  * gather-GEMM and tiled weight-gradient kernels (no strip or fused stride-2 forms): the same arithmetic in another
  * summation order.  The control of tests/test_gpu_bf16.py (two fp32 summation orders against the bf16 engine). */
 int dv_debug_general_kernels(int32_t on);
+/* process-wide: on = 0 sends the stride-1 3x3 layers of the fp32 engine through the direct kernels (strip form /
+ * gather-GEMM) instead of the Winograd F(2x2, 3x3) kernel (wino.hip); on = 1 restores the default */
+int dv_debug_winograd(int32_t on);
 int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, int32_t Cy, int32_t sx,
                    int32_t pad_before, int32_t single_tap, int32_t iters, float* ms_out);
 

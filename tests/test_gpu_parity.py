@@ -291,10 +291,42 @@ def test_specialised_kernels_match_the_general_gather_gemm():
                                  (4, 256, 8, 256, 0)):
         for epi in (0, 2):
             cases.append((3, hs, cs, ht, ct, 2, pb, 1, 1, epi))
-    for c in cases:
-        check(lib.dv_debug_gconv_check(ctx._h, *c, out))
-        assert out[1] > 0.1, c
-        assert out[0] <= 2e-5 * out[1], (c, out[0], out[1])
+    # stride-1 layers with >= 32 channels on both sides take the Winograd kernel by default (next test): switch it off so
+    # that the strip forms are what is checked here
+    check(lib.dv_debug_winograd(0))
+    try:
+        for c in cases:
+            check(lib.dv_debug_gconv_check(ctx._h, *c, out))
+            assert out[1] > 0.1, c
+            assert out[0] <= 2e-5 * out[1], (c, out[0], out[1])
+    finally:
+        check(lib.dv_debug_winograd(1))
+
+
+def test_winograd_kernel_matches_the_general_gather_gemm():
+    """wino.hip (F(2x2, 3x3) for the stride-1 layers with >= 32 channels: model.py:81-83,128-134 and their data gradients)
+    against gconv2 on the same random operands: every image size of the two architectures' stride-1 layers plus sizes
+    that leave partial 8 x 8 blocks and partial tiles, channel counts 32 ... 256 with one to eight 32-column tiles and two
+    to sixteen K chunks, both weight layouts / tap orders, every epilogue.  Same fp32 products in another association
+    (sums of four inputs, halves in G): stated 2e-5 of the largest output, measured <= 2.7e-6."""
+    import ctypes as C
+    from debvader_amd import engine as E
+    from debvader_amd._lib import lib, check
+    ctx = E.default_context()
+    out = (C.c_float * 2)()
+    worst = 0.0
+    for H in (64, 59, 40, 32, 30, 17, 16, 15, 8, 5):
+        for (cs, ct) in ((32, 32), (64, 64), (32, 64), (64, 32), (64, 128), (128, 128), (128, 256), (256, 256), (96, 160)):
+            if H > 32 and cs * ct > 64 * 64:
+                continue
+            for dgrad, nmajor in ((0, 0), (1, 1)):
+                for epi in (0, 1, 2):
+                    c = (3, H, cs, H, ct, 1, 1, dgrad, nmajor, epi)
+                    check(lib.dv_debug_gconv_check(ctx._h, *c, out))
+                    assert out[1] > 0.1, c
+                    assert out[0] <= 2e-5 * out[1], (c, out[0], out[1])
+                    worst = max(worst, out[0] / out[1])
+    print(f"\nWinograd vs gather-GEMM: worst relative difference {worst:.2e}")
 
 
 def test_channel_counts_that_are_not_powers_of_two():
