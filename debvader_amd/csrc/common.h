@@ -185,6 +185,20 @@ struct WinoWDesc {
   int Cin, Cout, nmajor;
   int wtmap[9];        // weight tap index of the input offset (r - 1, s - 1), r * 3 + s
 };
+// weight gradient of a stride-1 3x3 layer in the Winograd domain (wino.hip): out[9][Cx][Cy] = sum X (gathered, pad 1) x Y
+struct WinoWgradParams {
+  const float* X;      // [NB,H,H,Cx]
+  const float* Y;      // [NB,H,H,Cy]
+  float* part;         // partial slabs [S][16][Cx][Cy]
+  size_t part_capacity;
+  const float* zero;
+  int NB, H, Cx, Cy;
+  int nbh, nkt, nnt, nblocks, S, bps;   // filled by the launcher
+};
+bool wino_wgrad_supported(int NB, int H, int Cx, int Cy);
+size_t wino_wgrad_part_floats(int NB, int H, int Cx, int Cy, int* splits_out);
+int launch_wino_wgrad(WinoWgradParams p, float* out, hipStream_t s);   // 1 = not taken
+int launch_wino_wgrad_finish(const float* part, float* out, int S, int Cx, int Cy, hipStream_t s);
 bool wino_supported(int NB, int H, int Cin, int Cout);
 size_t wino_weight_floats(int Cin, int Cout);
 int launch_wino_weights(const WinoWDesc* descs_dev, const WinoWDesc* descs_host, int n, hipStream_t s);

@@ -323,11 +323,11 @@ struct ProfRec {
 // kernel families of the MFMA work, by the name rocprofv3 prints for them (per-kernel roofline rows of bench.py)
 enum {
   PF_NONE = -1, PF_GCONV2 = 0, PF_GCONV_S2, PF_GSTRIP, PF_GSTRIP8, PF_GCONV, PF_WGRAD, PF_WSTRIP, PF_BCONV, PF_BWGRAD,
-  PF_WINO, PF_COUNT
+  PF_WINO, PF_WINOW, PF_COUNT
 };
 static const char* const kProfFamName[PF_COUNT] = {
     "gconv2_kernel", "gconv_s2_kernel", "gconv_strip_kernel", "gconv_strip8_kernel", "gconv_kernel", "wgrad_kernel",
-    "wgrad_strip_kernel / wgrad_strip8_kernel", "bconv_kernel", "bwgrad_kernel", "wino_conv_kernel"};
+    "wgrad_strip_kernel / wgrad_strip8_kernel", "bconv_kernel", "bwgrad_kernel", "wino_conv_kernel", "wino_wgrad_kernel"};
 
 struct DataSlot {
   float* x = nullptr;
@@ -383,6 +383,8 @@ struct dv_model {
   size_t wino_descs_cap = 0;
   uint64_t param_epoch = 0;        // bumped whenever a parameter changes (Winograd weights are re-derived lazily)
   bool use_wino = true;
+  std::vector<std::pair<float*, size_t>> wino_wslabs;   // partial-slab buffer of the i-th Winograd weight-gradient launch of a step
+  int wino_wcount = 0;
   int Bc = 0;
   BfState bf;
   // flat parameter-shaped buffers
@@ -784,7 +786,11 @@ static int wino_conv(dv_model* m, const float* X, const float* W, bool nmajor, c
     DV_TRY(wino_register(m, W, nmajor, tp, Cin, Cout, &e));
     DV_TRY(wino_upload_descs(m, st));
   }
-  if (e->epoch != m->param_epoch) {            // not covered by the refresh at the head of the pass
+  // Staleness is dealt with at the head of a forward pass (wino_refresh_all), once for all layers.  Here only an entry
+  // that has never been computed is transformed (a layer registered on the fly: the debug harness): the parameter epoch
+  // also moves DURING a backward pass - the decoder bucket is updated on the comm stream while the encoder is still
+  // being differentiated - and the data-gradient forms must keep the weights the forward pass used.
+  if (e->epoch == ~(uint64_t)0) {
     const size_t i = (size_t)(e - m->wino.data());
     ProfScope ps(m, 2, st);
     DV_TRY(launch_wino_weights(m->wino_descs_dev + i, &e->d, 1, st));
@@ -1141,6 +1147,44 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
     m->ws_last = reg;
     return OK;
   };
+  if (!single_tap && sx == 1 && pb == 1 && Hx == Hy && cpad == creal && !fz && !g_force_v1 && !g_no_special && !g_no_wino &&
+      m->use_wino && !m->bf.on && m->zero_page && wino_wgrad_supported(NB, Hy, Cx, Cy)) {
+    // stride-1 layers with >= 64 channels on both sides: Winograd-domain weight gradient (wino.hip), its partial slabs in
+    // a buffer of this launch's own (allocated at first use: 64 MiB per launch at 256 CUs)
+    int S = 1;
+    const size_t need = wino_wgrad_part_floats(NB, Hy, Cx, Cy, &S);
+    const int wi = m->wino_wcount++;
+    if ((int)m->wino_wslabs.size() <= wi) m->wino_wslabs.resize(wi + 1, {nullptr, 0});
+    if (m->wino_wslabs[wi].second < need) {
+      float* q = nullptr;
+      if (hipMalloc((void**)&q, need * sizeof(float)) == hipSuccess) {
+        m->allocs.push_back(q);
+        m->wino_wslabs[wi] = {q, need};            // (a smaller predecessor stays in allocs until the model goes)
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    if (m->wino_wslabs[wi].second >= need) {
+      WinoWgradParams wp;
+      memset(&wp, 0, sizeof wp);
+      wp.X = X; wp.Y = Y; wp.part = m->wino_wslabs[wi].first; wp.part_capacity = m->wino_wslabs[wi].second;
+      wp.zero = m->zero_page; wp.NB = NB; wp.H = Hy; wp.Cx = Cx; wp.Cy = Cy;
+      int st;
+      {
+        ProfScope ps(m, 1, ws, PF_WINOW, wflops);
+        st = launch_wino_wgrad(wp, out, ws);
+      }
+      if (st < 0) return st;
+      if (st == 0) {
+        DV_TRY(hand_over());
+        {
+          ProfScope ps(m, 2, rs);
+          DV_TRY(launch_wino_wgrad_finish(wp.part, out, S, Cx, Cy, rs));
+        }
+        return reduced();
+      }
+    }
+  }
   if (!single_tap && !g_force_v1 && !(g_no_special && !fz) && cpad == creal && wgrad_strip_supported(Cx, Cy, sx, 9)) {
     WStripParams sp;
     memset(&sp, 0, sizeof sp);
@@ -1720,6 +1764,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   const int K = (ovl && (int)m->gbufs.size() >= 4 * A.L + 10) ? (int)m->gbufs.size() : 3;
   const bool no_reuse = K > 3;
   m->ws_count = 0;
+  m->wino_wcount = 0;
   m->ws_last_rs = nullptr;
   m->main_marked = false;
   float* const* bufs = m->gbufs.data();
@@ -3772,6 +3817,44 @@ int dv_debug_gconv_check(dv_ctx* ctx, int32_t NB, int32_t Hs, int32_t Cs, int32_
   return st;
 }
 
+// Winograd-domain weight gradient (wino.hip) against the direct kernels on the same pseudo-random operands:
+// out2 = {max |difference|, max |reference|}
+int dv_debug_wgrad_check(dv_ctx* ctx, int32_t NB, int32_t H, int32_t Cx, int32_t Cy, float* out2) {
+  if (!ctx || !out2) return DV_E_INVALID;
+  dv_model m;
+  m.ctx = ctx;
+  float *X, *Yb, *out;
+  const size_t nx = (size_t)NB * H * H * Cx, ny = (size_t)NB * H * H * Cy, nw = (size_t)9 * Cx * Cy;
+  DV_TRY(debug_buffers(ctx, nx, ny, 2 * nw, &X, &Yb, &out));
+  m.ws1_elems = (size_t)16 << 20;
+  DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
+  DV_HIP(hipMalloc((void**)&m.zero_page, 256));
+  DV_HIP(hipMemset(m.zero_page, 0, 256));
+  int st = OK;
+  for (int pass = 0; pass < 2 && st == OK; ++pass) {
+    g_no_wino = pass == 1;
+    m.wino_wcount = 0;
+    st = wgrad(&m, X, H, Cx, Yb, H, Cy, NB, 1, 1, false, out + pass * nw, Cx, Cx, nullptr);
+  }
+  g_no_wino = false;
+  DV_HIP(hipStreamSynchronize(ctx->stream));
+  if (st == OK) {
+    std::vector<float> a(nw), b(nw);
+    DV_HIP(hipMemcpy(a.data(), out, nw * sizeof(float), hipMemcpyDeviceToHost));
+    DV_HIP(hipMemcpy(b.data(), out + nw, nw * sizeof(float), hipMemcpyDeviceToHost));
+    double md = 0, mr = 0;
+    for (size_t i = 0; i < nw; ++i) {
+      md = std::max(md, (double)fabsf(a[i] - b[i]));
+      mr = std::max(mr, (double)fabsf(b[i]));
+    }
+    out2[0] = (float)md;
+    out2[1] = (float)mr;
+  }
+  (void)hipFree(X); (void)hipFree(Yb); (void)hipFree(out); (void)hipFree(m.ws1); (void)hipFree(m.zero_page);
+  for (void* q : m.allocs) (void)hipFree(q);
+  return st;
+}
+
 int dv_debug_winograd(int32_t on) {
   g_no_wino = on == 0;
   return DV_OK;
@@ -3850,6 +3933,7 @@ int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, 
     if (it == 0) DV_HIP(hipEventRecord(a, ctx->stream));
     g_force_v1 = (single_tap & 2) != 0;
     debug_set_strip(single_tap >> 2);
+    m.wino_wcount = 0;
     st = wgrad(&m, X, Hx, Cx, Yb, Hy, Cy, NB, sx, pb, (single_tap & 1) != 0, out, Cx, Cx, fused ? &fz : nullptr);
     g_force_v1 = false;
     debug_set_strip(0);
@@ -3866,6 +3950,7 @@ int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, 
       fprintf(stderr, "  wave %d: barrier %.0f  dma-issue %.0f  compute %.0f cycles over %.0f strips\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
   }
   (void)hipFree(X); (void)hipFree(Yb); (void)hipFree(out); (void)hipFree(m.ws1); (void)hipFree(m.zero_page);
+  for (void* q : m.allocs) (void)hipFree(q);      // Winograd slabs allocated on the fly
   if (fused) {
     (void)hipFree(U); (void)hipFree(al); (void)hipFree(gout); (void)hipFree(m.ws2); (void)hipFree(m.ws3);
     m.ws2 = m.ws3 = nullptr;

@@ -172,9 +172,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
     // All LDS reads of the chunk go out first - the 16 weight fragments (one per position) and the 4 x 4 input tile - so
     // that the MFMA stream below never waits for one (left to itself hipcc sinks every fragment read to just in front
     // of its four MFMAs: read latency + a dependent accumulator chain per position).
-    f32x4 bfr[16];
+    f32x4 bfr[16];                                    // (positions 8-15 are fetched behind the first MFMA groups)
 #pragma unroll
-    for (int pos = 0; pos < 16; ++pos) bfr[pos] = *reinterpret_cast<const f32x4*>(Uc + (pos * 32) * 16);
+    for (int pos = 0; pos < 8; ++pos) bfr[pos] = *reinterpret_cast<const f32x4*>(Uc + (pos * 32) * 16);
     f32x4 V[16];
     if (p.dbg & 2) {
 #pragma unroll
@@ -206,15 +206,61 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
     }
     STAMP(2);
     STAMP(3);
+    // epilogue geometry of this wave's block (used from the last chunk of an item on)
+    bool e_on = false, e_live = false;
+    int e_n = 0, e_by = 0, e_bx = 0, e_col = 0, e_col0 = 0;
+    unsigned e_aoff[4] = {0, 0, 0, 0};                // offsets of the lane's four float4 in the [H][H][Cout] plane
+    bool e_ok[4] = {false, false, false, false};
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al4[4];
     // 16 position GEMMs, two accumulator chains interleaved (a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles,
     // an independent one every 32)
     if (!(p.dbg & 4)) {
 #pragma unroll
       for (int pos = 0; pos < 16; pos += 2) {
+        if (pos == 2) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q2 = 8; q2 < 16; ++q2) bfr[q2] = *reinterpret_cast<const f32x4*>(Uc + (q2 * 32) * 16);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[pos][jj], bfr[pos][jj], acc[pos], 0, 0, 0);
           acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[pos + 1][jj], bfr[pos + 1][jj], acc[pos + 1], 0, 0, 0);
+        }
+        if (pos == 8 && c == NC - 1 && !(p.dbg & 1)) {
+          __builtin_amdgcn_sched_barrier(0);
+      const int item = item0 + it;
+          const int ct = item / p.groups, g = item - ct * p.groups;
+          const int mblock = g * WN_MB + mb;
+          e_live = mblock < p.NB * nb2;
+          e_n = e_live ? mblock / nb2 : 0;
+          const int rem = e_live ? mblock - e_n * nb2 : 0;
+          e_by = rem / p.nbh;
+          e_bx = rem - e_by * p.nbh;
+          e_col0 = ct * 32 + nh * 16;
+          e_on = e_col0 < Cout;                           // wave-uniform
+          e_col = e_col0 + (lane & 3) * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {                   // i = 2 a + k: pass a (block rows 2 lg + a), half k
+            const int sidx = (i & 1) * 16 + (lane >> 2);
+            const int row = e_by * 8 + 2 * (sidx >> 3) + (i >> 1), cl = e_bx * 8 + (sidx & 7);
+            e_ok[i] = e_live && e_on && row < H && cl < H;
+            e_aoff[i] = e_ok[i] ? (unsigned)((row * H + cl) * Cout + e_col) : 0u;
+          }
+        }
+        if (pos == 8 && c == NC - 1 && e_on) {
+          // The epilogue's bias and PReLU slopes, fetched now (half of the fragment registers are free again) by
+          // hand-written loads: a plain load's result makes hipcc wait vmcnt(0) at its first use while LDS-DMA is in
+          // flight - all of the next chunk's DMA and the previous item's stores - which cost the 32- and 64-channel
+          // layers a third of their time.  Four DMA pieces follow these loads, hence vmcnt(4) in the epilogue.
+          __builtin_amdgcn_sched_barrier(0);
+          if (p.epi >= 1) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias4) : "v"(p.bias + e_col) : "memory");
+          if (p.epi == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(al4[i]) : "v"(p.alpha + e_aoff[i]) : "memory");
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
         if (more && !(p.dbg & 32)) {
           __builtin_amdgcn_sched_barrier(0);
@@ -227,65 +273,55 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
       for (int k = 0; k < 2 * NPP; ++k) dma_piece(k);
     }
     STAMP(4);
-    if (c == NC - 1 && !(p.dbg & 1)) {
+    if (c == NC - 1 && e_on) {
       // ---- output transform Y = A^T M A on the accumulators, then bias / PReLU / stores through the staging tile ----
-      const int item = item0 + it;
-      const int ct = item / p.groups, g = item - ct * p.groups;   // column tile outermost: one weight slice hot in every L2
-      const int mblock = g * WN_MB + mb;
-      const bool live = mblock < p.NB * nb2;
-      const int n = live ? mblock / nb2 : 0;
-      const int rem = live ? mblock - n * nb2 : 0;
-      const int by = rem / p.nbh, bx = rem - by * p.nbh;
-      const int col0 = ct * 32 + nh * 16;
-      if (col0 < Cout) {                                // wave-uniform
-        float y[2][4][2];                               // [a][r][b]: pixel (2 lg + a, 2 r + b) of the 8 x 8 block
+      float y[2][4][2];                                 // [a][r][b]: pixel (2 lg + a, 2 r + b) of the 8 x 8 block
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float tt[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float m0 = acc[0 + j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
+          tt[0][j] = m0 + m1 + m2;
+          tt[1][j] = m1 - m2 - m3;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          y[a][r][0] = tt[a][0] + tt[a][1] + tt[a][2];
+          y[a][r][1] = tt[a][1] - tt[a][2] - tt[a][3];
+        }
+      }
+      // the hand-issued bias / slope loads have landed once at most the four DMA pieces issued behind them are pending
+      if (more && !(p.dbg & 32)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(bias4), "+v"(al4[0]), "+v"(al4[1]), "+v"(al4[2]), "+v"(al4[3]));
+      const int f4 = lane & 3;
+      const size_t obase = (size_t)e_n * H * H * Cout;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {                     // two passes of 32 pixels: block rows 2 lg + a
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float tt[2][4];
+          stg[(lg * 8 + 2 * r) * WN_LDS_STAGE + l15] = y[a][r][0];
+          stg[(lg * 8 + 2 * r + 1) * WN_LDS_STAGE + l15] = y[a][r][1];
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): wave-private region
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float m0 = acc[0 + j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
-            tt[0][j] = m0 + m1 + m2;
-            tt[1][j] = m1 - m2 - m3;
-          }
+        for (int k = 0; k < 2; ++k) {
+          const int i = 2 * a + k;
+          if (!e_ok[i]) continue;
+          const int sidx = k * 16 + (lane >> 2);
+          f32x4 v = *reinterpret_cast<const f32x4*>(stg + sidx * WN_LDS_STAGE + f4 * 4);
+          if (p.epi >= 1) v += bias4;
+          if (p.U) *reinterpret_cast<f32x4*>(p.U + obase + e_aoff[i]) = v;
+          if (p.epi == 2) {
+            f32x4 o;
 #pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            y[a][r][0] = tt[a][0] + tt[a][1] + tt[a][2];
-            y[a][r][1] = tt[a][1] - tt[a][2] - tt[a][3];
+            for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : al4[i][e] * v[e];
+            *reinterpret_cast<f32x4*>(p.A + obase + e_aoff[i]) = o;
           }
         }
-        const int f4 = lane & 3, col = col0 + f4 * 4;
-        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.epi >= 1) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {                   // two passes of 32 pixels: block rows 2 lg + a
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            stg[(lg * 8 + 2 * r) * WN_LDS_STAGE + l15] = y[a][r][0];
-            stg[(lg * 8 + 2 * r + 1) * WN_LDS_STAGE + l15] = y[a][r][1];
-          }
-          __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): wave-private region
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int s = k * 16 + (lane >> 2);
-            const int row = by * 8 + 2 * (s >> 3) + a, cl = bx * 8 + (s & 7);
-            if (!live || row >= H || cl >= H) continue;
-            const size_t aoff = ((size_t)row * H + cl) * Cout + col;
-            const size_t ooff = (size_t)n * H * H * Cout + aoff;
-            f32x4 v = *reinterpret_cast<const f32x4*>(stg + s * WN_LDS_STAGE + f4 * 4);
-            v += bias4;
-            if (p.U) *reinterpret_cast<f32x4*>(p.U + ooff) = v;
-            if (p.epi == 2) {
-              const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + aoff);
-              f32x4 o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : al[e] * v[e];
-              *reinterpret_cast<f32x4*>(p.A + ooff) = o;
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
+        __builtin_amdgcn_wave_barrier();
       }
     }
     STAMP(5);
@@ -334,6 +370,318 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const WinoWDesc* __re
       out[(i * 4 + 3) * 512] = t[i][2];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a stride-1 3x3 layer in the Winograd domain, F(3x3, 2x2):
+//     dW = G^T [ sum over 2x2 output tiles  (B^T d B) . (A dy A^T) ] G
+// d = 4x4 tile of the gathered operand X (pad 1), dy = 2x2 tile of the dense operand Y: 16 positions, each a
+// [Cx x tiles] x [tiles x Cy] contraction over ALL tiles of the batch - a GEMM with a tiny output (16 x Cx x Cy) and a
+// very long K, 4 multiply-adds per pixel and channel pair instead of 9.
+// A workgroup owns a 64 x 64 (cx, cy) output tile for all 16 positions and a contiguous range of 8 x 8-pixel blocks
+// (the M blocks of wino_conv_kernel); wave w owns the 32 x 32 quarter (w >> 1, w & 1): 16 x 2 x 2 accumulator blocks
+// (256 registers, one wave per SIMD).  Per block the 10 x 10 x 64 patch of X and the 8 x 8 x 64 tile of Y arrive by
+// LDS-DMA into a two-deep ring (41 KiB a stage: 5 bytes per MFMA cycle - the contraction re-uses every operand 32
+// times from registers).  MFMA roles (v_mfma_f32_16x16x4_f32): rows = 16 channels of X, columns = 16 channels of Y,
+// k = the four tiles of one tile row of the block; lane (l15, lg) transforms tile lg of its channel l15 itself (scalar
+// B^T d B and A dy A^T from 16 + 4 ds_read_b32) - no transposes, no transformed tensors in memory.
+// Each workgroup writes its partial [16][64][64] into slab s of `part`; wino_wgrad_finish_kernel sums the slabs in a fixed
+// order and applies G^T . G.  Out-of-image tiles contribute zeros (zero page on the DMA side), so there is no masking.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int WG_XP = 25;                       // 1-KiB DMA pieces of the X patch: 100 pixels x 256 B
+constexpr int WG_YP = 16;                       // of the Y tile: 64 pixels x 256 B
+constexpr int WG_STAGE = (WG_XP + WG_YP) * 256; // floats per ring stage
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WinoWgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][WG_STAGE]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int H = p.H, Cx = p.Cx, Cy = p.Cy;
+  const int nb2 = p.nbh * p.nbh;
+  // workgroup -> (output tile, split)
+  const int tile = blockIdx.x / p.S, split = blockIdx.x - tile * p.S;
+  const int kt = tile / p.nnt, nt = tile - kt * p.nnt;
+  const int b_begin = split * p.bps, b_end = min(p.nblocks, b_begin + p.bps);
+  const int kw = wave >> 1, nw = wave & 1;       // this wave's 32 x 32 quarter
+
+  // DMA of a block into a ring stage: 25 + 16 pieces of 1 KiB, this wave's are k = wave, wave + 4, ... in that order
+  // (dma_begin, then dma_next once per piece); slot e = 64 k + lane -> (pixel L = e >> 4, 16-byte piece e & 15).  The
+  // piece index is XOR-ed with 4 * ((L >> 1) & 1) so that the two tiles a 32-lane read group touches (pixels two apart)
+  // sit in different halves of the 32 banks.  (pr, pc) of the X patch pixel advance by 16 pixels per step: no division.
+  const int pc00 = (4 * wave + (lane >> 4)) % 10, pr00 = (4 * wave + (lane >> 4)) / 10;
+  int d_k = 0, d_pr = 0, d_pc = 0, d_n = 0, d_by = 0, d_bx = 0, d_st = 0;
+  auto dma_begin = [&](int blk, int stg) {
+    d_n = blk / nb2;
+    const int rem = blk - d_n * nb2;
+    d_by = rem / p.nbh;
+    d_bx = rem - d_by * p.nbh;
+    d_k = wave;
+    d_pr = pr00;
+    d_pc = pc00;
+    d_st = stg;
+  };
+  auto dma_next = [&]() {
+    if (d_k >= WG_XP + WG_YP) return;                  // wave-uniform
+    float* dst = smem + d_st * WG_STAGE + d_k * 256;
+    const float* src = p.zero;
+    const int pc0 = lane & 15;
+    if (d_k < WG_XP) {
+      const int L = d_pr * 10 + d_pc;
+      const int row = d_by * 8 - 1 + d_pr, col = d_bx * 8 - 1 + d_pc;
+      if ((unsigned)row < (unsigned)H && (unsigned)col < (unsigned)H)
+        src = p.X + ((size_t)(d_n * H + row) * H + col) * Cx + kt * 64 + ((pc0 ^ (((L >> 1) & 1) << 2)) << 2);
+      d_pc += 6;                                       // + 16 pixels
+      d_pr += 1;
+      if (d_pc >= 10) {
+        d_pc -= 10;
+        d_pr += 1;
+      }
+    } else {
+      const int L = (d_k - WG_XP) * 4 + (lane >> 4);
+      const int row = d_by * 8 + (L >> 3), col = d_bx * 8 + (L & 7);
+      if (row < H && col < H)
+        src = p.Y + ((size_t)(d_n * H + row) * H + col) * Cy + nt * 64 + ((pc0 ^ (((L >> 1) & 1) << 2)) << 2);
+    }
+    __builtin_amdgcn_global_load_lds((wn_gptr_t)src, (wn_lptr_t)dst, 16, 0, 0);
+    d_k += 4;
+  };
+  auto issue_block = [&](int blk, int stg) {
+    dma_begin(blk, stg);
+#pragma unroll 1
+    for (int i = 0; i < 11; ++i) dma_next();
+  };
+
+  f32x4 acc[16][2][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[i][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // raw operands of one tile quad (tile row ty of the block; this lane: tile tx = lg, channel l15 of each 16-block)
+  auto load_raw = [&](const float* Xs, const float* Ys, int ty, float (&xr)[2][16], float (&yr)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int L = (2 * ty + i) * 10 + 2 * lg + j;
+        const int sw = ((L >> 1) & 1) << 4;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) xr[kb][i * 4 + j] = Xs[L * 64 + (((kw * 2 + kb) * 16 + l15) ^ sw)];
+      }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int L = (2 * ty + a) * 8 + 2 * lg + b;
+        const int sw = ((L >> 1) & 1) << 4;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) yr[nb][a * 2 + b] = Ys[L * 64 + (((nw * 2 + nb) * 16 + l15) ^ sw)];
+      }
+  };
+
+  // transforms of one quad's raw operands: V = B^T d B (scalars), M = A dy A^T
+  auto transform = [&](const float (&xr)[2][16], const float (&yr)[2][4], float (&V)[2][16], float (&M)[2][16]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float t[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = xr[kb][0 * 4 + j] - xr[kb][2 * 4 + j];
+        t[1][j] = xr[kb][1 * 4 + j] + xr[kb][2 * 4 + j];
+        t[2][j] = xr[kb][2 * 4 + j] - xr[kb][1 * 4 + j];
+        t[3][j] = xr[kb][1 * 4 + j] - xr[kb][3 * 4 + j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        V[kb][i * 4 + 0] = t[i][0] - t[i][2];
+        V[kb][i * 4 + 1] = t[i][1] + t[i][2];
+        V[kb][i * 4 + 2] = t[i][2] - t[i][1];
+        V[kb][i * 4 + 3] = t[i][1] - t[i][3];
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      // rows of A dy: [y0; y0 + y1; y0 - y1; -y1], then the same on the columns
+      float r[4][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float y0 = yr[nb][0 * 2 + b], y1 = yr[nb][1 * 2 + b];
+        r[0][b] = y0;
+        r[1][b] = y0 + y1;
+        r[2][b] = y0 - y1;
+        r[3][b] = -y1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        M[nb][i * 4 + 0] = r[i][0];
+        M[nb][i * 4 + 1] = r[i][0] + r[i][1];
+        M[nb][i * 4 + 2] = r[i][0] - r[i][1];
+        M[nb][i * 4 + 3] = -r[i][1];
+      }
+    }
+  };
+
+  // Software pipeline, written out (one wave per SIMD: nothing else hides an LDS round trip; left to itself hipcc
+  // scatters the 40 reads of a quad between its MFMAs with a full wait in front of each group): per tile quad
+  //   wait for its raw operands -> transform (88 VALU) -> issue the NEXT quad's 40 reads -> 64 MFMAs,
+  // with the DMA pieces of the next block issued between the MFMA groups of this one.
+  if (b_begin < b_end) issue_block(b_begin, 0);
+  int st = 0;
+  for (int blk = b_begin; blk < b_end; ++blk) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool more = blk + 1 < b_end;
+    const float* Xs = smem + st * WG_STAGE;
+    const float* Ys = Xs + WG_XP * 256;
+    if (more) dma_begin(blk + 1, st ^ 1);
+    float xr[2][16], yr[2][4];
+    load_raw(Xs, Ys, 0, xr, yr);
+#pragma unroll 1
+    for (int ty = 0; ty < 4; ++ty) {
+      float V[2][16], M[2][16];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      transform(xr, yr, V, M);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ty + 1 < 4) load_raw(Xs, Ys, ty + 1, xr, yr);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pos = 0; pos < 16; ++pos) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[pos][kb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[kb][pos], M[nb][pos], acc[pos][kb][nb], 0, 0, 0);
+        if ((pos & 3) == 3 && more) {                  // DMA of the next block: one piece behind every 16th MFMA
+          __builtin_amdgcn_sched_barrier(0);
+          dma_next();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    st ^= 1;
+  }
+  // ---- partial slab: part[split][pos][cx][cy] ----
+  float* out = p.part + (size_t)split * 16 * Cx * Cy;
+#pragma unroll
+  for (int pos = 0; pos < 16; ++pos)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cx = kt * 64 + (kw * 2 + kb) * 16 + 4 * lg + r, cy = nt * 64 + (nw * 2 + nb) * 16 + l15;
+          out[((size_t)pos * Cx + cx) * Cy + cy] = acc[pos][kb][nb][r];
+        }
+}
+
+// out[(r * 3 + s) * Cx + cx][cy] = (G^T (sum_split part[split]) G)[r][s]; one thread per (cx, cy), fixed summation order
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                int S, int Cx, int Cy) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = (long)Cx * Cy;
+  if (e >= n) return;
+  float u[16];
+#pragma unroll
+  for (int pos = 0; pos < 16; ++pos) u[pos] = 0.f;
+  for (int sp = 0; sp < S; ++sp)
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) u[pos] += part[((size_t)sp * 16 + pos) * n + e];
+  // G^T = [[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]]
+  float t[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    t[0][j] = u[0 * 4 + j] + 0.5f * (u[1 * 4 + j] + u[2 * 4 + j]);
+    t[1][j] = 0.5f * (u[1 * 4 + j] - u[2 * 4 + j]);
+    t[2][j] = 0.5f * (u[1 * 4 + j] + u[2 * 4 + j]) + u[3 * 4 + j];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    out[(size_t)(r * 3 + 0) * n + e] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+    out[(size_t)(r * 3 + 1) * n + e] = 0.5f * (t[r][1] - t[r][2]);
+    out[(size_t)(r * 3 + 2) * n + e] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+  }
+}
+
+// first stage of the slab sum when a launch has many splits (few output tiles, e.g. 256 slabs for a 64 x 64 layer): group
+// g sums its splits [g * per, (g + 1) * per) in order into tmp[g]; the finish kernel then sums the (at most 16) groups
+__global__ __launch_bounds__(256) void wino_wgrad_presum_kernel(const float* __restrict__ part, float* __restrict__ tmp,
+                                                                int S, int per, long slab4) {
+  const long f = (long)blockIdx.x * 256 + threadIdx.x;
+  if (f >= slab4) return;
+  const int g = blockIdx.y;
+  const int s0 = g * per, s1 = min(S, s0 + per);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = s0; sp < s1; ++sp) a += reinterpret_cast<const f32x4*>(part)[(size_t)sp * slab4 + f];
+  reinterpret_cast<f32x4*>(tmp)[(size_t)g * slab4 + f] = a;
+}
+
+bool wino_wgrad_supported(int NB, int H, int Cx, int Cy) {
+  return Cx >= 64 && Cy >= 64 && Cx % 64 == 0 && Cy % 64 == 0 && H >= 5 && H <= 1024 && NB >= 1 &&
+         (size_t)H * H * (size_t)std::max(Cx, Cy) < ((size_t)1 << 31);
+}
+
+// floats of partial slabs a launch writes (the caller provides them): splits x 16 x Cx x Cy
+size_t wino_wgrad_part_floats(int NB, int H, int Cx, int Cy, int* splits_out) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  const int nbh = (H + 7) / 8;
+  const long nblocks = (long)NB * nbh * nbh;
+  const int tiles = (Cx / 64) * (Cy / 64);
+  long S = std::max(1, cus / tiles);
+  S = std::min(S, nblocks);
+  if (splits_out) *splits_out = (int)S;
+  return (size_t)(S + (S >= 64 ? 16 : 0)) * 16 * Cx * Cy;    // + the 16 group sums of the two-stage reduction
+}
+
+int launch_wino_wgrad(WinoWgradParams p, float* out, hipStream_t s_kernel) {
+  if (!wino_wgrad_supported(p.NB, p.H, p.Cx, p.Cy) || !p.zero || !p.part) return 1;
+  int S = 1;
+  const size_t need = wino_wgrad_part_floats(p.NB, p.H, p.Cx, p.Cy, &S);
+  if (need > p.part_capacity) return 1;
+  p.nbh = (p.H + 7) / 8;
+  p.nkt = p.Cx / 64;
+  p.nnt = p.Cy / 64;
+  p.nblocks = p.NB * p.nbh * p.nbh;
+  p.S = S;
+  p.bps = (p.nblocks + S - 1) / S;
+  const size_t smem = (size_t)2 * WG_STAGE * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wino_wgrad_kernel, dim3(p.nkt * p.nnt * S), dim3(256), smem, s_kernel, p);
+  DV_HIP(hipGetLastError());
+  (void)out;
+  return OK;
+}
+
+int launch_wino_wgrad_finish(const float* part, float* out, int S, int Cx, int Cy, hipStream_t s) {
+  const long n = (long)Cx * Cy;
+  if (S >= 64) {                                      // (with 32 splits the one-stage sum is faster: measured)
+    const int per = (S + 15) / 16, G = (S + per - 1) / per;
+    const long slab4 = 16 * n / 4;
+    float* tmp = const_cast<float*>(part) + (size_t)S * 16 * n;
+    hipLaunchKernelGGL(wino_wgrad_presum_kernel, dim3((unsigned)((slab4 + 255) / 256), G), dim3(256), 0, s, part, tmp, S, per, slab4);
+    part = tmp;
+    S = G;
+  }
+  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, out, S, Cx, Cy);
+  DV_HIP(hipGetLastError());
+  return OK;
 }
 
 size_t wino_weight_floats(int Cin, int Cout) { return (size_t)((Cout + 31) / 32) * (Cin / 16) * WN_UCH_FLOATS; }

@@ -27,6 +27,9 @@ int dv_debug_general_kernels(int32_t on);
 /* process-wide: on = 0 sends the stride-1 3x3 layers of the fp32 engine through the direct kernels (strip form /
  * gather-GEMM) instead of the Winograd F(2x2, 3x3) kernel (wino.hip); on = 1 restores the default */
 int dv_debug_winograd(int32_t on);
+/* weight gradient of a stride-1 3x3 layer X [NB,H,H,Cx] x Y [NB,H,H,Cy] through the Winograd-domain kernel and through the
+ * direct kernels on the same pseudo-random operands: out2 = {max |difference|, max |reference|} */
+int dv_debug_wgrad_check(dv_ctx* ctx, int32_t NB, int32_t H, int32_t Cx, int32_t Cy, float* out2);
 int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, int32_t Cy, int32_t sx,
                    int32_t pad_before, int32_t single_tap, int32_t iters, float* ms_out);
 

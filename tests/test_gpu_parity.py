@@ -329,6 +329,31 @@ def test_winograd_kernel_matches_the_general_gather_gemm():
     print(f"\nWinograd vs gather-GEMM: worst relative difference {worst:.2e}")
 
 
+def test_winograd_weight_gradient_matches_the_direct_kernels():
+    """wino_wgrad_kernel (F(3x3, 2x2): weight gradients of the stride-1 layers with >= 64 channels on both sides,
+    model.py:81-83,128-134) against the direct weight-gradient kernels on the same random operands: the image sizes of
+    those layers and sizes with partial blocks / tiles, one to sixteen 64 x 64 output tiles, batch sizes that give the
+    splits uneven block ranges.  fp32 sums in another association: stated 2e-5 of the largest gradient, measured 7e-7."""
+    import ctypes as C
+    from debvader_amd import engine as E
+    from debvader_amd._lib import lib, check
+    ctx = E.default_context()
+    out = (C.c_float * 2)()
+    worst = 0.0
+    for H in (32, 30, 17, 16, 15, 8, 5):
+        for (cx, cy) in ((64, 64), (64, 128), (128, 64), (128, 128), (128, 256), (256, 256), (192, 64)):
+            if H > 16 and cx * cy > 128 * 128:
+                continue
+            for NB in (3, 7, 40):
+                if NB == 40 and H > 16:
+                    continue
+                check(lib.dv_debug_wgrad_check(ctx._h, NB, H, cx, cy, out))
+                assert out[1] > 0.1, (H, cx, cy, NB)
+                assert out[0] <= 2e-5 * out[1], (H, cx, cy, NB, out[0], out[1])
+                worst = max(worst, out[0] / out[1])
+    print(f"\nWinograd weight gradient vs direct: worst relative difference {worst:.2e}")
+
+
 def test_channel_counts_that_are_not_powers_of_two():
     """filters (32, 96): 96 divides neither 1024 (the block size of the PReLU-backward bias sums) nor a column-tile width;
     such architectures used to be accepted and then fail in the first training step (found by tools/fuzz_configs.py).

@@ -39,3 +39,31 @@ if len(sys.argv) > 1 and sys.argv[1] in ("bench", "benchonly"):
         check(lib.dv_debug_winograd(1))
         fl = 2.0 * NB * ht * ht * 9 * cs * ct
         print(f"{name:18s} winograd {res[0]*1e3:7.1f} us ({fl/res[0]/1e9:6.1f} TF algorithmic)   direct {res[1]*1e3:7.1f} us ({fl/res[1]/1e9:6.1f} TF)", flush=True)
+
+# ---- weight gradient in the Winograd domain ----
+if len(sys.argv) > 1 and sys.argv[1] in ("wgrad", "bench"):
+    bad = 0
+    for H in (32, 30, 17, 16, 15, 8, 5):
+        for (cx, cy) in ((64, 64), (64, 128), (128, 64), (128, 128), (128, 256), (256, 256)):
+            if H > 16 and cx * cy > 128 * 128:
+                continue
+            for NB in (3, 7):
+                check(lib.dv_debug_wgrad_check(ctx._h, NB, H, cx, cy, out))
+                rel = out[0] / max(out[1], 1e-30)
+                flag = "" if rel <= 2e-5 else "   <-- BAD"
+                bad += rel > 2e-5
+                if flag or NB == 3:
+                    print(f"wgrad H={H:3d} {cx:3d}x{cy:3d} NB={NB}: maxdiff {out[0]:.3e} / max {out[1]:.3e} = {rel:.2e}{flag}", flush=True)
+    print("wgrad bad cases:", bad)
+    ms = C.c_float()
+    NB = 256
+    for name, H, cx, cy in (("enc conv4", 15, 64, 128), ("enc conv6", 8, 128, 256), ("dec convt1", 8, 256, 256),
+                            ("dec convt3", 16, 128, 128), ("dec convt5", 32, 64, 64)):
+        res = []
+        for wino in (1, 0):
+            check(lib.dv_debug_winograd(wino))
+            check(lib.dv_debug_wgrad(ctx._h, NB, H, cx, H, cy, 1, 1, 0, 30, C.byref(ms)))
+            res.append(ms.value)
+        check(lib.dv_debug_winograd(1))
+        fl = 2.0 * NB * H * H * 9 * cx * cy
+        print(f"wgrad {name:12s} winograd {res[0]*1e3:7.1f} us ({fl/res[0]/1e9:6.1f} TF algorithmic)   direct {res[1]*1e3:7.1f} us ({fl/res[1]/1e9:6.1f} TF)", flush=True)
