@@ -150,6 +150,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
     tprev = tn_;                                                        \
   }
   f32x4 acc[16];
+  unsigned long long clk0 = 0, rt0 = 0;
+  if (p.dbg & 64) {
+    clk0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   issue(0, 0);
   int buf = 0;
   for (int q = 0; q < qtotal; ++q) {
@@ -253,7 +259,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
           // The epilogue's bias and PReLU slopes, fetched now (half of the fragment registers are free again) by
           // hand-written loads: a plain load's result makes hipcc wait vmcnt(0) at its first use while LDS-DMA is in
           // flight - all of the next chunk's DMA and the previous item's stores - which cost the 32- and 64-channel
-          // layers a third of their time.  Four DMA pieces follow these loads, hence vmcnt(4) in the epilogue.
+          // layers a third of their time.  No DMA piece follows these loads (pos 8), hence vmcnt(0) in the epilogue waits for
+          // DMA issued >= 4 MFMA groups earlier and for these loads only.
           __builtin_amdgcn_sched_barrier(0);
           if (p.epi >= 1) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias4) : "v"(p.bias + e_col) : "memory");
           if (p.epi == 2) {
@@ -262,9 +269,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (more && !(p.dbg & 32)) {
+        if (more && !(p.dbg & 32) && pos < 8) {
+          // two DMA pieces of the next chunk behind each of the first four MFMA groups: spread out (issued back to back
+          // they hold the wave), but early - a piece needs ~2500 cycles under load, and what is still in flight at the
+          // next barrier is waited for by everybody
           __builtin_amdgcn_sched_barrier(0);
-          dma_piece(pos / 2);                         // one DMA piece of the next chunk behind every eighth MFMA
+          dma_piece(pos);
+          dma_piece(pos + 1);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -291,9 +302,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
           y[a][r][1] = tt[a][1] - tt[a][2] - tt[a][3];
         }
       }
-      // the hand-issued bias / slope loads have landed once at most the four DMA pieces issued behind them are pending
-      if (more && !(p.dbg & 32)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the hand-issued bias / slope loads are the youngest vector-memory operations of this wave
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("" : "+v"(bias4), "+v"(al4[0]), "+v"(al4[1]), "+v"(al4[2]), "+v"(al4[3]));
       const int f4 = lane & 3;
       const size_t obase = (size_t)e_n * H * H * Cout;
@@ -327,8 +337,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
     STAMP(5);
     buf ^= 1;
   }
-  if ((p.dbg & 64) && blockIdx.x == 0 && lane == 0 && p.dbg_out)
-    for (int k = 0; k < 8; ++k) p.dbg_out[wave * 8 + k] = (float)tsum[k] / (float)qtotal;
+  if ((p.dbg & 64) && blockIdx.x == 0 && lane == 0 && p.dbg_out) {
+    for (int k = 0; k < 6; ++k) p.dbg_out[wave * 8 + k] = (float)tsum[k] / (float)qtotal;
+    const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    p.dbg_out[wave * 8 + 6] = (float)(clk1 - clk0);     // shader cycles of the whole kernel
+    p.dbg_out[wave * 8 + 7] = (float)(rt1 - rt0);       // 100 MHz ticks
+  }
 #undef STAMP
 }
 
@@ -740,8 +755,9 @@ int launch_wino_conv(WinoParams p, hipStream_t s) {
     static int shown = 0;
     if (shown++ % 52 == 51)
       for (int w = 0; w < 8; ++w)
-        fprintf(stderr, "  wave %d cycles/chunk: sync+issue %.0f | (stamp) %.0f | reads+transform %.0f | mid sync %.0f | mfma %.0f | epilogue %.0f\n", w,
-                h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
+        fprintf(stderr, "  wave %d cycles/chunk: sync+issue %.0f | (stamp) %.0f | reads+transform %.0f | mid sync %.0f | mfma %.0f | epilogue %.0f | kernel %.0f cycles in %.1f us = %.0f MHz\n", w,
+                h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5], h[w * 8 + 6], h[w * 8 + 7] * 0.01,
+                h[w * 8 + 7] > 0 ? h[w * 8 + 6] / h[w * 8 + 7] * 100.f : 0.f);
   }
   return OK;
 }

@@ -12,7 +12,8 @@ d(alpha) / d(bias) <= 1e-2 * max.  (Measured values are printed with -s.)
 
 Batch 256 takes the 256-stamp tiles and, for the deep layers, the 128- / 64-stamp tiles (GT = 8 / 4) and the paired
 32-channel chunks (CH = 2) of bconv_uni_kernel; batch 64 takes the 64-stamp forms; batch 48 (not a multiple of 64) the
-general bconv_kernel and the separate PReLU backward.
+general bconv_kernel and the separate PReLU backward.  The 128 x 128 x 6 / six-level architecture (BASELINE configs[3],
+512-channel layers, no crop) runs at 16 stamps.
 """
 import numpy as np
 import pytest
@@ -39,19 +40,26 @@ def _check(report, what, got, ref, tol):
     assert err <= tol, (what, err, tol)
 
 
-@pytest.mark.parametrize("B", [256, 64, 48])
-def test_every_conv_layer_alone_against_the_oracle_primitives(B):
+ARCHS = {
+    "59px": dict(),                                                             # train.py:104-107
+    "128px": dict(input_shape=(128, 128, 6), latent_dim=32, filters=(32, 64, 128, 256, 512, 512), kernels=(3,) * 6),
+}
+
+
+@pytest.mark.parametrize("arch_name,B", [("59px", 256), ("59px", 64), ("59px", 48), ("128px", 16)])
+def test_every_conv_layer_alone_against_the_oracle_primitives(arch_name, B):
     from debvader_amd import engine as E
     from debvader_amd.data import synthetic_stamps
 
-    arch = vo.Arch()
+    arch = vo.Arch(**ARCHS[arch_name])
     L2 = 2 * len(arch.filters)
     p = vo.init_params(arch, seed=3, perturb=0.05)
     p["dec/head/bias"][arch.nb:] += 0.3          # sigma off its floor (see tests/test_gpu_bf16.py)
     p = {k: v.astype(np.float32).astype(np.float64) for k, v in p.items()}
-    x, y = synthetic_stamps(B, seed=11)
+    x, y = synthetic_stamps(B, seed=11, size=arch.input_shape[0], nb=arch.nb)
     eps = np.random.default_rng(5).normal(size=(B, arch.latent_dim)).astype(np.float32)
-    eng = E.Engine(E.make_config(max_batch=B, dtype=1))
+    eng = E.Engine(E.make_config(arch.input_shape, arch.latent_dim, tuple(arch.filters), tuple(arch.kernels), max_batch=B,
+                                 dtype=1))
     eng.set_params(p)
     eng.optimizer_reset(1e-4)
     eng.upload(0, x, y)
@@ -153,5 +161,5 @@ def test_every_conv_layer_alone_against_the_oracle_primitives(B):
             _check(report, "enc/bn/beta", eng.get_grad("enc/bn/beta"), (dw[:, :, C:C + 1, :] * W).sum((0, 1, 3)), TOL_SMALL)
     eng.close()
     worst = sorted(report, key=lambda r: -r[1])[:8]
-    print(f"\nB={B}: {len(report)} per-layer checks, largest relative errors: " +
+    print(f"\n{arch_name} B={B}: {len(report)} per-layer checks, largest relative errors: " +
           ", ".join(f"{n} {e:.2e}" for n, e in worst))
