@@ -148,7 +148,7 @@ def _git_head():
 def _pmc_traffic():
     """HBM bytes per step and kernel family from the committed rocprofv3 PMC passes of this round (FETCH_SIZE doubled as
     the micro-architecture guide prescribes for gfx950; tools/pmc_traffic.py spells out the collection)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic_v13.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as fh:
@@ -353,7 +353,16 @@ def main():
         pmc, src = _pmc_traffic()
         per_kernel = (pmc or {}).get("per_kernel_bytes", {})
         dom = max(rows, key=lambda r: r["ms_per_step"]) if rows else None
-        conv_rows = [r for r in rows if r["kernel"].startswith("gconv")]
+        # Winograd rows: `flops` are the ALGORITHMIC ones (2 x 9 x Cin x Cout per output pixel); the kernel
+        # EXECUTES 16 multiplies per 2 x 2 output tile and channel pair instead of 36, i.e. 1 / 2.25 of them on the matrix
+        # pipe (plus block padding): executed_tflops is what MFMA actually sustains and what SQ_VALU_MFMA_BUSY sees.
+        for r in rows:
+            if r["kernel"].startswith("wino_"):
+                r["executed_tflops"] = r["tflops"] / 2.25
+                r["executed_frac"] = r["executed_tflops"] / FP32_MFMA_PEAK_TFLOPS
+                r["note"] = ("Winograd F(2x2,3x3): tflops / frac are algorithmic (direct-conv FLOPs / time); the matrix pipe "
+                             "executes 1/2.25 of them (executed_tflops, block padding not counted)")
+        conv_rows = [r for r in rows if r["kernel"].startswith("gconv") or r["kernel"].startswith("wino_conv")]
         conv_ms = sum(r["ms_per_step"] for r in conv_rows)
         conv_fl = sum(r["flops_per_step"] for r in conv_rows)
         conv_tf = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -380,6 +389,8 @@ def main():
                 "bound": "mfma", "kernel": dom["kernel"] if dom else None,
                 "achieved": dom["tflops"] if dom else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["frac"] if dom else None, "traffic": traffic,
+                "executed": ({"tflops": dom["executed_tflops"], "frac": dom["executed_frac"], "note": dom["note"]}
+                             if dom and "executed_tflops" in dom else None),
                 "traffic_source": {"file": src, "commit": _git_head(),
                                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed; not "
                                            "re-measured in this run"} if src else None,
@@ -387,7 +398,7 @@ def main():
                 "launch": (f"one training step's launches of {dom['kernel']} ({dom['launches_per_step']:.0f} launches, "
                            f"batch {B})") if dom else None,
                 "kernels": rows,
-                "gather_gemm_family": {"ms_per_step": conv_ms, "flops_per_step": conv_fl, "tflops": conv_tf,
+                "conv_family": {"kernels": "gconv* + wino_conv (forward and data-gradient launches)", "ms_per_step": conv_ms, "flops_per_step": conv_fl, "tflops": conv_tf,
                                        "frac": conv_tf / FP32_MFMA_PEAK_TFLOPS},
                 "classes_ms_per_step": classes,
                 "whole_step_tflops": train_flops * B / (dt / args.steps) / 1e12,

@@ -125,6 +125,7 @@ SIGNATURES = {
     "dv_debug_mfma_peak": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "dv_debug_general_kernels": (C.c_int, [C.c_int32]),
     "dv_debug_winograd": (C.c_int, [C.c_int32]),
+    "dv_debug_fuse_prelu_bwd": (C.c_int, [C.c_int32]),
     "dv_debug_wgrad_check": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "dv_debug_wgrad": (C.c_int, [_p] + [C.c_int32] * 9 + [_f]),
 }

@@ -286,15 +286,15 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
   int buf = 0;
   for (int i = 0; i < nsteps; ++i) {
     // five DMA instructions per wave and stage: all but the youngest stage have landed
-    if (NST == 3 && i + 1 < nsteps && !(p.dbg & 1))
+    if (NST == 3 && i + 1 < nsteps)
       asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (NST == 3) {
-      if (i + 2 < nsteps && !(p.dbg & 1)) issue(i + 2, buf >= 1 ? buf - 1 : 2);   // (buf + 2) % 3: the stage read in step i - 1
+      if (i + 2 < nsteps) issue(i + 2, buf >= 1 ? buf - 1 : 2);   // (buf + 2) % 3: the stage read in step i - 1
     } else {
-      if (i + 1 < nsteps && !(p.dbg & 1)) issue(i + 1, buf ^ 1);
+      if (i + 1 < nsteps) issue(i + 1, buf ^ 1);
     }
     const unsigned char* sA = smem + buf * STAGE + wave * 4096 + fragoff;
     const unsigned char* sB = smem + buf * STAGE + BC_GT * 1024 + fragoff;
@@ -303,25 +303,14 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
     for (int gi = 0; gi < 4; ++gi) a[gi] = *reinterpret_cast<const bc_bf16x8*>(sA + gi * 1024);
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) b[j] = *reinterpret_cast<const bc_bf16x8*>(sB + j * 1024);
-    if (!(p.dbg & 2)) {
 #pragma unroll
-      for (int gi = 0; gi < 4; ++gi)
+    for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
-        for (int j = 0; j < NBLK; ++j)
-          acc[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gi], b[j], acc[gi][j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int gi = 0; gi < 4; ++gi) asm volatile("" ::"v"(a[gi]));
-#pragma unroll
-      for (int j = 0; j < NBLK; ++j) asm volatile("" ::"v"(b[j]));
-    }
+      for (int j = 0; j < NBLK; ++j)
+        acc[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gi], b[j], acc[gi][j], 0, 0, 0);
     buf = NST == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
   }
 
-  if (p.dbg & 4) {
-    if (acc[0][0][0] == 123.456f) reinterpret_cast<bc_bf16*>(p.U)[0] = (bc_bf16)1.f;
-    return;
-  }
   // ---- epilogue ---------------------------------------------------------------------------------------------------
   // Lane (c, g4) owns channels n0 + NBLK*c .. +NBLK-1 of stamps 4*g4 .. 4*g4+3 of each of its wave's 4 groups.  The
   // values go through a per-wave LDS tile [64 rows][BN] (the stage buffers are free once every wave has left the
@@ -821,8 +810,6 @@ __global__ __launch_bounds__(256, GT == 16 ? (CH == 1 ? 2 : 1) : (CH == 1 ? 4 : 
 
 int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   BConvParams p = p_in;
-  static const int dbg = getenv("DV_BCONV_DBG") ? atoi(getenv("DV_BCONV_DBG")) : 0;
-  p.dbg = dbg;
   if (p.NBp <= 0 || (p.NBp & 15) || p.Cout % 16 || p.Kpad % 32 || p.s < 1 || p.s > 2) {
     set_error("bconv: bad geometry (NBp %d, Cout %d, Kpad %d)", p.NBp, p.Cout, p.Kpad);
     return E_INVALID;
@@ -844,19 +831,18 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   int nblk = p.Cout % 64 == 0 ? 4 : (p.Cout % 32 == 0 ? 2 : 1);
   const long nbx = (p.Hout + 7) / 8;
   const long M16 = nbx * nbx * 64 * (p.NBp >> 4);   // 8 x 8 pixel blocks, see the kernel
-  static const bool no_uni = getenv("DV_BCONV_NO_UNI") != nullptr;
   // uniform-tile kernel: the stamp count must be a multiple of its stamp tile (256, 128 or 64 stamps); the first-layer
   // form (CINMODE 1) exists for 256-stamp tiles only, and a 64-stamp tile needs at least 32 output columns
   int gt0 = (p.NBp & 255) == 0 ? 16 : ((p.NBp & 127) == 0 ? 8 : ((p.NBp & 63) == 0 ? 4 : 0));
   if (mode == 1 && gt0 != 16) gt0 = 0;
   if (gt0 == 4 && nblk < 2) gt0 = 0;
-  const bool uni = gt0 != 0 && !no_uni && p.dbg == 0;
+  const bool uni = gt0 != 0;
   // Deep layers have few row tiles and a long K loop that one workgroup walks alone.  First smaller stamp tiles (uniform
   // kernel: 128 or 64 stamps per workgroup, 4-8 independent pipelines per CU; the weights are re-read from L2 once more
   // per halving), then narrower column tiles (the input is re-read once more per halving) put enough workgroups on the
   // chip; these launches are latency-bound and do not notice the extra L2 traffic.
   const long want_tiles = getenv("DV_BCONV_MIN_TILES") ? atol(getenv("DV_BCONV_MIN_TILES")) : 512;   // (read per call: the tests toggle it)
-  const long gt_tiles = getenv("DV_BCONV_GT_TILES") ? atol(getenv("DV_BCONV_GT_TILES")) : 1024;
+  const long gt_tiles = 1024;
   int gt = uni ? gt0 : BC_GT;
   auto ntiles = [&](int g, int nb) { return ((M16 + g - 1) / g) * (long)(p.Cout / (16 * nb)); };
   if (uni && mode == 0)
@@ -865,8 +851,7 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   // paired chunks (K step = 64 channels) where an operand row is half a cache line per chunk (Cin >= 64) AND the launch
   // is one of the deep, L2-resident ones that the tile rule above gave small stamp tiles: -10..20 % there; the large
   // launches (256-stamp tiles) are bound elsewhere and lose with the doubled stage (measured, tools/bconv_launches.py)
-  static const bool no_pair = getenv("DV_BCONV_NO_PAIR") != nullptr;
-  const bool pair = uni && mode == 0 && !no_pair && p.Cin % 64 == 0 && gt <= 8;
+  const bool pair = uni && mode == 0 && p.Cin % 64 == 0 && gt <= 8;
   const int ch = pair ? 2 : 1;
   const long tiles = ntiles(gt, nblk);
   const size_t lds = uni ? (size_t)3 * ch * (gt + nblk) * 1024 + 4096 : (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;

@@ -36,7 +36,6 @@ struct BConvParams {
   int form, s, pb;
   int Kpad;
   int epi;
-  int dbg;             // timing ablations (wrong results): 1 no DMA after the first stages, 2 no MFMA, 4 no epilogue
 };
 int launch_bconv(const BConvParams& p, hipStream_t s);
 // BWD epilogue is usable (a wave's four 16-stamp groups share one pixel)

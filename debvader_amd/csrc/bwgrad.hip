@@ -252,7 +252,7 @@ int launch_bwgrad(const BWgradParams& p, hipStream_t s, int* nsplit_out) {
   const size_t slab = (size_t)9 * p.Cx * p.Cy;
   // Y rows per workgroup: as few as the slab budget allows (more workgroups), never fewer than what keeps the slabs of
   // one launch under ~24 MB
-  static const long budget = getenv("DV_BWGRAD_SLAB_MB") ? atol(getenv("DV_BWGRAD_SLAB_MB")) << 20 : 24L << 20;
+  const long budget = 24L << 20;
   long copies = std::max<long>(gm.nsc4, budget / (long)(slab * sizeof(float)));   // (one slab per 64-stamp chunk at least)
   copies = std::min<long>(copies, (long)(p.part_capacity / slab));
   if (copies < gm.nsc4) {
@@ -261,7 +261,7 @@ int launch_bwgrad(const BWgradParams& p, hipStream_t s, int* nsplit_out) {
   }
   // ... and no more row segments than fill the chip once: a workgroup's fixed costs (window fill, the LDS reduction of
   // its four waves, a 9 x 32 x 32 slab written and reduced again) are paid per segment
-  static const long want_wgs = getenv("DV_BWGRAD_WGS") ? atol(getenv("DV_BWGRAD_WGS")) : 256;
+  const long want_wgs = 256;
   const long per_seg = (long)gm.nsc4 * gm.ntx * gm.nty;
   long nseg_want = std::max<long>(1, (want_wgs + per_seg - 1) / per_seg);
   int nrseg = (int)std::min<long>(std::min<long>(p.Hy, copies / gm.nsc4), nseg_want);

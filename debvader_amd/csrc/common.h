@@ -175,9 +175,6 @@ struct WinoParams {
   int NB, H, Cin, Cout;
   int epi;             // 0 raw, 1 +bias, 2 +bias then PReLU
   int nbh, nct, NC, groups, items, items_per_wg;   // filled by the launcher
-  int dbg;             // timing ablations (wrong results): 1 no epilogue, 2 no input transform, 4 no MFMA, 8 no stagger,
-                       // 16 no DMA, 64 phase stamps
-  float* dbg_out;
 };
 struct WinoWDesc {
   const float* W;      // nine taps, [wt][k][n] or (nmajor) [wt][n][k]

@@ -414,7 +414,7 @@ struct dv_model {
   bool split_forward = true;      // run the forward pass as two half-batch lanes on two streams (DV_NO_FWD_SPLIT)
   bool overlap_wgrad = true;
   bool fuse_first = true;     // DV_NO_FUSE_FIRST=1 keeps the first PReLU backward as a separate pass
-  bool no_fuse = true;        // DV_FUSE_PRELU_BWD=1 fuses the PReLU backward into the data-gradient epilogue (batch-major
+  bool no_fuse = true;        // dv_debug_fuse_prelu_bwd(1) fuses the PReLU backward into the data-gradient epilogue (batch-major
                               // tiles); measured 3 % slower than the separate pass on MI355X (scattered 128-byte rows), so off
   bool arena_reduce = true;   // queue d(alpha)/d(bias) reductions on the aux stream (tuning toggles: DV_NO_OVERLAP, DV_NO_ARENA)
   float *ws1 = nullptr, *ws2 = nullptr, *ws3 = nullptr;
@@ -612,6 +612,7 @@ static void fill_gconv_common(GConvParams& p, const Taps& t, int cin) {
 //    from a build session), so nothing is relaxed there.  DV_EVENT_SCOPE=relaxed opts a multi-rank job into the
 //    single-rank flags for exactly that experiment (compare parameters bit for bit against the default).
 //  * DV_EVENT_SCOPE=system / device force system scope / an explicit device-scope release everywhere.
+static bool g_fuse_prelu_bwd = false;   // dv_debug_fuse_prelu_bwd
 static bool g_multi_rank = false;      // set by dv_ctx_create (one context per process) before any event exists
 static unsigned sync_event_flags() {
   const char* e = getenv("DV_EVENT_SCOPE");
@@ -693,8 +694,7 @@ static int fuse_finish(dv_model* m, const GConv2Params& q, const FuseBwd* fz, lo
 // splitk_finish.  Returns 1 when it handled the launch, 0 when the caller should launch as usual, < 0 on error.
 static int gconv2_small_splitk(dv_model* m, GConv2Params& q, int NB, int Hout, int Cout, int nchunks, int epi,
                                const float* bias, const float* alpha, float* U, float* Aout, double flops) {
-  static const bool off = getenv("DV_NO_SMALL_SPLITK") != nullptr;
-  if (off || !m->tiny_call || NB > 16 || q.nclass < 1 || !m->ws4 || m->prof_on || epi > 2) return 0;
+  if (!m->tiny_call || NB > 16 || q.nclass < 1 || !m->ws4 || m->prof_on || epi > 2) return 0;
   const long M = (long)NB * Hout * Hout;
   const long MN = M * Cout;
   const long tiles64 = ((M + 63) / 64) * (long)((Cout + 63) / 64);
@@ -835,13 +835,12 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
   // algorithmic FLOPs of this launch (padding taps counted; the folded first conv and the padded head count their real channels)
   const double flops = 2.0 * NB * Hout * Hout * tp.n * (double)(W == m->W1p ? m->A.C : Cin) *
                        (double)(W == m->Whp ? 2 * m->A.C : Cout);
-  static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
   if (s == 1 && pb == 1 && Hin == Hout && tp.n == 9 && !single_tap && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse)) {
     const int r = wino_conv(m, X, W, nmajor, tp, bias, alpha, U, Aout, epi, NB, Hout, Cin, Cout, flops);
     if (r <= 0) return r;
   }
   if (Cin == 32 && (Cout == 16 || Cout == 32) && s == 1 && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
-      !single_tap && !g_force_v1 && !gs_off && !g_no_special && !(fz && !m->no_fuse)) {
+      !single_tap && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse)) {
     GStripParams g;
     memset(&g, 0, sizeof g);
     g.X = X; g.W = W; g.U = U; g.A = Aout; g.bias = bias; g.alpha = alpha; g.zero = m->zero_page;
@@ -855,7 +854,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     if (r <= 0) return r;
   }
   if (Cin == 8 && Cout == 32 && s == 1 && pb == 1 && !nmajor && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
-      !single_tap && !g_force_v1 && !gs_off && !g_no_special && !fz) {
+      !single_tap && !g_force_v1 && !g_no_special && !fz) {
     GStripParams g;                                  // first layer: strip form
     memset(&g, 0, sizeof g);
     g.X = X; g.W = W; g.U = U; g.A = Aout; g.bias = bias; g.alpha = alpha; g.zero = m->zero_page;
@@ -927,7 +926,6 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
   if (fused) *fused = false;
   // algorithmic FLOPs: every source pixel meets all nine taps; the padded head gradient counts 2*bands channels
   const double flops = 2.0 * NB * Hs * Hs * 9.0 * (double)(W == m->Whp ? 2 * m->A.C : Cs) * (double)Ct;
-  static const bool gs_off = getenv("DV_NO_GSTRIP") != nullptr;
   if (s == 1 && pb == 1 && Hs == Ht && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse)) {
     const Taps tp = taps_dgrad(1, pb, 0, 0);
     if (tp.n == 9) {
@@ -935,7 +933,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
       if (r <= 0) return r;
     }
   }
-  if (s == 1 && (Cs == 32 || (Cs == 16 && Ct == 32)) && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !gs_off && !g_no_special &&
+  if (s == 1 && (Cs == 32 || (Cs == 16 && Ct == 32)) && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !g_no_special &&
       !(fz && !m->no_fuse)) {
     const Taps tp = taps_dgrad(1, pb, 0, 0);
     if (tp.n == 9) {
@@ -952,10 +950,9 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
       if (r <= 0) return r;
     }
   }
-  static const bool no_s2f = getenv("DV_NO_S2F") != nullptr;
   // (tiny inference calls take the parity-class form below instead: it can slice K over workgroups, the fused kernel cannot)
-  const bool tiny_splitk = m->tiny_call && NB <= 16 && !fz && !getenv("DV_NO_SMALL_SPLITK");
-  if (s == 2 && Cs % 32 == 0 && Ct % 4 == 0 && nmajor && !g_force_v1 && !no_s2f && !g_no_special && !(fz && !m->no_fuse) &&
+  const bool tiny_splitk = m->tiny_call && NB <= 16 && !fz;
+  if (s == 2 && Cs % 32 == 0 && Ct % 4 == 0 && nmajor && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse) &&
       !tiny_splitk) {
     // all four parity classes in one workgroup (gconv_s2.hip)
     GConvS2Params q;
@@ -1277,8 +1274,8 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   long slab = (long)p.rows_total * Cy;
   long tiles = ((p.rows_total + 127) / 128) * (long)((Cy + 127) / 128);
   // one full round of resident workgroups (two 74 KB workgroups per CU x 256 CUs), never a round and a half:
-  // 540 workgroups run as long as 1024, 504 finish 8 % sooner (tools/layer_bench.py, DV_WGRAD_TARGET sweep)
-  static const long target = getenv("DV_WGRAD_TARGET") ? atol(getenv("DV_WGRAD_TARGET")) : 512;
+  // 540 workgroups run as long as 1024, 504 finish 8 % sooner (tools/layer_bench.py)
+  const long target = 512;
   long ns = std::max(1L, target / tiles);
   ns = std::min(ns, (long)std::max(1, p.P / 256));
   ns = std::min(ns, 256L);
@@ -1323,7 +1320,6 @@ static int wgrad_result_ready(dv_model* m, hipStream_t ws) {
 static void ensure_step_pool(dv_model* m) {
   if (m->step_pool_tried) return;
   m->step_pool_tried = true;
-  if (getenv("DV_NO_STEP_POOL")) return;
   const Arch& A = m->A;
   const int nbuf = 4 * A.L + 10, nreg = 4 * A.L + 8;
   const size_t cap = m->ws1_elems / 3;
@@ -1668,28 +1664,6 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
     DV_HIP(hipEventRecord(cx->ev_ready, s));
     for (int lane = 1; lane < nlanes; ++lane) DV_HIP(hipStreamWaitEvent(lstream[lane], cx->ev_ready, 0));
   }
-  // DV_LANE_TRACE=1: GPU timestamps of the lanes' starts and ends (timing events, printed every 64th forward)
-  static const bool lane_trace = getenv("DV_LANE_TRACE") != nullptr;
-  static hipEvent_t lt[6] = {nullptr};
-  static long lt_count = 0;
-  const bool lt_on = lane_trace && nlanes == 2 && training;
-  if (lt_on && !lt[0])
-    for (auto& e : lt) DV_HIP(hipEventCreate(&e));
-  if (lt_on && lt_count > 0 && lt_count % 64 == 0) {
-    DV_HIP(hipEventSynchronize(lt[5]));
-    float a = 0, b = 0, c = 0, d = 0;
-    (void)hipEventElapsedTime(&a, lt[0], lt[1]);
-    (void)hipEventElapsedTime(&b, lt[0], lt[2]);
-    (void)hipEventElapsedTime(&c, lt[0], lt[3]);
-    (void)hipEventElapsedTime(&d, lt[0], lt[4]);
-    fprintf(stderr, "[lanes] lane1 start +%.0f us, lane0 end +%.0f us, lane1 end +%.0f us, joined +%.0f us\n", a * 1e3,
-            b * 1e3, c * 1e3, d * 1e3);
-  }
-  if (lt_on) {
-    ++lt_count;
-    DV_HIP(hipEventRecord(lt[0], s));
-    DV_HIP(hipEventRecord(lt[1], lstream[1]));
-  }
   for (int lane = 0; lane < nlanes && st == OK; ++lane) {
     m->b0 = lane * per;
     m->lane_id = lane;
@@ -1702,7 +1676,6 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
     if (st == OK) st = decoder_forward(m, nb, keep_u);
     if (st == OK) st = head_lane(m, ysrc, idx, first, nb, Bg, want_grad, want_out, blk_done, &nblk);
     blk_done += nblk;
-    if (lt_on) DV_HIP(hipEventRecord(lt[2 + lane], lane ? lstream[lane] : s));
     if (st == OK && lane > 0) {
       if (hipEventRecord(cx->ev_lane[lane - 1], lstream[lane]) != hipSuccess ||
           hipStreamWaitEvent(s, cx->ev_lane[lane - 1], 0) != hipSuccess)
@@ -1713,10 +1686,6 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
   m->lane_id = 0;
   m->cs = nullptr;
   if (st != OK) return st;
-  if (lt_on) {
-    DV_HIP(hipEventRecord(lt[4], s));
-    DV_HIP(hipEventRecord(lt[5], s));
-  }
   const int blk0 = blk_done, blk1 = 0;
   if (ysrc) {
     ProfScope ps(m, 2, s);
@@ -1851,23 +1820,6 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     advance();
   }
   // dense trunk of the decoder
-  // DV_MID_TRACE=1: GPU time of the latency-bound middle of the backward pass (dense layers, sampler, first strided
-  // encoder layer), printed every 64th step - the profiler's traces are host-bound there
-  static const bool mid_trace = getenv("DV_MID_TRACE") != nullptr;
-  static hipEvent_t mt[2] = {nullptr, nullptr};
-  static long mt_count = 0;
-  if (mid_trace) {
-    if (!mt[0])
-      for (auto& e : mt) DV_HIP(hipEventCreate(&e));
-    if (mt_count > 0 && mt_count % 64 == 0) {
-      DV_HIP(hipEventSynchronize(mt[1]));
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, mt[0], mt[1]);
-      fprintf(stderr, "[mid] dense trunk .. data gradient of the last encoder conv: %.0f us\n", ms * 1e3);
-    }
-    ++mt_count;
-    DV_HIP(hipEventRecord(mt[0], s));
-  }
   int r = A.w0 * A.w0 * A.cfg.filters[A.L - 1];
   DV_TRY(prelu_bwd(m, cur, m->dec_ur, A.D0 + 6, A.D0 + 5, NB, r, r, dg));
   if (dg) {
@@ -1943,8 +1895,8 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
       // first conv + input BatchNorm: the gradient w.r.t. the folded 8-channel kernel gives d(kernel), d(gamma) and
       // d(beta) directly (bn_conv0_grads_kernel), so this layer needs no data-gradient pass at all
       // the last weight gradient of the step goes to the main stream, which would otherwise idle while the aux
-      // stream works off its backlog (DV_LAST_ON_AUX=1: old placement)
-      static const bool last_on_main = !getenv("DV_LAST_ON_AUX");
+      // stream works off its backlog
+      const bool last_on_main = true;
       hipStream_t ws = (m->wstream && !last_on_main) ? m->wstream : s;
       FuseBwd f0{m->enc_u[0], A.enc_al(0), A.enc_b(0), true};
       DV_TRY(wgrad(m, xin, hin, 8, cur, hout, cout, NB, st, pb, false, m->G0s, 8, 8, fuse0 ? &f0 : nullptr,
@@ -1966,7 +1918,6 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     DV_TRY(gconv_dgrad(m, cur, W, true, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout, hin, cin_phys, st, pb, &fz,
                        &cur_is_du));
     advance();
-    if (mid_trace && j == 2 * A.L - 1) DV_HIP(hipEventRecord(mt[1], s));
     if ((cx->comm || early) && j == A.L && A.L >= 2) {
       // Middle bucket: the gradients of the deep half of the encoder (conv L .. conv 2L-1, their PReLUs, the
       // flatten PReLU and the dense layer - 13.8 of the encoder's 15 MB) are final once this layer's weight-gradient
@@ -2104,8 +2055,7 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   const DataSlot& ds = m->slots[slot];
   const int* idx = nullptr;
   if (idx_host) {
-    static const bool no_idx_pre = getenv("DV_NO_IDX_PREFETCH") != nullptr;
-    if (mode == MODE_TRAIN && !no_idx_pre && !m->prof_on && m->idx_slots && m->bn_pre_part && m->ctx->comm_stream &&
+      if (mode == MODE_TRAIN && !m->prof_on && m->idx_slots && m->bn_pre_part && m->ctx->comm_stream &&
         m->overlap_wgrad) {
       // shuffled batches (fit): index vector and BN batch sums of THIS step go through the comm stream, which the
       // host reaches while the previous step is still running (steps are queued two ahead) - the forward pass below
@@ -2925,11 +2875,8 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   ALLOC(m->ws4, m->ws4_elems);
   m->wstream = ctx->stream;
   if (getenv("DV_NO_OVERLAP")) m->overlap_wgrad = false;
-  if (getenv("DV_NO_ARENA")) m->arena_reduce = false;
   if (getenv("DV_NO_FWD_SPLIT")) m->split_forward = false;
-  if (getenv("DV_FUSE_PRELU_BWD")) m->no_fuse = false;
-  if (getenv("DV_NO_FUSE_FIRST")) m->fuse_first = false;
-  if (getenv("DV_NO_WINO")) m->use_wino = false;
+  if (g_fuse_prelu_bwd) m->no_fuse = false;
   m->arena_elems = 0;
   for (auto& sp : A.specs)
     if (sp.name.size() > 6 && sp.name.compare(sp.name.size() - 6, 6, "/alpha") == 0)
@@ -3271,8 +3218,7 @@ static int infer_entry(dv_model* m, const void* x, bool x_f64, int64_t N, const 
   DV_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->stream;
   const size_t stamp = (size_t)A.H * A.H * A.C;
-  static const bool no_pipe = getenv("DV_NO_INFER_PIPE") != nullptr;
-  if (N > 256 && !no_pipe && !m->prof_on) {
+  if (N > 256 && !m->prof_on) {
     DV_TRY(infer_pipelined(m, x, x_f64, N, eps, seed, loc, scale, mu, zstd, z));
     return prof_flush(m);
   }
@@ -3299,11 +3245,10 @@ static int infer_entry(dv_model* m, const void* x, bool x_f64, int64_t N, const 
     // Launch-bound sizes (one forward lane, a single chunk, engine-drawn noise): replay a captured graph.  The first
     // call of a size runs eagerly (kernel attributes and other one-time host work must not fall into a capture), the
     // second is captured.
-    // Opt-in (dv_model_set_infer_graph / DV_INFER_GRAPH=1): measured on MI355X a replay takes exactly as long as the
+    // Opt-in (dv_model_set_infer_graph): measured on MI355X a replay takes exactly as long as the
     // eager launches (0.600 vs 0.603 ms for one stamp, 0.806 vs 0.803 ms for 32) - the chain of ~45 dependent
     // few-microsecond kernels is bound by the GPU's dispatch-to-dispatch latency, not by host submission.
-    static const bool env_graph = getenv("DV_INFER_GRAPH") != nullptr;
-    const bool graphable = (m->infer_graph || env_graph) && nb < 64 && N <= m->Bc && !eps && m->seed_dev != nullptr;
+    const bool graphable = m->infer_graph && nb < 64 && N <= m->Bc && !eps && m->seed_dev != nullptr;
     if (graphable) {
       const int key = nb | (zstd ? 1 << 20 : 0) | (m->normalise ? 1 << 21 : 0) | (loc ? 1 << 22 : 0);
       m->use_seed_dev = true;
@@ -3857,6 +3802,11 @@ int dv_debug_wgrad_check(dv_ctx* ctx, int32_t NB, int32_t H, int32_t Cx, int32_t
 
 int dv_debug_winograd(int32_t on) {
   g_no_wino = on == 0;
+  return DV_OK;
+}
+
+int dv_debug_fuse_prelu_bwd(int32_t on) {
+  g_fuse_prelu_bwd = on != 0;
   return DV_OK;
 }
 

@@ -352,10 +352,9 @@ int launch_gconv_s2(const GConvS2Params& p0, hipStream_t s) {
     set_error("gconv_s2: bias epilogue without bias");
     return E_INVALID;
   }
-  static const int env_tile = getenv("DV_S2_TILE") ? atoi(getenv("DV_S2_TILE")) : -1;
-  int t = s2_tile_override >= 0 ? s2_tile_override : env_tile;
+  int t = s2_tile_override;
   // 128 x 32 (four waves stacked along M, all sharing the class's 32-column weight tile) measured fastest on every
-  // stride-2 layer of the network (tools/layer_bench.py with DV_S2_TILE=0..3): 64 x 64 is 20-45 % slower
+  // stride-2 layer of the network (tools/layer_bench.py over the tile forms): 64 x 64 is 20-45 % slower
   if (t < 0) {
     // deep layers with few base pixels: half-height workgroups (64 x 32, three per CU) double the workgroup count
     // (4x4x256 -> 8x8x256: 66 -> 54 us); everywhere else the 128 x 32 tile wins

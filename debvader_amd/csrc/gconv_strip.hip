@@ -442,8 +442,7 @@ __global__ __launch_bounds__(GS_THREADS, 4) void gconv_strip8_kernel(const GStri
 
 // Returns 1 when the layer is not the first-layer shape (the caller then uses gconv2).
 int launch_gconv_strip8(GStripParams p, hipStream_t s) {
-  static const bool off = getenv("DV_NO_GSTRIP8") != nullptr;
-  if (off || p.Cin != 8 || p.Cout != 32 || !p.zero || p.Wd < 8 || p.Wd > 64 || p.H < 1 || p.epi < 0 || p.epi > 2) return 1;
+  if (p.Cin != 8 || p.Cout != 32 || !p.zero || p.Wd < 8 || p.Wd > 64 || p.H < 1 || p.epi < 0 || p.epi > 2) return 1;
   if (p.epi == 2 && (!p.alpha || !p.A)) return 1;
   if ((long)p.NB * p.H * p.Wd * 32 >= (1L << 30)) return 1;
   int R = 256 / p.Wd;
@@ -456,7 +455,7 @@ int launch_gconv_strip8(GStripParams p, hipStream_t s) {
   p.strips_per_stamp = (p.H + R - 1) / R;
   p.nstrips = p.NB * p.strips_per_stamp;
   // bandwidth-bound: two workgroups per CU keep stores of one strip and the DMA of the next in flight
-  static const int target = getenv("DV_GSTRIP8_WGS") ? atoi(getenv("DV_GSTRIP8_WGS")) : 512;
+  const int target = 512;
   p.strips_per_wg = (p.nstrips + target - 1) / target;
   const int grid = (p.nstrips + p.strips_per_wg - 1) / p.strips_per_wg;
   const size_t smem = ((size_t)2 * p.patch_floats + (size_t)5 * 32 * 16 + (size_t)GS_WAVES * 16 * GS_LDC) * sizeof(float);
@@ -487,8 +486,7 @@ static int launch_gs(const GStripParams& p, int grid, size_t smem, hipStream_t s
 
 // Returns 1 when the layer is not one this kernel takes (the caller then uses gconv2).
 int launch_gconv_strip(GStripParams p, bool nmajor, hipStream_t s) {
-  static const bool off = getenv("DV_NO_GSTRIP") != nullptr;
-  if (off || (p.Cin != 32 && p.Cin != 16) || (p.Cout != 32 && p.Cout != 16) || !p.zero) return 1;
+  if ((p.Cin != 32 && p.Cin != 16) || (p.Cout != 32 && p.Cout != 16) || !p.zero) return 1;
   if (p.Cin == 16 && p.Cout != 32) return 1;
   if (p.Wd < 8 || p.Wd > 64 || p.H < 1 || p.epi < 0 || p.epi > 2) return 1;
   if ((long)p.NB * p.H * p.Wd * 32 >= (1L << 30)) return 1;

@@ -217,10 +217,6 @@ int launch_wgrad(const WGradParams& p, hipStream_t s) {
     return E_INVALID;
   }
   const int rows = p.ntaps * p.Cx;
-  static const int force = getenv("DV_WGRAD_TILE") ? atoi(getenv("DV_WGRAD_TILE")) : 0;
-  if (force == 1 && p.Cy >= 128) return launch_w<64, 128, 2, 2>(p, s);
-  if (force == 2 && p.Cy >= 64) return launch_w<128, 64, 2, 2>(p, s);
-  if (force == 3 && p.Cy >= 64) return launch_w<64, 64, 2, 2>(p, s);
   if (p.Cy <= 16) return launch_w<128, 16, 4, 1>(p, s);
   if (p.Cy <= 32) return rows <= 32 ? launch_w<32, 32, 2, 2>(p, s) : launch_w<64, 32, 4, 1>(p, s);
   if (p.Cy <= 64) return rows <= 64 ? launch_w<64, 64, 2, 2>(p, s) : launch_w<128, 64, 2, 2>(p, s);

@@ -526,7 +526,7 @@ static int launch_strip8(WStripParams p, hipStream_t s, int* nsplit_out) {
     cap = std::min(cap, p.dal_capacity / (size_t)p.alpha_elems);
     if (cap < 1) return 1;
     // two 78 KB workgroups per CU: one full round of 512
-    static const int target = getenv("DV_W0_WGS") ? atoi(getenv("DV_W0_WGS")) : 512;
+    const int target = 512;
     p.groups = (int)std::min<size_t>(std::min(p.NB, std::max(1, target / p.strips_per_stamp)), cap);
     p.strips_per_wg = (p.NB + p.groups - 1) / p.groups;
     wgs = p.groups * p.strips_per_stamp;

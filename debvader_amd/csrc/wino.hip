@@ -99,7 +99,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
     dm_dstu = uch + b * WN_UCH_FLOATS + wave * 1024;
   };
   auto dma_piece = [&](int k) {                       // k is a compile-time constant at every call site
-    if (p.dbg & 16) return;
     if (k < NPP) {
       if (k0 + k < WN_PATCH_PIECES) {                 // wave-uniform
         const bool ok = dm_live && (unsigned)(dm_by * 8 + prow[k]) < (unsigned)H && (unsigned)(dm_bx * 8 + pcol[k]) < (unsigned)H;
@@ -139,42 +138,20 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  // diagnostic build (dbg & 64): s_memtime stamps per phase, summed per wave, written by workgroup 0
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-#define STAMP(k)                                                        \
-  if (p.dbg & 64) {                                                     \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
-    const unsigned long long tn_ = __builtin_amdgcn_s_memtime();        \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
-    if (tprev) tsum[k] += tn_ - tprev;                                  \
-    tprev = tn_;                                                        \
-  }
   f32x4 acc[16];
-  unsigned long long clk0 = 0, rt0 = 0;
-  if (p.dbg & 64) {
-    clk0 = __builtin_amdgcn_s_memtime();
-    rt0 = __builtin_amdgcn_s_memrealtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
   issue(0, 0);
   int buf = 0;
   for (int q = 0; q < qtotal; ++q) {
     const int it = q / NC, c = q - it * NC;
     sync_point();
     const bool more = q + 1 < qtotal;
-    if (more) {
-      if (p.dbg & 32) issue(q + 1, buf ^ 1);          // (ablation: all eight pieces up front)
-      else dma_setup(q + 1, buf ^ 1);
-    }
+    if (more) dma_setup(q + 1, buf ^ 1);
     if (c == 0) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    STAMP(0);
     const float* P = patch + (buf * WN_MB + mb) * WN_PATCH_FLOATS;
     const float* Uc = uch + buf * WN_UCH_FLOATS + b_off;
-    // A phase: the 4 x 4 input tile of this lane's tile and channel quad, then its transform
-    STAMP(1);
     // All LDS reads of the chunk go out first - the 16 weight fragments (one per position) and the 4 x 4 input tile - so
     // that the MFMA stream below never waits for one (left to itself hipcc sinks every fragment read to just in front
     // of its four MFMAs: read latency + a dependent accumulator chain per position).
@@ -182,11 +159,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
 #pragma unroll
     for (int pos = 0; pos < 8; ++pos) bfr[pos] = *reinterpret_cast<const f32x4*>(Uc + (pos * 32) * 16);
     f32x4 V[16];
-    if (p.dbg & 2) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) V[i] = *reinterpret_cast<const f32x4*>(P + a_off[i >> 2] + (i & 3) * 16);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
+    {
       // input transform V = B^T d B on the float4 channel quad of this lane's tile
       f32x4 d[4][4];
 #pragma unroll
@@ -210,8 +183,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
         V[i * 4 + 3] = t[i][1] - t[i][3];
       }
     }
-    STAMP(2);
-    STAMP(3);
     // epilogue geometry of this wave's block (used from the last chunk of an item on)
     bool e_on = false, e_live = false;
     int e_n = 0, e_by = 0, e_bx = 0, e_col = 0, e_col0 = 0;
@@ -220,7 +191,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al4[4];
     // 16 position GEMMs, two accumulator chains interleaved (a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles,
     // an independent one every 32)
-    if (!(p.dbg & 4)) {
+    {
 #pragma unroll
       for (int pos = 0; pos < 16; pos += 2) {
         if (pos == 2) {
@@ -234,7 +205,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
           acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[pos][jj], bfr[pos][jj], acc[pos], 0, 0, 0);
           acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[pos + 1][jj], bfr[pos + 1][jj], acc[pos + 1], 0, 0, 0);
         }
-        if (pos == 8 && c == NC - 1 && !(p.dbg & 1)) {
+        if (pos == 8 && c == NC - 1) {
           __builtin_amdgcn_sched_barrier(0);
       const int item = item0 + it;
           const int ct = item / p.groups, g = item - ct * p.groups;
@@ -269,7 +240,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (more && !(p.dbg & 32) && pos < 8) {
+        if (more && pos < 8) {
           // two DMA pieces of the next chunk behind each of the first four MFMA groups: spread out (issued back to back
           // they hold the wave), but early - a piece needs ~2500 cycles under load, and what is still in flight at the
           // next barrier is waited for by everybody
@@ -279,11 +250,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-    } else if (more && !(p.dbg & 32)) {
-#pragma unroll
-      for (int k = 0; k < 2 * NPP; ++k) dma_piece(k);
     }
-    STAMP(4);
     if (c == NC - 1 && e_on) {
       // ---- output transform Y = A^T M A on the accumulators, then bias / PReLU / stores through the staging tile ----
       float y[2][4][2];                                 // [a][r][b]: pixel (2 lg + a, 2 r + b) of the 8 x 8 block
@@ -334,17 +301,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
         __builtin_amdgcn_wave_barrier();
       }
     }
-    STAMP(5);
     buf ^= 1;
   }
-  if ((p.dbg & 64) && blockIdx.x == 0 && lane == 0 && p.dbg_out) {
-    for (int k = 0; k < 6; ++k) p.dbg_out[wave * 8 + k] = (float)tsum[k] / (float)qtotal;
-    const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    p.dbg_out[wave * 8 + 6] = (float)(clk1 - clk0);     // shader cycles of the whole kernel
-    p.dbg_out[wave * 8 + 7] = (float)(rt1 - rt0);       // 100 MHz ticks
-  }
-#undef STAMP
 }
 
 // ---- weight transform U = G g G^T, laid out [column tile][K chunk][pos][n 32][k 16] ----------------------------
@@ -741,24 +699,8 @@ int launch_wino_conv(WinoParams p, hipStream_t s) {
                                (int)smem));
     attr_set = true;
   }
-  static const int dbg = getenv("DV_WINO_DBG") ? atoi(getenv("DV_WINO_DBG")) : 0;
-  p.dbg = dbg;
-  static float* dbg_buf = nullptr;
-  if ((dbg & 64) && !dbg_buf) DV_HIP(hipMalloc((void**)&dbg_buf, 64 * sizeof(float)));
-  p.dbg_out = dbg_buf;
   hipLaunchKernelGGL(wino_conv_kernel, dim3(grid), dim3(WN_THREADS), smem, s, p);
   DV_HIP(hipGetLastError());
-  if (dbg & 64) {
-    float h[64];
-    DV_HIP(hipStreamSynchronize(s));
-    DV_HIP(hipMemcpy(h, dbg_buf, sizeof h, hipMemcpyDeviceToHost));
-    static int shown = 0;
-    if (shown++ % 52 == 51)
-      for (int w = 0; w < 8; ++w)
-        fprintf(stderr, "  wave %d cycles/chunk: sync+issue %.0f | (stamp) %.0f | reads+transform %.0f | mid sync %.0f | mfma %.0f | epilogue %.0f | kernel %.0f cycles in %.1f us = %.0f MHz\n", w,
-                h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5], h[w * 8 + 6], h[w * 8 + 7] * 0.01,
-                h[w * 8 + 7] > 0 ? h[w * 8 + 6] / h[w * 8 + 7] * 100.f : 0.f);
-  }
   return OK;
 }
 

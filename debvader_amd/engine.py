@@ -375,11 +375,6 @@ class Engine:
         off by default - a train step has no reader for them."""
         check(lib.dv_model_set_keep_outputs(self._h, 1 if on else 0))
 
-    def set_infer_graph(self, on: bool):
-        """Replay a captured hipGraph for the forward pass of small inference batches (< 64 stamps).  Same results;
-        measured no faster than the eager launches on MI355X, hence off by default."""
-        check(lib.dv_model_set_infer_graph(self._h, 1 if on else 0))
-
     def infer(self, x, eps=None, seed=0, want=("loc", "scale"), out=None) -> Dict[str, np.ndarray]:
         """One stochastic forward pass over all stamps.  float64 arrays (numpy's default, what the reference's callers
         pass) go to the engine as they are: the float32 cast of deblender.py:18 happens while the library stages them."""

@@ -156,13 +156,6 @@ int dv_model_set_normalise(dv_model* m, int32_t on);
  * The Python surface (debvader_amd.model) switches it on when compile(metrics=[..."mse"...]) asks for the Keras metric. */
 int dv_model_set_mse_sample(dv_model* m, int32_t on);
 
-/* Replay a captured hipGraph for the forward pass of small inference batches (< 64 stamps, one chunk, engine-drawn
- * noise) instead of launching its ~45 kernels one by one: BASELINE configs[4] "hipGraph-captured decode" /
- * SURVEY row A10.  Off by default: on MI355X the replay takes exactly as long as the eager launches - a one-stamp forward
- * is bound by the DURATION of its kernels (a handful of workgroups per layer walking K serially: 27 kernels, 520 us of
- * kernel time inside a 668 us span), not by host submission or dispatch.  Same results either way. */
-int dv_model_set_infer_graph(dv_model* m, int32_t on);
-
 /* Gradient / train steps also write the output distribution (loc, scale) of their forward pass, for
  * dv_model_get_activation("loc" / "scale") - what the parity tests compare with the oracle.  Off by default: the
  * train step of the reference (train.py:27) has no reader for them (42 MB of stores per 256-stamp step). */

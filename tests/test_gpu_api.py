@@ -181,6 +181,8 @@ import sys, numpy as np
 sys.path.insert(0, %r)
 from debvader_amd import engine as E
 from debvader_amd.data import synthetic_stamps
+from debvader_amd._lib import check, lib
+check(lib.dv_debug_fuse_prelu_bwd(1 if "fuse" in sys.argv[1:] else 0))
 x, y = synthetic_stamps(16, seed=3)
 eng = E.Engine(E.make_config(max_batch=8))
 eng.init(seed=4); eng.optimizer_reset(1e-4); eng.upload(0, x, y)
@@ -193,12 +195,10 @@ print(repr(out["loss"]), float(np.abs(w).sum()), float(np.abs(v).sum()), float(e
     for force in ("", "1", "fuse"):
         env = dict(os.environ)
         env.pop("DV_FORCE_COMM", None)
-        env.pop("DV_FUSE_PRELU_BWD", None)
         if force == "1":
             env["DV_FORCE_COMM"] = "1"
-        if force == "fuse":      # opt-in fused PReLU-backward epilogue: same math, different summation order
-            env["DV_FUSE_PRELU_BWD"] = "1"
-        r = subprocess.run([sys.executable, "-c", code % root], env=env, capture_output=True, text=True, timeout=300)
+        # "fuse": the parked fused PReLU-backward epilogue (debvader_hip_debug.h): same math, different summation order
+        r = subprocess.run([sys.executable, "-c", code % root] + (["fuse"] if force == "fuse" else []), env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1], outs
@@ -391,12 +391,13 @@ def test_graph_replayed_small_batch_inference_equals_eager_launches():
     (third call onwards) returns what the eager launches return for the same seed, and the seed - read from device
     memory by the replayed sampler - still changes the noise."""
     from debvader_amd import engine as E
+    from debvader_amd._lib import check, lib
 
     x, _ = _data(5, 21)
     eng = E.Engine(E.make_config(max_batch=64))
     eng.init(seed=2)
     eager = [eng.infer(x, seed=s, want=("loc", "scale", "z")) for s in (7, 8)]
-    eng.set_infer_graph(True)
+    check(lib.dv_model_set_infer_graph(eng._h, 1))          # debvader_hip_debug.h: kept as a measured experiment
     for s in (1, 2):                       # eager warm-up of this size, then the capture
         eng.infer(x, seed=s, want=("loc", "scale", "z"))
     replay = [eng.infer(x, seed=s, want=("loc", "scale", "z")) for s in (7, 8)]

@@ -1,10 +1,10 @@
 """Where do the bf16 and the fp32 engine's training curves separate, and why?  (VERDICT r2 "Next round" 1.)
 
-Three runs from the same initialisation on the same batches, each in its own process (the kernel choices are read from
-the environment once):
+Three runs from the same initialisation on the same batches, each in its own process:
   f32     the fp32 engine as shipped
-  f32alt  the fp32 engine with other kernels for the same layers (general gather-GEMM instead of the strip / fused
-          stride-2 forms, another slab count in the weight gradients): the SAME arithmetic in another summation order
+  f32alt  the fp32 engine with other kernels for the same layers (dv_debug_general_kernels(1): the general gather-GEMM
+          and direct weight-gradient kernels instead of the Winograd / strip / fused stride-2 forms; one forward lane):
+          the SAME arithmetic in another summation order
   bf16    the bf16-storage engine
 Per step: loss / NLL / KL, the smallest sigma of the batch, how many pixels sit on the 1e-4 floor (model.py:154-159),
 the largest |y - mu| / sigma, and every few steps the norm of the parameter update per group; validation loss on held-out
@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "f32": (0, {}),
-    "f32alt": (0, {"DV_NO_GSTRIP": "1", "DV_NO_S2F": "1", "DV_WGRAD_TARGET": "256", "DV_NO_FWD_SPLIT": "1"}),
+    "f32alt": (0, {"DV_NO_FWD_SPLIT": "1"}),
     "bf16": (1, {}),
 }
 
@@ -34,6 +34,9 @@ def run_variant(name, a):
     from debvader_amd.data import synthetic_stamps
 
     dtype = VARIANTS[name][0]
+    if name == "f32alt":
+        from debvader_amd._lib import check, lib
+        check(lib.dv_debug_general_kernels(1))
     B, steps = a.batch, a.steps
     ntrain, nval = a.ntrain, a.nval
     x, y = synthetic_stamps(ntrain + nval, seed=21)

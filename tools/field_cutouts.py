@@ -139,6 +139,10 @@ def _run_stream(ctx, eng, scene, starts, lo, hi, chunk, dtype, F, cs):
         "value": n / total, "unit": "stamps/s", "dtype": "bf16" if dtype else "f32", "n_cutouts": n, "chunk": chunk,
         "includes": "field H2D once, cutout gather + float32 cast on the GPU, forward, D2H of mean and stddev of every stamp "
                     "into the pinned ring, consumed in place (deblend_field_cutouts(on_chunk=...), dv_infer_cutouts_stream)",
+        # what bounds this entry: every stamp's mean and stddev cross PCIe (2 x 59*59*6 float32 = 167 088 bytes per stamp)
+        "d2h_bytes_per_stamp": 2 * cs * cs * 6 * 4, "d2h_gbs": n * 2 * cs * cs * 6 * 4 / total / 1e9,
+        "bound": "host link: d2h_gbs is this box's device-to-host rate (pinned ring, two copy streams); the GPU side alone "
+                 "runs at secondary.deblend_cutouts' resident_forward_stamps_per_s",
         "checksum": state["checksum"], "mean_stddev_centre_pixel": state["sum_std"] / n,
     }
 

@@ -10,6 +10,8 @@ mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel
 import csv, glob, json, sys
 
 FAMILIES = (("bconv_uni_kernel / bconv_kernel (bf16)", ("bconv_",)), ("bwgrad_kernel (bf16)", ("bwgrad_kernel",)),
+            ("wino_conv_kernel (Winograd F(2x2,3x3) forward / data gradient)", ("wino_conv_kernel",)),
+            ("wino_wgrad_kernel (Winograd-domain weight gradient)", ("wino_wgrad_kernel",)),
             ("gconv_strip (incl. first-layer form)", ("gconv_strip",)), ("gconv_s2", ("gconv_s2",)),
             ("gconv2 / gconv", ("gconv2_kernel", "gconv_kernel")), ("wgrad_strip (incl. first-layer form)", ("wgrad_strip",)),
             ("wgrad (tiled)", ("wgrad_kernel",)))
@@ -43,7 +45,7 @@ for i in ids:
     e["launches"] += 1
     e["mfma_busy_cycles"] += d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
     e["kernel_cycles"] += d.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
-    for extra in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):      # optional wave-level counters
+    for extra in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):      # optional wave-level counters
         if extra in d:
             e[extra] = e.get(extra, 0.0) + d[extra]
 for e in fams.values():

@@ -12,6 +12,8 @@ import csv, glob, json, sys
 
 FAMILIES = (("bconv_kernel / bconv_uni_kernel", ("bconv_",)),
             ("bwgrad_kernel", ("bwgrad_kernel",)),
+            ("wino_wgrad family (wino_wgrad, presum, finish)", ("wino_wgrad",)),
+            ("wino_conv_kernel (+ wino_weights_kernel)", ("wino_conv", "wino_weights")),
             ("gconv family (gconv2, gconv_s2, gconv_strip, gconv_strip8, gconv, splitk_finish)", ("gconv", "splitk_finish")),
             ("wgrad family (wgrad, wgrad_strip, wgrad_strip8, reduce_partials)", ("wgrad", "reduce_partials")),
             ("prelu_bwd_kernel", ("prelu_bwd",)))
