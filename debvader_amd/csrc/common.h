@@ -221,6 +221,7 @@ struct GConvS2Params {
 };
 int launch_gconv_s2(const GConvS2Params& p, hipStream_t s);
 void debug_set_gconv_s2_tile(int code);
+void debug_set_wino_variant(int v);   // 1: eight-wave Winograd conv kernel, 2: four-wave pipelined one (default)
 void debug_set_gconv_s2_dbg(unsigned* out);
 
 // ---------------------------------------------------------------------------------------------

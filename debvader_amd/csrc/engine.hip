@@ -3802,6 +3802,7 @@ int dv_debug_wgrad_check(dv_ctx* ctx, int32_t NB, int32_t H, int32_t Cx, int32_t
 
 int dv_debug_winograd(int32_t on) {
   g_no_wino = on == 0;
+  if (on >= 1) debug_set_wino_variant(on == 3 ? 1 : 2);       // 3: the first-generation eight-wave kernel
   return DV_OK;
 }
 

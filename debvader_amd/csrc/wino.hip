@@ -21,6 +21,7 @@
 // in G); agreement with the direct kernels 2e-6 of a layer's largest output (dv_debug_gconv_check, tests/test_gpu_parity).
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -302,6 +303,435 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const WinoPara
       }
     }
     buf ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Second generation of the same kernel: ONE wave per SIMD that stays on the matrix pipe.
+// The first kernel keeps the pipe ~0.42 busy: its per-chunk barrier puts all eight waves into the same phase, so for
+// ~2000 of ~8000 cycles per chunk every wave reads and transforms and nobody issues MFMAs.  Here a workgroup has four
+// waves (one per SIMD, up to 512 registers each); wave w owns M block w for ALL 32 columns (16 positions x 2 column
+// halves = 128 accumulator registers), so the input transform is done once per block instead of once per column half,
+// and everything that is not an MFMA is interleaved into the MFMA stream of the chunk BEFORE the one that needs it
+// (sched_group_barrier: one MFMA, then an LDS read, a few vector instructions and a DMA piece in its shadow):
+//   * the 4 x 4 input tile of chunk q + 1 is read from LDS during MFMA groups 0-3 of chunk q and transformed during
+//     groups 1-7 - the last step writes column j of the result straight into the V registers whose last readers, the
+//     MFMAs of groups 2 j and 2 j + 1, have just been issued -, the weight fragments of group g + 1 are read during group g;
+//   * the DMA of the weights of chunk q + 1 and of the patch of chunk q + 2 (patches are wave-private) goes out three
+//     pieces per group behind groups 0-4, a full chunk ahead of the barrier that waits for it;
+//   * bias and PReLU slopes of an item's 8 x 8 x 32 output block arrive by LDS-DMA during its last chunk, so that the
+//     epilogue holds no registers across the loop and needs no counted vmcnt.
+// LDS: patch ring 2 x 4 x 6.25 KiB (wave-private blocks), weight ring 2 x 32 KiB, staging 4 x 2.5 KiB, slopes + bias
+// 4 x 8.1 KiB = 156.5 KiB.
+namespace {
+constexpr int W4_WAVES = 4;
+constexpr int W4_THREADS = 64 * W4_WAVES;
+constexpr int W4_PATCH_FLOATS = 1600;                 // 100 pixels x 16 channels, no padding (piece 6: 16 lanes)
+constexpr int W4_ALPHA_FLOATS = 64 * 32 + 32;         // [pixel of the 8 x 8 block][column of the 32] + bias[32]
+// position order: the four positions of column j of the transform domain (rows 0-3) in two groups of two
+__device__ __forceinline__ constexpr int w4_pos(int g, int pp) { return (g >> 1) + 4 * (2 * (g & 1) + pp); }
+}  // namespace
+
+// fp32 MFMA and the vector ALU are the same lanes on gfx950 (the fp32 matrix peak IS the vector peak): every vector
+// instruction a wave issues is time its MFMA stream does not get.  Hence packed adds for the transforms and scalar-base
+// DMA with execution masks instead of per-lane address selects.
+typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 w4_add(f32x4 a, f32x4 b) {
+  w4_f32x2 lo, hi;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+  return (f32x4){lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ f32x4 w4_sub(f32x4 a, f32x4 b) {
+  w4_f32x2 lo, hi;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+      : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+      : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+  return (f32x4){lo.x, lo.y, hi.x, hi.y};
+}
+// one 1-KiB LDS-DMA piece, address = scalar base + 32-bit lane offset; the lanes outside `m_dma` (of the first 16 lanes
+// when LAST16: the piece that ends a buffer) get 16 bytes of the zero page instead
+template <bool LAST16>
+__device__ __forceinline__ void w4_dma_masked(unsigned lds, unsigned voff, const void* sbase, unsigned long long m_dma,
+                                              unsigned vnull, const void* zero) {
+  if (LAST16) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "s_andn2_b64 exec, 0xffff, %1\n\t"
+        "global_load_lds_dwordx4 %4, %5\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : "s"(lds), "s"(m_dma), "v"(voff), "s"(sbase), "v"(vnull), "s"(zero)
+        : "memory", "scc");
+  } else {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "s_not_b64 exec, %1\n\t"
+        "global_load_lds_dwordx4 %4, %5\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : "s"(lds), "s"(m_dma), "v"(voff), "s"(sbase), "v"(vnull), "s"(zero)
+        : "memory", "scc");
+  }
+}
+__device__ __forceinline__ w4_f32x2 w4_add2(w4_f32x2 a, w4_f32x2 b) {
+  w4_f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ w4_f32x2 w4_sub2(w4_f32x2 a, w4_f32x2 b) {
+  w4_f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// one LDS-DMA piece for the lanes of `mask` only (the other lanes' slots keep what they hold)
+__device__ __forceinline__ void w4_dma_exec(unsigned lds, unsigned voff, const void* sbase, unsigned long long mask) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_mov_b64 exec, %1\n\t"
+      "global_load_lds_dwordx4 %2, %3\n\t"
+      "s_mov_b64 exec, -1"
+      :
+      : "s"(lds), "s"(mask), "v"(voff), "s"(sbase)
+      : "memory");
+}
+__device__ __forceinline__ void w4_dma(unsigned lds, unsigned voff, const void* sbase) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2"
+      :
+      : "s"(lds), "v"(voff), "s"(sbase)
+      : "memory");
+}
+__global__ __launch_bounds__(W4_THREADS) void wino_conv4_kernel(const WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                                            // [2][4 blocks][W4_PATCH_FLOATS]
+  float* uch = smem + 2 * WN_MB * W4_PATCH_FLOATS;                // [2][WN_UCH_FLOATS]
+  float* stage = uch + 2 * WN_UCH_FLOATS;                         // [4 waves][32][WN_LDS_STAGE]
+  float* atile = stage + W4_WAVES * 32 * WN_LDS_STAGE;            // [4 waves][W4_ALPHA_FLOATS]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int mb = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave = M block
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int H = p.H, Cin = p.Cin, Cout = p.Cout, NC = p.NC;
+  const int nb2 = p.nbh * p.nbh;
+
+  // patch DMA: slot e = 64 k + lane -> (patch pixel L, channel quad), k = 0..6 (see wino_conv_kernel); poffb = byte offset
+  // of the lane's 16 bytes from pixel (-1, -1) of the block, channel 0 of the chunk
+  int prow[WN_PATCH_PIECES], pcol[WN_PATCH_PIECES];
+  unsigned poffb[WN_PATCH_PIECES];
+#pragma unroll
+  for (int k = 0; k < WN_PATCH_PIECES; ++k) {
+    const int e = 64 * k + lane;
+    const int L = e >> 2;
+    const int pr = L / 10, pc = L - pr * 10;
+    const int q = (e & 3) ^ (pr & 3);
+    prow[k] = L < 100 ? pr - 1 : -100000;
+    pcol[k] = pc - 1;
+    poffb[k] = (unsigned)(((pr * H + pc) * Cin + q * 4) * 4);
+  }
+  const unsigned lane16 = lane * 16;
+  const unsigned aoffb = (unsigned)(((lane >> 3) * Cout + (lane & 7) * 4) * 4);   // slopes: pixel column, channel quad
+  unsigned vnull = 0;
+  asm volatile("" : "+v"(vnull));                      // (a register that holds 0: offset of the zero-page lanes)
+
+  const int item0 = blockIdx.x * p.items_per_wg;
+  const int nitems = min(p.items, item0 + p.items_per_wg) - item0;
+  if (nitems <= 0) return;
+  const int qtotal = nitems * NC;
+
+  // ---- DMA streams: weights of chunk qw, patch of chunk qp (each advanced once per chunk) ----
+  struct Geo { bool live; int n, by, bx, ct; };
+  auto geometry = [&](int it) {
+    Geo gq;
+    const int item = item0 + it;
+    gq.ct = item / p.groups;
+    const int g = item - gq.ct * p.groups;                  // column tile outermost: one weight slice hot in every L2
+    const int mblock = g * WN_MB + mb;
+    gq.live = mblock < p.NB * nb2;
+    gq.n = gq.live ? mblock / nb2 : 0;
+    const int rem = gq.live ? mblock - gq.n * nb2 : 0;
+    gq.by = rem / p.nbh;
+    gq.bx = rem - gq.by * p.nbh;
+    return gq;
+  };
+  // patch stream: origin (pixel (-1, -1) of the block, channel 0) and lane masks of the current item
+  const char* p_org = reinterpret_cast<const char*>(p.zero);
+  unsigned long long m_dma[WN_PATCH_PIECES];
+  auto patch_item = [&](int it) {
+    const Geo gq = geometry(it);
+    p_org = reinterpret_cast<const char*>(p.X) +
+            ((long long)(gq.n * H + gq.by * 8 - 1) * H + (gq.bx * 8 - 1)) * (long long)Cin * 4;
+#pragma unroll
+    for (int k = 0; k < WN_PATCH_PIECES; ++k) {
+      const bool ok = gq.live && (unsigned)(gq.by * 8 + prow[k]) < (unsigned)H && (unsigned)(gq.bx * 8 + pcol[k]) < (unsigned)H;
+      const bool in = k < WN_PATCH_PIECES - 1 || lane < 16;     // slots 384-399: the block's buffer ends there
+      m_dma[k] = __builtin_amdgcn_ballot_w64(ok && in);
+    }
+  };
+  const unsigned patch_lds = (unsigned)(size_t)(wn_lptr_t)(patch + mb * W4_PATCH_FLOATS);   // + buffer * 4 * 6400
+  const unsigned uch_lds = (unsigned)(size_t)(wn_lptr_t)(uch + mb * 2048);                   // + buffer * 32768
+  const char* ps_base = p_org;                        // origin + chunk * 64 bytes
+  unsigned ps_lds = patch_lds;
+  auto piece_p = [&](int k) {
+    if (k < WN_PATCH_PIECES - 1) w4_dma_masked<false>(ps_lds + k * 1024, poffb[k], ps_base, m_dma[k], vnull, p.zero);
+    else w4_dma_masked<true>(ps_lds + k * 1024, poffb[k], ps_base, m_dma[k], vnull, p.zero);
+  };
+  const char* ws_base = reinterpret_cast<const char*>(p.Ut);   // this wave's 8 KiB of the chunk
+  unsigned ws_lds = uch_lds;
+  auto piece_w = [&](int k) { w4_dma(ws_lds + k * 1024, lane16, ws_base + k * 1024); };
+
+  // ---- fragment addressing (swizzles: see wino_conv_kernel) ----
+  const int ty = l15 >> 2, tx = l15 & 3;
+  int a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = ((2 * ty + i) * 10 + 2 * tx) * 16 + ((lg ^ ((2 * ty + i) & 3)) << 2);
+  const int b_off0 = l15 * 16 + ((lg ^ ((0x78 >> (2 * ((l15 >> 2) & 3))) & 3)) << 2);       // column half 1: + 256
+  float* stg = stage + mb * (32 * WN_LDS_STAGE);
+  float* alp = atile + mb * W4_ALPHA_FLOATS;
+  const unsigned alp_lds = (unsigned)(size_t)(wn_lptr_t)alp;
+
+  auto load_tile = [&](const float* P, f32x4 (&d)[16], int i) {          // row i of the 4 x 4 tile
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[i * 4 + j] = *reinterpret_cast<const f32x4*>(P + a_off[i] + j * 16);
+  };
+  auto tf_row = [&](f32x4 (&d)[16], int i) {                              // d B, row i (in place)
+    const f32x4 t0 = d[i * 4], t1 = d[i * 4 + 1], t2 = d[i * 4 + 2], t3 = d[i * 4 + 3];
+    d[i * 4] = w4_sub(t0, t2);
+    d[i * 4 + 1] = w4_add(t1, t2);
+    d[i * 4 + 2] = w4_sub(t2, t1);
+    d[i * 4 + 3] = w4_sub(t1, t3);
+  };
+  f32x4 V[16];
+  auto tf_col = [&](const f32x4 (&d)[16], int j) {                        // column j of V = B^T (d B)
+    const f32x4 d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
+    V[j] = w4_sub(d0, d2);
+    V[4 + j] = w4_add(d1, d2);
+    V[8 + j] = w4_sub(d2, d1);
+    V[12 + j] = w4_sub(d1, d3);
+  };
+
+  // ---- prologue: weights and patch of chunk 0, patch of chunk 1 (NC >= 2: same item); transform chunk 0 ----
+  const char* w_base = reinterpret_cast<const char*>(p.Ut + (size_t)(item0 / p.groups) * NC * WN_UCH_FLOATS + mb * 2048);
+  ws_base = w_base;
+  ws_lds = uch_lds;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) piece_w(k);
+  patch_item(0);
+  ps_base = p_org;
+  ps_lds = patch_lds;
+#pragma unroll
+  for (int k = 0; k < WN_PATCH_PIECES; ++k) piece_p(k);
+  ps_base = p_org + 64;
+  ps_lds = patch_lds + WN_MB * W4_PATCH_FLOATS * 4;
+#pragma unroll
+  for (int k = 0; k < WN_PATCH_PIECES; ++k) piece_p(k);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    f32x4 d0[16];
+    const float* P0 = patch + mb * W4_PATCH_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_tile(P0, d0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tf_row(d0, i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tf_col(d0, j);
+  }
+
+  f32x4 acc[16][2];
+  const int f4 = lane & 3;
+  // stream positions: the weights of chunk 0 and the patches of chunks 0 and 1 are on their way
+  int w_it = 0, w_c = 0, p_it = 0, p_c = 1;
+  int it = 0, c = 0;                                   // item / K chunk of chunk q
+  for (int q = 0; q < qtotal; ++q) {
+    // all DMA this wave issued during the previous chunk has landed (weights of chunk q, patch of chunk q + 1), and so have
+    // the stores of an epilogue in between; behind the barrier everybody's share of the weights is visible and nobody
+    // reads the other weight buffer any more
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int wb = q & 1;
+    const float* Uc = uch + wb * WN_UCH_FLOATS + b_off0;
+    const float* Pn = patch + ((wb ^ 1) * WN_MB + mb) * W4_PATCH_FLOATS;     // patch of chunk q + 1
+    const bool last = c == NC - 1;
+    // DMA targets of this chunk: weights of chunk q + 1, patch of chunk q + 2 (the two streams advance by one chunk per
+    // chunk; the divisions of an item's geometry are paid once per item).  Past the end of the stream the last chunk is
+    // fetched again (into buffers nobody reads any more): no branches around the DMA.
+    if (q + 1 < qtotal) {
+      if (++w_c == NC) { w_c = 0; ++w_it; }
+      if (w_c == 0)
+        w_base = reinterpret_cast<const char*>(p.Ut + (size_t)((item0 + w_it) / p.groups) * NC * WN_UCH_FLOATS + mb * 2048);
+    }
+    ws_base = w_base + (size_t)w_c * (WN_UCH_FLOATS * 4);
+    ws_lds = uch_lds + (wb ^ 1) * (WN_UCH_FLOATS * 4);
+    if (q + 2 < qtotal) {
+      if (++p_c == NC) { p_c = 0; ++p_it; }
+      if (p_c == 0) patch_item(p_it);
+    }
+    ps_base = p_org + p_c * 64;
+    ps_lds = patch_lds + wb * (WN_MB * W4_PATCH_FLOATS * 4);
+    Geo ge = {false, 0, 0, 0, 0};
+    if (last) {
+      // bias and slopes of this item's output block -> LDS: piece k = 8 pixels (block row k) x 32 columns, then the bias.
+      // Scalar row base + constant lane offset; lanes outside the image / beyond Cout and rows below the image are left
+      // out (nothing reads their slots).
+      ge = geometry(it);
+      const int col0 = ge.ct * 32;
+      if (p.epi == 2) {
+        const unsigned long long am = __builtin_amdgcn_ballot_w64(ge.live && ge.bx * 8 + (lane >> 3) < H && col0 + (lane & 7) * 4 < Cout);
+        const char* arow = reinterpret_cast<const char*>(p.alpha + ((size_t)(ge.by * 8) * H + ge.bx * 8) * Cout + col0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (ge.by * 8 + k < H) w4_dma_exec(alp_lds + k * 1024, aoffb, arow + (size_t)k * H * Cout * 4, am);
+      }
+      if (p.epi >= 1) {
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64(lane < 8 && col0 + lane * 4 < Cout);
+        w4_dma_exec(alp_lds + 8192, lane16, reinterpret_cast<const char*>(p.bias + col0), bm);
+      }
+    }
+    f32x4 bq[2][4];                                    // weight fragments of two groups: [g & 1][2 pp + nh]
+    auto load_b = [&](int g) {
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+          bq[g & 1][2 * pp + nh] = *reinterpret_cast<const f32x4*>(Uc + w4_pos(g, pp) * 512 + nh * 256);
+    };
+    f32x4 d[16];
+    load_b(0);
+    // FIRST: K chunk 0 of an item - the accumulators start from the constant 0 (no zeroing pass)
+    auto groups = [&](auto first_t) {
+    constexpr bool FIRST = decltype(first_t)::value;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < 8) load_b(g + 1);
+      if (g < 4) load_tile(Pn, d, g);                  // row g of the next chunk's 4 x 4 tile
+      // 15 DMA pieces, three per group: the patch first (it comes from HBM), then the weights (L2 hits).  Measured: where in
+      // the chunk they are issued makes no difference (they have landed when the chunk ends); each costs its issue slot.
+      if (g < 5) {
+#pragma unroll
+        for (int k = 3 * g; k < 3 * g + 3; ++k) {
+          if (k < 7) piece_p(k);
+          else piece_w(k - 7);
+        }
+      }
+      // (the empty asm statements pin each step to its group: the results are only read by the next iteration, and LLVM
+      // would otherwise sink the whole transform into the loop latch, behind the last MFMA)
+      if (g >= 1 && g <= 4) {
+        tf_row(d, g - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(d[(g - 1) * 4 + k]));
+      }
+      if (g == 5 || g == 6) {                          // (last readers of columns 0 / 1 / 2: groups 1 / 3 / 5)
+#pragma unroll
+        for (int j = (g == 5 ? 0 : 2); j < (g == 5 ? 2 : 3); ++j) {
+          tf_col(d, j);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(V[4 * i + j]));
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+            acc[w4_pos(g, pp)][nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                V[w4_pos(g, pp)][jj], bq[g & 1][2 * pp + nh][jj],
+                (FIRST && jj == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[w4_pos(g, pp)][nh], 0, 0, 0);
+      // spread the rest between the MFMAs (per MFMA: an LDS read, up to three vector instructions, a DMA piece)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    };
+    if (c == 0) groups(std::integral_constant<bool, true>{});
+    else groups(std::integral_constant<bool, false>{});
+    __builtin_amdgcn_sched_barrier(0);
+    tf_col(d, 3);
+    if (last) {
+      // ---- epilogue: output transform Y = A^T M A on the accumulators, bias / PReLU / stores through the staging tile ----
+      const int col0 = ge.ct * 32;
+      const size_t obase = (size_t)ge.n * H * H * Cout;
+      unsigned e_aoff[4];
+      bool e_ok[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                    // i = 2 a + k: pass a (block rows 2 lg' + a), half k
+        const int sidx = (i & 1) * 16 + (lane >> 2);
+        const int row = ge.by * 8 + 2 * (sidx >> 3) + (i >> 1), cl = ge.bx * 8 + (sidx & 7);
+        e_ok[i] = ge.live && row < H && cl < H;
+        e_aoff[i] = e_ok[i] ? (unsigned)((row * H + cl) * Cout + col0 + f4 * 4) : 0u;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's bias / slope pieces (wave-private tile)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        if (col0 + nh * 16 >= Cout) continue;           // wave-uniform
+        float y[2][4][2];                               // [a][r][b]: pixel (2 lg + a, 2 r + b) of the 8 x 8 block
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {                // tiles r = 2 rp, 2 rp + 1 as one packed pair
+          w4_f32x2 tt[2][4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const w4_f32x2 m0 = {acc[j][nh][2 * rp], acc[j][nh][2 * rp + 1]}, m1 = {acc[4 + j][nh][2 * rp], acc[4 + j][nh][2 * rp + 1]},
+                           m2 = {acc[8 + j][nh][2 * rp], acc[8 + j][nh][2 * rp + 1]},
+                           m3 = {acc[12 + j][nh][2 * rp], acc[12 + j][nh][2 * rp + 1]};
+            tt[0][j] = w4_add2(w4_add2(m0, m1), m2);
+            tt[1][j] = w4_sub2(w4_sub2(m1, m2), m3);
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const w4_f32x2 y0 = w4_add2(w4_add2(tt[a][0], tt[a][1]), tt[a][2]);
+            const w4_f32x2 y1 = w4_sub2(w4_sub2(tt[a][1], tt[a][2]), tt[a][3]);
+            y[a][2 * rp][0] = y0.x;
+            y[a][2 * rp + 1][0] = y0.y;
+            y[a][2 * rp][1] = y1.x;
+            y[a][2 * rp + 1][1] = y1.y;
+          }
+        }
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.epi >= 1) bias4 = *reinterpret_cast<const f32x4*>(alp + 2048 + nh * 16 + f4 * 4);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {                   // two passes of 32 pixels: block rows 2 lg + a
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            stg[(lg * 8 + 2 * r) * WN_LDS_STAGE + l15] = y[a][r][0];
+            stg[(lg * 8 + 2 * r + 1) * WN_LDS_STAGE + l15] = y[a][r][1];
+          }
+          __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): wave-private region
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int i = 2 * a + k;
+            if (!e_ok[i]) continue;
+            const int sidx = k * 16 + (lane >> 2);
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + sidx * WN_LDS_STAGE + f4 * 4);
+            v += bias4;
+            if (p.U) *reinterpret_cast<f32x4*>(p.U + obase + e_aoff[i] + nh * 16) = v;
+            if (p.epi == 2) {
+              const int px = (2 * (sidx >> 3) + a) * 8 + (sidx & 7);
+              const f32x4 al = *reinterpret_cast<const f32x4*>(alp + px * 32 + nh * 16 + f4 * 4);
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : al[e] * v[e];
+              *reinterpret_cast<f32x4*>(p.A + obase + e_aoff[i] + nh * 16) = o;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    if (++c == NC) { c = 0; ++it; }
   }
 }
 
@@ -674,6 +1104,9 @@ int launch_wino_weights(const WinoWDesc* descs_dev, const WinoWDesc* descs_host,
   return OK;
 }
 
+static int g_wino_variant = 2;                         // 1: wino_conv_kernel (eight waves), 2: wino_conv4_kernel
+void debug_set_wino_variant(int v) { g_wino_variant = v; }
+
 int launch_wino_conv(WinoParams p, hipStream_t s) {
   if (!wino_supported(p.NB, p.H, p.Cin, p.Cout) || !p.zero || !p.Ut || p.epi < 0 || p.epi > 2) return 1;
   if (p.epi == 2 && (!p.alpha || !p.A)) return 1;
@@ -692,6 +1125,22 @@ int launch_wino_conv(WinoParams p, hipStream_t s) {
   }
   p.items_per_wg = (p.items + cus - 1) / cus;
   const int grid = (p.items + p.items_per_wg - 1) / p.items_per_wg;
+  // the four-wave kernel wins where an item has >= 3 K chunks (measured per layer, tools/wino_check.py bench: 8-20 % on the
+  // 64- to 256-channel layers); with two chunks per item (32 input channels) its per-item work is not amortised and the
+  // eight-wave kernel is 1-4 % ahead
+  if (g_wino_variant == 2 && p.NC >= 3) {
+    const size_t smem4 = ((size_t)2 * WN_MB * W4_PATCH_FLOATS + 2 * WN_UCH_FLOATS + (size_t)W4_WAVES * 32 * WN_LDS_STAGE +
+                          (size_t)W4_WAVES * W4_ALPHA_FLOATS) * sizeof(float);
+    static bool attr4_set = false;
+    if (!attr4_set) {
+      DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)smem4));
+      attr4_set = true;
+    }
+    hipLaunchKernelGGL(wino_conv4_kernel, dim3(grid), dim3(W4_THREADS), smem4, s, p);
+    DV_HIP(hipGetLastError());
+    return OK;
+  }
   const size_t smem = ((size_t)2 * WN_MB * WN_PATCH_FLOATS + 2 * WN_UCH_FLOATS + (size_t)WN_WAVES * 32 * WN_LDS_STAGE) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

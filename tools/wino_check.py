@@ -20,6 +20,16 @@ for H in () if (len(sys.argv) > 1 and sys.argv[1] == "benchonly") else (64, 59, 
                 bad += rel > 2e-5
                 if flag or epi == 2:
                     print(f"H={H:3d} {cs:3d}->{ct:3d} dgrad={dgrad} epi={epi}: maxdiff {out[0]:.3e} / max {out[1]:.3e} = {rel:.2e}{flag}", flush=True)
+# several items per workgroup (the ring runs across item boundaries), ragged block groups
+for (NB, H, cs, ct) in () if (len(sys.argv) > 1 and sys.argv[1] == "benchonly") else (
+        (37, 30, 32, 64), (21, 64, 32, 32), (150, 8, 128, 256), (150, 8, 256, 256), (61, 16, 128, 128), (45, 15, 64, 128), (29, 59, 32, 48), (3, 10, 96, 96), (40, 10, 96, 32), (40, 10, 96, 96), (5, 13, 48, 96)):
+    for dgrad, nmajor in ((0, 0), (1, 1)):
+        for epi in (0, 2):
+            check(lib.dv_debug_gconv_check(ctx._h, NB, H, cs, H, ct, 1, 1, dgrad, nmajor, epi, out))
+            rel = out[0] / max(out[1], 1e-30)
+            flag = "" if rel <= 2e-5 else "   <-- BAD"
+            bad += rel > 2e-5
+            print(f"NB={NB:3d} H={H:3d} {cs:3d}->{ct:3d} dgrad={dgrad} epi={epi}: maxdiff {out[0]:.3e} / max {out[1]:.3e} = {rel:.2e}{flag}", flush=True)
 print("bad cases:", bad)
 if len(sys.argv) > 1 and sys.argv[1] in ("bench", "benchonly"):
     ms = C.c_float()
@@ -32,13 +42,13 @@ if len(sys.argv) > 1 and sys.argv[1] in ("bench", "benchonly"):
               ("dec convt7 bwd", 64, 32, 64, 32, 0, 0), ("head fwd", 64, 32, 64, 16, 0, 0), ("head dgrad", 64, 16, 64, 32, 1, 1)]
     for name, hs, cs, ht, ct, dgrad, nmajor in layers:
         res = []
-        for wino in (1, 0):
+        for wino in (1, 3, 0):                         # four-wave kernel, eight-wave kernel, direct
             check(lib.dv_debug_winograd(wino))
             check(lib.dv_debug_gconv(ctx._h, NB, hs, cs, ht, ct, 1, 1, dgrad, nmajor, 2, 0, -1, 50, C.byref(ms)))
             res.append(ms.value)
         check(lib.dv_debug_winograd(1))
         fl = 2.0 * NB * ht * ht * 9 * cs * ct
-        print(f"{name:18s} winograd {res[0]*1e3:7.1f} us ({fl/res[0]/1e9:6.1f} TF algorithmic)   direct {res[1]*1e3:7.1f} us ({fl/res[1]/1e9:6.1f} TF)", flush=True)
+        print(f"{name:18s} winograd4 {res[0]*1e3:7.1f} us ({fl/res[0]/1e9:6.1f} TF algorithmic)   winograd8 {res[1]*1e3:7.1f} us ({fl/res[1]/1e9:6.1f} TF)   direct {res[2]*1e3:7.1f} us ({fl/res[2]/1e9:6.1f} TF)", flush=True)
 
 # ---- weight gradient in the Winograd domain ----
 if len(sys.argv) > 1 and sys.argv[1] in ("wgrad", "bench"):
