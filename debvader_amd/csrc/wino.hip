@@ -389,6 +389,22 @@ __device__ __forceinline__ w4_f32x2 w4_sub2(w4_f32x2 a, w4_f32x2 b) {
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// packed adds with operand-half selection: {a.x - b.x, a.y + b.x}, {b.x - a.y, a.y - b.y}, {a.x + a.y, a.x - a.y}
+__device__ __forceinline__ w4_f32x2 w4_pk_h1(w4_f32x2 a, w4_f32x2 b) {
+  w4_f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ w4_f32x2 w4_pk_h2(w4_f32x2 a, w4_f32x2 b) {
+  w4_f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ w4_f32x2 w4_pk_pm(w4_f32x2 a) {
+  w4_f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a));
+  return r;
+}
 // one LDS-DMA piece for the lanes of `mask` only (the other lanes' slots keep what they hold)
 __device__ __forceinline__ void w4_dma_exec(unsigned lds, unsigned voff, const void* sbase, unsigned long long mask) {
   asm volatile(
@@ -810,51 +826,56 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WinoWgradParam
   const int b_begin = split * p.bps, b_end = min(p.nblocks, b_begin + p.bps);
   const int kw = wave >> 1, nw = wave & 1;       // this wave's 32 x 32 quarter
 
-  // DMA of a block into a ring stage: 25 + 16 pieces of 1 KiB, this wave's are k = wave, wave + 4, ... in that order
-  // (dma_begin, then dma_next once per piece); slot e = 64 k + lane -> (pixel L = e >> 4, 16-byte piece e & 15).  The
-  // piece index is XOR-ed with 4 * ((L >> 1) & 1) so that the two tiles a 32-lane read group touches (pixels two apart)
-  // sit in different halves of the 32 banks.  (pr, pc) of the X patch pixel advance by 16 pixels per step: no division.
-  const int pc00 = (4 * wave + (lane >> 4)) % 10, pr00 = (4 * wave + (lane >> 4)) / 10;
-  int d_k = 0, d_pr = 0, d_pc = 0, d_n = 0, d_by = 0, d_bx = 0, d_st = 0;
-  auto dma_begin = [&](int blk, int stg) {
-    d_n = blk / nb2;
-    const int rem = blk - d_n * nb2;
-    d_by = rem / p.nbh;
-    d_bx = rem - d_by * p.nbh;
-    d_k = wave;
-    d_pr = pr00;
-    d_pc = pc00;
-    d_st = stg;
-  };
-  auto dma_next = [&]() {
-    if (d_k >= WG_XP + WG_YP) return;                  // wave-uniform
-    float* dst = smem + d_st * WG_STAGE + d_k * 256;
-    const float* src = p.zero;
-    const int pc0 = lane & 15;
-    if (d_k < WG_XP) {
-      const int L = d_pr * 10 + d_pc;
-      const int row = d_by * 8 - 1 + d_pr, col = d_bx * 8 - 1 + d_pc;
-      if ((unsigned)row < (unsigned)H && (unsigned)col < (unsigned)H)
-        src = p.X + ((size_t)(d_n * H + row) * H + col) * Cx + kt * 64 + ((pc0 ^ (((L >> 1) & 1) << 2)) << 2);
-      d_pc += 6;                                       // + 16 pixels
-      d_pr += 1;
-      if (d_pc >= 10) {
-        d_pc -= 10;
-        d_pr += 1;
-      }
+  // fp32 MFMA and the vector ALU are the same lanes (see wino_conv4_kernel): the first version of this loop spent as long
+  // on its 356 vector instructions per 64 MFMAs - 270 of them integer address arithmetic - as on the MFMAs.  Now every
+  // address is a constant: LDS reads are a lane base + an immediate, a DMA piece is a scalar block origin + a lane offset
+  // fixed for the whole kernel, out-of-image lanes are switched to the zero page by an execution mask computed once per
+  // block, and the two 16-channel blocks of a wave go through the transforms as packed pairs.
+  //
+  // DMA of a block into a ring stage: 25 + 16 pieces of 1 KiB, this wave's are k = wave + 4 i, i = 0..10 (k < 41);
+  // slot e = 64 k + lane -> (pixel L = e >> 4, 16-byte piece e & 15).  The piece index is XOR-ed with 4 * ((L >> 1) & 1) so
+  // that the two tiles a 32-lane read group touches (pixels two apart) sit in different halves of the 32 banks.
+  constexpr int NPW = 11;
+  unsigned doff[NPW];                              // byte offset from the block's X origin (pixel (-1, -1), channel kt * 64) / Y origin
+  int drc[NPW];                                    // pixel relative to the block's first pixel: (row + 1) << 8 | (col + 1)
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int k = wave + 4 * i;
+    if (k < WG_XP) {
+      const int L = 4 * k + (lane >> 4);
+      const int pr = L / 10, pc = L - pr * 10;
+      drc[i] = (pr << 8) | pc;
+      doff[i] = (unsigned)(((pr * H + pc) * Cx + (((lane & 15) ^ (((L >> 1) & 1) << 2)) << 2)) * 4);
     } else {
-      const int L = (d_k - WG_XP) * 4 + (lane >> 4);
-      const int row = d_by * 8 + (L >> 3), col = d_bx * 8 + (L & 7);
-      if (row < H && col < H)
-        src = p.Y + ((size_t)(d_n * H + row) * H + col) * Cy + nt * 64 + ((pc0 ^ (((L >> 1) & 1) << 2)) << 2);
+      const int L = (k - WG_XP) * 4 + (lane >> 4);
+      drc[i] = (((L >> 3) + 1) << 8) | ((L & 7) + 1);
+      doff[i] = (unsigned)((((L >> 3) * H + (L & 7)) * Cy + (((lane & 15) ^ (((L >> 1) & 1) << 2)) << 2)) * 4);
     }
-    __builtin_amdgcn_global_load_lds((wn_gptr_t)src, (wn_lptr_t)dst, 16, 0, 0);
-    d_k += 4;
+  }
+  unsigned vnull = 0;
+  asm volatile("" : "+v"(vnull));
+  const unsigned smem_lds = (unsigned)(size_t)(wn_lptr_t)smem;
+  // block being fetched: scalar origins and the lane masks of this wave's pieces
+  const char* d_xorg = reinterpret_cast<const char*>(p.zero);
+  const char* d_yorg = d_xorg;
+  unsigned long long d_mask[NPW];
+  unsigned d_lds = smem_lds;
+  auto dma_begin = [&](int blk, int stg) {
+    const int n = blk / nb2;
+    const int rem = blk - n * nb2;
+    const int by = rem / p.nbh, bx = rem - by * p.nbh;
+    d_xorg = reinterpret_cast<const char*>(p.X) + (((long long)(n * H + by * 8 - 1) * H + (bx * 8 - 1)) * Cx + kt * 64) * 4;
+    d_yorg = reinterpret_cast<const char*>(p.Y) + (((long long)(n * H + by * 8) * H + bx * 8) * Cy + nt * 64) * 4;
+    d_lds = smem_lds + stg * (WG_STAGE * 4);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+      d_mask[i] = __builtin_amdgcn_ballot_w64((unsigned)(by * 8 - 1 + (drc[i] >> 8)) < (unsigned)H &&
+                                              (unsigned)(bx * 8 - 1 + (drc[i] & 255)) < (unsigned)H);
   };
-  auto issue_block = [&](int blk, int stg) {
-    dma_begin(blk, stg);
-#pragma unroll 1
-    for (int i = 0; i < 11; ++i) dma_next();
+  auto dma_piece = [&](int i) {                        // i is a compile-time constant at every call site
+    const int k = wave + 4 * i;
+    if (k >= WG_XP + WG_YP) return;                    // wave-uniform (i = 10: wave 0 only)
+    w4_dma_masked<false>(d_lds + k * 1024, doff[i], k < WG_XP ? d_xorg : d_yorg, d_mask[i], vnull, p.zero);
   };
 
   f32x4 acc[16][2][2];
@@ -865,93 +886,96 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WinoWgradParam
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[i][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // raw operands of one tile quad (tile row ty of the block; this lane: tile tx = lg, channel l15 of each 16-block)
-  auto load_raw = [&](const float* Xs, const float* Ys, int ty, float (&xr)[2][16], float (&yr)[2][4]) {
+  // LDS read bases (float index in a stage; the pixel / tile-row part of an address is an immediate).  X: pixel
+  // L = (2 ty + i) * 10 + 2 lg + j, swizzle bit ((L >> 1) & 1) = (i + (j >> 1) + lg) & 1 - two bases per channel block;
+  // Y: L = (2 ty + a) * 8 + 2 lg + b, swizzle bit lg & 1 - one base per channel block.
+  int xb[2][2], yb[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) xb[kb][c] = 2 * lg * 64 + (((kw * 2 + kb) * 16 + l15) ^ (((c ^ lg) & 1) << 4));
+    yb[kb] = WG_XP * 256 + 2 * lg * 64 + (((nw * 2 + kb) * 16 + l15) ^ ((lg & 1) << 4));
+  }
+  // raw operands of one tile quad (tile row ty of the block; this lane: tile tx = lg, channel l15 of each 16-block),
+  // the two channel blocks of a wave as one packed pair
+  auto load_raw = [&](const float* S, int ty, w4_f32x2 (&xr)[16], w4_f32x2 (&yr)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int L = (2 * ty + i) * 10 + 2 * lg + j;
-        const int sw = ((L >> 1) & 1) << 4;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) xr[kb][i * 4 + j] = Xs[L * 64 + (((kw * 2 + kb) * 16 + l15) ^ sw)];
+        const int c = (i + (j >> 1)) & 1, off = ((2 * ty + i) * 10 + j) * 64;
+        xr[i * 4 + j] = (w4_f32x2){S[xb[0][c] + off], S[xb[1][c] + off]};
       }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int L = (2 * ty + a) * 8 + 2 * lg + b;
-        const int sw = ((L >> 1) & 1) << 4;
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) yr[nb][a * 2 + b] = Ys[L * 64 + (((nw * 2 + nb) * 16 + l15) ^ sw)];
+        const int off = ((2 * ty + a) * 8 + b) * 64;
+        yr[a * 2 + b] = (w4_f32x2){S[yb[0] + off], S[yb[1] + off]};
       }
   };
-
-  // transforms of one quad's raw operands: V = B^T d B (scalars), M = A dy A^T
-  auto transform = [&](const float (&xr)[2][16], const float (&yr)[2][4], float (&V)[2][16], float (&M)[2][16]) {
+  // transforms of one quad's raw operands: V = B^T d B, M = A dy A^T (packed over the two channel blocks)
+  auto transform = [&](const w4_f32x2 (&xr)[16], const w4_f32x2 (&yr)[4], w4_f32x2 (&V)[16], w4_f32x2 (&M)[16]) {
+    w4_f32x2 t[4][4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      float t[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        t[0][j] = xr[kb][0 * 4 + j] - xr[kb][2 * 4 + j];
-        t[1][j] = xr[kb][1 * 4 + j] + xr[kb][2 * 4 + j];
-        t[2][j] = xr[kb][2 * 4 + j] - xr[kb][1 * 4 + j];
-        t[3][j] = xr[kb][1 * 4 + j] - xr[kb][3 * 4 + j];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        V[kb][i * 4 + 0] = t[i][0] - t[i][2];
-        V[kb][i * 4 + 1] = t[i][1] + t[i][2];
-        V[kb][i * 4 + 2] = t[i][2] - t[i][1];
-        V[kb][i * 4 + 3] = t[i][1] - t[i][3];
-      }
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = w4_sub2(xr[0 * 4 + j], xr[2 * 4 + j]);
+      t[1][j] = w4_add2(xr[1 * 4 + j], xr[2 * 4 + j]);
+      t[2][j] = w4_sub2(xr[2 * 4 + j], xr[1 * 4 + j]);
+      t[3][j] = w4_sub2(xr[1 * 4 + j], xr[3 * 4 + j]);
     }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      // rows of A dy: [y0; y0 + y1; y0 - y1; -y1], then the same on the columns
-      float r[4][2];
+    for (int i = 0; i < 4; ++i) {
+      V[i * 4 + 0] = w4_sub2(t[i][0], t[i][2]);
+      V[i * 4 + 1] = w4_add2(t[i][1], t[i][2]);
+      V[i * 4 + 2] = w4_sub2(t[i][2], t[i][1]);
+      V[i * 4 + 3] = w4_sub2(t[i][1], t[i][3]);
+    }
+    // rows of A dy: [y0; y0 + y1; y0 - y1; -y1], then the same on the columns
+    const w4_f32x2 zero2 = {0.f, 0.f};
+    w4_f32x2 r[4][2];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float y0 = yr[nb][0 * 2 + b], y1 = yr[nb][1 * 2 + b];
-        r[0][b] = y0;
-        r[1][b] = y0 + y1;
-        r[2][b] = y0 - y1;
-        r[3][b] = -y1;
-      }
+    for (int b = 0; b < 2; ++b) {
+      const w4_f32x2 y0 = yr[0 * 2 + b], y1 = yr[1 * 2 + b];
+      r[0][b] = y0;
+      r[1][b] = w4_add2(y0, y1);
+      r[2][b] = w4_sub2(y0, y1);
+      r[3][b] = w4_sub2(zero2, y1);
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        M[nb][i * 4 + 0] = r[i][0];
-        M[nb][i * 4 + 1] = r[i][0] + r[i][1];
-        M[nb][i * 4 + 2] = r[i][0] - r[i][1];
-        M[nb][i * 4 + 3] = -r[i][1];
-      }
+    for (int i = 0; i < 4; ++i) {
+      M[i * 4 + 0] = r[i][0];
+      M[i * 4 + 1] = w4_add2(r[i][0], r[i][1]);
+      M[i * 4 + 2] = w4_sub2(r[i][0], r[i][1]);
+      M[i * 4 + 3] = w4_sub2(zero2, r[i][1]);
     }
   };
 
-  // Software pipeline, written out (one wave per SIMD: nothing else hides an LDS round trip; left to itself hipcc
-  // scatters the 40 reads of a quad between its MFMAs with a full wait in front of each group): per tile quad
-  //   wait for its raw operands -> transform (88 VALU) -> issue the NEXT quad's 40 reads -> 64 MFMAs,
+  // Software pipeline, written out (one wave per SIMD: nothing else hides an LDS round trip): per tile quad
+  //   wait for its raw operands -> transform -> issue the NEXT quad's 40 reads -> 64 MFMAs,
   // with the DMA pieces of the next block issued between the MFMA groups of this one.
-  if (b_begin < b_end) issue_block(b_begin, 0);
+  if (b_begin < b_end) {
+    dma_begin(b_begin, 0);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) dma_piece(i);
+  }
   int st = 0;
   for (int blk = b_begin; blk < b_end; ++blk) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const bool more = blk + 1 < b_end;
-    const float* Xs = smem + st * WG_STAGE;
-    const float* Ys = Xs + WG_XP * 256;
-    if (more) dma_begin(blk + 1, st ^ 1);
-    float xr[2][16], yr[2][4];
-    load_raw(Xs, Ys, 0, xr, yr);
-#pragma unroll 1
+    const float* S = smem + st * WG_STAGE;
+    // the block after the last is the last once more (into the stage nobody reads): no branches around the DMA
+    dma_begin(min(blk + 1, b_end - 1), st ^ 1);
+    w4_f32x2 xr[16], yr[4];
+    load_raw(S, 0, xr, yr);
+#pragma unroll
     for (int ty = 0; ty < 4; ++ty) {
-      float V[2][16], M[2][16];
+      w4_f32x2 V[16], M[16];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       transform(xr, yr, V, M);
       __builtin_amdgcn_sched_barrier(0);
-      if (ty + 1 < 4) load_raw(Xs, Ys, ty + 1, xr, yr);
+      if (ty + 1 < 4) load_raw(S, ty + 1, xr, yr);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int pos = 0; pos < 16; ++pos) {
@@ -959,10 +983,10 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WinoWgradParam
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
-            acc[pos][kb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[kb][pos], M[nb][pos], acc[pos][kb][nb], 0, 0, 0);
-        if ((pos & 3) == 3 && more) {                  // DMA of the next block: one piece behind every 16th MFMA
+            acc[pos][kb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[pos][kb], M[pos][nb], acc[pos][kb][nb], 0, 0, 0);
+        if ((pos & 3) == 3 && ty * 4 + (pos >> 2) < NPW) {   // DMA of the next block: one piece behind every 16th MFMA
           __builtin_amdgcn_sched_barrier(0);
-          dma_next();
+          dma_piece(ty * 4 + (pos >> 2));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
