@@ -370,4 +370,44 @@ int launch_take_cols(const float* src, float* dst, int rows, int nsrc, int ndst,
 int launch_gather_rows(const float* src, const int* idx, int first, int NB, long row_elems, float* dst,
                        hipStream_t s);
 
+
+// ---- scalar-base LDS-DMA (device code only) -------------------------------------------------------------------
+// fp32 MFMA and the vector ALU are the same lanes on gfx950 (the fp32 matrix peak IS the vector peak), so every vector
+// instruction a wave issues - including the address selects in front of a gather - is time its MFMA stream does not get.
+// These helpers issue one 1-KiB global_load_lds piece whose address is a SCALAR base plus a 32-bit lane offset that can be
+// a kernel-long constant; lanes that must read zeros (outside the image) are switched by an execution mask, which costs one
+// compare per piece instead of a 64-bit select.  All lanes of the wave must be active at the call.
+#if defined(__HIPCC__)
+// one 1-KiB LDS-DMA piece, address = scalar base + 32-bit lane offset; the lanes outside `m_dma` (of the first 16 lanes
+// when LAST16: the piece that ends a buffer) get 16 bytes of the zero page instead
+__device__ __forceinline__ void dv_dma_exec(unsigned lds, unsigned voff, const void* sbase, unsigned long long mask);
+template <bool LAST16>
+__device__ __forceinline__ void dv_dma_masked(unsigned lds, unsigned voff, const void* sbase, unsigned long long m_dma,
+                                              unsigned vnull, const void* zero) {
+  dv_dma_exec(lds, voff, sbase, m_dma);
+  const unsigned long long m_zero = LAST16 ? (~m_dma & 0xffffull) : ~m_dma;
+  if (m_zero) dv_dma_exec(lds, vnull, zero, m_zero);   // (scalar branch: interior pieces issue one instruction)
+}
+// one LDS-DMA piece for the lanes of `mask` only (the other lanes' slots keep what they hold)
+__device__ __forceinline__ void dv_dma_exec(unsigned lds, unsigned voff, const void* sbase, unsigned long long mask) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_mov_b64 exec, %1\n\t"
+      "global_load_lds_dwordx4 %2, %3\n\t"
+      "s_mov_b64 exec, -1"
+      :
+      : "s"(lds), "s"(mask), "v"(voff), "s"(sbase)
+      : "memory");
+}
+__device__ __forceinline__ void dv_dma(unsigned lds, unsigned voff, const void* sbase) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2"
+      :
+      : "s"(lds), "v"(voff), "s"(sbase)
+      : "memory");
+}
+#endif
+
 }  // namespace dv

@@ -350,35 +350,6 @@ __device__ __forceinline__ f32x4 w4_sub(f32x4 a, f32x4 b) {
       : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
   return (f32x4){lo.x, lo.y, hi.x, hi.y};
 }
-// one 1-KiB LDS-DMA piece, address = scalar base + 32-bit lane offset; the lanes outside `m_dma` (of the first 16 lanes
-// when LAST16: the piece that ends a buffer) get 16 bytes of the zero page instead
-template <bool LAST16>
-__device__ __forceinline__ void w4_dma_masked(unsigned lds, unsigned voff, const void* sbase, unsigned long long m_dma,
-                                              unsigned vnull, const void* zero) {
-  if (LAST16) {
-    asm volatile(
-        "s_mov_b32 m0, %0\n\t"
-        "s_mov_b64 exec, %1\n\t"
-        "global_load_lds_dwordx4 %2, %3\n\t"
-        "s_andn2_b64 exec, 0xffff, %1\n\t"
-        "global_load_lds_dwordx4 %4, %5\n\t"
-        "s_mov_b64 exec, -1"
-        :
-        : "s"(lds), "s"(m_dma), "v"(voff), "s"(sbase), "v"(vnull), "s"(zero)
-        : "memory", "scc");
-  } else {
-    asm volatile(
-        "s_mov_b32 m0, %0\n\t"
-        "s_mov_b64 exec, %1\n\t"
-        "global_load_lds_dwordx4 %2, %3\n\t"
-        "s_not_b64 exec, %1\n\t"
-        "global_load_lds_dwordx4 %4, %5\n\t"
-        "s_mov_b64 exec, -1"
-        :
-        : "s"(lds), "s"(m_dma), "v"(voff), "s"(sbase), "v"(vnull), "s"(zero)
-        : "memory", "scc");
-  }
-}
 __device__ __forceinline__ w4_f32x2 w4_add2(w4_f32x2 a, w4_f32x2 b) {
   w4_f32x2 r;
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -404,26 +375,6 @@ __device__ __forceinline__ w4_f32x2 w4_pk_pm(w4_f32x2 a) {
   w4_f32x2 r;
   asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a));
   return r;
-}
-// one LDS-DMA piece for the lanes of `mask` only (the other lanes' slots keep what they hold)
-__device__ __forceinline__ void w4_dma_exec(unsigned lds, unsigned voff, const void* sbase, unsigned long long mask) {
-  asm volatile(
-      "s_mov_b32 m0, %0\n\t"
-      "s_mov_b64 exec, %1\n\t"
-      "global_load_lds_dwordx4 %2, %3\n\t"
-      "s_mov_b64 exec, -1"
-      :
-      : "s"(lds), "s"(mask), "v"(voff), "s"(sbase)
-      : "memory");
-}
-__device__ __forceinline__ void w4_dma(unsigned lds, unsigned voff, const void* sbase) {
-  asm volatile(
-      "s_mov_b32 m0, %0\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2"
-      :
-      : "s"(lds), "v"(voff), "s"(sbase)
-      : "memory");
 }
 __global__ __launch_bounds__(W4_THREADS) void wino_conv4_kernel(const WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -496,12 +447,12 @@ __global__ __launch_bounds__(W4_THREADS) void wino_conv4_kernel(const WinoParams
   const char* ps_base = p_org;                        // origin + chunk * 64 bytes
   unsigned ps_lds = patch_lds;
   auto piece_p = [&](int k) {
-    if (k < WN_PATCH_PIECES - 1) w4_dma_masked<false>(ps_lds + k * 1024, poffb[k], ps_base, m_dma[k], vnull, p.zero);
-    else w4_dma_masked<true>(ps_lds + k * 1024, poffb[k], ps_base, m_dma[k], vnull, p.zero);
+    if (k < WN_PATCH_PIECES - 1) dv_dma_masked<false>(ps_lds + k * 1024, poffb[k], ps_base, m_dma[k], vnull, p.zero);
+    else dv_dma_masked<true>(ps_lds + k * 1024, poffb[k], ps_base, m_dma[k], vnull, p.zero);
   };
   const char* ws_base = reinterpret_cast<const char*>(p.Ut);   // this wave's 8 KiB of the chunk
   unsigned ws_lds = uch_lds;
-  auto piece_w = [&](int k) { w4_dma(ws_lds + k * 1024, lane16, ws_base + k * 1024); };
+  auto piece_w = [&](int k) { dv_dma(ws_lds + k * 1024, lane16, ws_base + k * 1024); };
 
   // ---- fragment addressing (swizzles: see wino_conv_kernel) ----
   const int ty = l15 >> 2, tx = l15 & 3;
@@ -604,11 +555,11 @@ __global__ __launch_bounds__(W4_THREADS) void wino_conv4_kernel(const WinoParams
         const char* arow = reinterpret_cast<const char*>(p.alpha + ((size_t)(ge.by * 8) * H + ge.bx * 8) * Cout + col0);
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          if (ge.by * 8 + k < H) w4_dma_exec(alp_lds + k * 1024, aoffb, arow + (size_t)k * H * Cout * 4, am);
+          if (ge.by * 8 + k < H) dv_dma_exec(alp_lds + k * 1024, aoffb, arow + (size_t)k * H * Cout * 4, am);
       }
       if (p.epi >= 1) {
         const unsigned long long bm = __builtin_amdgcn_ballot_w64(lane < 8 && col0 + lane * 4 < Cout);
-        w4_dma_exec(alp_lds + 8192, lane16, reinterpret_cast<const char*>(p.bias + col0), bm);
+        dv_dma_exec(alp_lds + 8192, lane16, reinterpret_cast<const char*>(p.bias + col0), bm);
       }
     }
     f32x4 bq[2][4];                                    // weight fragments of two groups: [g & 1][2 pp + nh]
@@ -875,7 +826,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(const WinoWgradParam
   auto dma_piece = [&](int i) {                        // i is a compile-time constant at every call site
     const int k = wave + 4 * i;
     if (k >= WG_XP + WG_YP) return;                    // wave-uniform (i = 10: wave 0 only)
-    w4_dma_masked<false>(d_lds + k * 1024, doff[i], k < WG_XP ? d_xorg : d_yorg, d_mask[i], vnull, p.zero);
+    dv_dma_masked<false>(d_lds + k * 1024, doff[i], k < WG_XP ? d_xorg : d_yorg, d_mask[i], vnull, p.zero);
   };
 
   f32x4 acc[16][2][2];
