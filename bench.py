@@ -369,7 +369,10 @@ def main():
         traffic = None
         if dom is not None:
             # HBM bytes of the same launches (one step's launches of the dominant kernel), from the PMC passes
-            traffic = (per_kernel.get(dom["kernel"].split(" ")[0]) or {}).get("hbm_bytes")
+            # (a row may stand for several rocprof kernel names, "a / b": their bytes add up)
+            parts = [per_kernel.get(n.strip()) for n in dom["kernel"].split("/")]
+            if any(parts):
+                traffic = sum((q or {}).get("hbm_bytes", 0.0) for q in parts)
         if bf16:
             alg_bytes = ACT_ELEMS_PER_STAMP * 2 * TRAIN_PASSES * B + PARAM_STEP_BYTES
             ms_step = dt / args.steps * 1e3
@@ -389,6 +392,9 @@ def main():
                 "bound": "mfma", "kernel": dom["kernel"] if dom else None,
                 "achieved": dom["tflops"] if dom else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["frac"] if dom else None, "traffic": traffic,
+                "frac_note": ("algorithmic FLOPs of a direct convolution over the launch time, as SURVEY 8(d) prices the layer; "
+                              "a Winograd kernel executes 1/2.25 of them, so this fraction can exceed 1 - `executed` is what "
+                              "the matrix pipe sustains") if dom and "executed_tflops" in dom else None,
                 "executed": ({"tflops": dom["executed_tflops"], "frac": dom["executed_frac"], "note": dom["note"]}
                              if dom and "executed_tflops" in dom else None),
                 "traffic_source": {"file": src, "commit": _git_head(),

@@ -327,7 +327,7 @@ enum {
 };
 static const char* const kProfFamName[PF_COUNT] = {
     "gconv2_kernel", "gconv_s2_kernel", "gconv_strip_kernel", "gconv_strip8_kernel", "gconv_kernel", "wgrad_kernel",
-    "wgrad_strip_kernel / wgrad_strip8_kernel", "bconv_kernel", "bwgrad_kernel", "wino_conv_kernel", "wino_wgrad_kernel"};
+    "wgrad_strip_kernel / wgrad_strip8_kernel", "bconv_kernel", "bwgrad_kernel", "wino_conv4_kernel / wino_conv_kernel", "wino_wgrad_kernel"};
 
 struct DataSlot {
   float* x = nullptr;

@@ -10,7 +10,8 @@ mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel
 import csv, glob, json, sys
 
 FAMILIES = (("bconv_uni_kernel / bconv_kernel (bf16)", ("bconv_",)), ("bwgrad_kernel (bf16)", ("bwgrad_kernel",)),
-            ("wino_conv_kernel (Winograd F(2x2,3x3) forward / data gradient)", ("wino_conv_kernel",)),
+            ("wino_conv4_kernel (Winograd F(2x2,3x3) forward / data gradient, four-wave form)", ("wino_conv4_kernel",)),
+            ("wino_conv_kernel (same, eight-wave form: the 32-input-channel launches)", ("wino_conv_kernel",)),
             ("wino_wgrad_kernel (Winograd-domain weight gradient)", ("wino_wgrad_kernel",)),
             ("gconv_strip (incl. first-layer form)", ("gconv_strip",)), ("gconv_s2", ("gconv_s2",)),
             ("gconv2 / gconv", ("gconv2_kernel", "gconv_kernel")), ("wgrad_strip (incl. first-layer form)", ("wgrad_strip",)),
