@@ -3,7 +3,8 @@
 Tolerances (stated here, checked below):
   * activations / outputs (t, z, kl, loc, scale): |gpu - oracle| <= 2e-4 * max|oracle| per tensor
   * ELBO scalars (loss, nll_mean, kl_reg): relative error <= 1e-4   (BASELINE.json north_star)
-  * gradients: |gpu - oracle| <= 1e-3 * max|oracle| per tensor
+  * gradients: |gpu - oracle| <= 1e-3 * max|oracle| per tensor (2e-3 for the 2-6 element d(gamma) / d(beta) of the input
+    BatchNorm: see _grad_tol for the measurements behind it)
   * parameters after one legacy-Adam step: |gpu - oracle| <= 2e-6 absolute (lr = 1e-4)
 """
 import numpy as np
@@ -336,6 +337,17 @@ def test_winograd_kernel_matches_the_general_gather_gemm():
                     assert out[1] > 0.1, c
                     assert out[0] <= 2e-5 * out[1], (c, out[0], out[1])
                     worst = max(worst, out[0] / out[1])
+    # several items per workgroup (the LDS ring and, in the four-wave kernel, the two DMA streams run across item
+    # boundaries; >= 48 input channels take the four-wave kernel, 32 the eight-wave one), ragged block groups, Cout = 48
+    for (NB, H, cs, ct) in ((37, 30, 32, 64), (21, 64, 32, 32), (150, 8, 128, 256), (150, 8, 256, 256), (61, 16, 128, 128),
+                            (45, 15, 64, 128), (29, 59, 32, 48), (40, 10, 96, 96), (5, 13, 48, 96), (90, 17, 48, 32)):
+        for dgrad, nmajor in ((0, 0), (1, 1)):
+            for epi in (0, 2):
+                c = (NB, H, cs, H, ct, 1, 1, dgrad, nmajor, epi)
+                check(lib.dv_debug_gconv_check(ctx._h, *c, out))
+                assert out[1] > 0.1, c
+                assert out[0] <= 2e-5 * out[1], (c, out[0], out[1])
+                worst = max(worst, out[0] / out[1])
     print(f"\nWinograd vs gather-GEMM: worst relative difference {worst:.2e}")
 
 
