@@ -1,20 +1,26 @@
 // Winograd F(2x2, 3x3) form of the stride-1 3x3 layers in fp32: the four stride-1 Conv2D layers of the encoder
 // (model.py:81-83), the four stride-1 Conv2DTranspose layers of the decoder (model.py:128-134), the head conv
-// (model.py:137) and the data gradients of all of them - 62 % of the network's multiply-adds.
+// (model.py:137) and the data gradients of all of them - two thirds of the network's multiply-adds (the head conv, 16
+// output columns, stays with the strip kernel).
 //
 // A 3x3 stride-1 layer is  Y = A^T [ sum_c (G g_c G^T) . (B^T d_c B) ] A  per 4x4 input tile d / 2x2 output tile Y:
 // 16 element-wise positions, each an independent [tiles x Cin] x [Cin x Cout] contraction, 4 multiply-adds per output
-// pixel and channel pair instead of 9.  fp32 MFMA runs at the vector rate on gfx950 (157 TFLOP/s), so the 2.25x fewer
-// MFMA cycles are worth having; the transforms are adds on the (otherwise idle) vector pipe.  Everything is fused:
-// a workgroup DMAs raw input patches and pre-transformed weight chunks (wino_weights_kernel: U = G g G^T, once per
-// weight update) into LDS, every wave transforms the 4x4 input tiles of ITS 16 tiles in registers (B^T d B on float4
-// channel quads), runs the 16 position GEMMs on v_mfma_f32_16x16x4_f32 with 16 x 2 accumulator blocks, applies the
-// output transform to its accumulators and writes bias / PReLU outputs through a per-wave LDS staging tile.
+// pixel and channel pair instead of 9.  fp32 MFMA runs ON the vector lanes on gfx950 (157 TFLOP/s both ways), so the
+// 2.25x fewer MFMA cycles are worth having - and every vector instruction of the transforms and of the address
+// arithmetic costs MFMA time (measured: ~5.7 cycles each, whether or not it sits "in the shadow" of an MFMA; DESIGN.md
+// 4a).  Everything is fused: a workgroup DMAs raw input patches and pre-transformed weight chunks (wino_weights_kernel:
+// U = G g G^T, once per weight update) into LDS, transforms the 4x4 input tiles in registers (B^T d B on float4 channel
+// quads), runs the 16 position GEMMs on v_mfma_f32_16x16x4_f32, applies the output transform to its accumulators and
+// writes bias / PReLU outputs through a per-wave LDS staging tile.
+//
+// Three kernels: wino_conv_kernel (eight waves; wave = M block x 16 columns; used for 32 input channels),
+// wino_conv4_kernel (four waves, one per SIMD; wave = M block x 32 columns; built around the vector-instruction count;
+// >= 48 input channels) and wino_wgrad_kernel (weight gradient in the transform domain, F(3x3, 2x2)).
 //
 // Geometry: an M block is 4 x 4 tiles = 8 x 8 output pixels of one stamp (its input patch: 10 x 10 pixels); a
-// workgroup (4 waves) owns 4 consecutive M blocks x 32 output channels and walks K in chunks of 16 input channels
-// through a double-buffered LDS ring (patch chunk 4 x 6.25 KiB wave-private, weight chunk 32 KiB shared), persistent
-// over (block group, column tile) items with the ring running across item boundaries.
+// workgroup owns 4 consecutive M blocks x 32 output channels and walks K in chunks of 16 input channels through a
+// double-buffered LDS ring (patch chunk 4 x 6.25 KiB, weight chunk 32 KiB shared), persistent over (block group,
+// column tile) items with the ring running across item boundaries.
 // MFMA roles: A = transformed input V[tile][k], B = transformed weights U[k][n]; lane (l15, lg): A row l15 = tile
 // (ty, tx) = (l15 >> 2, l15 & 3), k = lg; C rows 4 lg + r = tile (lg, r), column l15.
 // Numerics: exact fp32 arithmetic in another association (sums of up to four inputs before the product, 0.5 factors
