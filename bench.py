@@ -103,7 +103,8 @@ def cpu_baseline_torch(batch: int, steps: int):
     for _ in range(steps):
         step()
     dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "stamps/s", "cores": cores, "kind": "torch-cpu restatement",
+    return {"value": batch * steps / dt, "unit": "stamps/s", "cores": cores, "kind": "port",
+            "impl": "torch-cpu restatement of the train step (tests/torch_ref.py); the reference's TensorFlow is not installable here",
             "sample": f"{steps} train steps of batch {batch} (torch {torch.__version__} CPU / oneDNN float32 conv2d + "
                       f"conv_transpose2d, autograd, Adam; tests/torch_ref.py), same model/config"}
 
@@ -427,7 +428,7 @@ def main():
                                text=True, timeout=900)
             cpu = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:                    # pragma: no cover
-            cpu = {"value": None, "unit": "stamps/s", "cores": _cores(), "kind": "torch-cpu restatement",
+            cpu = {"value": None, "unit": "stamps/s", "cores": _cores(), "kind": "port",
                    "sample": f"failed: {e!r}"}
         _progress("cpu baseline: numpy oracle")
         cpu["also"] = cpu_baseline_numpy(batch=64, steps=3)
