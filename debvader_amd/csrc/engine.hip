@@ -411,7 +411,7 @@ struct dv_model {
   hipStream_t cs = nullptr;       // stream of the forward lane being queued (null: main stream)
   int b0 = 0;                     // first stamp of the forward lane being queued
   int lane_id = 0;
-  bool split_forward = true;      // run the forward pass as two half-batch lanes on two streams (DV_NO_FWD_SPLIT)
+  bool split_forward = true;      // forward lanes allowed (DV_NO_FWD_SPLIT forbids them; DV_FWD_LANES=n asks for n)
   bool overlap_wgrad = true;
   bool fuse_first = true;     // DV_NO_FUSE_FIRST=1 keeps the first PReLU backward as a separate pass
   bool no_fuse = true;        // dv_debug_fuse_prelu_bwd(1) fuses the PReLU backward into the data-gradient epilogue (batch-major
@@ -1632,7 +1632,10 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
     set_error("head workspace too small");
     return E_STATE;
   }
-  static const int want_lanes = getenv("DV_FWD_LANES") ? atoi(getenv("DV_FWD_LANES")) : 2;
+  // One lane by default since round 3: the Winograd kernels are persistent, one workgroup per CU with the CU's whole LDS,
+  // so two half-batch lanes on two streams no longer fill gaps of each other - they queue (measured 4.885 ms with two
+  // lanes, 4.827 ms with one, same box).  DV_FWD_LANES=n forces n; batches above the per-launch limit still split below.
+  static const int want_lanes = getenv("DV_FWD_LANES") ? atoi(getenv("DV_FWD_LANES")) : 1;
   int nlanes = (m->split_forward && !m->prof_on && !m->bf.on && cx->aux_stream && NB >= 64) ? std::max(1, std::min(want_lanes, 4)) : 1;
   while (nlanes > 1 && NB / nlanes < 32) --nlanes;
   while (nlanes > 2 && !cx->lane_stream[nlanes - 3]) --nlanes;
