@@ -1273,9 +1273,11 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   p.rows_total = t.n * Cx;
   long slab = (long)p.rows_total * Cy;
   long tiles = ((p.rows_total + 127) / 128) * (long)((Cy + 127) / 128);
-  // one full round of resident workgroups (two 74 KB workgroups per CU x 256 CUs), never a round and a half:
-  // 540 workgroups run as long as 1024, 504 finish 8 % sooner (tools/layer_bench.py)
-  const long target = 512;
+  // At most one round of resident workgroups (two 74 KB workgroups per CU x 256 CUs), never a round and a half: alone, 540
+  // workgroups run as long as 1024 and 504 finish 8 % sooner (tools/layer_bench.py).  In the overlapped step - the kernel
+  // shares the chip with the main stream's persistent one-workgroup-per-CU Winograd launches - fewer, longer pixel ranges
+  // do better still: 384 gives 4.74 ms per step against 4.83 with 512 and 4.80 with 256 (same box, alternating runs)
+  const long target = 384;
   long ns = std::max(1L, target / tiles);
   ns = std::min(ns, (long)std::max(1, p.P / 256));
   ns = std::min(ns, 256L);
