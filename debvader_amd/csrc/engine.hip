@@ -2583,7 +2583,13 @@ static int ctx_build(dv_ctx* c, int world, int rank, const void* unique_id) {
   DV_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   DV_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-  DV_HIP(hipStreamCreateWithFlags(&c->red_stream, hipStreamNonBlocking));
+  {
+    // the reduction stream's five-microsecond launches feed the bucket all-reduces and the optimizer: highest priority,
+    // so that they are not queued behind whole matrix kernels (+0.3 % on the step; main / aux priorities: no effect)
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+    DV_HIP(hipStreamCreateWithPriority(&c->red_stream, hipStreamNonBlocking, hi));
+  }
   DV_HIP(hipEventCreateWithFlags(&c->ev_red, comm_gate_event_flags()));
   // HIP multiplexes streams onto a few hardware queues (4 by default) and work on streams that share a queue runs
   // in submission order, so the engine keeps to four streams: main, comm (also the D2H stream of the inference
