@@ -3615,6 +3615,7 @@ static int debug_buffers(dv_ctx* ctx, size_t nx, size_t nw, size_t ny, float** X
   DV_HIP(hipMemcpy(*X, h.data(), nx * sizeof(float), hipMemcpyHostToDevice));
   DV_HIP(hipMemcpy(*W, h.data(), nw * sizeof(float), hipMemcpyHostToDevice));
   DV_HIP(hipMemset(*Y, 0, ny * sizeof(float)));
+  DV_HIP(hipDeviceSynchronize());     // hipMemset runs on the null stream, the kernels under test on a non-blocking one
   return OK;
 }
 
@@ -3786,6 +3787,7 @@ int dv_debug_wgrad_check(dv_ctx* ctx, int32_t NB, int32_t H, int32_t Cx, int32_t
   DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
   DV_HIP(hipMalloc((void**)&m.zero_page, 256));
   DV_HIP(hipMemset(m.zero_page, 0, 256));
+  DV_HIP(hipDeviceSynchronize());   // (hipMemset runs on the null stream; the kernels on a non-blocking one)
   int st = OK;
   for (int pass = 0; pass < 2 && st == OK; ++pass) {
     g_no_wino = pass == 1;
@@ -3865,6 +3867,7 @@ int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, 
   DV_HIP(hipMalloc((void**)&m.ws1, m.ws1_elems * sizeof(float)));
   DV_HIP(hipMalloc((void**)&m.zero_page, 256));
   DV_HIP(hipMemset(m.zero_page, 0, 256));
+  DV_HIP(hipDeviceSynchronize());   // (hipMemset runs on the null stream; the kernels on a non-blocking one)
   hipEvent_t a, b;
   DV_HIP(hipEventCreate(&a));
   DV_HIP(hipEventCreate(&b));
@@ -3880,6 +3883,7 @@ int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, 
     DV_HIP(hipMemcpy(U, Yb, ny * sizeof(float), hipMemcpyDeviceToDevice));
     DV_HIP(hipMalloc((void**)&al, E * sizeof(float)));
     DV_HIP(hipMemset(al, 0, E * sizeof(float)));
+    DV_HIP(hipDeviceSynchronize());
     DV_HIP(hipMalloc((void**)&gout, (E + 64) * sizeof(float)));
     m.ws2_elems = 32 * E;
     DV_HIP(hipMalloc((void**)&m.ws2, m.ws2_elems * sizeof(float)));
