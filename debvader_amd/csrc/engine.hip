@@ -367,6 +367,8 @@ struct BfState {
   dv::BCastDesc* descs_dev = nullptr;
   float* G0s16 = nullptr;        // not used directly: slabs of the first layer reduce into G0s
   void* zero = nullptr;          // 1 KiB of zeros
+  float* trunk[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // fp32 gradient rows of the dense trunk, one buffer per
+                                 // stage of a backward pass (its weight gradients read them from the aux stream)
 };
 
 // Winograd-domain weights of one stride-1 3x3 layer in one form (forward or data gradient), see wino.hip

@@ -3,7 +3,8 @@
 // the sampler and the head arithmetic on the fp32 kernels the f32 engine uses.  Seams: the encoder's last
 // activation leaves the stamp-inner bf16 layout as fp32 rows (input of the flatten PReLU, model.py:94-95), the
 // decoder's Reshape (model.py:119) enters it; the backward pass crosses the same two seams in reverse.
-// Everything runs on the main stream (no stream choreography: the kernels are short and bandwidth-bound).
+// Forward on the main stream; in the backward pass the conv and dense weight gradients and their reductions run on the
+// weight-gradient / reduction streams beside the data-gradient chain.
 
 static int bf_pad32(int k) { return (k + 31) & ~31; }
 
@@ -62,6 +63,10 @@ static int bf_alloc(dv_model* m) {
   DV_TRY(balloc((void**)&bf.tpre32, (size_t)A.dec_out * A.dec_out * Bp * 16 * 4));
   DV_TRY(balloc(&bf.dt, (size_t)A.dec_out * A.dec_out * Bp * 16 * 2));
   DV_TRY(balloc((void**)&bf.flat_in, (size_t)m->Bc * A.flat * 4));
+  {
+    const size_t w[5] = {r, (size_t)A.dec_hidden, (size_t)A.d, (size_t)A.tw, (size_t)A.flat};
+    for (int k = 0; k < 5; ++k) DV_TRY(balloc((void**)&bf.trunk[k], (size_t)m->Bc * w[k] * 4));
+  }
   bf.gpool.resize(4 * A.L + 4);
   for (auto& g : bf.gpool) DV_TRY(balloc(&g, max_e * Bp * 2));
   // slab pool of one backward pass: ~9.4 MB per launch with the launcher's 256-workgroup rule (bwgrad.hip), 17 launches
@@ -270,8 +275,10 @@ static int bf_flush_wred(dv_model* m) {
 // weight gradient of one layer: partial slabs into this launch's region of the pool; the fixed-order sum over the slabs
 // is registered and runs with all the others of the pass in one launch (17 five-microsecond reductions otherwise sit
 // between the weight-gradient kernels of the aux stream, which is the tail of the step)
+// on_main: queue the kernel on the main stream (the last launch of a pass: the main stream has nothing left to do while
+// the weight-gradient stream works off its backlog); the caller orders the slab reduction behind it
 static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, int Hy, int Cy, int s, int pb, float* out,
-                    int cpad, int creal) {
+                    int cpad, int creal, bool on_main = false) {
   BfState& bf = m->bf;
   const size_t slab = (size_t)9 * Cx * Cy;
   if (bf.wred.count >= DV_WRED_MAX || bf.slab_off + 4 * ((size_t)(bf.NBp + 63) / 64) * slab > bf.slab_elems)
@@ -281,7 +288,7 @@ static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, i
   p.X = X; p.Y = Y; p.zero = bf.zero; p.part = bf.slab + bf.slab_off; p.part_capacity = bf.slab_elems - bf.slab_off;
   p.Hx = Hx; p.Cx = Cx; p.Hy = Hy; p.Cy = Cy; p.NBp = bf.NBp; p.s = s; p.pb = pb;
   int ns = 0;
-  hipStream_t st = bf_wstream(m);
+  hipStream_t st = on_main ? m->ctx->stream : bf_wstream(m);
   if (st != m->ctx->stream) {
     DV_HIP(hipEventRecord(m->ctx->ev_ready, m->ctx->stream));
     DV_HIP(hipStreamWaitEvent(st, m->ctx->ev_ready, 0));
@@ -414,26 +421,32 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     cur = oth;
   }
   bf.d_dec_in = cur;
-  // ---- dense trunk of the decoder, sampler, encoder dense: fp32 rows in m->gA / m->gB ----
+  // ---- dense trunk of the decoder, sampler, encoder dense: fp32 rows in bf.trunk[] ----
   const int fl = A.cfg.filters[A.L - 1];
   const int r = A.w0 * A.w0 * fl;
-  float* c32 = m->gA;
-  float* o32 = m->gB;
+  // One buffer per stage: the dense weight gradients read these rows from the weight-gradient stream (wgrad() with
+  // m->wstream = ws: kernel on the aux stream, slab sum and the d(alpha) / d(bias) sums of prelu_bwd on the reduction
+  // stream), so the main stream only carries the chain prelu_bwd -> data gradient and never rewrites a row buffer.
+  float* const tr0 = bf.trunk[0];   // d(decoder trunk output)   [NB, r]
+  float* const tr1 = bf.trunk[1];   // d(hidden)                 [NB, dec_hidden]
+  float* const tr2 = bf.trunk[2];   // d(z)                      [NB, d]
+  float* const tr3 = bf.trunk[3];   // d(t)                      [NB, tw]
+  float* const tr4 = bf.trunk[4];   // d(flatten)                [NB, flat]
+  m->wstream = ws;
   {
     ProfScope ps(m, 2, s);
-    DV_TRY(launch_bf_to_rows(cur, c32, NB, bf.NBp, A.w0 * A.w0, fl, s));
+    DV_TRY(launch_bf_to_rows(cur, tr0, NB, bf.NBp, A.w0 * A.w0, fl, s));
   }
-  DV_TRY(prelu_bwd(m, c32, m->dec_ur, A.D0 + 6, A.D0 + 5, NB, r, r, dg));
-  if (dg) DV_TRY(wgrad(m, m->dec_ah, 1, A.dec_hidden, c32, 1, r, NB, 1, 0, true, G + A.specs[A.D0 + 4].off, 1, 1));
-  DV_TRY(gconv_fprop(m, c32, P + A.specs[A.D0 + 4].off, true, nullptr, nullptr, o32, nullptr, 0, NB, 1, r, 1,
+  DV_TRY(prelu_bwd(m, tr0, m->dec_ur, A.D0 + 6, A.D0 + 5, NB, r, r, dg));
+  if (dg) DV_TRY(wgrad(m, m->dec_ah, 1, A.dec_hidden, tr0, 1, r, NB, 1, 0, true, G + A.specs[A.D0 + 4].off, 1, 1));
+  DV_TRY(gconv_fprop(m, tr0, P + A.specs[A.D0 + 4].off, true, nullptr, nullptr, tr1, nullptr, 0, NB, 1, r, 1,
                      A.dec_hidden, 1, 0, true));
-  std::swap(c32, o32);
-  DV_TRY(prelu_bwd(m, c32, m->dec_uh, A.D0 + 3, A.D0 + 2, NB, A.dec_hidden, A.dec_hidden, dg));
-  if (dg) DV_TRY(wgrad(m, m->dec_ain, 1, A.d, c32, 1, A.dec_hidden, NB, 1, 0, true, G + A.specs[A.D0 + 1].off, 1, 1));
-  DV_TRY(gconv_fprop(m, c32, P + A.specs[A.D0 + 1].off, true, nullptr, nullptr, o32, nullptr, 0, NB, 1, A.dec_hidden, 1,
+  DV_TRY(prelu_bwd(m, tr1, m->dec_uh, A.D0 + 3, A.D0 + 2, NB, A.dec_hidden, A.dec_hidden, dg));
+  if (dg) DV_TRY(wgrad(m, m->dec_ain, 1, A.d, tr1, 1, A.dec_hidden, NB, 1, 0, true, G + A.specs[A.D0 + 1].off, 1, 1));
+  DV_TRY(gconv_fprop(m, tr1, P + A.specs[A.D0 + 1].off, true, nullptr, nullptr, tr2, nullptr, 0, NB, 1, A.dec_hidden, 1,
                      A.d, 1, 0, true));
-  std::swap(c32, o32);
-  DV_TRY(prelu_bwd(m, c32, m->z, A.D0, -1, NB, A.d, A.d, dg));
+  DV_TRY(prelu_bwd(m, tr2, m->z, A.D0, -1, NB, A.d, A.d, dg));
+  const bool trunk_red = ws != s && m->arena_reduce && m->ctx->red_stream != nullptr;   // sums on the reduction stream
   // Every decoder gradient has been queued and no later kernel of the step reads a decoder parameter: finish the
   // decoder's reductions now (slab sums and d(alpha) / d(bias) partials, one launch each, on the weight-gradient
   // stream), all-reduce the bucket on the comm stream while the encoder backward runs and - early_adam - update it there
@@ -461,6 +474,10 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
         DV_HIP(hipEventRecord(cx->ev_join, ws));
         DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_join, 0));
       }
+      if (trunk_red) {                                   // the decoder trunk's slab / d(alpha) / d(bias) sums
+        DV_HIP(hipEventRecord(cx->ev_red, cx->red_stream));
+        DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_red, 0));
+      }
       if (cx->comm)
         DV_NCCL(ncclAllReduce(G + A.n_enc_train, G + A.n_enc_train, A.n_train - A.n_enc_train, ncclFloat, ncclSum, cx->comm,
                               cx->comm_stream));
@@ -475,15 +492,15 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   const float kls = (float)((double)A.cfg.kl_multiplicity * A.cfg.kl_weight / ((double)Bg * (double)Bg));
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, c32, o32, NB, A.d, A.cfg.diag_shift, kls, s));
+    DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, tr2, tr3, NB, A.d, A.cfg.diag_shift, kls, s));
   }
-  std::swap(c32, o32);   // d(t) [NB, tw]
-  DV_TRY(bias_grad_colsum(m, c32, NB, A.tw, A.tw, A.enc_db()));
-  DV_TRY(wgrad(m, m->flat_a, 1, A.flat, c32, 1, A.tw, NB, 1, 0, true, G + A.specs[A.enc_dk()].off, 1, 1));
-  DV_TRY(gconv_fprop(m, c32, P + A.specs[A.enc_dk()].off, true, nullptr, nullptr, o32, nullptr, 0, NB, 1, A.tw, 1, A.flat,
+  DV_TRY(bias_grad_colsum(m, tr3, NB, A.tw, A.tw, A.enc_db()));
+  DV_TRY(wgrad(m, m->flat_a, 1, A.flat, tr3, 1, A.tw, NB, 1, 0, true, G + A.specs[A.enc_dk()].off, 1, 1));
+  DV_TRY(gconv_fprop(m, tr3, P + A.specs[A.enc_dk()].off, true, nullptr, nullptr, tr4, nullptr, 0, NB, 1, A.tw, 1, A.flat,
                      1, 0, true));
-  std::swap(c32, o32);
-  DV_TRY(prelu_bwd(m, c32, bf.flat_in, A.enc_flat_al(), -1, NB, A.flat, A.flat, true));
+  DV_TRY(prelu_bwd(m, tr4, bf.flat_in, A.enc_flat_al(), -1, NB, A.flat, A.flat, true));
+  m->wstream = s;
+  float* const c32 = tr4;
   // ---- back into the stamp-inner layout: d(activation) of the last encoder conv, then its PReLU backward ----
   {
     const int jl = 2 * A.L - 1;
@@ -511,7 +528,12 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     if (j == 0) {
       // first conv with the folded input BatchNorm: the gradient w.r.t. the 16-channel folded kernel (channels
       // 0..C-1 = bands, C = the constant one) yields d(kernel), d(gamma), d(beta); no data gradient
-      DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8));
+      const bool lm = ws != s;                           // last launch of the pass: on the (otherwise idle) main stream
+      DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8, lm));
+      if (lm) {                                          // its slabs are summed on the weight-gradient stream
+        DV_HIP(hipEventRecord(m->ctx->ev_ready, s));
+        DV_HIP(hipStreamWaitEvent(ws, m->ctx->ev_ready, 0));
+      }
       // every slab reduction of the pass, then what reads the two scratch gradients (padded head kernel, folded first conv)
       DV_TRY(bf_flush_wred(m));
       ProfScope ps(m, 2, ws);
@@ -548,6 +570,10 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
         bf.red.count = 0;
         DV_HIP(hipEventRecord(cx->ev_mid, ws));
         DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_mid, 0));
+        if (trunk_red) {                                 // encoder dense slab sum, flatten d(alpha)
+          DV_HIP(hipEventRecord(cx->ev_red, cx->red_stream));
+          DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_red, 0));
+        }
         DV_HIP(hipEventRecord(cx->ev_dec, s));           // the main stream has finished reading those parameters
         DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_dec, 0));
         if (cx->comm) {
@@ -568,6 +594,10 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   if (ws != s) {                                         // join: every parameter gradient is final past this point
     DV_HIP(hipEventRecord(m->ctx->ev_join, ws));
     DV_HIP(hipStreamWaitEvent(s, m->ctx->ev_join, 0));
+  }
+  if (trunk_red) {
+    DV_HIP(hipEventRecord(m->ctx->ev_red, m->ctx->red_stream));
+    DV_HIP(hipStreamWaitEvent(s, m->ctx->ev_red, 0));
   }
   // data parallelism: the decoder bucket went out above; the encoder bucket [0, n_enc_train) is all-reduced by
   // enqueue_step behind this pass (with a frozen decoder it is the only one)
