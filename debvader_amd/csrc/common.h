@@ -332,6 +332,8 @@ int launch_prelu_fwd(const float* u, const float* alpha, float* a, long NB, int 
 int launch_prelu_bwd(float* da, const float* u, const float* alpha, int NB, int E, int C, int nsplit,
                      float* dalpha_part, float* dbias_part, int* dbias_rows, hipStream_t s);
 int launch_colsum(const float* x, long rows, int C, float* part, int* nrows_part, hipStream_t s);
+// out[b][n] = sum_k x[b][k] * W[n][k], N <= 64 (one wave per row)
+int launch_dense_narrow(const float* x, const float* W, float* out, int NB, int K, int N, hipStream_t s);
 
 
 struct SamplerParams {

@@ -360,6 +360,8 @@ struct BfState {
   float* slab = nullptr;         // weight-gradient partial slabs (aux stream): a per-pass pool, every launch its region
   size_t slab_elems = 0;
   size_t slab_off = 0;
+  size_t slab_tail = 0;          // extra region behind the pool for the one launch queued on the main stream (never
+                                 // touched by the weight-gradient stream, whose reductions may lag behind the main stream)
   dv::WRedBatch wred;            // their reductions, all in one launch at the end of the pass (bf_flush_wred)
   std::vector<BfW> enc_w, dec_w;
   BfW head_w;
@@ -867,6 +869,12 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
       r = launch_gconv_strip8(g, fwd_stream(m));
     }
     if (r <= 0) return r;
+  }
+  if (single_tap && nmajor && Hin == 1 && Hout == 1 && Cout <= 64 && Cin <= 1024 && epi == 0 && !bias && !fz && !g_force_v1 &&
+      !g_no_special) {
+    // narrow dense data gradient (hidden -> latent_dim): one wave per stamp instead of two serial 128 x 32 tiles
+    ProfScope ps(m, 0, nullptr, PF_GCONV, flops);
+    return launch_dense_narrow(X, W, U, NB, Cin, Cout, fwd_stream(m));
   }
   if ((Cin % 32 == 0 || ((Cin == 8 || Cin == 16) && Cout <= 32 && !single_tap)) && !g_force_v1) {
     GConv2Params q;

@@ -74,7 +74,8 @@ static int bf_alloc(dv_model* m) {
   bf.slab_elems = (size_t)64 << 20;
   for (auto& sp : A.specs)          // a launch needs one slab per 64-stamp chunk at least: room for two such launches
     if (sp.ndim == 4) bf.slab_elems = std::max(bf.slab_elems, sp.count * 2 * std::max<size_t>(4, (Bp + 63) / 64));
-  DV_TRY(balloc((void**)&bf.slab, bf.slab_elems * 4));
+  bf.slab_tail = (size_t)4 << 20;
+  DV_TRY(balloc((void**)&bf.slab, (bf.slab_elems + bf.slab_tail) * 4));
 
   // bf16 weight matrices and the descriptors the cast kernel walks
   float* P = m->P;
@@ -286,6 +287,10 @@ static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, i
   BWgradParams p;
   memset(&p, 0, sizeof p);
   p.X = X; p.Y = Y; p.zero = bf.zero; p.part = bf.slab + bf.slab_off; p.part_capacity = bf.slab_elems - bf.slab_off;
+  if (on_main) {                 // its own region: the pool may still be read by a reduction the aux stream has not run yet
+    p.part = bf.slab + bf.slab_elems;
+    p.part_capacity = bf.slab_tail;
+  }
   p.Hx = Hx; p.Cx = Cx; p.Hy = Hy; p.Cy = Cy; p.NBp = bf.NBp; p.s = s; p.pb = pb;
   int ns = 0;
   hipStream_t st = on_main ? m->ctx->stream : bf_wstream(m);
@@ -304,7 +309,7 @@ static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, i
   }
   WRedEntry& e = bf.wred.e[bf.wred.count++];
   e.part = p.part; e.out = out; e.nsplit = ns; e.slab4 = (int)(slab / 4); e.ncols4 = Cy / 4; e.cpad = cpad; e.creal = creal;
-  bf.slab_off += (((size_t)ns * slab + 63) / 64) * 64;
+  if (!on_main) bf.slab_off += (((size_t)ns * slab + 63) / 64) * 64;
   return OK;
 }
 
@@ -494,6 +499,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     ProfScope ps(m, 2);
     DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, tr2, tr3, NB, A.d, A.cfg.diag_shift, kls, s));
   }
+  m->main_marked = false;   // (the record prelu_bwd left behind predates the sampler: the dense weight gradient below needs its own)
   DV_TRY(bias_grad_colsum(m, tr3, NB, A.tw, A.tw, A.enc_db()));
   DV_TRY(wgrad(m, m->flat_a, 1, A.flat, tr3, 1, A.tw, NB, 1, 0, true, G + A.specs[A.enc_dk()].off, 1, 1));
   DV_TRY(gconv_fprop(m, tr3, P + A.specs[A.enc_dk()].off, true, nullptr, nullptr, tr4, nullptr, 0, NB, 1, A.tw, 1, A.flat,
@@ -528,7 +534,8 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     if (j == 0) {
       // first conv with the folded input BatchNorm: the gradient w.r.t. the 16-channel folded kernel (channels
       // 0..C-1 = bands, C = the constant one) yields d(kernel), d(gamma), d(beta); no data gradient
-      const bool lm = ws != s;                           // last launch of the pass: on the (otherwise idle) main stream
+      // last launch of the pass: on the (otherwise idle) main stream, slabs in the pool's tail region
+      const bool lm = ws != s && (size_t)((bf.NBp + 63) / 64) * 9 * 16 * cout <= bf.slab_tail;
       DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8, lm));
       if (lm) {                                          // its slabs are summed on the weight-gradient stream
         DV_HIP(hipEventRecord(m->ctx->ev_ready, s));

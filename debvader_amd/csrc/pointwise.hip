@@ -254,6 +254,57 @@ int launch_prelu_fwd(const float* u, const float* alpha, float* a, long NB, int 
   return OK;
 }
 
+// Narrow dense contraction out[b][n] = sum_k x[b][k] * W[n][k] for N <= 64 (the data gradient of the decoder's first
+// Dense layer, model.py:113-114: 560 -> latent_dim): one wave per row, lanes stride K, one butterfly per output.  As a
+// 128 x 32-tile gather-GEMM this was two workgroups walking K serially (27 us alone, 49 us beside the weight-gradient
+// stream); here NB waves read a 72 KB weight matrix from L2.
+template <int KC>   // KC = ceil(K / 64) row values per lane, held in registers
+__global__ __launch_bounds__(256) void dense_narrow_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                           float* __restrict__ out, int NB, int K, int N) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x;                      // one row per workgroup, wave w owns outputs n = w, w + 4, ...
+  const float* xr = x + (size_t)b * K;
+  float xv[KC];
+#pragma unroll
+  for (int t = 0; t < KC; ++t) xv[t] = lane + 64 * t < K ? xr[lane + 64 * t] : 0.f;
+  for (int n0 = w; n0 < N; n0 += 16) {           // four outputs per trip: their loads are issued together
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 4 * j;
+      const float* wr = W + (size_t)(n < N ? n : 0) * K;
+#pragma unroll
+      for (int t = 0; t < KC; ++t) {
+        const int k = lane + 64 * t;
+        acc[j] = fmaf(xv[t], k < K ? wr[k] : 0.f, acc[j]);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += __shfl_xor(acc[j], o);
+    }
+    if (lane < 4 && n0 + 4 * lane < N)
+      out[(size_t)b * N + n0 + 4 * lane] = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+  }
+}
+
+int launch_dense_narrow(const float* x, const float* W, float* out, int NB, int K, int N, hipStream_t s) {
+  if (N > 64 || N < 1 || K < 1 || K > 1024) {
+    set_error("dense_narrow: N must be in 1..64 and K in 1..1024");
+    return E_INVALID;
+  }
+  if (NB == 0) return OK;
+  if (K <= 256)
+    hipLaunchKernelGGL(dense_narrow_kernel<4>, dim3((unsigned)NB), dim3(256), 0, s, x, W, out, NB, K, N);
+  else if (K <= 576)
+    hipLaunchKernelGGL(dense_narrow_kernel<9>, dim3((unsigned)NB), dim3(256), 0, s, x, W, out, NB, K, N);
+  else
+    hipLaunchKernelGGL(dense_narrow_kernel<16>, dim3((unsigned)NB), dim3(256), 0, s, x, W, out, NB, K, N);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
 // du = da * (u>0 ? 1 : alpha) in place; d(alpha)[e] = sum_n da*min(u,0); d(bias)[c] = sum_{n,hw} du.
 // grid (ceil(E/1024), nsplit): thread owns 4 consecutive elements e, loops over its slice of the batch.
 // dbias_mode 0: none; 1: E == C (dense), partial [nsplit][E]; 2: C % 4 == 0 and C <= 1024, partial [nsplit*gridDim.x][C]
