@@ -369,6 +369,46 @@ print(repr(out["loss"]), " ".join(repr(float(np.abs(eng.get_param(n).astype(np.f
     assert outs[0] == outs[1] == outs[2] == outs[3], outs
 
 
+def test_bf16_queued_steps_at_full_batch_are_bit_reproducible_across_stream_orders():
+    """Forty queued 256-stamp train steps (conv and dense-trunk weight gradients on the aux stream, their sums on the
+    reduction stream, one launch on the main stream with its own slab region, early Adam per bucket on the comm stream)
+    must leave bit-identical parameters on every run and in the single-stream order (DV_NO_OVERLAP=1).  Round 3: a slab
+    region that the main stream rewrote before the aux stream had summed it showed up exactly here - a loss that changed
+    from run to run at this batch size while the 64-stamp / 3-step test above stayed green."""
+    import os
+    import subprocess
+    import sys
+    import zlib
+
+    code = r'''
+import sys, zlib, numpy as np
+sys.path.insert(0, %r)
+from debvader_amd import engine as E
+from debvader_amd.data import synthetic_stamps
+x, y = synthetic_stamps(256, seed=0)
+eng = E.Engine(E.make_config(max_batch=256, dtype=1))
+eng.init(seed=4); eng.optimizer_reset(1e-4); eng.upload(0, x, y)
+out = eng.train_steps(0, 0, 256, 40, seed=2)
+crc = 0
+for name, _, tr in eng.specs:
+    if tr:
+        crc = zlib.crc32(np.ascontiguousarray(eng.get_param(name)).tobytes(), crc)
+print(repr(out["loss"]), crc)
+eng.close()
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ({}, {}, {}, {"DV_NO_OVERLAP": "1"}):
+        env = dict(os.environ)
+        for k in ("DV_FORCE_COMM", "DV_NO_EARLY_ADAM", "DV_NO_OVERLAP"):
+            env.pop(k, None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code % root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2] == outs[3], outs
+
+
 def test_python_surface_with_the_bf16_engine(tmp_path):
     """create_model_vae(..., dtype="bf16") behind the reference's call surface (train.py:27-37,118-130,
     deblender.py:6-24): compile / fit with validation / History, deblend on float64 stamps, TF-format checkpoint round trip
