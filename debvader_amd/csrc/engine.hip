@@ -876,7 +876,9 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     ProfScope ps(m, 0, nullptr, PF_GCONV, flops);
     return launch_dense_narrow(X, W, U, NB, Cin, Cout, fwd_stream(m));
   }
-  if ((Cin % 32 == 0 || ((Cin == 8 || Cin == 16) && Cout <= 32 && !single_tap)) && !g_force_v1) {
+  // (dense operands whose width is a multiple of 4 but not of 32 - the 560-wide ones - take the ragged-K form of gconv2)
+  const bool ragged_dense = single_tap && Cin > 32 && (Cin & 3) == 0 && (Cin % 32) != 0 && !fz && !g_no_special;
+  if ((Cin % 32 == 0 || ragged_dense || ((Cin == 8 || Cin == 16) && Cout <= 32 && !single_tap)) && !g_force_v1) {
     GConv2Params q;
     memset(&q, 0, sizeof q);
     q.X = X; q.W = W; q.U = U; q.A = Aout; q.bias = bias; q.alpha = alpha;
@@ -888,7 +890,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     // dense-shaped contractions (few output tiles, long K): slice K over blockIdx.y into ws1 slabs
     const long MN = (long)NB * Hout * Hout * Cout;
     const long tiles64 = ((q.cls[0].M + 63) / 64) * (long)((Cout + 63) / 64);
-    const int nchunks = tp.n * (Cin / 32);
+    const int nchunks = tp.n * ((Cin + 31) / 32);
     if (single_tap && tiles64 < 256 && nchunks >= 32 && m->ws4) {
       const size_t ws4_cap = m->ws4_elems / 4;
       float* ws4 = m->ws4 + (size_t)m->lane_id * ws4_cap;   // each forward lane owns a quarter of the split-K workspace

@@ -28,7 +28,9 @@ __device__ __forceinline__ int t_wt(unsigned long long code, int t) { return (in
 }  // namespace
 
 // SUB = taps per 32-wide K chunk: 1 for Cin % 32 == 0, 2 for Cin == 16, 4 for Cin == 8 (tap then varies per lane)
-template <int BM, int BN, int WGM, int WGN, bool NMAJOR, int SUB = 1>
+// RAG: Cin is a multiple of 4 but not of 32 (the 560-wide dense operands, model.py:96-98,113-117): the last chunk of a tap
+// is ragged, its missing quads / rows are zero-filled through the same masks that handle out-of-image rows
+template <int BM, int BN, int WGM, int WGN, bool NMAJOR, int SUB = 1, bool RAG = false>
 // occupancy target: two workgroups per CU for the 128 x 128 tile (LDS-limited anyway), three for the smaller ones -
 // with the second register set the compiler otherwise settles just above the 168-register line of three waves / SIMD
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || BM >= 256) ? 2 : 3) void gconv2_kernel(const GConv2Params p) {
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || BM >= 256) ? 2 : 3) v
   f32x4 areg[2][AROWS];
   f32x4 breg[2][NMAJOR ? BROWS_N : BPASS];
   unsigned amask2[2] = {0, 0}, bmaskv2[2] = {0xffffffffu, 0xffffffffu};
-  const int cpt = SUB == 1 ? p.Cin / BK2 : 1;     // chunks per tap
+  const int cpt = SUB == 1 ? (RAG ? (p.Cin + BK2 - 1) / BK2 : p.Cin / BK2) : 1;     // chunks per tap
   int tap = 0, cc = 0;                            // chunk -> (tap, channel slab), advanced incrementally
 
   auto load_global = [&](auto setc) {             // loads chunk (tap, cc) into register set S, then advances
@@ -155,26 +157,31 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || BM >= 256) ? 2 : 3) v
       const int dh = t_dh(cl.tapcode, tap), dw = t_dw(cl.tapcode, tap);
       const int wt = t_wt(cl.wtcode, tap);
       const int tapoff = (dh * p.Win + dw) * p.Cin + cc * BK2;
+      const bool kv = !RAG || cc * BK2 + kq * 4 < p.Cin;       // this lane's channel quad exists
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
-        const bool ok = (rmask[i] >> tap) & 1;
+        const bool ok = ((rmask[i] >> tap) & 1) && kv;
         const unsigned off = ok ? (unsigned)(rin[i] + tapoff) : 0u;
         areg[S][i] = *reinterpret_cast<const f32x4*>(p.X + off);
         amask |= (ok ? 1u : 0u) << i;
       }
       if (NMAJOR) {
         const int wbase = wt * p.Cout * p.Cin + cc * BK2;
+        if (RAG) bmaskv = kv ? 0xffffffffu : 0u;
 #pragma unroll
         for (int i = 0; i < BROWS_N; ++i) {
-          const unsigned off = ((wok >> i) & 1u) ? (unsigned)(wbase + wthr[i]) : 0u;
+          const unsigned off = (((wok >> i) & 1u) && kv) ? (unsigned)(wbase + wthr[i]) : 0u;
           breg[S][i] = *reinterpret_cast<const f32x4*>(p.W + off);
         }
       } else {
         const int wbase = (wt * p.Cin + cc * BK2) * p.Cout;
+        if (RAG) bmaskv = 0;
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
-          const unsigned off = ((wok >> i) & 1u) ? (unsigned)(wbase + wthr[i]) : 0u;
+          const bool kvb = !RAG || cc * BK2 + (int)(tid / BQ) + BKR * i < p.Cin;   // this pass's weight row exists
+          const unsigned off = (((wok >> i) & 1u) && kvb) ? (unsigned)(wbase + wthr[i]) : 0u;
           breg[S][i] = *reinterpret_cast<const f32x4*>(p.W + off);
+          if (RAG) bmaskv |= (kvb ? 1u : 0u) << i;
         }
       }
       if (++cc == cpt) {
@@ -462,13 +469,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || BM >= 256) ? 2 : 3) v
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool NMAJOR, int SUB = 1>
+template <int BM, int BN, int WGM, int WGN, bool NMAJOR, int SUB = 1, bool RAG = false>
 static int launch2_cfg(GConv2Params p, hipStream_t s) {
   constexpr int A_ELEMS = BM * BK2;
   constexpr int B_ELEMS = NMAJOR ? BN * BK2 : BK2 * (BN + 4);
   constexpr size_t smem = (size_t)(2 * A_ELEMS + 2 * B_ELEMS) * sizeof(float) + 4 * BM * sizeof(int);
   static bool attr_set = false;
-  auto kern = gconv2_kernel<BM, BN, WGM, WGN, NMAJOR, SUB>;
+  auto kern = gconv2_kernel<BM, BN, WGM, WGN, NMAJOR, SUB, RAG>;
   if (!attr_set) {
     DV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
@@ -493,6 +500,7 @@ void debug_set_gconv2_tile(int code) { g2_tile_override = code; }
 // 5 128x16 (4), 6 256x32 (4), 7 256x16 (4)
 static int choose_tile(const GConv2Params& p) {
   const int N = p.Cout;
+  if (p.Cin % BK2 && p.Cin > 32) return 2;       // ragged-K form exists for the 64 x 64 tile only
   if (p.Cin == 8 || p.Cin == 16) return N <= 16 ? 5 : 3;
   if (g2_tile_override >= 0 && g2_tile_override <= 7) return g2_tile_override;
   long Mtot = 0;
@@ -524,6 +532,7 @@ void gconv2_tile_geometry(const GConv2Params& p, int* bm, int* wgm, long* mtiles
 template <bool NMAJOR>
 static int dispatch2(const GConv2Params& p, hipStream_t s) {
   const int t = choose_tile(p);
+  if (p.Cin % BK2 && p.Cin > 32) return launch2_cfg<64, 64, 2, 2, NMAJOR, 1, true>(p, s);   // ragged K (dense, 560 wide)
   if (p.Cin == 8) return t == 5 ? launch2_cfg<128, 16, 4, 1, NMAJOR, 4>(p, s) : launch2_cfg<128, 32, 4, 1, NMAJOR, 4>(p, s);
   if (p.Cin == 16) return t == 5 ? launch2_cfg<128, 16, 4, 1, NMAJOR, 2>(p, s) : launch2_cfg<128, 32, 4, 1, NMAJOR, 2>(p, s);
   switch (t) {
@@ -584,7 +593,8 @@ int launch_gconv2(const GConv2Params& p0, hipStream_t s) {
   p.dbg_out = g2_dbg_out;
   p.prio = g2_prio;
   const bool small_cin = (p.Cin == 8 || p.Cin == 16) && p.Cout <= 32 && p.ksplit <= 1;
-  if (p.nclass < 1 || p.nclass > 4 || ((p.Cin % BK2) && !small_cin) || (p.Cout & 3)) {
+  const bool ragged = p.Cin > 32 && (p.Cin & 3) == 0 && p.nclass == 1 && p.cls[0].ntaps == 1 && p.epi != 3;
+  if (p.nclass < 1 || p.nclass > 4 || ((p.Cin % BK2) && !small_cin && !ragged) || (p.Cout & 3)) {
     set_error("gconv2: unsupported shape (Cin=%d Cout=%d nclass=%d)", p.Cin, p.Cout, p.nclass);
     return E_INVALID;
   }
