@@ -74,7 +74,7 @@ static int bf_alloc(dv_model* m) {
   bf.slab_elems = (size_t)64 << 20;
   for (auto& sp : A.specs)          // a launch needs one slab per 64-stamp chunk at least: room for two such launches
     if (sp.ndim == 4) bf.slab_elems = std::max(bf.slab_elems, sp.count * 2 * std::max<size_t>(4, (Bp + 63) / 64));
-  bf.slab_tail = (size_t)4 << 20;
+  bf.slab_tail = (size_t)8 << 20;       // BF_MAIN_SLOTS regions (the launches a pass may queue on the main stream)
   DV_TRY(balloc((void**)&bf.slab, (bf.slab_elems + bf.slab_tail) * 4));
 
   // bf16 weight matrices and the descriptors the cast kernel walks
@@ -273,23 +273,32 @@ static int bf_flush_wred(dv_model* m) {
   return OK;
 }
 
+constexpr int BF_MAIN_SLOTS = 2;   // slab regions behind the pool for the launches queued on the main stream (layers 0, 1)
 // weight gradient of one layer: partial slabs into this launch's region of the pool; the fixed-order sum over the slabs
 // is registered and runs with all the others of the pass in one launch (17 five-microsecond reductions otherwise sit
 // between the weight-gradient kernels of the aux stream, which is the tail of the step)
 // on_main: queue the kernel on the main stream (the last launch of a pass: the main stream has nothing left to do while
 // the weight-gradient stream works off its backlog); the caller orders the slab reduction behind it
 static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, int Hy, int Cy, int s, int pb, float* out,
-                    int cpad, int creal, bool on_main = false) {
+                    int cpad, int creal, bool on_main = false, int main_slot = 0) {
   BfState& bf = m->bf;
   const size_t slab = (size_t)9 * Cx * Cy;
-  if (bf.wred.count >= DV_WRED_MAX || bf.slab_off + 4 * ((size_t)(bf.NBp + 63) / 64) * slab > bf.slab_elems)
+  if (bf.wred.count >= DV_WRED_MAX || bf.slab_off + 4 * ((size_t)(bf.NBp + 63) / 64) * slab > bf.slab_elems) {
+    // (rare: a pass without bucket boundaries on a deep net, or a full pool.)  The batch may hold a launch that was queued
+    // on the main stream: the reduction, on the weight-gradient stream, has to wait for it
+    hipStream_t wst = bf_wstream(m);
+    if (wst != m->ctx->stream) {
+      DV_HIP(hipEventRecord(m->ctx->ev_ready, m->ctx->stream));
+      DV_HIP(hipStreamWaitEvent(wst, m->ctx->ev_ready, 0));
+    }
     DV_TRY(bf_flush_wred(m));
+  }
   BWgradParams p;
   memset(&p, 0, sizeof p);
   p.X = X; p.Y = Y; p.zero = bf.zero; p.part = bf.slab + bf.slab_off; p.part_capacity = bf.slab_elems - bf.slab_off;
   if (on_main) {                 // its own region: the pool may still be read by a reduction the aux stream has not run yet
-    p.part = bf.slab + bf.slab_elems;
-    p.part_capacity = bf.slab_tail;
+    p.part = bf.slab + bf.slab_elems + (size_t)main_slot * (bf.slab_tail / BF_MAIN_SLOTS);
+    p.part_capacity = bf.slab_tail / BF_MAIN_SLOTS;
   }
   p.Hx = Hx; p.Cx = Cx; p.Hy = Hy; p.Cy = Cy; p.NBp = bf.NBp; p.s = s; p.pb = pb;
   int ns = 0;
@@ -526,6 +535,13 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     DV_TRY(launch_reduce_rows_f64(dbr, (int)Pn, fl, G + A.specs[A.enc_b(jl)].off, 1.0f, s));
   }
   // ---- encoder conv stack: cur = d(pre-activation) of layer j ----
+  // The tail of a pass is the weight-gradient stream's backlog: when the main stream has queued its last data gradient
+  // the aux stream still owes the launches of the last three or four layers.  Layer 1's launch is therefore held back and
+  // queued on the MAIN stream behind that data gradient, next to layer 0's (2.110 -> 2.093 ms; layers 2 and 3 as well:
+  // no further gain, four alternating same-box runs each).
+  const int want_defer = 1;
+  bool deferred[BF_MAIN_SLOTS] = {false, false};
+  bool any_deferred = false;
   for (int j = 2 * A.L - 1; j >= 0; --j) {
     int hin, cin, hout, cout, st;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
@@ -535,9 +551,16 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       // first conv with the folded input BatchNorm: the gradient w.r.t. the 16-channel folded kernel (channels
       // 0..C-1 = bands, C = the constant one) yields d(kernel), d(gamma), d(beta); no data gradient
       // last launch of the pass: on the (otherwise idle) main stream, slabs in the pool's tail region
-      const bool lm = ws != s && (size_t)((bf.NBp + 63) / 64) * 9 * 16 * cout <= bf.slab_tail;
+      const bool lm = ws != s && (size_t)((bf.NBp + 63) / 64) * 9 * 16 * cout <= bf.slab_tail / BF_MAIN_SLOTS;
       DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8, lm));
-      if (lm) {                                          // its slabs are summed on the weight-gradient stream
+      for (int jd = 1; jd < BF_MAIN_SLOTS; ++jd) {       // the launches held back behind the last data gradient
+        if (!deferred[jd]) continue;
+        int h1, c1, ho1, co1, s1;
+        A.enc_layer(jd, &h1, &c1, &ho1, &co1, &s1);
+        DV_TRY(bf_wgrad(m, bf.enc_a[jd - 1], h1, c1, bf.du_enc[jd], ho1, co1, s1, same_pad_before(h1, 3, s1, nullptr),
+                        G + A.specs[A.enc_k(jd)].off, c1, c1, true, jd));
+      }
+      if (lm || any_deferred) {                          // their slabs are summed on the weight-gradient stream
         DV_HIP(hipEventRecord(m->ctx->ev_ready, s));
         DV_HIP(hipStreamWaitEvent(ws, m->ctx->ev_ready, 0));
       }
@@ -550,7 +573,12 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
                                    ws));
       break;
     }
-    DV_TRY(bf_wgrad(m, bf.enc_a[j - 1], hin, cin, cur, hout, cout, st, pb, G + A.specs[A.enc_k(j)].off, cin, cin));
+    if (j <= want_defer && ws != s && j < BF_MAIN_SLOTS && j < A.L &&
+        (size_t)((bf.NBp + 63) / 64) * 9 * cin * cout <= bf.slab_tail / BF_MAIN_SLOTS) {
+      deferred[j] = any_deferred = true;                 // queued on the main stream behind the last data gradient
+    } else {
+      DV_TRY(bf_wgrad(m, bf.enc_a[j - 1], hin, cin, cur, hout, cout, st, pb, G + A.specs[A.enc_k(j)].off, cin, cin));
+    }
     oth = next_buf();
     DV_TRY(bf_dgrad_prelu(m, cur, bf.enc_w[j].d, bf.enc_w[j].Kd, 1, hout, cout, hin, cin, st, pb, oth, bf.enc_u[j - 1],
                           A.enc_al(j - 1), A.enc_b(j - 1), true));
