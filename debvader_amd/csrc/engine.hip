@@ -873,7 +873,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
   if (single_tap && nmajor && Hin == 1 && Hout == 1 && Cout <= 64 && Cin <= 1024 && epi == 0 && !bias && !fz && !g_force_v1 &&
       !g_no_special) {
     // narrow dense data gradient (hidden -> latent_dim): one wave per stamp instead of two serial 128 x 32 tiles
-    ProfScope ps(m, 0, nullptr, PF_GCONV, flops);
+    ProfScope ps(m, 2);                                // (9 MFLOP per step: timed with the small kernels, not as a matrix family)
     return launch_dense_narrow(X, W, U, NB, Cin, Cout, fwd_stream(m));
   }
   // (dense operands whose width is a multiple of 4 but not of 32 - the 560-wide ones - take the ragged-K form of gconv2)
