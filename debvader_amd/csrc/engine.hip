@@ -2097,6 +2097,15 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   // the last gradient bucket anyway, so it does not stop here for this latency-bound collective
   DV_TRY(allreduce_small(m->ctx, m->scal, 4, !bwd));
   if (mode == MODE_TRAIN && m->hint_next_first >= 0 && !m->prof_on) {
+    // fp32 engine: the statistics pass of the NEXT batch (35 us, HBM-bound, comm stream) is held until this forward pass
+    // has drained: beside the forward's persistent one-workgroup-per-CU Winograd kernels it takes CU slots one of their
+    // launches then finishes without (4.685 -> 4.655 ms per step, three alternating same-box runs; later gates - the
+    // decoder trunk, the encoder trunk - 4.66 / 4.67).  The bf16 engine's forward kernels share a CU: no gate (2.09 ms
+    // without, 2.11 with).
+    if (!m->bf.on && m->ctx->comm_stream && !m->ctx->comm) {   // (with a communicator allreduce_small above is that gate)
+      DV_HIP(hipEventRecord(m->ctx->ev_small, s));
+      DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, m->ctx->ev_small, 0));
+    }
     DV_TRY(bn_prefetch(m, ds.x, m->hint_next_first, B));
     m->hint_next_first = -1;
   }
