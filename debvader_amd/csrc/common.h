@@ -241,6 +241,10 @@ struct WGradParams {
   int rows_total;     // 9*Cx (slab rows; launch covers rows wt*Cx..)
   int nsplit;
   int pchunk;         // pixels per split (multiple of 32)
+  // filled by launch_wgrad: exact division of a pixel index by Hc*Wc and by Wc as multiply-high + shifts (the gather
+  // decodes its pixel once per chunk and thread; a 32-bit division is ~35 vector instructions, this is 5 - and on
+  // gfx950 every vector instruction is fp32-MFMA time)
+  unsigned div_hw_m, div_hw_s1, div_hw_s2, div_w_m, div_w_s1, div_w_s2;
 };
 int launch_wgrad(const WGradParams& p, hipStream_t s);
 

@@ -74,26 +74,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
     const bool pv = pp < pend;
     int nb = 0, ii = 0, jj = 0;
     if (pv) {
-      nb = pp / HcWc;
-      int rem = pp - nb * HcWc;
-      ii = rem / p.Wc;
-      jj = rem - ii * p.Wc;
+      // exact n / d for any 32-bit n (Granlund-Montgomery: t = mulhi(m, n); q = (t + ((n - t) >> s1)) >> s2)
+      const unsigned n = (unsigned)pp;
+      const unsigned t1 = __umulhi(p.div_hw_m, n);
+      nb = (int)((t1 + ((n - t1) >> p.div_hw_s1)) >> p.div_hw_s2);
+      const unsigned rem = n - (unsigned)nb * (unsigned)HcWc;
+      const unsigned t2 = __umulhi(p.div_w_m, rem);
+      ii = (int)((t2 + ((rem - t2) >> p.div_w_s1)) >> p.div_w_s2);
+      jj = (int)rem - ii * p.Wc;
     }
+    // (element offsets fit 32 bits: launch_wgrad refuses tensors of 2^31 elements or more)
+    const int xrow0 = nb * p.Hx;
 #pragma unroll
     for (int i = 0; i < AQ; ++i) {
       int ih = ii * p.sx + adh[i], iw = jj * p.sx + adw[i];
       bool ok = pv && aok[i] && (unsigned)ih < (unsigned)p.Hx && (unsigned)iw < (unsigned)p.Wx;
-      size_t off = ok ? ((size_t)((nb * p.Hx + ih) * p.Wx + iw)) * p.Cx + acx[i] : 0;
+      const unsigned off = ok ? (unsigned)(((xrow0 + ih) * p.Wx + iw) * p.Cx + acx[i]) : 0u;
       areg[S][i] = *reinterpret_cast<const f32x4*>(p.X + off);
       amask |= (ok ? 1u : 0u) << i;
     }
-    const size_t ypix = (size_t)((nb * p.Hy + ii * p.sy + p.ph) * p.Wy + jj * p.sy + p.pw) * p.Cy;
+    const unsigned ypix = (unsigned)(((nb * p.Hy + ii * p.sy + p.ph) * p.Wy + jj * p.sy + p.pw) * p.Cy);
 #pragma unroll
     for (int i = 0; i < BQ; ++i) {
       int cl = 4 * (q + 8 * i);
       int c = n0 + cl;
       bool ok = pv && cl < BNW && c < p.Cy;
-      breg[S][i] = *reinterpret_cast<const f32x4*>(p.Y + (ok ? ypix + c : 0));
+      breg[S][i] = *reinterpret_cast<const f32x4*>(p.Y + (ok ? ypix + (unsigned)c : 0u));
       bmask |= (ok ? 1u : 0u) << i;
     }
     amask2[S] = amask;
@@ -210,8 +216,23 @@ static int launch_w(const WGradParams& p, hipStream_t s) {
   return OK;
 }
 
-int launch_wgrad(const WGradParams& p, hipStream_t s) {
-  if (p.P <= 0) return OK;
+static void fast_div_consts(unsigned d, unsigned* m, unsigned* s1, unsigned* s2) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;                     // ceil(log2 d), d >= 1
+  *m = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  *s1 = l < 1 ? l : 1;
+  *s2 = l - *s1;
+}
+
+int launch_wgrad(const WGradParams& p0, hipStream_t s) {
+  if (p0.P <= 0) return OK;
+  WGradParams p = p0;
+  if (p.Hc < 1 || p.Wc < 1 || (long)p.NB * p.Hx * p.Wx * p.Cx >= (1L << 31) || (long)p.NB * p.Hy * p.Wy * p.Cy >= (1L << 31)) {
+    set_error("wgrad: tensor too large for 32-bit element offsets; lower max_batch");
+    return E_INVALID;
+  }
+  fast_div_consts((unsigned)(p.Hc * p.Wc), &p.div_hw_m, &p.div_hw_s1, &p.div_hw_s2);
+  fast_div_consts((unsigned)p.Wc, &p.div_w_m, &p.div_w_s1, &p.div_w_s2);
   if ((p.Cx & 3) || (p.Cy & 3) || (p.pchunk % BKP) || p.nsplit < 1 || (long)p.nsplit * p.pchunk < p.P) {
     set_error("wgrad: bad parameters (Cx=%d Cy=%d pchunk=%d nsplit=%d P=%d)", p.Cx, p.Cy, p.pchunk, p.nsplit, p.P);
     return E_INVALID;
