@@ -320,10 +320,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(float* __restrict__ da, 
   if (act) {
     const f32x4 al = *reinterpret_cast<const f32x4*>(alpha + e);
     const int nbeg = split * nper, nend = min(NB, nbeg + nper);
-    for (int n = nbeg; n < nend; ++n) {
-      const size_t off = (size_t)n * E + e;
-      f32x4 g = *reinterpret_cast<const f32x4*>(da + off);
-      f32x4 uv = *reinterpret_cast<const f32x4*>(u + off);
+    auto one = [&](const f32x4& g, const f32x4& uv, size_t off) {
       f32x4 d;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -333,6 +330,25 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(float* __restrict__ da, 
         dbs[k] += d[k];
       }
       *reinterpret_cast<f32x4*>(da + off) = d;
+    };
+    // four stamps per trip, all eight loads issued before the first in-place store (the compiler will not move a load of
+    // `da` above a store to `da`): same sums in the same order
+    int n = nbeg;
+    for (; n + 4 <= nend; n += 4) {
+      const size_t o0 = (size_t)n * E + e, o1 = o0 + E, o2 = o1 + E, o3 = o2 + E;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(da + o0), u0 = *reinterpret_cast<const f32x4*>(u + o0);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(da + o1), u1 = *reinterpret_cast<const f32x4*>(u + o1);
+      const f32x4 g2 = *reinterpret_cast<const f32x4*>(da + o2), u2 = *reinterpret_cast<const f32x4*>(u + o2);
+      const f32x4 g3 = *reinterpret_cast<const f32x4*>(da + o3), u3 = *reinterpret_cast<const f32x4*>(u + o3);
+      one(g0, u0, o0);
+      one(g1, u1, o1);
+      one(g2, u2, o2);
+      one(g3, u3, o3);
+    }
+    for (; n < nend; ++n) {
+      const size_t off = (size_t)n * E + e;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(da + off), uv = *reinterpret_cast<const f32x4*>(u + off);
+      one(g, uv, off);
     }
     if (dalpha_part) *reinterpret_cast<f32x4*>(dalpha_part + (size_t)split * E + e) = dal;
     if (dbias_mode == 1) *reinterpret_cast<f32x4*>(dbias_part + (size_t)split * E + e) = dbs;
