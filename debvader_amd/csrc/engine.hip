@@ -420,7 +420,7 @@ struct dv_model {
   bool fuse_first = true;     // DV_NO_FUSE_FIRST=1 keeps the first PReLU backward as a separate pass
   bool no_fuse = true;        // dv_debug_fuse_prelu_bwd(1) fuses the PReLU backward into the data-gradient epilogue (batch-major
                               // tiles); measured 3 % slower than the separate pass on MI355X (scattered 128-byte rows), so off
-  bool arena_reduce = true;   // queue d(alpha)/d(bias) reductions on the aux stream (tuning toggles: DV_NO_OVERLAP, DV_NO_ARENA)
+  bool arena_reduce = true;   // queue d(alpha)/d(bias) reductions on the aux stream (off with DV_NO_OVERLAP)
   float *ws1 = nullptr, *ws2 = nullptr, *ws3 = nullptr;
   size_t ws1_elems = 0, ws2_elems = 0, ws3_elems = 0;
   float *scal = nullptr, *bnstate = nullptr, *bnsums = nullptr;
