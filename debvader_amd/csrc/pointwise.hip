@@ -53,38 +53,74 @@ int launch_reduce_rows_f64(const float* part, int nrows, int ncols, float* out, 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm over the band axis
 constexpr int BN_MAXC = 8;
-constexpr int BN_PIX_PER_BLOCK = 4096;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int BN_PIX_PER_BLOCK = 1024;
 
+// Per-band sums of x and x^2 over a block's 1024 pixels.  Four pixels per thread, all of their loads issued before the
+// first add (six bands: three 8-byte loads per pixel - a pixel is 24 bytes); one LDS stage for the 16 block sums.
+// (Round 3: 4096 pixels per block were 218 blocks for 256 CUs, sixteen dependent trips of six scalar loads each and 32
+// block-wide barriers at the end: 35 us for 21 MB; this form: see DESIGN 4.)
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, const int* __restrict__ idx,
                                                        int first, int NB, int HW, int C, float* __restrict__ part) {
-  __shared__ float sh[4];
-  const long total = (long)NB * HW;
-  const long p0 = (long)blockIdx.x * BN_PIX_PER_BLOCK;
+  __shared__ float sh[4][2 * BN_MAXC];
+  const int total = NB * HW;
+  const int p0 = blockIdx.x * BN_PIX_PER_BLOCK + threadIdx.x;
   float s[BN_MAXC], ss[BN_MAXC];
 #pragma unroll
   for (int c = 0; c < BN_MAXC; ++c) s[c] = ss[c] = 0.f;
-  for (long pp = p0 + threadIdx.x; pp < min(total, p0 + BN_PIX_PER_BLOCK); pp += 256) {
-    int b = (int)(pp / HW);
-    int pix = (int)(pp - (long)b * HW);
-    long row = idx ? idx[b] : first + b;
-    const float* px = x + (row * HW + pix) * C;
+  const float* px[4];
+  bool ok[4];
 #pragma unroll
-    for (int c = 0; c < BN_MAXC; ++c)
-      if (c < C) {
-        float v = px[c];
-        s[c] += v;
-        ss[c] += v * v;
+  for (int k = 0; k < 4; ++k) {
+    const int pp = p0 + 256 * k;
+    ok[k] = pp < total;
+    const int b = ok[k] ? pp / HW : 0;
+    const int pix = ok[k] ? pp - b * HW : 0;
+    const long row = idx ? idx[b] : first + b;
+    px[k] = x + (row * HW + pix) * C;
+  }
+  if (C == 6) {
+    f32x2 v[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v[k][j] = ok[k] ? reinterpret_cast<const f32x2*>(px[k])[j] : (f32x2){0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        s[2 * j] += v[k][j][0];
+        ss[2 * j] += v[k][j][0] * v[k][j][0];
+        s[2 * j + 1] += v[k][j][1];
+        ss[2 * j + 1] += v[k][j][1] * v[k][j][1];
       }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < BN_MAXC; ++c)
+        if (c < C && ok[k]) {
+          const float v = px[k][c];
+          s[c] += v;
+          ss[c] += v * v;
+        }
   }
 #pragma unroll
   for (int c = 0; c < BN_MAXC; ++c) {
-    float a = block_sum(s[c], sh);
-    float b = block_sum(ss[c], sh);
-    if (threadIdx.x == 0) {
-      part[blockIdx.x * 2 * BN_MAXC + c] = a;
-      part[blockIdx.x * 2 * BN_MAXC + BN_MAXC + c] = b;
+    s[c] = wave_sum(s[c]);
+    ss[c] = wave_sum(ss[c]);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int c = 0; c < BN_MAXC; ++c) {
+      sh[threadIdx.x >> 6][c] = s[c];
+      sh[threadIdx.x >> 6][BN_MAXC + c] = ss[c];
     }
   }
+  __syncthreads();
+  if (threadIdx.x < 2 * BN_MAXC)
+    part[blockIdx.x * 2 * BN_MAXC + threadIdx.x] =
+        (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 int launch_bn_stats(const float* x, const int* idx, int first, int NB, int HW, int C, float* part, int* nblocks,
@@ -94,6 +130,10 @@ int launch_bn_stats(const float* x, const int* idx, int first, int NB, int HW, i
     return E_INVALID;
   }
   long total = (long)NB * HW;
+  if (total >= (1L << 31) - BN_PIX_PER_BLOCK) {
+    set_error("bn: batch too large (pixel count must fit 31 bits)");
+    return E_INVALID;
+  }
   int nb = (int)((total + BN_PIX_PER_BLOCK - 1) / BN_PIX_PER_BLOCK);
   *nblocks = nb;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, s, x, idx, first, NB, HW, C, part);
@@ -497,7 +537,6 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
 
 // 6-band specialisation (the reference's only exercised band count): 3 x 16-byte loads/stores per pixel for the
 // 12-channel head tensors, 8-byte accesses for the 6-channel label / output rows.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void head6_kernel(const HeadParams p) {
   __shared__ float sh[4];
   const long total = (long)p.NB * p.Hd * p.Hd;
