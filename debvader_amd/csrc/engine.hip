@@ -2653,7 +2653,14 @@ static int ctx_build(dv_ctx* c, int world, int rank, const void* unique_id) {
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
     StdoutToStderr quiet;
-    DV_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+    if (getenv("DV_DEBUG_FAKE_PEERS")) {
+      // rehearsal hook (see parallel.make_context): a one-rank communicator per rank, so that several ranks can share the
+      // one GPU of a build box; everything else believes in `world` ranks
+      DV_NCCL(ncclGetUniqueId(&id));
+      DV_NCCL(ncclCommInitRank(&c->comm, 1, id, 0));
+    } else {
+      DV_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+    }
   }
   return DV_OK;
 }

@@ -245,6 +245,12 @@ def make_context(rank: int, world: int, local_rank: Optional[int] = None, group=
     context (ctx.group) for the caller's barriers and is closed with it."""
     if local_rank is None:
         local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    if os.environ.get("DV_DEBUG_SAME_GPU"):
+        # rehearsal of a multi-rank launch on a one-GPU box: every rank opens device 0 (a real RCCL communicator refuses
+        # two ranks on one device; with DV_DEBUG_FAKE_PEERS=1 the engine gives each rank a one-rank communicator instead,
+        # so the gradients are NOT summed - the launch line, the rendezvous, the multi-rank event scopes and the step
+        # structure run for real, the numbers mean nothing)
+        local_rank = 0
     if world == 1:
         ctx = E.Context(local_rank, 0, 1, None)
         ctx.group = group

@@ -560,3 +560,33 @@ def test_config0_plumbing_1000_stamps_batch_5_and_256():
         r = vo.losses(arch, c, y[:5].astype(np.float64))
         for k in ("loss", "nll_mean", "kl_reg"):
             assert abs(out[k] - r[k]) <= 1e-4 * abs(r[k]) + 1e-7, (batch, k, out[k], r[k])
+
+
+@pytest.mark.gpu
+def test_multi_rank_bench_launch_rehearsed_on_one_gpu():
+    """The driver's N > 1 launch line with the REAL engine: `python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2`.  A build box has one GPU and RCCL refuses two ranks on one device, so DV_DEBUG_SAME_GPU=1 opens device 0
+    on every rank and DV_DEBUG_FAKE_PEERS=1 gives each rank a one-rank communicator (the gradients are not summed: the
+    numbers mean nothing).  What runs for real: the torch-free rendezvous beside torchrun's own store, rank 0's RCCL id
+    reaching every rank, a context that believes in two ranks (system-scope ordering events, global batch 2 x 256 in the
+    loss scale and the BN statistics, collectives on the comm stream), the barriers and the MAX over ranks, ONE JSON
+    line from rank 0, and a clean exit of every process."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update({"DV_DEBUG_SAME_GPU": "1", "DV_DEBUG_FAKE_PEERS": "1"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3",
+           "--no-roofline", "--no-secondary", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
+    assert d["steps"] == 8 and d["value"] > 0 and np.isfinite(d["last_loss"])
+
