@@ -61,7 +61,9 @@ def deblend_sharded(net, images, normalise=False, dist=None, gather=True, rank=N
 
     parameters:
         net, images, normalise: as deblend().  Every rank passes the same `images` (or at least its own range of it).
-        dist: torch.distributed-like object with gather_object (gloo); only used to bring the pieces to rank 0
+        dist: how the pieces reach rank 0 - a parallel.HostGroup (default: the group of the network's context, i.e. the
+              torch-free rendezvous the ranks already met in) or a torch.distributed-like object with
+              gather_object(obj, object_gather_list, dst) (gloo)
         gather: True - rank 0 returns the full (mean, stddev) arrays in input order, other ranks (None, None);
                 False - every rank returns its own shard (mean, stddev) and (begin, end); nothing is exchanged
                 (the 1M-cutout case: 83 KB of output per stamp does not belong on one host)
@@ -85,9 +87,15 @@ def deblend_sharded(net, images, normalise=False, dist=None, gather=True, rank=N
     if world == 1:
         return mean, std
     if dist is None:
-        raise ValueError("gather=True with more than one rank needs a torch.distributed-like `dist` (gather_object)")
-    pieces = [None] * world if rank == 0 else None
-    dist.gather_object((lo, hi, mean, std), pieces, dst=0)
+        dist = getattr(ctx, "group", None)
+    if dist is None:
+        raise ValueError("gather=True with more than one rank needs the context's HostGroup or a torch.distributed-like "
+                         "`dist` (gather_object)")
+    if hasattr(dist, "allgather") and not hasattr(dist, "get_backend"):
+        pieces = dist.gather_object((lo, hi, mean, std), dst=0)          # parallel.HostGroup: returns the list on dst
+    else:
+        pieces = [None] * world if rank == 0 else None
+        dist.gather_object((lo, hi, mean, std), pieces, dst=0)           # torch.distributed form: fills the list
     if rank != 0:
         return None, None
     full_m = np.empty((images.shape[0],) + mean.shape[1:], np.float32)

@@ -162,3 +162,49 @@ def test_deblend_sharded_ranges_and_gather_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == {0: "ok", 1: "ok"}, res
+
+
+def _shard_worker_hostgroup(rank, world, port, q):
+    """The same through the torch-free rendezvous: dist = parallel.HostGroup, and dist = None with the group attached to
+    the network's context (what parallel.make_context does)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    group = None
+    try:
+        from debvader_amd.deblend_cutout.deblender import deblend_sharded
+        from debvader_amd.parallel import HostGroup
+
+        group = HostGroup(rank, world)
+        rng = np.random.default_rng(4)
+        for n, explicit in ((7, True), (1, False), (64, False)):
+            x = rng.normal(size=(n, 5, 5, 2))
+            net = _StubNet(rank, world)
+            net._core.ctx.group = group
+            m, s = deblend_sharded(net, x, dist=group) if explicit else deblend_sharded(net, x)
+            if rank == 0:
+                np.testing.assert_array_equal(m, (x.astype(np.float32) * 2.0 + 1.0))
+                np.testing.assert_array_equal(s, np.abs(x.astype(np.float32)) + 0.5)
+            else:
+                assert m is None and s is None
+        group.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:                            # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        if group is not None:
+            group.close()
+
+
+def test_deblend_sharded_gathers_through_the_host_group_world2():
+    """Round 3: deblend_sharded(dist=ctx.group) called HostGroup.gather_object with torch.distributed's signature and
+    failed with a TypeError the first time it ran with two real ranks (tools/fit_multirank_rehearsal.py on a GPU box)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker_hostgroup, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: "ok", 1: "ok"}, res
+

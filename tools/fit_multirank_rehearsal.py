@@ -20,6 +20,18 @@ x, y = synthetic_stamps(4 * B, seed=3)
 xv, yv = synthetic_stamps(B, seed=4)
 net, _, _, _ = model.create_model_vae((59, 59, 6), 32, [32, 64, 128, 256], [3, 3, 3, 3], max_batch=B // world, ctx=ctx)
 net.compile(optimizer=model.Adam(learning_rate=1e-4), loss=vae_loss, metrics=["mse"])
+# inference sharded by contiguous index ranges (configs[4]), gathered on rank 0 through the rendezvous group (each rank
+# draws its own latent noise - the Philox stream id is the rank - so the pieces are not comparable bit for bit with a
+# one-rank call; shapes, finiteness and the order of the pieces are)
+from debvader_amd.deblend_cutout.deblender import deblend_sharded
+ms, ss = deblend_sharded(net, xv)                    # dist defaults to the context's HostGroup
+if rank == 0:
+    good = ms.shape == xv.shape and ss.shape == xv.shape and np.isfinite(ms).all() and (ss > 0).all()
+    print("deblend_sharded over", world, "ranks gathered on rank 0:", ms.shape, "finite:", bool(good), flush=True)
+    if not good:
+        sys.exit(1)
+else:
+    assert ms is None and ss is None
 tmp = tempfile.mkdtemp() if rank == 0 else None
 cbs = [ModelCheckpoint(os.path.join(tmp or "/nonexistent", "w", "weights"), save_weights_only=True)]   # (only rank 0 writes)
 h = net.fit(x, y, epochs=2, batch_size=B, validation_data=(xv, yv), callbacks=cbs, verbose=0)
