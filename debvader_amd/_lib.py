@@ -80,6 +80,9 @@ SIGNATURES = {
     "dv_ctx_destroy": (C.c_int, [_p]),
     "dv_ctx_sync": (C.c_int, [_p]),
     "dv_ctx_allreduce_host": (C.c_int, [_p, _f, C.c_int32]),
+    "dv_ctx_comm_info": (C.c_int, [_p, _i32, _i32, _i32, C.c_char_p, C.c_size_t, _i32]),
+    "dv_comm_prof_enable": (C.c_int, [_p, C.c_int32]),
+    "dv_comm_prof_read": (C.c_int, [_p, _i64, C.POINTER(C.c_double), _i64, C.POINTER(C.c_double)]),
     "dv_model_create": (C.c_int, [_p, C.POINTER(DvConfig), C.POINTER(_p)]),
     "dv_model_destroy": (C.c_int, [_p]),
     "dv_model_init": (C.c_int, [_p, C.c_uint64]),
@@ -102,7 +105,6 @@ SIGNATURES = {
     "dv_train_steps": (C.c_int, [_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _f]),
     "dv_model_set_normalise": (C.c_int, [_p, C.c_int32]),
     "dv_model_set_mse_sample": (C.c_int, [_p, C.c_int32]),
-    "dv_model_set_infer_graph": (C.c_int, [_p, C.c_int32]),
     "dv_model_set_keep_outputs": (C.c_int, [_p, C.c_int32]),
     "dv_infer": (C.c_int, [_p, _f, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
     "dv_infer_f64": (C.c_int, [_p, _d, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
@@ -120,20 +122,18 @@ SIGNATURES = {
     "dv_prof_reset": (C.c_int, [_p]),
     "dv_prof_read_family": (C.c_int, [_p, C.c_int32, C.c_char_p, C.c_size_t, _i64, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double)]),
-    "dv_debug_gconv": (C.c_int, [_p] + [C.c_int32] * 13 + [_f]),
-    "dv_debug_gconv_check": (C.c_int, [_p] + [C.c_int32] * 10 + [_f]),
-    "dv_debug_mfma_peak": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
-    "dv_debug_general_kernels": (C.c_int, [C.c_int32]),
-    "dv_debug_winograd": (C.c_int, [C.c_int32]),
-    "dv_debug_fuse_prelu_bwd": (C.c_int, [C.c_int32]),
-    "dv_debug_wgrad_check": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
-    "dv_debug_wgrad": (C.c_int, [_p] + [C.c_int32] * 9 + [_f]),
 }
 
-for _name, (_res, _args) in SIGNATURES.items():
-    _fn = getattr(lib, _name)
-    _fn.restype = _res
-    _fn.argtypes = _args
+def bind(handle, signatures):
+    """restype / argtypes of every listed symbol on a loaded library (raises AttributeError for a missing export)."""
+    for _name, (_res, _args) in signatures.items():
+        _fn = getattr(handle, _name)
+        _fn.restype = _res
+        _fn.argtypes = _args
+    return handle
+
+
+bind(lib, SIGNATURES)
 
 
 def last_error() -> str:

@@ -73,6 +73,14 @@ __device__ __forceinline__ float dv_philox_normal(unsigned row, unsigned col, un
 // Conv2D forward, Conv2DTranspose forward (stride-2 as 4 parity classes), their data gradients and
 // the Dense layers are all instances of this one contraction.
 // ---------------------------------------------------------------------------------------------
+// Tap table of the general kernels (gconv.hip, wgrad.hip): any kernel size up to 5 x 5 (model.py:81-91,121-134 take
+// kernels[i] freely).  Entry t = (dh + 8) | (dw + 8) << 4 | weight tap index << 8.
+#define DV_MAX_TAPS 25
+struct TapTab {
+  int n;
+  unsigned t[DV_MAX_TAPS];
+};
+
 struct GConvParams {
   const float* X;
   const float* W;
@@ -85,8 +93,7 @@ struct GConvParams {
   int Hc, Wc;
   int sin, sout, ph, pw;
   int ntaps;
-  unsigned long long tapcode;  // 4 bits per tap: (dh+1) | (dw+1)<<2
-  unsigned long long wtcode;   // 4 bits per tap: weight tap index
+  TapTab xt;                   // the taps: (dh, dw) source offset and weight tap index of each
   int M, K;
   int w_nmajor;
   int epi;             // 0 raw, 1 +bias, 2 +bias then PReLU (alpha)
@@ -236,9 +243,9 @@ struct WGradParams {
   int Hy, Wy, Cy;
   int Hc, Wc, sx, sy, ph, pw;
   int ntaps;
-  unsigned long long tapcode, wtcode;
+  TapTab xt;          // the taps (dh, dw, weight tap index)
   int P;              // NB*Hc*Wc
-  int rows_total;     // 9*Cx (slab rows; launch covers rows wt*Cx..)
+  int rows_total;     // ntaps*Cx (slab rows; launch covers rows wt*Cx..)
   int nsplit;
   int pchunk;         // pixels per split (multiple of 32)
   // filled by launch_wgrad: exact division of a pixel index by Hc*Wc and by Wc as multiply-high + shifts (the gather

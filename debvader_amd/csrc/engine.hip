@@ -23,7 +23,9 @@
 #include <vector>
 
 #include "../../include/debvader_hip.h"
+#ifdef DV_DEBUG_EXPORTS
 #include "../../include/debvader_hip_debug.h"
+#endif
 #include <chrono>
 #include "common.h"
 #include "bf16.h"
@@ -80,6 +82,10 @@ struct Arch {
   int64_t n_enc_params = 0, n_dec_params = 0, n_trainable_params = 0;
   int D0 = 0;
 
+  // kernel size of encoder conv j / decoder conv-transpose j (model.py:81-91: both convs of level i use kernels[i];
+  // model.py:120-134: the decoder walks the levels in reverse)
+  int enc_ksz(int j) const { return cfg.kernels[j / 2]; }
+  int dec_ksz(int j) const { return cfg.kernels[L - 1 - j / 2]; }
   int enc_k(int j) const { return 4 + 3 * j; }
   int enc_b(int j) const { return 5 + 3 * j; }
   int enc_al(int j) const { return 6 + 3 * j; }
@@ -128,8 +134,12 @@ struct Arch {
       return E_INVALID;
     }
     for (int i = 0; i < L; ++i) {
-      if (c->kernels[i] != 3) {
-        set_error("only 3x3 kernels are implemented (kernels[%d]=%d)", i, c->kernels[i]);
+      if (c->kernels[i] < 1 || c->kernels[i] > 5) {
+        set_error("kernel sizes 1 .. 5 are implemented (kernels[%d]=%d)", i, c->kernels[i]);
+        return E_INVALID;
+      }
+      if (c->kernels[i] != 3 && c->dtype == DV_DTYPE_BF16) {
+        set_error("the bf16 engine implements 3x3 kernels only (kernels[%d]=%d): use dtype f32", i, c->kernels[i]);
         return E_INVALID;
       }
       if (c->filters[i] < 4 || (c->filters[i] & 3)) {
@@ -173,7 +183,7 @@ struct Arch {
       enc_layer(j, &hin, &cin, &hout, &cout, &s);
       char b[64];
       snprintf(b, sizeof b, "enc/conv%d/kernel", j);
-      add(b, {3, 3, cin, cout}, true);
+      add(b, {enc_ksz(j), enc_ksz(j), cin, cout}, true);
       snprintf(b, sizeof b, "enc/conv%d/bias", j);
       add(b, {cout}, true);
       snprintf(b, sizeof b, "enc/prelu%d/alpha", j);
@@ -195,7 +205,7 @@ struct Arch {
       dec_layer(j, &hin, &cin, &hout, &cout, &s);
       char b[64];
       snprintf(b, sizeof b, "dec/convt%d/kernel", j);
-      add(b, {3, 3, cout, cin}, true);
+      add(b, {dec_ksz(j), dec_ksz(j), cout, cin}, true);
       snprintf(b, sizeof b, "dec/convt%d/bias", j);
       add(b, {cout}, true);
       snprintf(b, sizeof b, "dec/prelut%d/alpha", j);
@@ -203,8 +213,10 @@ struct Arch {
     }
     add("dec/head/kernel", {3, 3, c->filters[0], 2 * C}, true);
     add("dec/head/bias", {2 * C}, true);
-    if (tw & 3 || dec_hidden & 3 || d & 3 || (2 * C) & 3) {
-      set_error("latent_dim and 2*bands must be multiples of 4 for the vectorised kernels");
+    // (any band count 1 .. 7: the first conv reads bands + 1 of 8 folded channels, the head stores 2*bands of C2p
+    // columns, and the label / output rows of the head kernels are addressed per element unless bands == 6)
+    if (tw & 3 || dec_hidden & 3 || d & 3) {
+      set_error("latent_dim must be a multiple of 4 for the vectorised kernels");
       return E_INVALID;
     }
     // flat layout: [encoder trainables | decoder trainables | non-trainables], every tensor 16-byte aligned
@@ -235,14 +247,14 @@ struct Arch {
     for (int j = 0; j < 2 * L; ++j) {
       int hin, cin, hout, cout, s;
       enc_layer(j, &hin, &cin, &hout, &cout, &s);
-      e += (int64_t)hout * hout * 9 * cin * cout;
+      e += (int64_t)hout * hout * enc_ksz(j) * enc_ksz(j) * cin * cout;
     }
     e += (int64_t)flat * tw;
     dd += (int64_t)d * dec_hidden + (int64_t)dec_hidden * w0 * w0 * cfg.filters[L - 1];
     for (int j = 0; j < 2 * L; ++j) {
       int hin, cin, hout, cout, s;
       dec_layer(j, &hin, &cin, &hout, &cout, &s);
-      dd += (int64_t)hin * hin * 9 * cin * cout;  // every input pixel meets all 9 taps
+      dd += (int64_t)hin * hin * dec_ksz(j) * dec_ksz(j) * cin * cout;  // every input pixel meets all k*k taps
     }
     dd += (int64_t)dec_out * dec_out * 9 * cfg.filters[0] * 2 * C;
     *enc = e;
@@ -255,30 +267,41 @@ struct Arch {
 // --------------------------------------------------------------------------------------------
 struct Taps {
   int n = 0;
+  // legacy 4-bit codes of the 3 x 3 kernel families (gconv2 / strip / Winograd: offsets -1 .. 2, at most 16 taps) ...
   unsigned long long tapcode = 0, wtcode = 0;
+  bool legacy = true;      // ... which cannot express this tap set when false
+  // ... and the general table (gconv / wgrad kernels, any kernel size up to 5 x 5)
+  TapTab xt = {};
   void add(int dh, int dw, int wt) {
-    tapcode |= (unsigned long long)(((dh + 1) & 3) | (((dw + 1) & 3) << 2)) << (4 * n);
-    wtcode |= (unsigned long long)(wt & 15) << (4 * n);
+    if (n < DV_MAX_TAPS) xt.t[n] = (unsigned)(dh + 8) | ((unsigned)(dw + 8) << 4) | ((unsigned)wt << 8);
+    if (n < 16 && dh >= -1 && dh <= 2 && dw >= -1 && dw <= 2 && wt < 16) {
+      tapcode |= (unsigned long long)(((dh + 1) & 3) | (((dw + 1) & 3) << 2)) << (4 * n);
+      wtcode |= (unsigned long long)(wt & 15) << (4 * n);
+    } else {
+      legacy = false;
+    }
     ++n;
+    xt.n = n;
   }
 };
-// input pixel = out*s + k - pad_before
-static Taps taps_fprop(int pb) {
+// input pixel = out*s + k - pad_before, k x k kernel
+static Taps taps_fprop(int pb, int k = 3) {
   Taps t;
-  for (int kh = 0; kh < 3; ++kh)
-    for (int kw = 0; kw < 3; ++kw) t.add(kh - pb, kw - pb, kh * 3 + kw);
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) t.add(kh - pb, kw - pb, kh * k + kw);
   return t;
 }
 // data-gradient form: target pixel o = s*i~ + ph, source i = i~ + (ph + pb - kh)/s for kh == ph+pb (mod s)
-static Taps taps_dgrad(int s, int pb, int ph, int pw) {
+static Taps taps_dgrad(int s, int pb, int ph, int pw, int k = 3) {
   Taps t;
-  for (int kh = 0; kh < 3; ++kh) {
+  for (int kh = 0; kh < k; ++kh) {
     int nh = ph + pb - kh;
     if (((nh % s) + s) % s) continue;
-    for (int kw = 0; kw < 3; ++kw) {
+    for (int kw = 0; kw < k; ++kw) {
       int nw = pw + pb - kw;
       if (((nw % s) + s) % s) continue;
-      t.add(nh / s, nw / s, kh * 3 + kw);
+      // floor division: nh is a multiple of s here, so / is exact
+      t.add(nh / s, nw / s, kh * k + kw);
     }
   }
   return t;
@@ -311,6 +334,12 @@ struct dv_ctx {
   hipEvent_t ev_dec = nullptr, ev_enc = nullptr, ev_comm = nullptr, ev_small = nullptr, ev_small2 = nullptr;
   hipEvent_t ev_mid = nullptr;
   ncclComm_t comm = nullptr;
+  // timing of the collectives (dv_comm_prof_*: the multi-rank bench's "comm time vs exposed comm time"): event pairs around
+  // every collective on the comm stream, and around the main stream's waits for them
+  bool cprof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> cprof_comm, cprof_wait;
+  std::vector<hipEvent_t> cprof_pool;
+  bool fake_peers = false;   // DV_DEBUG_FAKE_PEERS rehearsal: world > 1 but a one-rank communicator (results mean nothing)
   float* red_dev = nullptr;  // small device buffer for host all-reduce
   std::vector<dv_model*> models;   // live models of this context: dv_ctx_destroy destroys them first
 };
@@ -403,6 +432,10 @@ struct dv_model {
   // activations
   float* xn = nullptr;
   std::vector<float*> enc_u, enc_a, dec_u, dec_a;
+  std::vector<float*> du_enc, du_dec;   // where the last backward pass left d(pre-activation) of every conv layer (the
+                                        // per-step buffer pool keeps them until the next pass; tests/test_gpu_layers.py)
+  bool du_valid = false;
+  float* da_enc0 = nullptr;
   float *flat_a = nullptr, *t = nullptr, *eps = nullptr, *z = nullptr, *zstd = nullptr, *kl = nullptr;
   float *dec_ain = nullptr, *dec_uh = nullptr, *dec_ah = nullptr, *dec_ur = nullptr, *dec_ar = nullptr;
   float *tpre = nullptr, *loc = nullptr, *scale = nullptr;
@@ -583,14 +616,55 @@ static bool g_no_wino = false;    // cross-check aid: stride-1 layers take the d
 // Every collective of a context is issued on ONE stream (comm_stream), the usual single-stream-per-communicator
 // pattern; the main stream hands data over and takes it back through events.
 // wait = false: the main stream does not wait for the result (the caller joins the comm stream later anyway).
+static hipEvent_t cprof_event(dv_ctx* c) {
+  hipEvent_t e = nullptr;
+  if (!c->cprof_pool.empty()) {
+    e = c->cprof_pool.back();
+    c->cprof_pool.pop_back();
+  } else {
+    (void)hipEventCreate(&e);          // timing enabled
+  }
+  return e;
+}
+// one all-reduce on the comm stream (every collective of the engine goes through here)
+static int comm_allreduce(dv_ctx* c, float* buf, size_t n) {
+  hipEvent_t a = nullptr;
+  if (c->cprof_on) {
+    a = cprof_event(c);
+    DV_HIP(hipEventRecord(a, c->comm_stream));
+  }
+  DV_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, c->comm, c->comm_stream));
+  if (a) {
+    hipEvent_t b = cprof_event(c);
+    DV_HIP(hipEventRecord(b, c->comm_stream));
+    c->cprof_comm.push_back({a, b});
+  }
+  return OK;
+}
+// the main stream waits for `ev` (recorded on the comm stream behind a collective): with comm profiling the wait is
+// bracketed by two timed events - what it costs the main stream is the EXPOSED part of the communication
+static int main_waits_for_comm(dv_ctx* c, hipEvent_t ev) {
+  hipEvent_t a = nullptr;
+  if (c->cprof_on) {
+    a = cprof_event(c);
+    DV_HIP(hipEventRecord(a, c->stream));
+  }
+  DV_HIP(hipStreamWaitEvent(c->stream, ev, 0));
+  if (a) {
+    hipEvent_t b = cprof_event(c);
+    DV_HIP(hipEventRecord(b, c->stream));
+    c->cprof_wait.push_back({a, b});
+  }
+  return OK;
+}
 static int allreduce_small(dv_ctx* c, float* buf, size_t n, bool wait = true) {
   if (!c->comm) return OK;
   DV_HIP(hipEventRecord(c->ev_small, c->stream));
   DV_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_small, 0));
-  DV_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, c->comm, c->comm_stream));
+  DV_TRY(comm_allreduce(c, buf, n));
   if (wait) {
     DV_HIP(hipEventRecord(c->ev_small2, c->comm_stream));
-    DV_HIP(hipStreamWaitEvent(c->stream, c->ev_small2, 0));
+    DV_TRY(main_waits_for_comm(c, c->ev_small2));
   }
   return OK;
 }
@@ -598,8 +672,7 @@ static int allreduce_small(dv_ctx* c, float* buf, size_t n, bool wait = true) {
 // ---- layer launch helpers ---------------------------------------------------------------------
 static void fill_gconv_common(GConvParams& p, const Taps& t, int cin) {
   p.ntaps = t.n;
-  p.tapcode = t.tapcode;
-  p.wtcode = t.wtcode;
+  p.xt = t.xt;
   p.K = t.n * cin;
   p.cin_shift = ilog2_exact(cin);
 }
@@ -809,9 +882,11 @@ static int wino_conv(dv_model* m, const float* X, const float* W, bool nmajor, c
 }
 
 // fprop-form gconv over an [NB,Hin,Hin,Cin] tensor: out[NB,Hout,Hout,Cout], in pixel = out*s + k - pb
+// ksz: kernel size (model.py:81-91,121-134 take kernels[i] freely).  3 (and the one-tap dense form) have the specialised
+// kernel families; every other size takes the general gather-GEMM (gconv.hip) with its tap table.
 static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor, const float* bias, const float* alpha,
                        float* U, float* Aout, int epi, int NB, int Hin, int Cin, int Hout, int Cout, int s, int pb,
-                       bool single_tap = false, const FuseBwd* fz = nullptr, bool* fused = nullptr) {
+                       bool single_tap = false, const FuseBwd* fz = nullptr, bool* fused = nullptr, int ksz = 3) {
   if (fused) *fused = false;
   GConvParams p;
   memset(&p, 0, sizeof p);
@@ -835,15 +910,16 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
   p.epi = epi;
   Taps one;
   one.add(0, 0, 0);
-  const Taps tp = single_tap ? one : taps_fprop(pb);
+  const Taps tp = single_tap ? one : taps_fprop(pb, ksz);
+  const bool k3 = single_tap || ksz == 3;          // the specialised families speak the 3 x 3 tap code
   // algorithmic FLOPs of this launch (padding taps counted; the folded first conv and the padded head count their real channels)
   const double flops = 2.0 * NB * Hout * Hout * tp.n * (double)(W == m->W1p ? m->A.C : Cin) *
                        (double)(W == m->Whp ? 2 * m->A.C : Cout);
-  if (s == 1 && pb == 1 && Hin == Hout && tp.n == 9 && !single_tap && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse)) {
+  if (k3 && s == 1 && pb == 1 && Hin == Hout && tp.n == 9 && !single_tap && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse)) {
     const int r = wino_conv(m, X, W, nmajor, tp, bias, alpha, U, Aout, epi, NB, Hout, Cin, Cout, flops);
     if (r <= 0) return r;
   }
-  if (Cin == 32 && (Cout == 16 || Cout == 32) && s == 1 && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
+  if (k3 && Cin == 32 && (Cout == 16 || Cout == 32) && s == 1 && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
       !single_tap && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse)) {
     GStripParams g;
     memset(&g, 0, sizeof g);
@@ -857,7 +933,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     }
     if (r <= 0) return r;
   }
-  if (Cin == 8 && Cout == 32 && s == 1 && pb == 1 && !nmajor && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
+  if (k3 && Cin == 8 && Cout == 32 && s == 1 && pb == 1 && !nmajor && Hin == Hout && Hout >= 8 && Hout <= 64 && tp.n == 9 &&
       !single_tap && !g_force_v1 && !g_no_special && !fz) {
     GStripParams g;                                  // first layer: strip form
     memset(&g, 0, sizeof g);
@@ -878,7 +954,8 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
   }
   // (dense operands whose width is a multiple of 4 but not of 32 - the 560-wide ones - take the ragged-K form of gconv2)
   const bool ragged_dense = single_tap && Cin > 32 && (Cin & 3) == 0 && (Cin % 32) != 0 && !fz && !g_no_special;
-  if ((Cin % 32 == 0 || ragged_dense || ((Cin == 8 || Cin == 16) && Cout <= 32 && !single_tap)) && !g_force_v1) {
+  if ((Cin % 32 == 0 || ragged_dense || ((Cin == 8 || Cin == 16) && Cout <= 32 && !single_tap)) && !g_force_v1 && k3 &&
+      tp.legacy) {
     GConv2Params q;
     memset(&q, 0, sizeof q);
     q.X = X; q.W = W; q.U = U; q.A = Aout; q.bias = bias; q.alpha = alpha;
@@ -934,18 +1011,19 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
 // target pixel o satisfies o + pb = s*i + k for source pixel i.
 static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor, const float* bias, const float* alpha,
                        float* U, float* Aout, int epi, int NB, int Hs, int Cs, int Ht, int Ct, int s, int pb,
-                       const FuseBwd* fz = nullptr, bool* fused = nullptr) {
+                       const FuseBwd* fz = nullptr, bool* fused = nullptr, int ksz = 3) {
   if (fused) *fused = false;
-  // algorithmic FLOPs: every source pixel meets all nine taps; the padded head gradient counts 2*bands channels
-  const double flops = 2.0 * NB * Hs * Hs * 9.0 * (double)(W == m->Whp ? 2 * m->A.C : Cs) * (double)Ct;
-  if (s == 1 && pb == 1 && Hs == Ht && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse)) {
+  // algorithmic FLOPs: every source pixel meets all k*k taps; the padded head gradient counts 2*bands channels
+  const double flops = 2.0 * NB * Hs * Hs * (double)(ksz * ksz) * (double)(W == m->Whp ? 2 * m->A.C : Cs) * (double)Ct;
+  const bool k3 = ksz == 3;
+  if (k3 && s == 1 && pb == 1 && Hs == Ht && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse)) {
     const Taps tp = taps_dgrad(1, pb, 0, 0);
     if (tp.n == 9) {
       const int r = wino_conv(m, X, W, nmajor, tp, bias, alpha, U, Aout, epi, NB, Ht, Cs, Ct, flops);
       if (r <= 0) return r;
     }
   }
-  if (s == 1 && (Cs == 32 || (Cs == 16 && Ct == 32)) && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !g_no_special &&
+  if (k3 && s == 1 && (Cs == 32 || (Cs == 16 && Ct == 32)) && (Ct == 16 || Ct == 32) && Hs == Ht && Ht >= 8 && Ht <= 64 && !g_force_v1 && !g_no_special &&
       !(fz && !m->no_fuse)) {
     const Taps tp = taps_dgrad(1, pb, 0, 0);
     if (tp.n == 9) {
@@ -964,7 +1042,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
   }
   // (tiny inference calls take the parity-class form below instead: it can slice K over workgroups, the fused kernel cannot)
   const bool tiny_splitk = m->tiny_call && NB <= 16 && !fz;
-  if (s == 2 && Cs % 32 == 0 && Ct % 4 == 0 && nmajor && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse) &&
+  if (k3 && s == 2 && Cs % 32 == 0 && Ct % 4 == 0 && nmajor && !g_force_v1 && !g_no_special && !(fz && !m->no_fuse) &&
       !tiny_splitk) {
     // all four parity classes in one workgroup (gconv_s2.hip)
     GConvS2Params q;
@@ -1001,7 +1079,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
       return launch_gconv_s2(q, fwd_stream(m));
     }
   }
-  if ((Cs % 32 == 0 || ((Cs == 8 || Cs == 16) && Ct <= 32)) && s <= 2 && !g_force_v1) {
+  if (k3 && (Cs % 32 == 0 || ((Cs == 8 || Cs == 16) && Ct <= 32)) && s <= 2 && !g_force_v1) {
     GConv2Params q;
     memset(&q, 0, sizeof q);
     q.X = X; q.W = W; q.U = U; q.A = Aout; q.bias = bias; q.alpha = alpha;
@@ -1049,7 +1127,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
     for (int pw = 0; pw < s; ++pw) {
       int hc = (Ht - ph + s - 1) / s, wc = (Ht - pw + s - 1) / s;
       if (hc <= 0 || wc <= 0) continue;
-      Taps t = taps_dgrad(s, pb, ph, pw);
+      Taps t = taps_dgrad(s, pb, ph, pw, ksz);
       GConvParams p;
       memset(&p, 0, sizeof p);
       p.X = X;
@@ -1072,12 +1150,10 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
       p.M = NB * hc * wc;
       p.w_nmajor = nmajor ? 1 : 0;
       p.epi = epi;
-      if (t.n == 0) {
-        set_error("empty parity class");
-        return E_INVALID;
-      }
+      // (a class without taps - odd output pixels of a 1x1 stride-2 Conv2DTranspose - is legal: its pixels receive the
+      // bias alone, or a zero gradient; the kernel then runs its epilogue on zero accumulators)
       fill_gconv_common(p, t, Cs);
-      ProfScope ps(m, 0, nullptr, PF_GCONV, flops * t.n / 9.0 / (s * s));
+      ProfScope ps(m, 0, nullptr, PF_GCONV, flops * t.n / (double)(ksz * ksz));
       DV_TRY(launch_gconv(p, fwd_stream(m)));
     }
   return OK;
@@ -1085,14 +1161,15 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
 
 // dW = sum_p Xg[p,t][cx] * Y[p][cy]; X pixel = grid*sx + k - pb; result rows (wt,cx) x cols cy into `out`
 static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB,
-                      int sx, int pb, bool single_tap, float* out, int cpad, int creal, const FuseBwd* fz);
+                      int sx, int pb, bool single_tap, float* out, int cpad, int creal, const FuseBwd* fz, int ksz);
 
 // Weight gradients are queued on m->wstream.  When that is the aux stream, the call first makes it wait for
 // everything the main stream has produced so far (the operand d(pre-activation) is final at this point).
 // on_main: queue this launch (and its slab reduction) on the main stream even when the weight gradients run on the
 // aux stream - used for the last one of the step, when the main stream has nothing else left to do.
 static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB, int sx, int pb,
-                 bool single_tap, float* out, int cpad, int creal, const FuseBwd* fz = nullptr, bool on_main = false) {
+                 bool single_tap, float* out, int cpad, int creal, const FuseBwd* fz = nullptr, bool on_main = false,
+                 int ksz = 3) {
   hipStream_t ws = (m->wstream && !on_main) ? m->wstream : m->ctx->stream;
   if (ws != m->ctx->stream) {
     // the PReLU backward just queued may already have recorded the main stream's position (for its reductions)
@@ -1100,17 +1177,18 @@ static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, in
     DV_HIP(hipStreamWaitEvent(ws, m->ctx->ev_ready, 0));
   }
   m->main_marked = false;
-  return wgrad_impl(m, ws, X, Hx, Cx, Y, Hy, Cy, NB, sx, pb, single_tap, out, cpad, creal, fz);
+  return wgrad_impl(m, ws, X, Hx, Cx, Y, Hy, Cy, NB, sx, pb, single_tap, out, cpad, creal, fz, ksz);
 }
 
 // fz (first layer only, Cx == 8): Y is d(activation); the strip kernel applies the PReLU backward of fz on the fly
 // and also produces d(alpha) / d(bias), see wgrad_strip8_kernel<true>.
 static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB,
-                      int sx, int pb, bool single_tap, float* out, int cpad, int creal, const FuseBwd* fz) {
+                      int sx, int pb, bool single_tap, float* out, int cpad, int creal, const FuseBwd* fz, int ksz) {
+  const bool k3 = ksz == 3;
   // slab region and the stream that sums the slabs: with the weight gradients on the aux stream the reduction goes to
   // the reduction stream and the slabs rotate through three regions of ws1
   dv_ctx* cx = m->ctx;
-  const double wflops = 2.0 * NB * Hy * Hy * (single_tap ? 1.0 : 9.0) * (double)(X == m->xn ? m->A.C : Cx) *
+  const double wflops = 2.0 * NB * Hy * Hy * (single_tap ? 1.0 : (double)(ksz * ksz)) * (double)(X == m->xn ? m->A.C : Cx) *
                         (double)(out == m->Ghs ? 2 * m->A.C : Cy);
   // the regions rotate whenever weight-gradient work may be in flight on the aux stream, also for a launch that is
   // itself queued on the main stream (which then reduces its own slabs: no stream hop)
@@ -1156,7 +1234,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
     m->ws_last = reg;
     return OK;
   };
-  if (!single_tap && sx == 1 && pb == 1 && Hx == Hy && cpad == creal && !fz && !g_force_v1 && !g_no_special && !g_no_wino &&
+  if (k3 && !single_tap && sx == 1 && pb == 1 && Hx == Hy && cpad == creal && !fz && !g_force_v1 && !g_no_special && !g_no_wino &&
       m->use_wino && !m->bf.on && m->zero_page && wino_wgrad_supported(NB, Hy, Cx, Cy)) {
     // stride-1 layers with >= 64 channels on both sides: Winograd-domain weight gradient (wino.hip), its partial slabs in
     // a buffer of this launch's own (allocated at first use: 64 MiB per launch at 256 CUs)
@@ -1194,7 +1272,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
       }
     }
   }
-  if (!single_tap && !g_force_v1 && !(g_no_special && !fz) && cpad == creal && wgrad_strip_supported(Cx, Cy, sx, 9)) {
+  if (k3 && !single_tap && !g_force_v1 && !(g_no_special && !fz) && cpad == creal && wgrad_strip_supported(Cx, Cy, sx, 9)) {
     WStripParams sp;
     memset(&sp, 0, sizeof sp);
     sp.X = X; sp.Y = Y; sp.part = part; sp.part_capacity = part_cap;
@@ -1265,7 +1343,11 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   if (single_tap)
     t.add(0, 0, 0);
   else
-    t = taps_fprop(pb);
+    t = taps_fprop(pb, ksz);
+  if (fz) {
+    set_error("the fused first-layer weight gradient exists for 3x3 kernels only");
+    return E_STATE;
+  }
   p.X = X;
   p.Y = Y;
   p.part = part;
@@ -1279,8 +1361,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   p.sy = 1;
   p.ph = p.pw = 0;
   p.ntaps = t.n;
-  p.tapcode = t.tapcode;
-  p.wtcode = t.wtcode;
+  p.xt = t.xt;
   p.P = NB * Hy * Hy;
   p.rows_total = t.n * Cx;
   long slab = (long)p.rows_total * Cy;
@@ -1444,8 +1525,8 @@ static int refresh_w1p(dv_model* m) {
   const Arch& A = m->A;
   m->bf.dirty = true;
   m->param_epoch++;
-  return launch_pad_w1(m->P + A.specs[A.enc_k(0)].off, m->P + A.specs[0].off, m->P + A.specs[1].off, m->W1p, 9, A.C, 8,
-                       A.cfg.filters[0], m->ctx->stream);
+  return launch_pad_w1(m->P + A.specs[A.enc_k(0)].off, m->P + A.specs[0].off, m->P + A.specs[1].off, m->W1p,
+                       A.enc_ksz(0) * A.enc_ksz(0), A.C, 8, A.cfg.filters[0], m->ctx->stream);
 }
 
 // ---- forward ----------------------------------------------------------------------------------
@@ -1466,11 +1547,16 @@ static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first,
         NB == m->bn_pre_B && !m->prof_on) {
       // the batch sums (they depend on the data only) were computed and all-reduced on the comm stream during the
       // previous step: no reduction kernels and no latency-bound collective at the head of this step
-      DV_HIP(hipStreamWaitEvent(s, m->ev_bnpre, 0));
+      DV_TRY(main_waits_for_comm(m->ctx, m->ev_bnpre));
       sums = m->bn_pre_sums;
     } else {
       int nblk = 0;
       ProfScope ps(m, 2, s);
+      // one 16-float partial row per 1024 pixels (pointwise.hip BN_PIX_PER_BLOCK): checked BEFORE the launch writes them
+      if (((size_t)NB * HW + 1023) / 1024 * 16 > m->ws3_elems) {
+        set_error("BN statistics workspace too small for %d stamps", NB);
+        return E_STATE;
+      }
       DV_TRY(launch_bn_stats(xsrc, idx, first, NB, HW, A.C, m->ws3, &nblk, s));
       DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 16, m->bnsums, 1.0f, s));
       DV_TRY(allreduce_small(m->ctx, m->bnsums, 16));
@@ -1516,13 +1602,14 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
   for (int j = 0; j < 2 * A.L; ++j) {
     int hin, cin, hout, cout, st;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
-    int pb = same_pad_before(hin, 3, st, nullptr);
+    const int ksz = A.enc_ksz(j);
+    int pb = same_pad_before(hin, ksz, st, nullptr);
     const float* W = j == 0 ? m->W1p : P + A.specs[A.enc_k(j)].off;
     int cin_phys = j == 0 ? 8 : cin;
     const size_t e_out = (size_t)hout * hout * cout;
     DV_TRY(gconv_fprop(m, in, W, false, P + A.specs[A.enc_b(j)].off, P + A.specs[A.enc_al(j)].off,
                        keep_u ? LANE(m->enc_u[j], e_out) : nullptr, LANE(m->enc_a[j], e_out), 2, NB, hin, cin_phys,
-                       hout, cout, st, pb));
+                       hout, cout, st, pb, false, nullptr, nullptr, ksz));
     in = LANE(m->enc_a[j], e_out);
   }
   {
@@ -1553,12 +1640,13 @@ static int decoder_forward(dv_model* m, int NB, bool keep_u) {
   for (int j = 0; j < 2 * A.L; ++j) {
     int hin, cin, hout, cout, st;
     A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
-    int pb = same_pad_before(hout, 3, st, nullptr);
+    const int ksz = A.dec_ksz(j);
+    int pb = same_pad_before(hout, ksz, st, nullptr);
     const size_t e_out = (size_t)hout * hout * cout;
     // Conv2DTranspose = data gradient of a SAME conv over the output grid; kernel (kh,kw,cout,cin) is n-major
     DV_TRY(gconv_dgrad(m, in, P + A.specs[A.dec_k(j)].off, true, P + A.specs[A.dec_b(j)].off,
                        P + A.specs[A.dec_al(j)].off, keep_u ? LANE(m->dec_u[j], e_out) : nullptr,
-                       LANE(m->dec_a[j], e_out), 2, NB, hin, cin, hout, cout, st, pb));
+                       LANE(m->dec_a[j], e_out), 2, NB, hin, cin, hout, cout, st, pb, nullptr, nullptr, ksz));
     in = LANE(m->dec_a[j], e_out);
   }
   return gconv_fprop(m, in, m->Whp, false, m->bhp, nullptr, LANE(m->tpre, (size_t)A.dec_out * A.dec_out * A.C2p),
@@ -1816,11 +1904,14 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   for (int j = 2 * A.L - 1; j >= 0; --j) {
     int hin, cin, hout, cout, st;
     A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
-    int pb = same_pad_before(hout, 3, st, nullptr);
+    const int ksz = A.dec_ksz(j);
+    int pb = same_pad_before(hout, ksz, st, nullptr);
     if (!cur_is_du) DV_TRY(prelu_bwd(m, cur, m->dec_u[j], A.dec_al(j), A.dec_b(j), NB, hout * hout * cout, cout, dg));
+    m->du_dec[j] = cur;
     const float* xin = j == 0 ? m->dec_ar : m->dec_a[j - 1];
     if (dg) {
-      DV_TRY(wgrad(m, cur, hout, cout, xin, hin, cin, NB, st, pb, false, G + A.specs[A.dec_k(j)].off, cout, cout));
+      DV_TRY(wgrad(m, cur, hout, cout, xin, hin, cin, NB, st, pb, false, G + A.specs[A.dec_k(j)].off, cout, cout, nullptr,
+                   false, ksz));
       DV_TRY(wgrad_read());
     }
     // d(input) = strided conv of d(pre-activation) with K[kh,kw,co,ci] (rows (tap,co), cols ci: k-major)
@@ -1828,10 +1919,10 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     if (j > 0) {   // the input of conv-transpose j is the PReLU output of conv-transpose j-1: fuse its backward
       FuseBwd fz{m->dec_u[j - 1], A.dec_al(j - 1), A.dec_b(j - 1), dg};
       DV_TRY(gconv_fprop(m, cur, P + A.specs[A.dec_k(j)].off, false, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout,
-                         hin, cin, st, pb, false, &fz, &cur_is_du));
+                         hin, cin, st, pb, false, &fz, &cur_is_du, ksz));
     } else {
       DV_TRY(gconv_fprop(m, cur, P + A.specs[A.dec_k(j)].off, false, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout,
-                         hin, cin, st, pb));
+                         hin, cin, st, pb, false, nullptr, nullptr, ksz));
       cur_is_du = false;
     }
     advance();
@@ -1870,8 +1961,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
       DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, cx->ev_red, 0));
     }
     if (m->ctx->comm)
-      DV_NCCL(ncclAllReduce(G + A.n_enc_train, G + A.n_enc_train, A.n_train - A.n_enc_train, ncclFloat, ncclSum,
-                            m->ctx->comm, m->ctx->comm_stream));
+      DV_TRY(comm_allreduce(m->ctx, G + A.n_enc_train, A.n_train - A.n_enc_train));
     if (early && m->opt_dec) {
       DV_TRY(adam_range(m, A.n_enc_train, A.n_train, cx->comm_stream));
       DV_TRY(refresh_head_pad(m, cx->comm_stream));
@@ -1900,12 +1990,15 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   for (int j = 2 * A.L - 1; j >= 0; --j) {
     int hin, cin, hout, cout, st;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
-    int pb = same_pad_before(hin, 3, st, nullptr);
+    const int ksz = A.enc_ksz(j);
+    int pb = same_pad_before(hin, ksz, st, nullptr);
     // first layer: its PReLU backward is folded into the weight-gradient kernel (no data gradient follows it)
-    const bool fuse0 = j == 0 && !cur_is_du && m->fuse_first && cout == 32 && st == 1 && pb == 1 && !g_no_special &&
+    const bool fuse0 = j == 0 && !cur_is_du && m->fuse_first && cout == 32 && st == 1 && pb == 1 && ksz == 3 && !g_no_special &&
                        wgrad_strip8_fusable(hout, hout);
     if (!cur_is_du && !fuse0)
       DV_TRY(prelu_bwd(m, cur, m->enc_u[j], A.enc_al(j), A.enc_b(j), NB, hout * hout * cout, cout, true));
+    m->du_enc[j] = fuse0 ? nullptr : cur;      // (fused first layer: d(pre-activation) is never materialised,
+    if (j == 0) m->da_enc0 = fuse0 ? cur : nullptr;   //  its d(activation) is what the pass leaves)
     const float* xin = j == 0 ? m->xn : m->enc_a[j - 1];
     int cin_phys = j == 0 ? 8 : cin;
     if (j == 0) {
@@ -1917,23 +2010,23 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
       hipStream_t ws = (m->wstream && !last_on_main) ? m->wstream : s;
       FuseBwd f0{m->enc_u[0], A.enc_al(0), A.enc_b(0), true};
       DV_TRY(wgrad(m, xin, hin, 8, cur, hout, cout, NB, st, pb, false, m->G0s, 8, 8, fuse0 ? &f0 : nullptr,
-                   last_on_main));
+                   last_on_main, ksz));
       DV_TRY(wgrad_result_ready(m, ws));
       ProfScope ps(m, 2, ws);
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
-                                   G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, 9, A.C, 8,
-                                   cout, ws));
+                                   G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, ksz * ksz, A.C,
+                                   8, cout, ws));
       DV_TRY(wgrad_read());
       break;
     }
     DV_TRY(wgrad(m, xin, hin, cin_phys, cur, hout, cout, NB, st, pb, false, G + A.specs[A.enc_k(j)].off, cin_phys,
-                 cin_phys));
+                 cin_phys, nullptr, false, ksz));
     DV_TRY(wgrad_read());
     const float* W = P + A.specs[A.enc_k(j)].off;
     DV_NEXT_OUT();
     FuseBwd fz{m->enc_u[j - 1], A.enc_al(j - 1), A.enc_b(j - 1), true};   // j >= 1 here (j == 0 left the loop above)
     DV_TRY(gconv_dgrad(m, cur, W, true, nullptr, nullptr, oth, nullptr, 0, NB, hout, cout, hin, cin_phys, st, pb, &fz,
-                       &cur_is_du));
+                       &cur_is_du, ksz));
     advance();
     if ((cx->comm || early) && j == A.L && A.L >= 2) {
       // Middle bucket: the gradients of the deep half of the encoder (conv L .. conv 2L-1, their PReLUs, the
@@ -1953,7 +2046,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
           DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_dec, 0));
         }
         if (cx->comm) {
-          DV_NCCL(ncclAllReduce(G + split, G + split, A.n_enc_train - split, ncclFloat, ncclSum, cx->comm, cx->comm_stream));
+          DV_TRY(comm_allreduce(cx, G + split, A.n_enc_train - split));
           m->enc_reduced_from = split;
         }
         if (early && m->opt_enc) {
@@ -1970,6 +2063,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     DV_HIP(hipStreamWaitEvent(s, cx->ev_red, 0));
   }
   m->wstream = s;
+  m->du_valid = no_reuse;        // (with three rotating buffers the tensors have been overwritten by now)
 #undef DV_NEXT_OUT
   return OK;
 }
@@ -2049,13 +2143,13 @@ static int bn_prefetch(dv_model* m, const float* x, int64_t first, int NB, int* 
   DV_HIP(hipStreamWaitEvent(c->comm_stream, m->ev_bnpre_go, 0));
   if (idx_host)
     DV_HIP(hipMemcpyAsync(idx_dev, idx_host, (size_t)NB * sizeof(int), hipMemcpyHostToDevice, c->comm_stream));
-  DV_TRY(launch_bn_stats(x, idx_dev, (int)first, NB, HW, A.C, m->bn_pre_part, &nblk, c->comm_stream));
-  if ((size_t)nblk * 16 > m->bn_pre_part_elems) {
+  if (((size_t)NB * HW + 1023) / 1024 * 16 > m->bn_pre_part_elems) {      // before the launch, not after it has written
     set_error("bn prefetch workspace too small");
     return E_STATE;
   }
+  DV_TRY(launch_bn_stats(x, idx_dev, (int)first, NB, HW, A.C, m->bn_pre_part, &nblk, c->comm_stream));
   DV_TRY(launch_reduce_rows_f64(m->bn_pre_part, nblk, 16, m->bn_pre_sums, 1.0f, c->comm_stream));
-  if (c->comm) DV_NCCL(ncclAllReduce(m->bn_pre_sums, m->bn_pre_sums, 16, ncclFloat, ncclSum, c->comm, c->comm_stream));
+  if (c->comm) DV_TRY(comm_allreduce(c, m->bn_pre_sums, 16));
   DV_HIP(hipEventRecord(m->ev_bnpre, c->comm_stream));
   m->bn_pre_valid = true;
   m->bn_pre_x = x;
@@ -2124,10 +2218,9 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
       // encoder bucket (the decoder bucket was queued inside backward()); the optimizer waits for both
       DV_HIP(hipEventRecord(m->ctx->ev_enc, s));
       DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, m->ctx->ev_enc, 0));
-      if (m->enc_reduced_from > 0)
-        DV_NCCL(ncclAllReduce(m->G, m->G, m->enc_reduced_from, ncclFloat, ncclSum, m->ctx->comm, m->ctx->comm_stream));
+      if (m->enc_reduced_from > 0) DV_TRY(comm_allreduce(m->ctx, m->G, m->enc_reduced_from));
       DV_HIP(hipEventRecord(m->ctx->ev_comm, m->ctx->comm_stream));
-      DV_HIP(hipStreamWaitEvent(s, m->ctx->ev_comm, 0));
+      DV_TRY(main_waits_for_comm(m->ctx, m->ctx->ev_comm));
     }
   }
   if (mode == MODE_TRAIN) DV_TRY(optimizer_step(m));
@@ -2656,6 +2749,10 @@ static int ctx_build(dv_ctx* c, int world, int rank, const void* unique_id) {
     if (getenv("DV_DEBUG_FAKE_PEERS")) {
       // rehearsal hook (see parallel.make_context): a one-rank communicator per rank, so that several ranks can share the
       // one GPU of a build box; everything else believes in `world` ranks
+      fprintf(stderr, "[libdebvader_hip] WARNING: DV_DEBUG_FAKE_PEERS is set: rank %d of %d gets a ONE-RANK communicator - "
+                      "gradients and BN statistics are NOT summed across ranks; this is a launch rehearsal, not a job\n",
+              rank, world);
+      c->fake_peers = true;
       DV_NCCL(ncclGetUniqueId(&id));
       DV_NCCL(ncclCommInitRank(&c->comm, 1, id, 0));
     } else {
@@ -2717,6 +2814,10 @@ int dv_ctx_destroy(dv_ctx* c) {
   if (c->ev_dec) (void)hipEventDestroy(c->ev_dec);
   if (c->ev_enc) (void)hipEventDestroy(c->ev_enc);
   if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+  for (auto& pr : c->cprof_comm) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto& pr : c->cprof_wait) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto e : c->cprof_pool) (void)hipEventDestroy(e);
+  c->cprof_comm.clear(); c->cprof_wait.clear(); c->cprof_pool.clear();
   if (c->ev_small) (void)hipEventDestroy(c->ev_small);
   if (c->ev_small2) (void)hipEventDestroy(c->ev_small2);
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
@@ -2828,6 +2929,26 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   const Arch& A = m->A;
   const size_t Bc = (size_t)cfg->max_batch;
   m->Bc = cfg->max_batch;
+  if (cfg->dtype == DV_DTYPE_F32) {
+    // The fp32 weight-gradient and tiled kernels address a layer's tensors with 32-bit ELEMENT offsets.  A training step
+    // has no lanes, so a max_batch whose largest activation reaches 2^31 elements would fail inside the first step, with
+    // half of it queued (and, with several ranks, peers left inside collectives): refuse it here.
+    size_t per_stamp = (size_t)A.H * A.H * 8;
+    for (int j = 0; j < 2 * A.L; ++j) {
+      int hin, cin, hout, cout, s;
+      A.enc_layer(j, &hin, &cin, &hout, &cout, &s);
+      per_stamp = std::max(per_stamp, (size_t)hout * hout * cout);
+      A.dec_layer(j, &hin, &cin, &hout, &cout, &s);
+      per_stamp = std::max(per_stamp, (size_t)hout * hout * cout);
+    }
+    per_stamp = std::max(per_stamp, (size_t)A.dec_out * A.dec_out * A.C2p);
+    if (Bc * per_stamp >= ((size_t)1 << 31)) {
+      set_error("max_batch %d x %zu elements of the largest activation reaches 2^31: the fp32 engine addresses a layer with "
+                "32-bit element offsets; use max_batch <= %zu (inference splits larger inputs into chunks by itself)",
+                cfg->max_batch, per_stamp, (((size_t)1 << 31) - 1) / per_stamp);
+      return dv_model_destroy(m), DV_E_INVALID;
+    }
+  }
   if (cfg->dtype != DV_DTYPE_F32 && cfg->dtype != DV_DTYPE_BF16) {
     set_error("unknown dtype %d", cfg->dtype);
     return dv_model_destroy(m), DV_E_INVALID;
@@ -2849,8 +2970,9 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   ALLOC(m->G, A.n_total);
   ALLOC(m->Mm, A.n_total);
   ALLOC(m->Vv, A.n_total);
-  ALLOC(m->W1p, 9 * 8 * cfg->filters[0]);
-  ALLOC(m->G0s, 9 * 8 * cfg->filters[0]);
+  const size_t k0sq = (size_t)cfg->kernels[0] * cfg->kernels[0];
+  ALLOC(m->W1p, k0sq * 8 * cfg->filters[0]);
+  ALLOC(m->G0s, k0sq * 8 * cfg->filters[0]);
   ALLOC(m->Whp, 9 * cfg->filters[0] * A.C2p);
   ALLOC(m->Ghs, 9 * cfg->filters[0] * A.C2p);
   ALLOC(m->bhp, A.C2p);
@@ -2862,6 +2984,8 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   m->enc_a.resize(2 * A.L);
   m->dec_u.resize(2 * A.L);
   m->dec_a.resize(2 * A.L);
+  m->du_enc.assign(2 * A.L, nullptr);
+  m->du_dec.assign(2 * A.L, nullptr);
   for (int j = 0; j < 2 * A.L; ++j) {
     int hin, cin, hout, cout, s;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &s);
@@ -2913,7 +3037,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   size_t max_w = 0;
   for (auto& s : A.specs)
     if (s.ndim >= 2) max_w = std::max(max_w, s.count);
-  max_w = std::max(max_w, (size_t)9 * 8 * cfg->filters[0]);
+  max_w = std::max(max_w, k0sq * 8 * cfg->filters[0]);
   m->ws1_elems = std::max((size_t)32 << 20, (max_w + 1024) * 3);   // three rotating regions, each at least one slab
   ALLOC(m->ws1, m->ws1_elems);
   m->ws4_elems = (size_t)4 * 16 * Bc * std::max((size_t)A.flat, (size_t)A.tw);
@@ -2932,13 +3056,16 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   size_t head_blocks = (Bc * A.dec_out * A.dec_out + 255) / 256;
   m->ws3_elems = std::max((size_t)1 << 20, head_blocks * 2 + 64);
   m->ws3_elems = std::max(m->ws3_elems, (size_t)64 * std::max((size_t)A.flat, r));
+  // BN statistics / BN backward partials: one 16-float row per 1024 pixels of the batch (the capacity used to
+  // be derived from other users of the buffer and overran silently above ~19k stamps of 59 px)
+  m->ws3_elems = std::max(m->ws3_elems, ((Bc * (size_t)A.H * A.H + 1023) / 1024 + 1) * 16);
   ALLOC(m->ws3, m->ws3_elems);
   ALLOC(m->scal, 16);
   ALLOC(m->zero_page, 64);
   ALLOC(m->bnstate, 32);
   ALLOC(m->bnsums, 16);
   ALLOC(m->bn_pre_sums, 16);
-  m->bn_pre_part_elems = (size_t)16 * (((size_t)Bc * A.H * A.H + 255) / 256 + 16);
+  m->bn_pre_part_elems = (size_t)16 * (((size_t)Bc * A.H * A.H + 1023) / 1024 + 16);
   ALLOC(m->bn_pre_part, m->bn_pre_part_elems);
   for (int k = 0; k < 3; ++k)
     if (hipEventCreateWithFlags(&m->ev_wk[k], sync_event_flags()) != hipSuccess ||
@@ -3349,11 +3476,13 @@ int dv_model_set_keep_outputs(dv_model* m, int32_t on) {
   return DV_OK;
 }
 
+#ifdef DV_DEBUG_EXPORTS      // libdebvader_hip_debug.so only (include/debvader_hip_debug.h)
 int dv_model_set_infer_graph(dv_model* m, int32_t on) {
   if (!m) return DV_E_INVALID;
   m->infer_graph = on != 0;
   return DV_OK;
 }
+#endif
 
 
 int dv_model_set_mse_sample(dv_model* m, int32_t on) {
@@ -3613,6 +3742,28 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
     return DV_OK;
   }
   else if (n == "xn") { src = m->xn; elems = B * A.H * A.H * 8; }
+  else if (n == "dec_in") { src = m->dec_ar; elems = B * A.w0 * A.w0 * A.cfg.filters[A.L - 1]; }
+  else if (n == "d_head_pre" || n == "enc_da0" || n.rfind("enc_du", 0) == 0 || n.rfind("dec_du", 0) == 0) {
+    // gradients the last backward pass left in its per-step buffer pool (tests/test_gpu_layers.py)
+    if (!m->du_valid) {
+      set_error("activation %s: no backward pass with the per-step buffer pool has run (DV_NO_OVERLAP / profiling rotate three buffers)", name);
+      return DV_E_STATE;
+    }
+    if (n == "d_head_pre") { src = m->gbufs[0]; elems = B * A.dec_out * A.dec_out * A.C2p; }
+    else if (n == "enc_da0") { src = m->da_enc0; elems = B * A.H * A.H * A.cfg.filters[0]; }
+    else {
+      const int j = atoi(n.c_str() + 6);
+      if (j < 0 || j >= 2 * A.L) return DV_E_INVALID;
+      int hin, cin, hout, cout, s;
+      if (n[0] == 'e') A.enc_layer(j, &hin, &cin, &hout, &cout, &s); else A.dec_layer(j, &hin, &cin, &hout, &cout, &s);
+      elems = B * hout * hout * cout;
+      src = n[0] == 'e' ? m->du_enc[j] : m->du_dec[j];
+    }
+    if (!src) {
+      set_error("activation %s is not materialised by this configuration", name);
+      return DV_E_STATE;
+    }
+  }
   else if (n.rfind("enc_u", 0) == 0 || n.rfind("enc_a", 0) == 0 || n.rfind("dec_u", 0) == 0 || n.rfind("dec_a", 0) == 0) {
     int j = atoi(n.c_str() + 5);
     if (j < 0 || j >= 2 * A.L) return DV_E_INVALID;
@@ -3634,6 +3785,7 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
   return DV_OK;
 }
 
+#ifdef DV_DEBUG_EXPORTS      // everything down to the matching #endif exists in libdebvader_hip_debug.so only
 // ---- kernel micro-benchmarks (bench / tuning aid): time one layer-shaped launch on random data -----------
 static int debug_buffers(dv_ctx* ctx, size_t nx, size_t nw, size_t ny, float** X, float** W, float** Y) {
   DV_HIP(hipSetDevice(ctx->device));
@@ -3957,6 +4109,62 @@ int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, 
   }
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   return st;
+}
+
+#endif   // DV_DEBUG_EXPORTS
+
+int dv_ctx_comm_info(dv_ctx* c, int32_t* comm_ranks, int32_t* comm_rank, int32_t* device, char* bus_id, size_t bus_len,
+                     int32_t* rehearsal) {
+  if (!c) return DV_E_INVALID;
+  int n = 0, r = 0;
+  if (c->comm) {
+    DV_NCCL(ncclCommCount(c->comm, &n));
+    DV_NCCL(ncclCommUserRank(c->comm, &r));
+  }
+  if (comm_ranks) *comm_ranks = n;
+  if (comm_rank) *comm_rank = r;
+  if (device) *device = c->device;
+  if (bus_id && bus_len) {
+    bus_id[0] = 0;
+    if (bus_len >= 16) (void)hipDeviceGetPCIBusId(bus_id, (int)bus_len, c->device);
+  }
+  if (rehearsal) *rehearsal = c->fake_peers ? 1 : 0;
+  return DV_OK;
+}
+
+static void cprof_drain(dv_ctx* c, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, int64_t* n, double* ms) {
+  for (auto& pr : v) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) {
+      *ms += t;
+      *n += 1;
+    }
+    c->cprof_pool.push_back(pr.first);
+    c->cprof_pool.push_back(pr.second);
+  }
+  v.clear();
+}
+
+int dv_comm_prof_enable(dv_ctx* c, int32_t on) {
+  if (!c) return DV_E_INVALID;
+  c->cprof_on = on != 0;
+  return DV_OK;
+}
+
+int dv_comm_prof_read(dv_ctx* c, int64_t* n_collectives, double* comm_ms, int64_t* n_waits, double* exposed_ms) {
+  if (!c) return DV_E_INVALID;
+  DV_HIP(hipSetDevice(c->device));
+  DV_HIP(hipStreamSynchronize(c->stream));
+  if (c->comm_stream) DV_HIP(hipStreamSynchronize(c->comm_stream));
+  int64_t n1 = 0, n2 = 0;
+  double a = 0, b = 0;
+  cprof_drain(c, c->cprof_comm, &n1, &a);
+  cprof_drain(c, c->cprof_wait, &n2, &b);
+  if (n_collectives) *n_collectives = n1;
+  if (comm_ms) *comm_ms = a;
+  if (n_waits) *n_waits = n2;
+  if (exposed_ms) *exposed_ms = b;
+  return DV_OK;
 }
 
 int dv_prof_enable(dv_model* m, int32_t on) {

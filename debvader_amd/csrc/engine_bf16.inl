@@ -493,8 +493,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
         DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_red, 0));
       }
       if (cx->comm)
-        DV_NCCL(ncclAllReduce(G + A.n_enc_train, G + A.n_enc_train, A.n_train - A.n_enc_train, ncclFloat, ncclSum, cx->comm,
-                              cx->comm_stream));
+        DV_TRY(comm_allreduce(cx, G + A.n_enc_train, A.n_train - A.n_enc_train));
       if (early && m->opt_dec) {
         DV_TRY(adam_range(m, A.n_enc_train, A.n_train, cx->comm_stream));
         DV_TRY(refresh_head_pad(m, cx->comm_stream));
@@ -612,7 +611,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
         DV_HIP(hipEventRecord(cx->ev_dec, s));           // the main stream has finished reading those parameters
         DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_dec, 0));
         if (cx->comm) {
-          DV_NCCL(ncclAllReduce(G + split, G + split, A.n_enc_train - split, ncclFloat, ncclSum, cx->comm, cx->comm_stream));
+          DV_TRY(comm_allreduce(cx, G + split, A.n_enc_train - split));
           enc_reduced = split;
         }
         if (early && m->opt_enc) {

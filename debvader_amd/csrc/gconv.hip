@@ -17,9 +17,10 @@ namespace dv {
 constexpr int BK = 32;
 constexpr int LDA = BK + 4;
 
-__device__ __forceinline__ int tap_dh(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 3) - 1; }
-__device__ __forceinline__ int tap_dw(unsigned long long code, int t) { return (int)((code >> (4 * t + 2)) & 3) - 1; }
-__device__ __forceinline__ int tap_wt(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 15); }
+// tap table entry (common.h TapTab): (dh + 8) | (dw + 8) << 4 | weight tap index << 8
+__device__ __forceinline__ int tap_dh(unsigned e) { return (int)(e & 15u) - 8; }
+__device__ __forceinline__ int tap_dw(unsigned e) { return (int)((e >> 4) & 15u) - 8; }
+__device__ __forceinline__ int tap_wt(unsigned e) { return (int)(e >> 8); }
 
 template <int BM, int BN, int WGM, int WGN, bool NMAJOR>
 __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
@@ -38,8 +39,13 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                              // [2][BM][LDA]
   float* Bs = smem + 2 * A_ELEMS;                // [2][...]
+  // the tap of a K element varies per lane here (generic K decode), so the table sits in LDS; entries past the last
+  // tap repeat tap 0 (K elements past the end are masked anyway)
+  __shared__ unsigned s_tap[32];
 
   const int tid = threadIdx.x;
+  if (tid < 32) s_tap[tid] = p.xt.t[tid < p.ntaps ? tid : 0];
+  __syncthreads();
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm0 = (wave / WGN) * WM;
@@ -94,7 +100,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
       ci = kk - tap * p.Cin;
     }
     const bool kvalid = kk < p.K;
-    const int dh = tap_dh(p.tapcode, tap), dw = tap_dw(p.tapcode, tap);
+    const unsigned te = s_tap[kvalid ? tap : 0];
+    const int dh = tap_dh(te), dw = tap_dw(te);
     amask = 0;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
     }
     bmask = 0;
     if (NMAJOR) {
-      const int wt = tap_wt(p.wtcode, tap);
+      const int wt = tap_wt(te);
 #pragma unroll
       for (int i = 0; i < BROWS_N; ++i) {
         int n = n0 + r0 + 32 * i;
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
           tb = kb / p.Cin;
           cb = kb - tb * p.Cin;
         }
-        int wt = tap_wt(p.wtcode, ok ? tb : 0);
+        int wt = tap_wt(s_tap[ok ? tb : 0]);
         size_t off = ok ? ((size_t)(wt * p.Cin + cb)) * p.Cout + n : 0;
         breg[i] = *reinterpret_cast<const f32x4*>(p.W + off);
         bmask |= (ok ? 1u : 0u) << i;
@@ -358,7 +365,7 @@ int launch_gconv(const GConvParams& p, hipStream_t s) {
     set_error("gconv: Cin (%d) and Cout (%d) must be multiples of 4", p.Cin, p.Cout);
     return E_INVALID;
   }
-  if (p.ntaps < 1 || p.ntaps > 9 || p.K != p.ntaps * p.Cin) {
+  if (p.ntaps < 0 || p.ntaps > DV_MAX_TAPS || p.ntaps != p.xt.n || p.K != p.ntaps * p.Cin) {
     set_error("gconv: bad tap table (ntaps=%d K=%d Cin=%d)", p.ntaps, p.K, p.Cin);
     return E_INVALID;
   }

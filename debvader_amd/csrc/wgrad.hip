@@ -14,9 +14,10 @@ namespace dv {
 
 constexpr int BKP = 32;  // pixels per LDS stage
 
-__device__ __forceinline__ int wtap_dh(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 3) - 1; }
-__device__ __forceinline__ int wtap_dw(unsigned long long code, int t) { return (int)((code >> (4 * t + 2)) & 3) - 1; }
-__device__ __forceinline__ int wtap_wt(unsigned long long code, int t) { return (int)((code >> (4 * t)) & 15); }
+// tap table entry (common.h TapTab): (dh + 8) | (dw + 8) << 4 | weight tap index << 8
+__device__ __forceinline__ int wtap_dh(unsigned e) { return (int)(e & 15u) - 8; }
+__device__ __forceinline__ int wtap_dw(unsigned e) { return (int)((e >> 4) & 15u) - 8; }
+__device__ __forceinline__ int wtap_wt(unsigned e) { return (int)(e >> 8); }
 
 template <int V>
 struct WSet {
@@ -35,10 +36,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * A_ELEMS;
+  __shared__ unsigned s_tap[32];     // a row's tap varies per lane: the table is read from LDS (prologue and epilogue only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int l15 = lane & 15, lg = lane >> 4;
+  if (tid < 32) s_tap[tid] = p.xt.t[tid < p.ntaps ? tid : 0];
+  __syncthreads();
 
   const int rows_launch = p.ntaps * p.Cx;
   const int ntn = (p.Cy + BNW - 1) / BNW;
@@ -58,8 +62,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
     aok[i] = (rl < BMW) && (r < rows_launch);
     int t = aok[i] ? r / p.Cx : 0;
     acx[i] = r - t * p.Cx;
-    adh[i] = wtap_dh(p.tapcode, t);
-    adw[i] = wtap_dw(p.tapcode, t);
+    adh[i] = wtap_dh(s_tap[t]);
+    adw[i] = wtap_dw(s_tap[t]);
   }
   const int HcWc = p.Hc * p.Wc;
 
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradParams p) {
       if (rl >= rows_launch) continue;
       int t = rl / p.Cx;
       int cx = rl - t * p.Cx;
-      size_t grow = (size_t)(wtap_wt(p.wtcode, t) * p.Cx + cx) * p.Cy;
+      size_t grow = (size_t)(wtap_wt(s_tap[t]) * p.Cx + cx) * p.Cy;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         int c = n0 + wn0 + tn * 16 + l15;
@@ -233,6 +237,10 @@ int launch_wgrad(const WGradParams& p0, hipStream_t s) {
   }
   fast_div_consts((unsigned)(p.Hc * p.Wc), &p.div_hw_m, &p.div_hw_s1, &p.div_hw_s2);
   fast_div_consts((unsigned)p.Wc, &p.div_w_m, &p.div_w_s1, &p.div_w_s2);
+  if (p.ntaps < 1 || p.ntaps > DV_MAX_TAPS || p.ntaps != p.xt.n) {
+    set_error("wgrad: bad tap table (ntaps=%d)", p.ntaps);
+    return E_INVALID;
+  }
   if ((p.Cx & 3) || (p.Cy & 3) || (p.pchunk % BKP) || p.nsplit < 1 || (long)p.nsplit * p.pchunk < p.P) {
     set_error("wgrad: bad parameters (Cx=%d Cy=%d pchunk=%d nsplit=%d P=%d)", p.Cx, p.Cy, p.pchunk, p.nsplit, p.P);
     return E_INVALID;

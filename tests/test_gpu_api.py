@@ -181,8 +181,10 @@ import sys, numpy as np
 sys.path.insert(0, %r)
 from debvader_amd import engine as E
 from debvader_amd.data import synthetic_stamps
-from debvader_amd._lib import check, lib
-check(lib.dv_debug_fuse_prelu_bwd(1 if "fuse" in sys.argv[1:] else 0))
+from debvader_amd._lib import check
+if "fuse" in sys.argv[1:]:          # the parked fused epilogue lives in the development build of the library
+    from tests import debug_lib
+    check(debug_lib.use_for_process().dv_debug_fuse_prelu_bwd(1))
 x, y = synthetic_stamps(16, seed=3)
 eng = E.Engine(E.make_config(max_batch=8))
 eng.init(seed=4); eng.optimizer_reset(1e-4); eng.upload(0, x, y)
@@ -391,21 +393,23 @@ def test_graph_replayed_small_batch_inference_equals_eager_launches():
     (third call onwards) returns what the eager launches return for the same seed, and the seed - read from device
     memory by the replayed sampler - still changes the noise."""
     from debvader_amd import engine as E
-    from debvader_amd._lib import check, lib
+    from debvader_amd._lib import check
+    from tests import debug_lib
 
     x, _ = _data(5, 21)
-    eng = E.Engine(E.make_config(max_batch=64))
-    eng.init(seed=2)
-    eager = [eng.infer(x, seed=s, want=("loc", "scale", "z")) for s in (7, 8)]
-    check(lib.dv_model_set_infer_graph(eng._h, 1))          # debvader_hip_debug.h: kept as a measured experiment
-    for s in (1, 2):                       # eager warm-up of this size, then the capture
-        eng.infer(x, seed=s, want=("loc", "scale", "z"))
-    replay = [eng.infer(x, seed=s, want=("loc", "scale", "z")) for s in (7, 8)]
-    for a, b in zip(eager, replay):
-        for k in ("loc", "scale", "z"):
-            np.testing.assert_array_equal(a[k], b[k])
-    assert np.abs(replay[0]["z"] - replay[1]["z"]).max() > 0
-    eng.close()
+    with debug_lib.debug_build() as lib:   # the switch is an export of libdebvader_hip_debug.so (debvader_hip_debug.h)
+        eng = E.Engine(E.make_config(max_batch=64))
+        eng.init(seed=2)
+        eager = [eng.infer(x, seed=s, want=("loc", "scale", "z")) for s in (7, 8)]
+        check(lib.dv_model_set_infer_graph(eng._h, 1))      # kept as a measured experiment
+        for s in (1, 2):                   # eager warm-up of this size, then the capture
+            eng.infer(x, seed=s, want=("loc", "scale", "z"))
+        replay = [eng.infer(x, seed=s, want=("loc", "scale", "z")) for s in (7, 8)]
+        for a, b in zip(eager, replay):
+            for k in ("loc", "scale", "z"):
+                np.testing.assert_array_equal(a[k], b[k])
+        assert np.abs(replay[0]["z"] - replay[1]["z"]).max() > 0
+        eng.close()
 
 
 def test_deblend_sharded_single_rank_equals_deblend():

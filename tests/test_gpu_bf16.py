@@ -217,32 +217,38 @@ def _training_run(kind, steps, sigma_floor, shift, data, val, B=64, lr=1e-4):
     weight-gradient kernels instead of the strip and fused stride-2 forms: the SAME arithmetic in another summation
     order) or "bf16".  Returns per-step losses, per-step count of pixels on the sigma floor, final validation loss."""
     from debvader_amd import engine as E
-    from debvader_amd._lib import check, lib
+    from debvader_amd._lib import check
+    from tests import debug_lib
+    import contextlib
 
     x, y = data
     xv, yv = val
-    check(lib.dv_debug_general_kernels(1 if kind == "f32alt" else 0))
-    try:
-        eng = E.Engine(E.make_config(max_batch=B, dtype=1 if kind == "bf16" else 0, sigma_floor=sigma_floor))
-        eng.init(seed=5)
-        if shift:
-            hb = eng.get_param("dec/head/bias")
-            hb[6:] += shift
-            eng.set_param("dec/head/bias", hb)
-        eng.optimizer_reset(lr)
-        eng.upload(0, x, y)
-        eng.upload(1, xv, yv)
-        eng.keep_outputs(True)
-        nb = x.shape[0] // B
-        losses, floor_px = [], []
-        for s in range(steps):
-            out = eng.train_step(0, first=(s % nb) * B, B=B, seed=100 + s)
-            losses.append(out["loss"])
-            floor_px.append(int((eng.activation("scale", (B, 59, 59, 6)) <= sigma_floor * (1 + 1e-5)).sum()))
-        v = np.mean([eng.eval_step(1, first=k * B, B=B, seed=7000 + k)["loss"] for k in range(xv.shape[0] // B)])
-        eng.close()
-    finally:
-        check(lib.dv_debug_general_kernels(0))
+    # "f32alt" runs on the development build of the library, whose process-wide switch selects the other kernel family
+    with (debug_lib.debug_build() if kind == "f32alt" else contextlib.nullcontext()) as dlib:
+        if dlib is not None:
+            check(dlib.dv_debug_general_kernels(1))
+        try:
+            eng = E.Engine(E.make_config(max_batch=B, dtype=1 if kind == "bf16" else 0, sigma_floor=sigma_floor))
+            eng.init(seed=5)
+            if shift:
+                hb = eng.get_param("dec/head/bias")
+                hb[6:] += shift
+                eng.set_param("dec/head/bias", hb)
+            eng.optimizer_reset(lr)
+            eng.upload(0, x, y)
+            eng.upload(1, xv, yv)
+            eng.keep_outputs(True)
+            nb = x.shape[0] // B
+            losses, floor_px = [], []
+            for s in range(steps):
+                out = eng.train_step(0, first=(s % nb) * B, B=B, seed=100 + s)
+                losses.append(out["loss"])
+                floor_px.append(int((eng.activation("scale", (B, 59, 59, 6)) <= sigma_floor * (1 + 1e-5)).sum()))
+            v = np.mean([eng.eval_step(1, first=k * B, B=B, seed=7000 + k)["loss"] for k in range(xv.shape[0] // B)])
+            eng.close()
+        finally:
+            if dlib is not None:
+                check(dlib.dv_debug_general_kernels(0))
     return np.asarray(losses, np.float64), np.asarray(floor_px), float(v)
 
 

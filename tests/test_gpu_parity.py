@@ -32,9 +32,10 @@ def _relmax(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def _case(arch, B, seed, data=None):
+def _case(arch, B, seed, data=None, sigma_bias=0.0):
     rng = np.random.default_rng(seed)
     p = vo.init_params(arch, seed=seed + 1, perturb=0.05)
+    p["dec/head/bias"][arch.nb:] += sigma_bias      # > 0: sigma off its 1e-4 floor (tests/test_gpu_0_fullsize_oracle.py)
     H, W, C = arch.input_shape
     if data is None:
         x = rng.normal(0, 0.4, size=(B, H, W, C)).astype(np.float32)
@@ -56,8 +57,23 @@ def _grad_tol(name):
     return 2e-3 if name in ("enc/bn/gamma", "enc/bn/beta") else 1e-3
 
 
-def _run_parity(arch, B, seed, data=None, train_decoder=True):
-    p, x, y, eps = _case(arch, B, seed, data)
+def _f32_floor(arch, p, x, y, eps, g, train_decoder):
+    """What float32 itself costs on this case: the SAME step evaluated by the numpy oracle in float32 (float32 parameters,
+    activations, BLAS accumulation), per gradient tensor as |g32 - g64| / max|g64|.  An independent fp32 evaluation, not
+    the engine: tests/test_gpu_0_fullsize_oracle.py uses it to tell float32's noise at 256 stamps from a kernel error."""
+    p32 = {k: v.astype(np.float32) for k, v in p.items()}
+    c32 = vo.forward(arch, p32, x.astype(np.float32), eps.astype(np.float32), training=True)
+    g32 = vo.backward(arch, p32, c32, y.astype(np.float32), train_decoder=train_decoder)
+    return {k: _relmax(g32[k], g[k]) for k in g}
+
+
+def _run_parity(arch, B, seed, data=None, train_decoder=True, sigma_bias=0.0, f32_floor=False):
+    """f32_floor: gradient tolerance per tensor = max(_grad_tol, HALF the error of a numpy float32 evaluation of the same
+    step against the float64 oracle) - at the quoted batch sizes a gradient is a sum over ~10^6 signed pixel terms that
+    went through 25 layers, and a plain float32 evaluation misses float64 by up to 2e-2 * max on the early encoder
+    tensors (measured: enc/conv4/kernel 1.8e-2, enc/prelu1/alpha 1.7e-2 at 256 stamps where the engine is at 1.5e-3);
+    the engine has to stay within 1e-3 or be at least twice as close to float64 as that evaluation."""
+    p, x, y, eps = _case(arch, B, seed, data, sigma_bias)
     eng = _engine(arch, max_batch=B)
     eng.set_params(p)
     eng.set_trainable(True, train_decoder)
@@ -68,6 +84,10 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True):
     c = vo.forward(arch, p, x64, e64, training=True)
     ref = vo.losses(arch, c, y64)
     g = vo.backward(arch, p, c, y64, train_decoder=train_decoder)
+    floor = _f32_floor(arch, p, x, y, eps, g, train_decoder) if f32_floor else {}
+
+    def tol(name):
+        return max(_grad_tol(name), 0.5 * floor.get(name, 0.0))
 
     eng.keep_outputs(True)          # loc / scale of the step are compared below
     out = eng.grad_step(0, first=0, B=B, eps=eps)
@@ -91,7 +111,7 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True):
         e = _relmax(eng.get_grad(name), g[name])
         if e > worst[1]:
             worst = (name, e)
-        assert e <= _grad_tol(name), (name, e)
+        assert e <= tol(name), (name, e, tol(name))
 
     # the production form of the step: no loc / scale stores in the head kernel
     eng.keep_outputs(False)
@@ -100,7 +120,7 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True):
         assert abs(outf[k] - ref[k]) <= 1e-4 * abs(ref[k]) + 1e-12, (k, outf[k], ref[k])
     for name in g:
         e = _relmax(eng.get_grad(name), g[name])
-        assert e <= _grad_tol(name), ("without outputs", name, e)
+        assert e <= tol(name), ("without outputs", name, e)
     eng.keep_outputs(True)
     eng.grad_step(0, first=0, B=B, eps=eps)          # gradients of the form the train step below repeats
 
@@ -132,6 +152,10 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True):
             np.testing.assert_allclose(eng.get_slot(name, 1), st.v[name], rtol=5e-5, atol=1e-30)
     assert eng.iterations == 1
     eng.close()
+    if floor:
+        wf = max(floor.items(), key=lambda kv: kv[1])
+        print(f"\n  numpy float32 evaluation of the same step: largest gradient error {wf[1]:.2e} * max ({wf[0]}); "
+              f"engine: {worst[1]:.2e} ({worst[0]}; numpy float32 there: {floor[worst[0]]:.2e})")
     return worst
 
 
@@ -282,8 +306,8 @@ def test_specialised_kernels_match_the_general_gather_gemm():
     layouts and every epilogue.  fp32 sums in a different order: 2e-5 of the largest output."""
     import ctypes as C
     from debvader_amd import engine as E
-    from debvader_amd._lib import lib, check
-    ctx = E.default_context()
+    from debvader_amd._lib import check
+    from tests import debug_lib
     out = (C.c_float * 2)()
     cases = []
     for H in (64, 59, 40, 17, 8):
@@ -304,14 +328,16 @@ def test_specialised_kernels_match_the_general_gather_gemm():
             cases.append((3, hs, cs, ht, ct, 2, pb, 1, 1, epi))
     # stride-1 layers with >= 32 channels on both sides take the Winograd kernel by default (next test): switch it off so
     # that the strip forms are what is checked here
-    check(lib.dv_debug_winograd(0))
-    try:
-        for c in cases:
-            check(lib.dv_debug_gconv_check(ctx._h, *c, out))
-            assert out[1] > 0.1, c
-            assert out[0] <= 2e-5 * out[1], (c, out[0], out[1])
-    finally:
-        check(lib.dv_debug_winograd(1))
+    with debug_lib.debug_build() as lib:        # the cross-check harness lives in libdebvader_hip_debug.so
+        ctx = E.default_context()
+        check(lib.dv_debug_winograd(0))
+        try:
+            for c in cases:
+                check(lib.dv_debug_gconv_check(ctx._h, *c, out))
+                assert out[1] > 0.1, c
+                assert out[0] <= 2e-5 * out[1], (c, out[0], out[1])
+        finally:
+            check(lib.dv_debug_winograd(1))
 
 
 def test_winograd_kernel_matches_the_general_gather_gemm():
@@ -322,9 +348,15 @@ def test_winograd_kernel_matches_the_general_gather_gemm():
     (sums of four inputs, halves in G): stated 2e-5 of the largest output, measured <= 2.7e-6."""
     import ctypes as C
     from debvader_amd import engine as E
-    from debvader_amd._lib import lib, check
-    ctx = E.default_context()
+    from debvader_amd._lib import check
+    from tests import debug_lib
     out = (C.c_float * 2)()
+    with debug_lib.debug_build() as lib:
+        worst = _winograd_cases(lib, E.default_context(), check, out)
+    print(f"\nWinograd vs gather-GEMM: worst relative difference {worst:.2e}")
+
+
+def _winograd_cases(lib, ctx, check, out):
     worst = 0.0
     for H in (64, 59, 40, 32, 30, 17, 16, 15, 8, 5):
         for (cs, ct) in ((32, 32), (64, 64), (32, 64), (64, 32), (64, 128), (128, 128), (128, 256), (256, 256), (96, 160)):
@@ -348,7 +380,7 @@ def test_winograd_kernel_matches_the_general_gather_gemm():
                 assert out[1] > 0.1, c
                 assert out[0] <= 2e-5 * out[1], (c, out[0], out[1])
                 worst = max(worst, out[0] / out[1])
-    print(f"\nWinograd vs gather-GEMM: worst relative difference {worst:.2e}")
+    return worst
 
 
 def test_winograd_weight_gradient_matches_the_direct_kernels():
@@ -358,9 +390,15 @@ def test_winograd_weight_gradient_matches_the_direct_kernels():
     splits uneven block ranges.  fp32 sums in another association: stated 2e-5 of the largest gradient, measured 7e-7."""
     import ctypes as C
     from debvader_amd import engine as E
-    from debvader_amd._lib import lib, check
-    ctx = E.default_context()
+    from debvader_amd._lib import check
+    from tests import debug_lib
     out = (C.c_float * 2)()
+    with debug_lib.debug_build() as lib:
+        worst = _winograd_wgrad_cases(lib, E.default_context(), check, out)
+    print(f"\nWinograd weight gradient vs direct: worst relative difference {worst:.2e}")
+
+
+def _winograd_wgrad_cases(lib, ctx, check, out):
     worst = 0.0
     for H in (32, 30, 17, 16, 15, 8, 5):
         for (cx, cy) in ((64, 64), (64, 128), (128, 64), (128, 128), (128, 256), (256, 256), (192, 64)):
@@ -373,7 +411,7 @@ def test_winograd_weight_gradient_matches_the_direct_kernels():
                 assert out[1] > 0.1, (H, cx, cy, NB)
                 assert out[0] <= 2e-5 * out[1], (H, cx, cy, NB, out[0], out[1])
                 worst = max(worst, out[0] / out[1])
-    print(f"\nWinograd weight gradient vs direct: worst relative difference {worst:.2e}")
+    return worst
 
 
 def test_channel_counts_that_are_not_powers_of_two():

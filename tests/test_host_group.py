@@ -20,6 +20,8 @@ def _free_port():
 def _worker(rank, world, env, q):
     try:
         os.environ.update(env)
+        if not os.environ.get("DV_RDZV_TOKEN"):
+            os.environ.pop("DV_RDZV_TOKEN", None)
         from debvader_amd import parallel
 
         with parallel.HostGroup(rank, world, timeout=60) as g:
@@ -34,11 +36,13 @@ def _worker(rank, world, env, q):
         q.put((rank, None, None, None, None, None, repr(e)))
 
 
-@pytest.mark.parametrize("mode", ["master_port", "port_file"])
+@pytest.mark.parametrize("mode", ["master_port", "port_file", "env_token"])
 def test_three_ranks_meet_and_exchange(mode, monkeypatch):
     world = 3
     port = _free_port()
-    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "DV_RDZV_TOKEN": ""}
+    if mode == "env_token":                     # the launcher exports the secret: no file at all
+        env["DV_RDZV_TOKEN"] = "ab" * 16
     holder = None
     stale = None
     if mode == "port_file":
@@ -49,7 +53,9 @@ def test_three_ranks_meet_and_exchange(mode, monkeypatch):
         holder.listen(1)
         env["TORCHELASTIC_USE_AGENT_STORE"] = "True"
         # a stale file of an earlier job with the same launcher pid / port: a dead port and another token
-        stale = os.path.join(tempfile.gettempdir(), f"dv_rdzv_{os.getuid()}_{os.getpid()}_{port}")
+        from debvader_amd import parallel
+
+        stale = os.path.join(parallel._private_dir(), f"job_{port}_{os.getpid()}")
         with open(stale, "w") as fh:
             fh.write(f"{_free_port()} {'00' * 16}\n")
     else:
@@ -116,3 +122,125 @@ def test_make_context_hands_rank0s_id_to_every_rank(tmp_path):
         ev = [json.loads(ln) for ln in open(f"{log}.{r}")]
         uids.append(next(e["uid"] for e in ev if e["event"] == "ctx"))
     assert uids[0] == uids[1] and len(uids[0]) == 256
+
+
+def _hub_only(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_USE_AGENT_STORE="")
+    os.environ.pop("DV_RDZV_TOKEN", None)
+    from debvader_amd import parallel
+
+    try:
+        parallel.HostGroup(0, 2, timeout=3)
+        q.put("joined")
+    except TimeoutError:
+        q.put("timeout")
+
+
+def test_a_stranger_on_master_port_cannot_join_as_a_rank():
+    """in the direct mode (mpirun / srun / a shell loop: rank 0 listens on MASTER_PORT itself) any process that
+    could reach the port used to be admitted, and rank 0 then unpickled its bytes.  Now every handshake carries the job's
+    secret; a hello with the right magic, world and rank but without it is refused, and the hub times out cleanly
+    (listener closed, token file gone)."""
+    from debvader_amd import parallel
+
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    hub = ctx.Process(target=_hub_only, args=(port, q))
+    hub.start()
+    answer = None
+    import time
+    for _ in range(100):
+        try:
+            s = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+            s.sendall(parallel._MAGIC + struct.pack("<II", 1, 2) + b"\0" * 16)
+            answer = s.recv(2)
+            s.close()
+            break
+        except OSError:
+            time.sleep(0.05)
+    assert answer == b"NO"
+    assert q.get(timeout=30) == "timeout"
+    hub.join(30)
+    assert not os.path.exists(os.path.join(parallel._private_dir(), f"job_{port}"))
+
+
+def test_token_file_is_private_and_payloads_are_not_pickled(tmp_path, monkeypatch):
+    from debvader_amd import parallel
+    import numpy as np
+    import stat
+
+    d = parallel._private_dir()
+    st = os.lstat(d)
+    assert stat.S_ISDIR(st.st_mode) and (st.st_mode & 0o077) == 0 and st.st_uid == os.getuid()
+    # a world-accessible directory in its place is refused, not used
+    monkeypatch.setenv("XDG_RUNTIME_DIR", str(tmp_path))
+    bad = tmp_path / f"dv_rdzv_{os.getuid()}"
+    bad.mkdir(mode=0o755)
+    os.chmod(bad, 0o755)
+    with pytest.raises(PermissionError):
+        parallel._private_dir()
+    # the wire format: plain types and numeric arrays only
+    piece = (3, 9, np.arange(24, dtype=np.float32).reshape(2, 3, 4), np.zeros((0, 5), np.float64))
+    back = parallel._unpack(parallel._pack(piece))
+    assert back[:2] == (3, 9) and np.array_equal(back[2], piece[2]) and back[3].shape == (0, 5)
+    with pytest.raises(TypeError):
+        parallel._pack(object())
+    with pytest.raises(TypeError):
+        parallel._pack(np.array([object()]))
+    import inspect
+    assert "pickle" not in inspect.getsource(parallel).replace("never pickle", "").replace("never pickled", "").replace("pickle.loads on a socket", "").replace("unpickled", "")
+
+
+def _gather_worker(rank, world, env, q):
+    try:
+        os.environ.update(env)
+        os.environ.pop("DV_RDZV_TOKEN", None)
+        import numpy as np
+        from debvader_amd import parallel
+
+        sent = []
+        with parallel.HostGroup(rank, world, timeout=60) as g:
+            if g._sock is not None:                       # count what a spoke RECEIVES during the gather
+                real = g._sock.recv
+
+                def counting(n, *a):
+                    b = real(n, *a)
+                    sent.append(len(b))
+                    return b
+
+                class Wrap:
+                    def __init__(self, s): self._s = s
+                    def recv(self, n, *a): return counting(n, *a)
+                    def __getattr__(self, k): return getattr(self._s, k)
+                g._sock = Wrap(g._sock)
+            piece = (rank, rank + 1, np.full((1000, 7), float(rank), np.float32))
+            got = g.gather_object(piece, dst=0)
+            to2 = g.gather_object({"r": rank}, dst=2)
+            g.barrier()
+        q.put((rank, None if got is None else [(a, b, float(c.sum())) for a, b, c in got], to2, sum(sent), None))
+    except Exception as e:                                # pragma: no cover
+        q.put((rank, None, None, 0, repr(e)))
+
+
+def test_gather_sends_pieces_to_the_hub_only():
+    """gather_object was built on allgather - rank 0 sent the whole blob back to every spoke.  Now a spoke
+    receives a 1-byte ack (and the small barrier frames), not world x 28 KB."""
+    world = 3
+    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "TORCHELASTIC_USE_AGENT_STORE": ""}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, env, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    for rank, got, to2, nrecv, err in res:
+        assert err is None, err
+        if rank == 0:
+            assert got == [(r, r + 1, 7000.0 * r) for r in range(world)]
+        else:
+            assert got is None
+            assert nrecv < 2000, nrecv                        # acks + barrier frames + (rank 2) three tiny dicts
+        assert to2 == ([{"r": r} for r in range(world)] if rank == 2 else None)

@@ -35,7 +35,9 @@ def run_variant(name, a):
 
     dtype = VARIANTS[name][0]
     if name == "f32alt":
-        from debvader_amd._lib import check, lib
+        from debvader_amd._lib import check
+        from tests import debug_lib
+        lib = debug_lib.use_for_process()   # dv_debug_* live in libdebvader_hip_debug.so (include/debvader_hip_debug.h)
         check(lib.dv_debug_general_kernels(1))
     B, steps = a.batch, a.steps
     ntrain, nval = a.ntrain, a.nval

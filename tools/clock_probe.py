@@ -2,7 +2,9 @@
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from debvader_amd import engine as E
-from debvader_amd._lib import lib, check
+from debvader_amd._lib import check
+from tests import debug_lib
+lib = debug_lib.use_for_process()   # dv_debug_* live in libdebvader_hip_debug.so (include/debvader_hip_debug.h)
 ctx = E.Context()
 ms = C.c_float()
 cases = {"convt3_fwd_s1": (16, 128, 16, 128, 1, 1, 1, 1, 2), "convt1_fwd_s1": (8, 256, 8, 256, 1, 1, 1, 1, 2), "convt7_fwd_s1": (64, 32, 64, 32, 1, 1, 1, 1, 2)}

@@ -1,7 +1,9 @@
 import ctypes as C, os, sys
 sys.path.insert(0, "/root/repo")
 from debvader_amd import engine as E
-from debvader_amd._lib import lib, check
+from debvader_amd._lib import check
+from tests import debug_lib
+lib = debug_lib.use_for_process()   # dv_debug_* live in libdebvader_hip_debug.so (include/debvader_hip_debug.h)
 ctx = E.Context()
 def gconv(B, Hs, Cs, Ht, Ct, s, pb, dgrad, nmajor, epi=2, iters=300):
     ms = C.c_float()

@@ -3,7 +3,9 @@ import ctypes as C
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from debvader_amd import engine as E
-from debvader_amd._lib import lib, check
+from debvader_amd._lib import check
+from tests import debug_lib
+lib = debug_lib.use_for_process()   # dv_debug_* live in libdebvader_hip_debug.so (include/debvader_hip_debug.h)
 
 B = int(os.environ.get("LB_BATCH", "256"))
 ITERS = int(os.environ.get("LB_ITERS", "300"))   # long enough that clocks have ramped (10 iterations read ~12 % slow)

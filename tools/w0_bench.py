@@ -3,7 +3,9 @@ dbg bits: 1 no refill DMA, 2 no MFMA loop, 16 no transform pass (results wrong w
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from debvader_amd import engine as E
-from debvader_amd._lib import lib, check
+from debvader_amd._lib import check
+from tests import debug_lib
+lib = debug_lib.use_for_process()   # dv_debug_* live in libdebvader_hip_debug.so (include/debvader_hip_debug.h)
 
 B = int(os.environ.get("LB_BATCH", "256"))
 ctx = E.Context()

@@ -1,7 +1,9 @@
 import ctypes as C, sys, os
 sys.path.insert(0, "/root/repo")
 from debvader_amd import engine as E
-from debvader_amd._lib import lib, check
+from debvader_amd._lib import check
+from tests import debug_lib
+lib = debug_lib.use_for_process()   # dv_debug_* live in libdebvader_hip_debug.so (include/debvader_hip_debug.h)
 ctx = E.Context()
 ms = C.c_float()
 for name, a in {"convt7 wgrad (32,32 s1 64x64)": (64, 32, 64, 32, 1, 1), "convt5 wgrad (64,64 s1 32x32)": (32, 64, 32, 64, 1, 1),

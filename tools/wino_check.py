@@ -3,7 +3,9 @@ against the direct kernels (dv_debug_gconv) for the stride-1 layers of the 59 x 
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from debvader_amd import engine as E
-from debvader_amd._lib import lib, check
+from debvader_amd._lib import check
+from tests import debug_lib
+lib = debug_lib.use_for_process()   # dv_debug_* live in libdebvader_hip_debug.so (include/debvader_hip_debug.h)
 ctx = E.default_context()
 out = (C.c_float * 2)()
 bad = 0
