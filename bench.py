@@ -2,9 +2,15 @@
 """Headline benchmark: galaxy stamps/sec of the conv-VAE training step (fwd + ELBO + bwd + Adam),
 59x59x6 stamps, batch 256 per GPU, latent 32, fp32 (BASELINE.json configs[1]); weak scaling over N GPUs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config {1,2,3,4}]
+
+--config selects the BASELINE configuration the line is about (default 1, the headline): 2 the same step on the bf16
+engine, 3 the 128x128x6 / six-level net at 64 stamps per GPU (global 512 on 8), 4 sharded deblend() inference over field
+cutouts at 8192 per call (index ranges per rank, no collective).  With N > 1 the line carries `multi_rank`: the
+communicator size RCCL itself reports on every rank (ncclCommCount), each rank's device (PCI bus id), and the
+communication of a step - time inside the all-reduces against the part the main stream waited for.
 
 One process per GPU.  The compute path is the HIP engine (libdebvader_hip.so through ctypes) with RCCL
 gradient all-reduce.  Rank 0's RCCL id, the barriers around the timed region and the max-over-ranks of the
@@ -149,7 +155,7 @@ def _git_head():
 def _pmc_traffic():
     """HBM bytes per step and kernel family from the committed rocprofv3 PMC passes of this round (FETCH_SIZE doubled as
     the micro-architecture guide prescribes for gfx950; tools/pmc_traffic.py spells out the collection)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as fh:
@@ -181,6 +187,8 @@ def _family_table(eng, B, steps, peak_tflops, seed):
         ms = f["ms"] / steps
         tf = f["flops"] / steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         rows.append({"kernel": f["name"], "launches_per_step": f["launches"] / steps, "flops_per_step": f["flops"] / steps,
+                     "executed_flops_per_step": f.get("executed_flops", f["flops"]) / steps,
+                     "algorithmic_bytes_per_step": (f.get("algorithmic_bytes") or 0.0) / steps or None,
                      "ms_per_step": ms, "avg_us": ms * 1e3 / max(1.0, f["launches"] / steps), "tflops": tf,
                      "frac": tf / peak_tflops})
     classes = {k: eng.prof_read(i)[1] / steps for i, k in enumerate(("conv", "wgrad", "other"))}
@@ -271,15 +279,188 @@ def secondary_entries(E, ctx, synthetic_stamps, quick: bool):
     return out
 
 
+ARCH128 = dict(input_shape=(128, 128, 6), latent_dim=32, filters=(32, 64, 128, 256, 512, 512), kernels=(3,) * 6)
+CONFIGS = {
+    1: dict(dtype=0, batch=256, arch={}, label="BASELINE configs[1]: 6-band 59x59 stamps, batch=256 per GPU, latent_dim=32, "
+                                               "filters [32,64,128,256], fp32, stage-1 VAE train step"),
+    2: dict(dtype=1, batch=256, arch={}, label="BASELINE configs[2]: same model and step, bf16 storage + bf16 MFMA operands, fp32 "
+                                               "accumulation / master weights / head, batch=256 per GPU"),
+    3: dict(dtype=0, batch=64, arch=ARCH128, label="BASELINE configs[3]: 128x128x6 stamps, 6 levels, filters "
+                                                   "[32,64,128,256,512,512], fp32, batch=64 per GPU (512 on 8 GPUs)"),
+    4: dict(dtype=0, batch=8192, arch={}, label="BASELINE configs[4]: deblend() inference over cutouts of a field_img_2.npy-style "
+                                                "scene, 8192 per network call, index ranges sharded over the GPUs, no collective"),
+}
+
+
+def _roofline_f32(rows, classes, pmc, src, B, dt, steps, train_flops):
+    """The roofline object of an fp32 train configuration (MFMA-bound), from the per-family rows of the serialised pass.
+    `frac` is PHYSICAL: the FLOPs the matrix pipe executes for the dominant kernel's launches (Winograd-domain multiplies,
+    block / column-tile padding included) over their duration over the dense fp32 MFMA peak - what SQ_VALU_MFMA_BUSY sees.
+    The direct-convolution rate SURVEY 8(d) prices the layers with is carried beside it as algorithmic_*."""
+    per_kernel = (pmc or {}).get("per_kernel_bytes", {})
+    for r in rows:
+        ms = r["ms_per_step"]
+        r["algorithmic_tflops"] = r["tflops"]
+        r["algorithmic_frac"] = r["tflops"] / FP32_MFMA_PEAK_TFLOPS
+        r["executed_tflops"] = r["executed_flops_per_step"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        r["executed_frac"] = r["executed_tflops"] / FP32_MFMA_PEAK_TFLOPS
+        r["frac"] = r["executed_frac"]
+        if r["kernel"].startswith("wino_"):
+            r["note"] = ("Winograd: algorithmic_* price the launch as a direct convolution (SURVEY 8(d)); executed_* count the "
+                         "16 multiplies per 2x2 tile and channel pair the matrix pipe really does, padding included")
+    dom = max(rows, key=lambda r: r["ms_per_step"]) if rows else None
+    conv_rows = [r for r in rows if r["kernel"].startswith("gconv") or r["kernel"].startswith("wino_conv")]
+    conv_ms = sum(r["ms_per_step"] for r in conv_rows)
+    conv_fl = sum(r["flops_per_step"] for r in conv_rows)
+    conv_ex = sum(r["executed_flops_per_step"] for r in conv_rows)
+    traffic = None
+    if dom is not None:
+        # HBM bytes of the same launches (one step's launches of the dominant kernel), from the committed PMC passes
+        # (a row may stand for several rocprof kernel names, "a / b": their bytes add up)
+        parts = [per_kernel.get(n.strip()) for n in dom["kernel"].split("/")]
+        if any(parts):
+            traffic = sum((q or {}).get("hbm_bytes", 0.0) for q in parts)
+    alg_bytes = dom["algorithmic_bytes_per_step"] if dom and dom.get("algorithmic_bytes_per_step") else None
+    whole = train_flops * B / (dt / steps) / 1e12
+    return {
+        "bound": "mfma", "kernel": dom["kernel"] if dom else None,
+        "achieved": dom["executed_tflops"] if dom else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": dom["executed_frac"] if dom else None,
+        "frac_definition": "executed matrix FLOPs of the dominant kernel's launches (tile / block padding included) / their "
+                           "duration / 157.3 TFLOP/s; comparable with SQ_VALU_MFMA_BUSY of profiles/*_pmc_f32_mfma.json",
+        "algorithmic_tflops": dom["algorithmic_tflops"] if dom else None,
+        "algorithmic_frac": dom["algorithmic_frac"] if dom else None,
+        "algorithmic_bytes": alg_bytes, "traffic": traffic,
+        "traffic_over_algorithmic": (traffic / alg_bytes) if traffic and alg_bytes else None,
+        "traffic_source": {"file": src, "commit": _git_head(),
+                           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed; not "
+                                   "re-measured in this run"} if src and traffic else None,
+        "mode": "streams serialised (the per-kernel rows); `value` is measured with the streams overlapped",
+        "launch": (f"one training step's launches of {dom['kernel']} ({dom['launches_per_step']:.0f} launches, "
+                   f"batch {B})") if dom else None,
+        "kernels": rows,
+        "conv_family": {"kernels": "gconv* + wino_conv (forward and data-gradient launches)", "ms_per_step": conv_ms,
+                        "flops_per_step": conv_fl,
+                        "algorithmic_tflops": conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+                        "executed_frac": conv_ex / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS if conv_ms > 0 else 0.0},
+        "classes_ms_per_step": classes,
+        "whole_step_tflops": whole, "whole_step_frac": whole / FP32_MFMA_PEAK_TFLOPS,
+        "whole_step_note": "algorithmic train FLOPs (3 x forward, SURVEY 8(d)) of the overlapped step over the fp32 MFMA peak",
+    }
+
+
+def _multi_rank_block(ctx, group, eng, B, Bg, steps, world):
+    """What makes an N > 1 line checkable: the size RCCL itself reports for the communicator on every rank, the device
+    each rank drives, and the communication of a step - time inside the collectives on the comm stream against the part
+    of it the main stream actually waited for (a separate pass with timed events: they perturb the step a little)."""
+    info = ctx.comm_info() if hasattr(ctx, "comm_info") else {}
+    prof = None
+    if eng is not None and hasattr(ctx, "comm_prof"):
+        ctx.comm_prof(True)
+        eng.train_steps(0, 0, B, steps, global_batch=Bg, seed=300)
+        prof = ctx.comm_prof_read()
+        ctx.comm_prof(False)
+    mine = {"info": info, "prof": prof}
+    allr = group.gather_object(mine, dst=0) if group is not None else [mine]
+    if allr is None:
+        return None
+    infos = [a["info"] for a in allr]
+    profs = [a["prof"] for a in allr if a["prof"]]
+    blk = {
+        "world": world,
+        "rccl_ranks": [i.get("comm_ranks") for i in infos],          # ncclCommCount on every rank: must all equal world
+        "rccl_rank_ids": [i.get("comm_rank") for i in infos],
+        "devices": [{"rank": r, "hip_device": i.get("device"), "pci_bus_id": i.get("bus_id")} for r, i in enumerate(infos)],
+        "distinct_devices": len({i.get("bus_id") for i in infos}),
+        "rehearsal": any(i.get("rehearsal") for i in infos) or bool(os.environ.get("DV_DEBUG_SAME_GPU")),
+    }
+    if profs:
+        blk.update({
+            "collectives_per_step": profs[0]["collectives"] / steps,
+            "comm_ms_per_step": max(p["comm_ms"] for p in profs) / steps,
+            "exposed_comm_ms_per_step": max(p["exposed_ms"] for p in profs) / steps,
+            "comm_note": "max over ranks; comm = time inside all-reduces on the comm stream (3 gradient buckets, BN sums, "
+                         "loss sums), exposed = what the main stream waited for them; separate pass with timed events",
+        })
+    blk["verified"] = (not blk["rehearsal"]) and all(n == world for n in blk["rccl_ranks"]) and blk["distinct_devices"] == world
+    return blk
+
+
+def run_inference_config(args, E, ctx, group, rank, world):
+    """BASELINE configs[4]: a "step" is one 8192-cutout deblend() call per GPU; rank r takes the contiguous index range
+    parallel.shard_range(N, r, world) of the cutout list (no collective on the data path)."""
+    from tools.field_cutouts import synthetic_field
+    from debvader_amd.parallel import shard_range
+
+    chunk = args.batch or CONFIGS[4]["batch"]
+    dtype = 1 if args.dtype == "bf16" else 0
+    scene = np.ascontiguousarray(np.tile(synthetic_field(), (8, 8, 1)))
+    F, cs = scene.shape[0], 59
+    n_total = chunk * world * (args.steps + args.warmup)
+    starts = np.random.default_rng(0).integers(0, F - cs + 1, size=(n_total, 2)).astype(np.int32)
+    eng = E.Engine(E.make_config(max_batch=chunk, dtype=dtype), ctx)
+    eng.init(seed=0)
+    state = {"n": 0, "checksum": 0.0}
+
+    def consume(first, mean, std):
+        state["n"] += mean.shape[0]
+        state["checksum"] += float(mean[::97, 29, 29, 2].sum())
+
+    def barrier():
+        ctx.sync()
+        if group is not None:
+            group.barrier()
+
+    wlo, whi = shard_range(chunk * world * max(args.warmup, 2), rank, world)          # the pinned ring wants two chunks
+    eng.infer_cutouts_stream(scene, starts[wlo:whi], lambda *a: None, seed=1)
+    n_timed = chunk * world * args.steps
+    lo, hi = shard_range(n_timed, rank, world)
+    off = n_total - n_timed
+    barrier()
+    t0 = time.perf_counter()
+    eng.infer_cutouts_stream(scene, starts[off + lo:off + hi], consume, seed=2)
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if group is not None:
+        dt = group.max(dt)
+    eng.close()
+    mr = _multi_rank_block(ctx, group, None, 0, 0, 1, world) if world > 1 else None     # who ran where (no timing pass)
+    if rank != 0:
+        return None
+    enc_macs, dec_macs = E.arch_macs(E.make_config())
+    fwd_flops = 2.0 * (enc_macs + dec_macs + 32 * 33 // 2)
+    val = n_timed / dt
+    return {
+        "metric": "galaxy stamps/sec (deblend inference over field cutouts) 59x59x6",
+        "value": val, "unit": "stamps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if dtype else "f32", "data": "synthetic",
+        "config": {"workload": CONFIGS[4]["label"], "global_batch": chunk * world, "per_gpu_batch": chunk,
+                   "parallelism": f"shard{world} (no collective)"},
+        "includes": "field H2D once, cutout gather + float32 cast on the GPU, forward, D2H of mean and stddev of every stamp "
+                    "into the pinned ring, consumed in place (PCIe-inclusive: 167 KB per stamp cross the host link)",
+        "d2h_gbs": val * 2 * cs * cs * 6 * 4 / 1e9,
+        "roofline": {"bound": "mfma", "achieved": val * fwd_flops / world / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS if dtype else FP32_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": val * fwd_flops / world / 1e12 / (BF16_MFMA_PEAK_TFLOPS if dtype else FP32_MFMA_PEAK_TFLOPS),
+                     "traffic": None, "note": "algorithmic forward FLOPs per GPU (658.7 MFLOP per stamp) over the dense MFMA peak of "
+                                              "the dtype; the entry is host-link-bound where d2h_gbs reaches the box's link rate"},
+        "cpu_baseline": None, "checksum": state["checksum"], **({"multi_rank": mr} if mr else {}),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="stamps per GPU per step")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="f32: BASELINE configs[1] (the headline, reference precision); bf16: BASELINE configs[2] - the same "
-                         "step on the bf16 engine, e.g. `--gpus 8 --dtype bf16` for its 8-GPU data-parallel form")
+    ap.add_argument("--config", type=int, choices=(1, 2, 3, 4), default=None,
+                    help="BASELINE configs[k]: 1 fp32 59 px batch 256 (the headline, default), 2 the same step on the bf16 "
+                         "engine, 3 128x128x6 / six levels at 64 stamps per GPU (512 on 8), 4 sharded deblend() inference at "
+                         "8192 cutouts per call (no collective)")
+    ap.add_argument("--batch", type=int, default=None, help="stamps per GPU per step (default: the configuration's)")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
+                    help="bf16 without --config selects configs[2]; with --config 4 the bf16 engine's inference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -289,6 +470,11 @@ def main():
     if args.cpu_baseline_child:
         print(json.dumps(cpu_baseline_torch(batch=256, steps=5)), flush=True)
         return
+    if args.config is None:
+        args.config = 2 if args.dtype == "bf16" else 1
+    conf = CONFIGS[args.config]
+    if args.dtype is None:
+        args.dtype = "bf16" if conf["dtype"] else "f32"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -313,13 +499,31 @@ def main():
     ctx = parallel.make_context(rank, world, local_rank)     # world > 1: the ranks meet in a parallel.HostGroup
     group = ctx.group
 
-    B = args.batch
+    if args.config == 4:
+        line = run_inference_config(args, E, ctx, group, rank, world)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if group is not None:
+            group.barrier()
+        ctx.close()
+        if group is not None:
+            group.close()
+        return
+
+    B = args.batch or conf["batch"]
     bf16 = args.dtype == "bf16"
-    cfg = E.make_config(max_batch=B, dtype=1) if bf16 else E.make_config(max_batch=B)
+    cfg = E.make_config(max_batch=B, dtype=1 if bf16 else 0, **conf["arch"])
     eng = E.Engine(cfg, ctx)
     eng.init(seed=0)                                     # same weights on every rank
     pool = 4 * B                                         # per-rank shard of the synthetic set, resident in HBM
-    x, y = synthetic_stamps(pool, seed=1000 + rank)
+    if conf["arch"]:
+        H, C = cfg.height, cfg.bands
+        rng = np.random.default_rng(5 + rank)
+        x = rng.normal(0, 0.3, size=(2 * B, H, H, C)).astype(np.float32)
+        y = np.abs(x) * 0.5
+        pool = 2 * B
+    else:
+        x, y = synthetic_stamps(pool, seed=1000 + rank)
     eng.upload(0, x, y)
     eng.optimizer_reset(1e-4)
     Bg = B * world
@@ -345,81 +549,53 @@ def main():
     train_flops = 3.0 * fwd_flops                         # fwd + dgrad + wgrad
 
     _progress(f"headline: {Bg * args.steps / dt:.0f} stamps/s")
+    multi = None
+    if world > 1:
+        multi = _multi_rank_block(ctx, group, eng, B, Bg, min(args.steps, 20), world)
     roofline = None
-    if not args.no_roofline:
+    if world > 1 and rank == 0:
+        whole = train_flops * B / (dt / args.steps) / 1e12      # per GPU
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+        roofline = {"bound": "hbm" if bf16 else "mfma", "kernel": None, "achieved": whole, "peak": peak, "unit": "TFLOP/s",
+                    "frac": whole / peak, "traffic": None, "whole_step_tflops": whole, "whole_step_frac": whole / peak,
+                    "note": "N > 1: whole-step algorithmic train FLOPs PER GPU over the dense MFMA peak of the dtype (the "
+                            "per-kernel rows need the serialised single-GPU pass: run with --gpus 1)"}
+    if not args.no_roofline and world == 1:
         # HIP-event timing per kernel family on the stream each launch is queued on, over K steps of the same workload,
         # with the engine's streams SERIALISED (a separate pass: the records would perturb `value`, and overlapped
         # kernels cannot be told apart by events)
         rows, classes = _family_table(eng, B, args.steps, BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS, 200)
         pmc, src = _pmc_traffic()
-        per_kernel = (pmc or {}).get("per_kernel_bytes", {})
-        dom = max(rows, key=lambda r: r["ms_per_step"]) if rows else None
-        # Winograd rows: `flops` are the ALGORITHMIC ones (2 x 9 x Cin x Cout per output pixel); the kernel
-        # EXECUTES 16 multiplies per 2 x 2 output tile and channel pair instead of 36, i.e. 1 / 2.25 of them on the matrix
-        # pipe (plus block padding): executed_tflops is what MFMA actually sustains and what SQ_VALU_MFMA_BUSY sees.
-        for r in rows:
-            if r["kernel"].startswith("wino_"):
-                r["executed_tflops"] = r["tflops"] / 2.25
-                r["executed_frac"] = r["executed_tflops"] / FP32_MFMA_PEAK_TFLOPS
-                r["note"] = ("Winograd F(2x2,3x3): tflops / frac are algorithmic (direct-conv FLOPs / time); the matrix pipe "
-                             "executes 1/2.25 of them (executed_tflops, block padding not counted)")
-        conv_rows = [r for r in rows if r["kernel"].startswith("gconv") or r["kernel"].startswith("wino_conv")]
-        conv_ms = sum(r["ms_per_step"] for r in conv_rows)
-        conv_fl = sum(r["flops_per_step"] for r in conv_rows)
-        conv_tf = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        traffic = None
-        if dom is not None:
-            # HBM bytes of the same launches (one step's launches of the dominant kernel), from the PMC passes
-            # (a row may stand for several rocprof kernel names, "a / b": their bytes add up)
-            parts = [per_kernel.get(n.strip()) for n in dom["kernel"].split("/")]
-            if any(parts):
-                traffic = sum((q or {}).get("hbm_bytes", 0.0) for q in parts)
+        if conf["arch"]:
+            pmc, src = None, None                       # the committed PMC passes are of the 59-px step
         if bf16:
+            dom = max(rows, key=lambda r: r["ms_per_step"]) if rows else None
             alg_bytes = ACT_ELEMS_PER_STAMP * 2 * TRAIN_PASSES * B + PARAM_STEP_BYTES
             ms_step = dt / args.steps * 1e3
+            traffic = (pmc or {}).get("bf16_per_step_bytes", {}).get("total")
             roofline = {
                 "bound": "hbm", "kernel": dom["kernel"] if dom else None,
                 "achieved": alg_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": (pmc or {}).get("bf16_per_step_bytes", {}).get("total"),
-                "traffic_source": src if (pmc or {}).get("bf16_per_step_bytes") else None,
+                "algorithmic_bytes": alg_bytes, "traffic": traffic,
+                "traffic_over_algorithmic": traffic / alg_bytes if traffic else None,
+                "traffic_source": src if traffic else None,
                 "launch": "one training step per GPU (all launches), algorithmic bytes 8.36 MB per stamp + 5 x 33.3 MB",
                 "mode": "streams serialised (the per-kernel rows); `value` is measured with the streams overlapped",
                 "kernels": rows, "classes_ms_per_step": classes,
                 "mfma_whole_step_tflops": train_flops * B / (dt / args.steps) / 1e12,
             }
         else:
-            roofline = {
-                "bound": "mfma", "kernel": dom["kernel"] if dom else None,
-                "achieved": dom["tflops"] if dom else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": dom["frac"] if dom else None, "traffic": traffic,
-                "frac_note": ("algorithmic FLOPs of a direct convolution over the launch time, as SURVEY 8(d) prices the layer; "
-                              "a Winograd kernel executes 1/2.25 of them, so this fraction can exceed 1 - `executed` is what "
-                              "the matrix pipe sustains") if dom and "executed_tflops" in dom else None,
-                "executed": ({"tflops": dom["executed_tflops"], "frac": dom["executed_frac"], "note": dom["note"]}
-                             if dom and "executed_tflops" in dom else None),
-                "traffic_source": {"file": src, "commit": _git_head(),
-                                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed; not "
-                                           "re-measured in this run"} if src else None,
-                "mode": "streams serialised (the per-kernel rows); `value` is measured with the streams overlapped",
-                "launch": (f"one training step's launches of {dom['kernel']} ({dom['launches_per_step']:.0f} launches, "
-                           f"batch {B})") if dom else None,
-                "kernels": rows,
-                "conv_family": {"kernels": "gconv* + wino_conv (forward and data-gradient launches)", "ms_per_step": conv_ms, "flops_per_step": conv_fl, "tflops": conv_tf,
-                                       "frac": conv_tf / FP32_MFMA_PEAK_TFLOPS},
-                "classes_ms_per_step": classes,
-                "whole_step_tflops": train_flops * B / (dt / args.steps) / 1e12,
-                "whole_step_frac": train_flops * B / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-            }
+            roofline = _roofline_f32(rows, classes, pmc, src, B, dt, args.steps, train_flops)
     last_loss = scal["loss"]
     eng.close()
 
     secondary = None
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if rank == 0 and world == 1 and not args.no_secondary and args.config == 1:
         secondary = secondary_entries(E, ctx, synthetic_stamps, args.quick)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config in (1, 2):
         # in a child process: torch brings its own copy of the HIP runtime, and a process that has loaded both it and
         # /opt/rocm's (libdebvader_hip.so) aborts in the static destructors at exit ("free(): invalid pointer")
         _progress("cpu baseline: torch-CPU restatement (child process)")
@@ -436,19 +612,24 @@ def main():
 
     if rank == 0:
         value = Bg * args.steps / dt
+        rehearsal = bool(multi and multi.get("rehearsal"))
+        stamp = f"{cfg.height}x{cfg.width}x{cfg.bands}"
         line = {
-            "metric": "galaxy stamps/sec (train fwd+bwd+Adam) 59x59x6",
-            "value": value, "unit": "stamps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": f"galaxy stamps/sec (train fwd+bwd+Adam) {stamp}",
+            # a REHEARSAL (every rank on one GPU, one-rank communicators: DV_DEBUG_SAME_GPU / DV_DEBUG_FAKE_PEERS) exercises
+            # the launch line and the step structure; its throughput means nothing and is not reported as a value
+            "value": None if rehearsal else value, "unit": "stamps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[2]: same model and step, bf16 storage + bf16 MFMA operands, fp32 "
-                                    "accumulation / master weights / head, batch=256 per GPU" if bf16 else
-                                    "BASELINE configs[1]: 6-band 59x59 stamps, batch=256 per GPU, latent_dim=32, "
-                                    "filters [32,64,128,256], fp32, stage-1 VAE train step"),
-                       "global_batch": Bg, "per_gpu_batch": B, "parallelism": f"dp{world}"},
+            "config": {"workload": conf["label"], "global_batch": Bg, "per_gpu_batch": B, "parallelism": f"dp{world}"},
             "last_loss": last_loss,
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }
+        if multi is not None:
+            line["multi_rank"] = multi
+        if rehearsal:
+            line["rehearsal"] = True
+            line["rehearsal_stamps_per_s"] = value
         print(json.dumps(line), flush=True)
     if group is not None:
         group.barrier()          # nobody tears its communicator down while another rank is still inside a collective

@@ -111,6 +111,8 @@ SIGNATURES = {
     "dv_infer_cutouts": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_uint64, _f, _f, _f, _f, _f]),
     "dv_infer_cutouts_stream": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_uint64,
                                           C.c_void_p, C.c_void_p]),
+    "dv_infer_cutouts_composite": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64,
+                                             C.c_uint64, _d, _d, _d, _d]),
     "dv_scene_extract": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _d]),
     "dv_scene_composite": (C.c_int, [_p, _d, C.c_int32, C.c_int32, _d, _d, C.c_int32, C.c_int32, C.c_double]),
     "dv_infer_mc": (C.c_int, [_p, _f, C.c_int64, C.c_int32, C.c_uint64, _f, _f]),
@@ -121,7 +123,7 @@ SIGNATURES = {
     "dv_prof_read": (C.c_int, [_p, C.c_int32, _i64, C.POINTER(C.c_double)]),
     "dv_prof_reset": (C.c_int, [_p]),
     "dv_prof_read_family": (C.c_int, [_p, C.c_int32, C.c_char_p, C.c_size_t, _i64, C.POINTER(C.c_double),
-                                      C.POINTER(C.c_double)]),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 def bind(handle, signatures):

@@ -148,6 +148,12 @@ void debug_set_gconv2_tile(int code);
 // device-resident gather + float32 cast (dv_infer_cutouts): starts_dev points at the first cutout of the chunk
 int launch_scene_extract_f32(const double* field_dev, int F, int nb, const int* starts_dev, long count, int cs,
                              float* out_dev, hipStream_t s);
+// compositing of one inference chunk on the device (dv_infer_cutouts_composite): mean / stddev / residual fields += the
+// chunk's stamps at integer placements, in object order; per-stamp centre MSE against the field's own cutout
+int launch_scene_composite_chunk(double* mean_f, double* std_f, double* res_f, int F, int nb, const float* loc,
+                                 const float* scale, const int* places_dev, int n, int cs, hipStream_t s);
+int launch_scene_center_mse(const double* field_dev, int F, int nb, const int* starts_dev, const float* loc, int n, int cs,
+                            double* out_dev, hipStream_t s);
 int scene_extract(const double* field_h, int F, int nb, const int32_t* starts_h, int N, int cs, double* out_h,
                   hipStream_t s);
 int scene_composite(double* field_h, int F, int nb, const double* stamps_h, const double* pos_h, int N, int cs,

@@ -528,7 +528,7 @@ struct dv_model {
   bool prof_open = false;
   int prof_open_fam = -1;
   int64_t fam_launches[16] = {0};
-  double fam_ms[16] = {0}, fam_flops[16] = {0};
+  double fam_ms[16] = {0}, fam_flops[16] = {0}, fam_exec[16] = {0}, fam_bytes[16] = {0};
   int prof_open_klass = 0;
   hipStream_t prof_open_stream = nullptr;
   hipEvent_t prof_open_ev = nullptr;
@@ -568,14 +568,20 @@ static void prof_close(dv_model* m) {
   m->prof_open = false;
 }
 struct ProfScope {
-  // fam / flops: kernel family of an MFMA launch and its algorithmic FLOPs (padding taps counted)
-  ProfScope(dv_model* m, int k, hipStream_t s = nullptr, int fam = PF_NONE, double flops = 0.0) {
+  // fam / flops: kernel family of an MFMA launch and its algorithmic FLOPs (padding taps counted);
+  // exec: the FLOPs the matrix pipe EXECUTES for it (< 0: the algorithmic ones) - a Winograd launch executes 16 multiplies
+  // per 2 x 2 tile and channel pair instead of 36, over blocks / column tiles padded to the kernel's geometry;
+  // bytes: algorithmic HBM bytes of the launch (operands read once, results written once)
+  ProfScope(dv_model* m, int k, hipStream_t s = nullptr, int fam = PF_NONE, double flops = 0.0, double exec = -1.0,
+            double bytes = 0.0) {
     if (!m->prof_on) return;
     hipStream_t st = s ? s : (m->cs ? m->cs : m->ctx->stream);
     m->prof_launches[k] += 1;
     if (fam >= 0) {
       m->fam_launches[fam] += 1;
       m->fam_flops[fam] += flops;
+      m->fam_exec[fam] += exec < 0 ? flops : exec;
+      m->fam_bytes[fam] += bytes;
     }
     if (m->prof_open && m->prof_open_klass == k && m->prof_open_fam == fam && m->prof_open_stream == st) return;   // extend the open run
     prof_close(m);
@@ -877,7 +883,12 @@ static int wino_conv(dv_model* m, const float* X, const float* W, bool nmajor, c
   memset(&p, 0, sizeof p);
   p.X = X; p.Ut = e->d.Ut; p.U = U; p.A = Aout; p.bias = bias; p.alpha = alpha; p.zero = m->zero_page;
   p.NB = NB; p.H = H; p.Cin = Cin; p.Cout = Cout; p.epi = epi;
-  ProfScope ps(m, 0, nullptr, PF_WINO, flops);
+  // executed: groups of four 8 x 8-pixel blocks (16 tiles each) x 16 positions x Cin x Cout padded to 32-column tiles
+  const double nbh = (H + 7) / 8, groups = ceil((double)NB * nbh * nbh / 4.0);
+  const double exec = 2.0 * groups * 4.0 * 16.0 * 16.0 * (double)Cin * (double)(((Cout + 31) / 32) * 32);
+  const double bytes = 4.0 * ((double)NB * H * H * (Cin + (U ? Cout : 0) + (Aout ? Cout : 0)) + 16.0 * Cin * Cout +
+                              (epi == 2 ? (double)H * H * Cout : 0.0));
+  ProfScope ps(m, 0, nullptr, PF_WINO, flops, exec, bytes);
   return launch_wino_conv(p, st);
 }
 
@@ -1258,7 +1269,10 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
       wp.zero = m->zero_page; wp.NB = NB; wp.H = Hy; wp.Cx = Cx; wp.Cy = Cy;
       int st;
       {
-        ProfScope ps(m, 1, ws, PF_WINOW, wflops);
+        const double nbh = (Hy + 7) / 8;
+        const double exec = 2.0 * (double)NB * nbh * nbh * 16.0 * 16.0 * (double)Cx * (double)Cy;
+        const double bytes = 4.0 * ((double)NB * Hy * Hy * (Cx + Cy) + (double)S * 16.0 * Cx * Cy);
+        ProfScope ps(m, 1, ws, PF_WINOW, wflops, exec, bytes);
         st = launch_wino_wgrad(wp, out, ws);
       }
       if (st < 0) return st;
@@ -2285,6 +2299,7 @@ struct InferPipe {
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_h2d[2] = {}, ev_comp[2] = {}, ev_d2h[3] = {};
   int threads = 4;
+  bool host_ok = false;             // the pinned image buffers exist (calls that keep their results on the device skip them)
 };
 
 static void pipe_free(InferPipe* p) {
@@ -2302,9 +2317,25 @@ static void pipe_free(InferPipe* p) {
   delete p;
 }
 
-static int pipe_get(dv_model* m, int cap, InferPipe** out) {
+static int pipe_host_buffers(dv_model* m, InferPipe* p) {
+  if (p->host_ok) return OK;
+  const Arch& A = m->A;
+  const size_t img = (size_t)p->cap * A.H * A.H * A.C * sizeof(float);
+  for (int b = 0; b < 3; ++b) {
+    DV_HIP(hipHostMalloc((void**)&p->hloc[b], img, hipHostMallocDefault));
+    DV_HIP(hipHostMalloc((void**)&p->hscale[b], img, hipHostMallocDefault));
+  }
+  for (int b = 0; b < 2; ++b) DV_HIP(hipHostMalloc((void**)&p->hin[b], img, hipHostMallocDefault));
+  p->host_ok = true;
+  return OK;
+}
+
+// need_host: the call moves stamps through pinned host memory (every form except the device-resident compositing call,
+// which then does not pay for ~8 GB of pinned transfer rings at 8192 stamps per chunk)
+static int pipe_get(dv_model* m, int cap, InferPipe** out, bool need_host = true) {
   const Arch& A = m->A;
   if (m->pipe && m->pipe->cap >= cap) {
+    if (need_host) DV_TRY(pipe_host_buffers(m, m->pipe));
     *out = m->pipe;
     return OK;
   }
@@ -2316,13 +2347,10 @@ static int pipe_get(dv_model* m, int cap, InferPipe** out) {
   int st = OK;
 #define PP_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { st = hip_fail(e__, #call, __FILE__, __LINE__); pipe_free(p); return st; } } while (0)
   for (int b = 0; b < 3; ++b) {
-    PP_HIP(hipHostMalloc((void**)&p->hloc[b], img, hipHostMallocDefault));
-    PP_HIP(hipHostMalloc((void**)&p->hscale[b], img, hipHostMallocDefault));
     PP_HIP(hipHostMalloc((void**)&p->hsmall[b], small, hipHostMallocDefault));
     PP_HIP(hipEventCreateWithFlags(&p->ev_d2h[b], hipEventDisableTiming));
   }
   for (int b = 0; b < 2; ++b) {
-    PP_HIP(hipHostMalloc((void**)&p->hin[b], img, hipHostMallocDefault));
     PP_HIP(hipMalloc((void**)&p->din[b], img + 64));
     PP_HIP(hipMalloc((void**)&p->dloc[b], img + 64));
     PP_HIP(hipMalloc((void**)&p->dscale[b], img + 64));
@@ -2333,6 +2361,13 @@ static int pipe_get(dv_model* m, int cap, InferPipe** out) {
   p->s_in = m->ctx->red_stream;       // both idle during inference; a fifth stream would share a hardware queue
   p->s_out = m->ctx->comm_stream;
 #undef PP_HIP
+  if (need_host) {
+    st = pipe_host_buffers(m, p);
+    if (st != OK) {
+      pipe_free(p);
+      return st;
+    }
+  }
   const char* e = getenv("DV_COPY_THREADS");
   int hw = (int)std::thread::hardware_concurrency();
   p->threads = e ? std::max(1, atoi(e)) : std::max(1, std::min(8, hw > 0 ? hw / 2 : 4));
@@ -2372,9 +2407,17 @@ struct CutoutSrc {
   int F, nb, cs;
 };
 
+// results of the pipeline composited on the device instead of copied out (dv_infer_cutouts_composite): every chunk's mean
+// and stddev stamps are added into float64 fields in HBM right behind its forward pass, on the same stream
+struct CompositeSink {
+  double *mean_f, *std_f, *res_f;   // device [F][F][nb]; res_f may be null
+  const int* places;                // device [N][2]: field position (row, col) of each stamp's top-left corner
+  double* mse;                      // device [N] centre MSE of every stamp against its cutout, or null
+};
+
 static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, const float* eps, uint64_t seed,
                            float* loc, float* scale, float* mu, float* zstd, float* z, const CutoutSrc* cut = nullptr,
-                           dv_chunk_fn sink = nullptr, void* sink_user = nullptr) {
+                           dv_chunk_fn sink = nullptr, void* sink_user = nullptr, const CompositeSink* comp = nullptr) {
   const Arch& A = m->A;
   hipStream_t s = m->ctx->stream;
   const size_t stamp = (size_t)A.H * A.H * A.C;
@@ -2382,7 +2425,7 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
   int chunk = m->Bc;
   if (N < 2 * (int64_t)m->Bc) chunk = (int)std::min<int64_t>(m->Bc, std::max<int64_t>(128, ((N + 3) / 4 + 63) / 64 * 64));
   InferPipe* p = nullptr;
-  DV_TRY(pipe_get(m, chunk, &p));
+  DV_TRY(pipe_get(m, chunk, &p, !(comp && cut)));
   const int64_t K = (N + chunk - 1) / chunk;
   const int d = A.d;
   auto finish = [&](int64_t k) -> int {       // stage D: pinned -> caller's arrays
@@ -2466,7 +2509,16 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
       m->scale = keep_scale;
       DV_TRY(st);
     }
-    if (m->normalise && (loc || sink)) DV_TRY(launch_normalise(p->dloc[b], (long)nb * stamp, true, s));
+    if (m->normalise && (loc || sink || comp)) DV_TRY(launch_normalise(p->dloc[b], (long)nb * stamp, true, s));
+    if (comp) {
+      // the consumer that follows in the reference (field_deblender.py:99-189) runs here, on the chunk as it lies in HBM
+      ProfScope ps(m, 2, s);
+      DV_TRY(launch_scene_composite_chunk(comp->mean_f, comp->std_f, comp->res_f, cut->F, cut->nb, p->dloc[b], p->dscale[b],
+                                          comp->places + 2 * o, nb, cut->cs, s));
+      if (comp->mse)
+        DV_TRY(launch_scene_center_mse(cut->field, cut->F, cut->nb, cut->starts + 2 * o, p->dloc[b], nb, cut->cs,
+                                       comp->mse + o, s));
+    }
     if (mu)
       DV_HIP(hipMemcpy2DAsync(p->dsmall[b], d * sizeof(float), m->t, A.tw * sizeof(float), d * sizeof(float), nb,
                               hipMemcpyDeviceToDevice, s));
@@ -3561,6 +3613,81 @@ static int infer_cutouts_impl(dv_model* m, const double* field, int32_t F, int32
   return prof_flush(m);
 }
 
+int dv_infer_cutouts_composite(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts,
+                               const int32_t* places, int64_t N, uint64_t seed, double* mean_field, double* stddev_field,
+                               double* residual_field, double* mse_center) {
+  if (!m || !field || !starts || !places || !mean_field || !stddev_field || N < 0 || F < 1) return DV_E_INVALID;
+  const Arch& A = m->A;
+  const int cs = A.H;
+  if (nb != A.C || cs > F) {
+    set_error("dv_infer_cutouts_composite: the field has %d bands and %d pixels, the network takes %d x %d x %d stamps", nb, F,
+              cs, cs, A.C);
+    return DV_E_INVALID;
+  }
+  for (int64_t i = 0; i < N; ++i) {
+    const int x = starts[2 * i], y = starts[2 * i + 1];
+    if (x < 0 || y < 0 || x > F - cs || y > F - cs) {
+      set_error("dv_infer_cutouts_composite: cutout %ld (start %d,%d size %d) leaves the %d-pixel field", (long)i, x, y, cs, F);
+      return DV_E_INVALID;
+    }
+    const int pr = places[2 * i], pc = places[2 * i + 1];
+    if (pr < -(1 << 28) || pr > (1 << 28) || pc < -(1 << 28) || pc > (1 << 28)) {
+      set_error("dv_infer_cutouts_composite: placement %ld (%d,%d) out of range", (long)i, pr, pc);
+      return DV_E_INVALID;
+    }
+  }
+  const size_t felems = (size_t)F * F * nb, fb = felems * sizeof(double);
+  if (N == 0) {
+    memset(mean_field, 0, fb);
+    memset(stddev_field, 0, fb);
+    if (residual_field) memcpy(residual_field, field, fb);
+    return DV_OK;
+  }
+  TinyCall tiny(m, N);
+  DV_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  double *fdev = nullptr, *mf = nullptr, *sf = nullptr, *rf = nullptr, *mse = nullptr;
+  int *sdev = nullptr, *pdev = nullptr;
+  const size_t sb = (size_t)N * 2 * sizeof(int);
+  auto cleanup = [&]() {
+    (void)hipFree(fdev); (void)hipFree(mf); (void)hipFree(sf); (void)hipFree(rf); (void)hipFree(mse);
+    (void)hipFree(sdev); (void)hipFree(pdev);
+  };
+  int st = OK;
+#define CC_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { st = hip_fail(e__, #call, __FILE__, __LINE__); cleanup(); return st; } } while (0)
+  CC_HIP(hipMalloc((void**)&fdev, fb));
+  CC_HIP(hipMalloc((void**)&mf, fb));
+  CC_HIP(hipMalloc((void**)&sf, fb));
+  if (residual_field) CC_HIP(hipMalloc((void**)&rf, fb));
+  if (mse_center) CC_HIP(hipMalloc((void**)&mse, (size_t)N * sizeof(double)));
+  CC_HIP(hipMalloc((void**)&sdev, sb));
+  CC_HIP(hipMalloc((void**)&pdev, sb));
+  CC_HIP(hipMemcpyAsync(fdev, field, fb, hipMemcpyHostToDevice, s));
+  CC_HIP(hipMemcpyAsync(sdev, starts, sb, hipMemcpyHostToDevice, s));
+  CC_HIP(hipMemcpyAsync(pdev, places, sb, hipMemcpyHostToDevice, s));
+  CC_HIP(hipMemsetAsync(mf, 0, fb, s));
+  CC_HIP(hipMemsetAsync(sf, 0, fb, s));
+  if (rf) CC_HIP(hipMemcpyAsync(rf, fdev, fb, hipMemcpyDeviceToDevice, s));
+  CC_HIP(hipStreamSynchronize(s));               // the gather runs on the pipeline's copy stream
+  {
+    CutoutSrc cut{fdev, sdev, F, nb, cs};
+    CompositeSink comp{mf, sf, rf, pdev, mse};
+    st = infer_pipelined(m, nullptr, false, N, nullptr, seed, nullptr, nullptr, nullptr, nullptr, nullptr, &cut, nullptr,
+                         nullptr, &comp);
+  }
+  if (st == OK) {
+    CC_HIP(hipMemcpyAsync(mean_field, mf, fb, hipMemcpyDeviceToHost, s));
+    CC_HIP(hipMemcpyAsync(stddev_field, sf, fb, hipMemcpyDeviceToHost, s));
+    if (rf) CC_HIP(hipMemcpyAsync(residual_field, rf, fb, hipMemcpyDeviceToHost, s));
+    if (mse) CC_HIP(hipMemcpyAsync(mse_center, mse, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  (void)hipStreamSynchronize(s);
+#undef CC_HIP
+  cleanup();
+  if (st != OK) return st;
+  return prof_flush(m);
+}
+
 int dv_infer_cutouts(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
                      uint64_t seed, float* loc, float* scale, float* mu, float* zstd, float* z) {
   return infer_cutouts_impl(m, field, F, nb, starts, N, seed, loc, scale, mu, zstd, z, nullptr, nullptr);
@@ -4181,7 +4308,7 @@ int dv_prof_read(dv_model* m, int32_t klass, int64_t* launches, double* total_ms
   return DV_OK;
 }
 int dv_prof_read_family(dv_model* m, int32_t fam, char* name, size_t name_len, int64_t* launches, double* total_ms,
-                        double* flops) {
+                        double* flops, double* executed_flops, double* algorithmic_bytes) {
   if (!m) return DV_E_INVALID;
   if (fam < 0 || fam >= PF_COUNT) return DV_E_INVALID;
   DV_TRY(prof_flush(m));
@@ -4189,6 +4316,8 @@ int dv_prof_read_family(dv_model* m, int32_t fam, char* name, size_t name_len, i
   if (launches) *launches = m->fam_launches[fam];
   if (total_ms) *total_ms = m->fam_ms[fam];
   if (flops) *flops = m->fam_flops[fam];
+  if (executed_flops) *executed_flops = m->fam_exec[fam];
+  if (algorithmic_bytes) *algorithmic_bytes = m->fam_bytes[fam];
   return DV_OK;
 }
 
@@ -4203,6 +4332,8 @@ int dv_prof_reset(dv_model* m) {
     m->fam_launches[f] = 0;
     m->fam_ms[f] = 0;
     m->fam_flops[f] = 0;
+    m->fam_exec[f] = 0;
+    m->fam_bytes[f] = 0;
   }
   return DV_OK;
 }

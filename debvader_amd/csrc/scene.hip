@@ -172,6 +172,118 @@ __global__ __launch_bounds__(256) void scene_composite_kernel(double* __restrict
   }
   field[e] = acc;
 }
+
+// ---- compositing of one inference chunk, device resident (dv_infer_cutouts_composite) --------------------------------
+// field += stamp_i placed with its top-left corner at places[i] = (row, col), for the n stamps of a chunk IN OBJECT ORDER
+// per field element - the order of the reference's loop over res_deblend (field_deblender.py:112-183: one
+// scipy.ndimage.shift of a padded image per object, integer shifts) and of scene_composite_kernel above, so the sums are
+// bit-identical to the host-composited path.  Stamps are the network's float32 outputs as the forward pass left them in
+// HBM (mean and stddev of every stamp, 167 KB per stamp that never cross the host link).
+//
+// A workgroup owns a 16 x 16-pixel tile of the field and scans the chunk's objects in segments of 256 (one per thread):
+// the objects whose window meets the tile are compacted IN ORDER into an LDS list (wave ballots + prefix counts), then
+// every thread walks the list for its pixel.  Uniformly scattered cutouts leave ~0.3 entries per segment and tile; a
+// pile of objects on one spot just makes the lists long - no capacity limit, no atomics, no float non-determinism.
+constexpr int CT = 16;   // tile edge
+template <int NBMAX>
+__global__ __launch_bounds__(256) void scene_composite_chunk_kernel(double* __restrict__ mean_f, double* __restrict__ std_f,
+                                                                    double* __restrict__ res_f, int F, int nb,
+                                                                    const float* __restrict__ loc,
+                                                                    const float* __restrict__ scale,
+                                                                    const int* __restrict__ places, int n, int cs) {
+  __shared__ int s_list[256];
+  __shared__ int s_wcount[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntx = (F + CT - 1) / CT;
+  const int tr0 = (blockIdx.x / ntx) * CT, tc0 = (blockIdx.x % ntx) * CT;
+  const int r = tr0 + (tid >> 4), c = tc0 + (tid & 15);
+  const bool inside = r < F && c < F;
+  double am[NBMAX], as[NBMAX], ar[NBMAX];
+#pragma unroll
+  for (int b = 0; b < NBMAX; ++b) am[b] = as[b] = ar[b] = 0.0;
+  const long e0 = ((long)r * F + c) * nb;
+  if (inside) {
+#pragma unroll
+    for (int b = 0; b < NBMAX; ++b)
+      if (b < nb) {
+        am[b] = mean_f[e0 + b];
+        as[b] = std_f[e0 + b];
+        if (res_f) ar[b] = res_f[e0 + b];
+      }
+  }
+  bool touched = false;
+  for (int seg = 0; seg < n; seg += 256) {
+    const int o = seg + tid;
+    bool hit = false;
+    if (o < n) {
+      const int pr = places[2 * o], pc = places[2 * o + 1];
+      hit = pr < tr0 + CT && pr + cs > tr0 && pc < tc0 + CT && pc + cs > tc0;
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) s_wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (w < wave) base += s_wcount[w];
+    const int total = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+    if (hit) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = o;
+    __syncthreads();
+    if (inside) {
+      for (int k = 0; k < total; ++k) {
+        const int ob = s_list[k];
+        const int rr = r - places[2 * ob], cc = c - places[2 * ob + 1];
+        if ((unsigned)rr < (unsigned)cs && (unsigned)cc < (unsigned)cs) {
+          const long so = (((long)ob * cs + rr) * cs + cc) * nb;
+          touched = true;
+#pragma unroll
+          for (int b = 0; b < NBMAX; ++b)
+            if (b < nb) {
+              const double v = (double)loc[so + b];
+              am[b] += v;
+              ar[b] -= v;
+              as[b] += (double)scale[so + b];
+            }
+        }
+      }
+    }
+    __syncthreads();                       // the list is rewritten by the next segment
+  }
+  if (inside && touched) {
+#pragma unroll
+    for (int b = 0; b < NBMAX; ++b)
+      if (b < nb) {
+        mean_f[e0 + b] = am[b];
+        std_f[e0 + b] = as[b];
+        if (res_f) res_f[e0 + b] = ar[b];
+      }
+  }
+}
+
+// mse_center[i] = mean over the centre 10 x 10 pixels and all bands of (cutout_i - mean_i)^2 in float64
+// (field_deblender.py:323-327: mse(cutout_images[k, c0:c1, c0:c1], output_images_mean[i, c0:c1, c0:c1]) with
+// c0 = int(cs/2) - 5, c1 = int(cs/2) + 5; training/metrics.py:4-12); one wave per stamp
+__global__ __launch_bounds__(256) void scene_center_mse_kernel(const double* __restrict__ field, int F, int nb,
+                                                               const int* __restrict__ starts,
+                                                               const float* __restrict__ loc, int n, int cs,
+                                                               double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int c0 = cs / 2 - 5, w = 10;
+  const int x0 = starts[2 * i], y0 = starts[2 * i + 1];
+  double acc = 0.0;
+  const int total = w * w * nb;
+  for (int e = lane; e < total; e += 64) {
+    const int b = e % nb, q = e / nb, cc = q % w, rr = q / w;
+    const double a = field[((long)(x0 + c0 + rr) * F + (y0 + c0 + cc)) * nb + b];
+    const double m = (double)loc[(((long)i * cs + c0 + rr) * cs + c0 + cc) * nb + b];
+    acc += (a - m) * (a - m);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) out[i] = acc / (double)total;
+}
 }  // namespace
 
 int scene_extract(const double* field_h, int F, int nb, const int32_t* starts_h, int N, int cs, double* out_h,
@@ -286,4 +398,33 @@ int scene_composite(double* field_h, int F, int nb, const double* stamps_h, cons
 #undef SC_HIP
 }
 
+}  // namespace dv
+
+namespace dv {
+int launch_scene_composite_chunk(double* mean_f, double* std_f, double* res_f, int F, int nb, const float* loc,
+                                 const float* scale, const int* places_dev, int n, int cs, hipStream_t s) {
+  if (n <= 0) return OK;
+  if (nb < 1 || nb > 8) {
+    set_error("scene composite: 1 .. 8 bands");
+    return E_INVALID;
+  }
+  const int ntx = (F + CT - 1) / CT;
+  hipLaunchKernelGGL(scene_composite_chunk_kernel<8>, dim3((unsigned)(ntx * ntx)), dim3(256), 0, s, mean_f, std_f, res_f, F, nb,
+                     loc, scale, places_dev, n, cs);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
+int launch_scene_center_mse(const double* field_dev, int F, int nb, const int* starts_dev, const float* loc, int n, int cs,
+                            double* out_dev, hipStream_t s) {
+  if (n <= 0) return OK;
+  if (cs < 10) {
+    set_error("centre MSE needs stamps of at least 10 pixels");
+    return E_INVALID;
+  }
+  hipLaunchKernelGGL(scene_center_mse_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, field_dev, F, nb, starts_dev, loc,
+                     n, cs, out_dev);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
 }  // namespace dv

@@ -39,6 +39,7 @@ class DeblendField:
         self.res_deblend = None
         self.mse = []
         self._ctx = getattr(getattr(net, "_core", None), "ctx", None) or E.default_context()
+        self._device_fields = None      # fields composited on the GPU by deblend_field(on_device=True)
 
     # -- compositing -------------------------------------------------------------------------------
     @staticmethod
@@ -53,6 +54,8 @@ class DeblendField:
 
     def get_residual_field(self, res_deblend=None):
         """Field minus every predicted galaxy at its position (field_deblender.py:46-97); shape of the input field."""
+        if res_deblend is None and self._device_fields is not None:
+            return self._device_fields["residual_field"][None].copy()
         if res_deblend is None:
             res_deblend = self.res_deblend
         deblended_image = self.field_image.copy()
@@ -63,6 +66,11 @@ class DeblendField:
 
     def get_predicted_field(self, res_deblend=None):
         """Predicted mean / stddev / epistemic fields (field_deblender.py:99-189), each (size, size, bands)."""
+        if res_deblend is None and self._device_fields is not None:
+            # deblend_field(on_device=True) composited them on the GPU behind the forward passes
+            return {"predicted_mean_field": self._device_fields["mean_field"].copy(),
+                    "predicted_stddev_field": self._device_fields["stddev_field"].copy(),
+                    "predicted_epistemic_field": np.zeros_like(self._device_fields["mean_field"])}
         if res_deblend is None:
             res_deblend = self.res_deblend
         zeros = np.zeros((self.field_size, self.field_size, self.nb_of_bands))
@@ -85,13 +93,24 @@ class DeblendField:
 
     # -- one deblending pass -----------------------------------------------------------------------
     def deblend_field(self, galaxy_distances_to_center, cutout_images=None, optimise_positions=False,
-                      epistemic_criterion=100.0, mse_criterion=100.0, field_image=None):
+                      epistemic_criterion=100.0, mse_criterion=100.0, field_image=None, on_device=False):
         """Deblend the galaxies at `galaxy_distances_to_center` (field_deblender.py:219-383).
 
         returns a np.recarray with, per deblended galaxy: cutout_images, output_images_mean, output_images_stddev,
         shifts, list_idx, galaxy_distances_to_center_x/_y, epistemic_uncertainty, passed_cuts
         (a dict of None entries when no galaxy could be extracted, as the reference does).
+
+        on_device=True (engine-specific): the whole chain - cutout gather, network, and the compositing that
+        get_predicted_field / get_residual_field do afterwards - runs on the GPU in one engine call
+        (dv_infer_cutouts_composite) and only the field-sized results come back: BASELINE configs[4]'s million cutouts are
+        167 GB of mean and stddev stamps that no longer cross the host link.  The recarray then carries the per-galaxy
+        scalars (list_idx, positions, shifts, passed_cuts, mse_center) but no stamp images, and get_predicted_field() /
+        get_residual_field() return the fields composited on the GPU - the same sums in the same order, bit for bit, as
+        compositing the stamps of the default path.  Needs integer positions (no optimise_positions), no epistemic pass.
         """
+        if on_device:
+            return self._deblend_field_on_device(galaxy_distances_to_center, mse_criterion, field_image)
+        self._device_fields = None
         if optimise_positions:
             raise NotImplementedError("optimise_positions=True needs the scipy.optimize position fit of "
                                       "deblend_cutout/optimization.py, which is outside this engine's scope")
@@ -148,4 +167,48 @@ class DeblendField:
         res_deblend["epistemic_uncertainty"] = epistemic_uncertainty
         res_deblend["passed_cuts"] = passed_cuts
         self.res_deblend = pd.DataFrame(res_deblend).to_records(index=False)
+        return self.res_deblend
+
+    def _deblend_field_on_device(self, galaxy_distances_to_center, mse_criterion, field_image):
+        from debvader_amd.extract.extraction import cutout_windows
+
+        if self.epistemic_uncertainty_estimation:
+            raise NotImplementedError("on_device=True composites the mean and stddev fields; the epistemic estimate needs the "
+                                      "default path")
+        if field_image is None:
+            field_image = self.field_image
+        field = np.ascontiguousarray(np.asarray(field_image, dtype=np.float64)[0])
+        F, cs = field.shape[0], self.cutout_size
+        d = np.asarray(galaxy_distances_to_center, dtype=np.float64).reshape(-1, 2)
+        starts, ok = cutout_windows(F, d, cs)
+        list_idx = [int(i) for i in np.nonzero(ok)[0]]
+        res = {"cutout_images": None, "output_images_mean": None, "output_images_stddev": None, "shifts": None,
+               "list_idx": None}
+        if not list_idx:
+            print("No galaxy deblended. End of the iterative procedure.")
+            return res
+        if not ok.all():
+            print("Some galaxies are too close from the border of the field to be considered here.")
+        dd = d[ok]
+        if not np.array_equal(dd, np.floor(dd)):
+            raise ValueError("on_device=True places stamps at integer positions; fractional distances need the default path")
+        # where get_predicted_field puts a stamp: padded at int((F - cs) / 2) and shifted by the distance to the centre
+        # (field_deblender.py:128-160)
+        places = (int((F - cs) / 2) + dd).astype(np.int64)
+        core = self.net._core
+        eng = core.engine
+        eng.set_normalise(bool(self.normalise))
+        try:
+            out = eng.infer_cutouts_composite(field, starts[ok], places, seed=core.next_seed())
+        finally:
+            eng.set_normalise(False)
+        self._device_fields = out
+        self.nb_of_detected_objects += [len(d)]
+        self.nb_of_deblended_galaxies += [len(list_idx)]
+        n = len(list_idx)
+        self.res_deblend = pd.DataFrame({
+            "list_idx": list_idx, "shifts": [np.array([0, 0])] * n,
+            "galaxy_distances_to_center_x": list(dd[:, 0]), "galaxy_distances_to_center_y": list(dd[:, 1]),
+            "mse_center": list(out["mse_center"]), "passed_cuts": list(~(out["mse_center"] > mse_criterion)),
+        }).to_records(index=False)
         return self.res_deblend

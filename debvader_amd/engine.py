@@ -132,6 +132,25 @@ class Context:
     def sync(self):
         check(lib.dv_ctx_sync(self._h))
 
+    def comm_info(self) -> Dict:
+        """What the RCCL communicator of this context really spans: {comm_ranks (ncclCommCount, 0 without one), comm_rank,
+        device, bus_id (PCI), rehearsal (DV_DEBUG_FAKE_PEERS: a one-rank communicator although world > 1)}."""
+        n, r, d, reh = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        bus = C.create_string_buffer(32)
+        check(lib.dv_ctx_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d), bus, 32, C.byref(reh)))
+        return dict(comm_ranks=n.value, comm_rank=r.value, device=d.value, bus_id=bus.value.decode(),
+                    rehearsal=bool(reh.value), world=self.world, rank=self.rank)
+
+    def comm_prof(self, on: bool):
+        """Time every collective on the comm stream and every wait of the main stream for one (dv_comm_prof_enable)."""
+        check(lib.dv_comm_prof_enable(self._h, int(on)))
+
+    def comm_prof_read(self) -> Dict:
+        """{collectives, comm_ms, waits, exposed_ms} since the last read (synchronises)."""
+        n1, n2, a, b = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        check(lib.dv_comm_prof_read(self._h, C.byref(n1), C.byref(a), C.byref(n2), C.byref(b)))
+        return dict(collectives=n1.value, comm_ms=a.value, waits=n2.value, exposed_ms=b.value)
+
     def allreduce(self, values: Sequence[float]) -> np.ndarray:
         a = np.ascontiguousarray(values, dtype=np.float32)
         check(lib.dv_ctx_allreduce_host(self._h, _fp(a), a.size))
@@ -431,6 +450,34 @@ class Engine:
                                    _fp(bufs["scale"]), _fp(bufs["mu"]), _fp(bufs["zstd"]), _fp(bufs["z"])))
         return {k: v for k, v in bufs.items() if v is not None}
 
+    def infer_cutouts_composite(self, field, starts, places, seed=0, residual=True, mse_center=True) -> Dict[str, np.ndarray]:
+        """infer_cutouts() with the compositing that follows it in the reference done on the GPU (dv_infer_cutouts_composite):
+        returns {"mean_field", "stddev_field", ["residual_field"], ["mse_center"]} - float64 (F, F, bands) sums of the
+        network's mean / stddev stamps placed at `places` (row, col of each stamp's top-left corner; off-field parts are
+        dropped) in object order, the field minus the mean stamps, and each stamp's centre-10x10 MSE against its cutout.
+        No stamp visits the host."""
+        field = np.ascontiguousarray(field, dtype=np.float64)
+        starts = _i32_rows(starts, "cutout starts")
+        places = _i32_rows(places, "stamp placements")
+        if field.ndim != 3 or field.shape[0] != field.shape[1]:
+            raise ValueError(f"expected a square field (F, F, bands), got {field.shape}")
+        if places.shape != starts.shape:
+            raise ValueError(f"{starts.shape[0]} cutout starts but {places.shape[0]} placements")
+        N = starts.shape[0]
+        dp = C.POINTER(C.c_double)
+        out = {"mean_field": np.empty(field.shape, np.float64), "stddev_field": np.empty(field.shape, np.float64)}
+        if residual:
+            out["residual_field"] = np.empty(field.shape, np.float64)
+        if mse_center:
+            out["mse_center"] = np.empty((N,), np.float64)
+        opt = lambda k: out[k].ctypes.data_as(dp) if k in out else None
+        check(lib.dv_infer_cutouts_composite(self._h, field.ctypes.data_as(dp), field.shape[0], field.shape[2],
+                                             starts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             places.ctypes.data_as(C.POINTER(C.c_int32)), N, int(seed),
+                                             out["mean_field"].ctypes.data_as(dp), out["stddev_field"].ctypes.data_as(dp),
+                                             opt("residual_field"), opt("mse_center")))
+        return out
+
     def infer_cutouts_stream(self, field, starts, consumer, seed=0):
         """infer_cutouts() for inputs whose outputs do not belong on one host (a million cutouts: 167 GB): every finished
         chunk is handed to consumer(first, mean, stddev) - float32 views (count, H, H, bands) of the pinned transfer
@@ -499,16 +546,20 @@ class Engine:
         check(lib.dv_prof_reset(self._h))
 
     def prof_families(self) -> List[Dict]:
-        """[{name, launches, ms, flops}] per MFMA kernel family since the last prof_reset (names as rocprofv3 prints them)."""
+        """[{name, launches, ms, flops, executed_flops, algorithmic_bytes}] per MFMA kernel family since the last prof_reset
+        (names as rocprofv3 prints them; executed_flops: what the matrix pipe executes - Winograd kernels execute fewer
+        than the direct-convolution count they are priced with)."""
         out = []
         fam = 0
         while True:
             name = C.create_string_buffer(96)
-            n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
-            if lib.dv_prof_read_family(self._h, fam, name, 96, C.byref(n), C.byref(ms), C.byref(fl)) != 0:
+            n, ms, fl, ex, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
+            if lib.dv_prof_read_family(self._h, fam, name, 96, C.byref(n), C.byref(ms), C.byref(fl), C.byref(ex),
+                                       C.byref(by)) != 0:
                 break
             if n.value:
-                out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value))
+                out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value,
+                                executed_flops=ex.value, algorithmic_bytes=by.value))
             fam += 1
         return out
 

@@ -205,6 +205,22 @@ typedef int (*dv_chunk_fn)(void* user, int64_t first, int32_t count, const float
 int dv_infer_cutouts_stream(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
                             uint64_t seed, dv_chunk_fn consumer, void* user);
 
+/* The same forward passes with the consumer that FOLLOWS in the reference fused in, so that no stamp crosses the host link:
+ * DeblendField.deblend_field + get_predicted_field + get_residual_field (deblend/field_deblender.py:219-383, :99-189,
+ * :46-97) for integer positions.  For every cutout i (window start starts[i], as extract_cutouts computes it) the
+ * network's mean and stddev stamps are added on the GPU, in object order, into
+ *   mean_field   += stamp placed with its top-left corner at places[i] = (row, col)   (predicted_mean_field)
+ *   stddev_field += the stddev stamp at the same place                                  (predicted_stddev_field)
+ *   residual_field (optional) = field - the same mean stamps                            (get_residual_field)
+ * places[i] is int((F - cs) / 2) + the galaxy's distance to the field centre, as the reference pads and shifts
+ * (field_deblender.py:70,130-160); parts of a stamp that leave the field are dropped (scipy.ndimage.shift, mode
+ * "constant").  mse_center (optional, [N]) receives each stamp's centre-10x10 MSE against its cutout (:323-327), the input
+ * of the reference's quality cut.  Only the F x F x bands float64 fields (and N doubles) travel back.  Sums are in float64
+ * and in object order: bit-identical to dv_scene_composite on the stamps dv_infer_cutouts returns for the same seed. */
+int dv_infer_cutouts_composite(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts,
+                               const int32_t* places, int64_t N, uint64_t seed, double* mean_field, double* stddev_field,
+                               double* residual_field, double* mse_center);
+
 /* Monte-Carlo epistemic uncertainty: encode each stamp once, decode it `nsamples` times with fresh eps, return the
  * mean and the standard deviation (ddof 0) of the predicted means over the samples.  Replaces the per-object loop
  * `np.std(deblend(net, [stamp]*100)[0], axis=0)` of deblend/field_deblender.py:303-313. */
@@ -236,9 +252,13 @@ int dv_prof_enable(dv_model* m, int32_t on);
 int dv_prof_read(dv_model* m, int32_t klass, int64_t* launches, double* total_ms);
 int dv_prof_reset(dv_model* m);
 /* the same timing per MFMA kernel family (fam = 0 .. until DV_E_INVALID): `name` is the kernel name rocprofv3 prints
- * (without template arguments), flops the algorithmic FLOPs of the timed launches (padding taps counted) */
+ * (without template arguments), flops the algorithmic FLOPs of the timed launches (padding taps counted),
+ * executed_flops what the matrix pipe executes for them (a Winograd kernel: 16 multiplies per 2 x 2 tile and channel pair
+ * instead of 36, over blocks / column tiles padded to its geometry; direct kernels: the algorithmic count),
+ * algorithmic_bytes the HBM bytes of the launches with every operand read once and every result written once (0 for
+ * families that do not report them).  Any out pointer may be NULL. */
 int dv_prof_read_family(dv_model* m, int32_t fam, char* name, size_t name_len, int64_t* launches, double* total_ms,
-                        double* flops);
+                        double* flops, double* executed_flops, double* algorithmic_bytes);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

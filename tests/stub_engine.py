@@ -33,6 +33,17 @@ class Context:
     def sync(self):
         _log(self.rank, event="sync", t=time.time())
 
+    def comm_info(self):
+        return dict(comm_ranks=self.world if self.world > 1 else 0, comm_rank=self.rank, device=self.device,
+                    bus_id=f"0000:{self.device:02x}:00.0", rehearsal=False, world=self.world, rank=self.rank)
+
+    def comm_prof(self, on):
+        self._prof = bool(on)
+
+    def comm_prof_read(self):
+        return dict(collectives=5 * getattr(self, "_steps", 0), comm_ms=0.4 * getattr(self, "_steps", 0),
+                    waits=2 * getattr(self, "_steps", 0), exposed_ms=0.05 * (1 + self.rank) * getattr(self, "_steps", 0))
+
     def close(self):
         _log(self.rank, event="close", torch_loaded="torch" in sys.modules)
 
@@ -53,6 +64,8 @@ class Engine:
 
     def train_steps(self, slot, first, B, steps, global_batch=None, seed=0):
         # rank r is slower by 20 ms per step: the reported time must be the slowest rank's
+        if getattr(self.ctx, "_prof", False):
+            self.ctx._steps = steps
         time.sleep(steps * (0.005 + 0.02 * self.ctx.rank))
         _log(self.ctx.rank, event="train_steps", B=B, steps=steps, global_batch=global_batch, t=time.time(),
              torch_loaded="torch" in sys.modules)

@@ -42,6 +42,15 @@ def test_two_rank_bench_launch_with_a_stub_engine(tmp_path):
     # the slow rank (rank 1: 25 ms per step) sets the time: MAX over ranks, not rank 0's own 5 ms per step
     assert d["ms_per_step"] >= 24.0, d["ms_per_step"]
     assert abs(d["value"] - 256 * world * steps / (d["ms_per_step"] * 1e-3 * steps)) <= 1e-6 * d["value"]
+    # the N > 1 line is self-verifying: what RCCL reports for the communicator on EVERY rank, which
+    # device each rank drives, the communication of a step and its exposed part, and a whole-step fraction
+    mr = d["multi_rank"]
+    assert mr["world"] == world and mr["rccl_ranks"] == [world] * world and mr["rccl_rank_ids"] == [0, 1]
+    assert [v["rank"] for v in mr["devices"]] == [0, 1] and mr["distinct_devices"] == world
+    assert len({v["pci_bus_id"] for v in mr["devices"]}) == world and mr["verified"] is True and mr["rehearsal"] is False
+    assert mr["collectives_per_step"] == 5 and abs(mr["comm_ms_per_step"] - 0.4) < 1e-9
+    assert abs(mr["exposed_comm_ms_per_step"] - 0.1) < 1e-9          # MAX over ranks (rank 1: 0.05 * 2)
+    assert d["roofline"]["whole_step_frac"] > 0 and d["roofline"]["bound"] == "mfma" and "rehearsal" not in d
     logs = {}
     for f in glob.glob(log + ".*"):
         logs[int(f.rsplit(".", 1)[1])] = [json.loads(ln) for ln in open(f)]
@@ -50,7 +59,7 @@ def test_two_rank_bench_launch_with_a_stub_engine(tmp_path):
     assert uids[0] == uids[1] and len(uids[0]) == 256         # rank 0's 128 bytes on both ranks
     for rk, ev in logs.items():
         ts = [e for e in ev if e["event"] == "train_steps"]
-        assert [t["steps"] for t in ts] == [warmup, steps]
+        assert [t["steps"] for t in ts] == [warmup, steps, steps]       # warm-up, the timed region, the comm-timing pass
         assert all(t["global_batch"] == 256 * world and t["B"] == 256 for t in ts)
         assert sum(e["event"] == "sync" for e in ev) >= 3      # before the timed region, inside it and at its end
         assert not any(e.get("torch_loaded") for e in ev), "torch was imported into a rank process"
@@ -76,3 +85,20 @@ def test_two_plain_processes_meet_on_master_port(tmp_path):
     assert len(lines0) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.strip().startswith("{")]
     d = json.loads(lines0[0])
     assert d["n_gpus"] == world and d["ms_per_step"] >= 24.0
+
+
+def test_bench_config_flag_selects_the_baseline_configuration(tmp_path):
+    """--config 3 (128 px, 64 per GPU) and --config 2 (bf16) under the driver's launch line: the line names the
+    configuration, the per-GPU batch and the stamp geometry it ran."""
+    for conf, want_batch, want in ((3, 64, "128x128x6"), (2, 256, "59x59x6")):
+        log = str(tmp_path / f"stub{conf}")
+        env = dict(os.environ, DV_BENCH_STUB_ENGINE="tests.stub_engine", DV_STUB_LOG=log, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--config", str(conf)]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+        assert f"configs[{conf}]" in d["config"]["workload"] and d["config"]["per_gpu_batch"] == want_batch
+        assert d["config"]["global_batch"] == 2 * want_batch and want in d["metric"]
+        assert d["dtype"] == ("bf16" if conf == 2 else "f32") and d["multi_rank"]["verified"]

@@ -4,8 +4,9 @@ of 64 - the persistent multi-item paths of the Winograd kernels (several items p
 boundaries), the split ranges of the Winograd weight gradient, the 870-block BN statistics pass, the 384-workgroup tiled
 weight gradients.  Same checks and tolerances as tests/test_gpu_parity.py::_run_parity (outputs 2e-4 * max, ELBO 1e-4
 relative, Adam update against the oracle's), both keep_outputs forms, one train step.  Gradients: 1e-3 * max per tensor,
-widened per tensor to HALF of what a numpy float32 evaluation of the same step misses float64 by (_run_parity's f32_floor:
-at these sizes float32 itself is up to 2e-2 * max away from float64 on the early encoder tensors, the engine 1.5e-3).
+or - per tensor - no worse than 1.5 x what a numpy float32 evaluation of the same step misses float64 by, capped at 1e-2
+(_run_parity's f32_floor: at these sizes float32 itself is up to 2e-2 * max away from float64 on the early encoder tensors
+where the engine is at 1.5e-3; the per-layer bound of 2e-5 is tests/test_gpu_0_layers_f32.py's).
 Reference semantics: training/train.py:27-37 (fit's train_function at the BASELINE batch), model.py:61-161.
 
 This file sorts in front of the HIP-vs-HIP kernel cross-checks (test_gpu_parity.py) so that `-x` reaches the oracle first.
