@@ -252,6 +252,13 @@ def secondary_entries(E, ctx, synthetic_stamps, quick: bool):
     out["deblend_field_cutouts_stream"] = cutouts_run(ctx, n_cutouts=65536 if quick else 262144, chunk=8192, dtype=0, stream=True)
     out["deblend_field_cutouts_stream_bf16"] = cutouts_run(ctx, n_cutouts=65536 if quick else 262144, chunk=8192, dtype=1,
                                                            stream=True)
+    # ... and with the consumer that follows in the reference (get_predicted_field / get_residual_field) on the GPU as well:
+    # no stamp crosses the host link (DeblendField.deblend_field(on_device=True), dv_infer_cutouts_composite)
+    _progress("secondary: deblend_field on the device (fp32, then bf16)")
+    # (the full million of configs[4] unless --quick: the call has a fixed cost of three 206 MB float64 fields coming back)
+    out["deblend_field_on_device"] = cutouts_run(ctx, n_cutouts=131072 if quick else 1000000, chunk=8192, dtype=0, on_device=True)
+    out["deblend_field_on_device_bf16"] = cutouts_run(ctx, n_cutouts=131072 if quick else 1000000, chunk=8192, dtype=1,
+                                                      on_device=True)
     _progress("secondary: deblend over field cutouts (fp32, then bf16)")
     out["deblend_cutouts"] = cutouts_run(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=0)
     out["deblend_cutouts_bf16"] = cutouts_run(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=1)
@@ -387,8 +394,13 @@ def _multi_rank_block(ctx, group, eng, B, Bg, steps, world):
 
 
 def run_inference_config(args, E, ctx, group, rank, world):
-    """BASELINE configs[4]: a "step" is one 8192-cutout deblend() call per GPU; rank r takes the contiguous index range
-    parallel.shard_range(N, r, world) of the cutout list (no collective on the data path)."""
+    """BASELINE configs[4]: a "step" is one 8192-cutout network call per GPU; rank r takes the contiguous index range
+    parallel.shard_range(N, r, world) of the cutout list (no collective on the data path).  What is timed is
+    the reference's own chain for a field (deblend/field_deblender.py:219-383 and :46-189): cut the stamps out of the
+    field, run the network on them, composite the predicted mean / stddev / residual fields - here as ONE engine call per
+    rank with everything on the GPU (DeblendField.deblend_field(on_device=True)); each rank returns its partial fields.
+    The form that ships every stamp's mean and stddev to the host instead (deblend_field_cutouts(on_chunk=...), 167 KB
+    per stamp over the host link) is measured beside it as `stamps_to_host`."""
     from tools.field_cutouts import synthetic_field
     from debvader_amd.parallel import shard_range
 
@@ -396,34 +408,59 @@ def run_inference_config(args, E, ctx, group, rank, world):
     dtype = 1 if args.dtype == "bf16" else 0
     scene = np.ascontiguousarray(np.tile(synthetic_field(), (8, 8, 1)))
     F, cs = scene.shape[0], 59
-    n_total = chunk * world * (args.steps + args.warmup)
+    n_total = chunk * world * (args.steps + max(args.warmup, 2))
     starts = np.random.default_rng(0).integers(0, F - cs + 1, size=(n_total, 2)).astype(np.int32)
     eng = E.Engine(E.make_config(max_batch=chunk, dtype=dtype), ctx)
     eng.init(seed=0)
-    state = {"n": 0, "checksum": 0.0}
-
-    def consume(first, mean, std):
-        state["n"] += mean.shape[0]
-        state["checksum"] += float(mean[::97, 29, 29, 2].sum())
 
     def barrier():
         ctx.sync()
         if group is not None:
             group.barrier()
 
-    wlo, whi = shard_range(chunk * world * max(args.warmup, 2), rank, world)          # the pinned ring wants two chunks
-    eng.infer_cutouts_stream(scene, starts[wlo:whi], lambda *a: None, seed=1)
     n_timed = chunk * world * args.steps
-    lo, hi = shard_range(n_timed, rank, world)
     off = n_total - n_timed
+    wlo, whi = shard_range(off, rank, world)
+    lo, hi = shard_range(n_timed, rank, world)
+    eng.infer_cutouts_composite(scene, starts[wlo:whi], starts[wlo:whi], seed=1)                    # warm-up
     barrier()
     t0 = time.perf_counter()
-    eng.infer_cutouts_stream(scene, starts[off + lo:off + hi], consume, seed=2)
+    out = eng.infer_cutouts_composite(scene, starts[off + lo:off + hi], starts[off + lo:off + hi], seed=2)
     ctx.sync()
     barrier()
     dt = time.perf_counter() - t0
     if group is not None:
         dt = group.max(dt)
+    # the same cutouts with every stamp's mean and stddev shipped to the host (PCIe-inclusive)
+    state = {"n": 0}
+
+    def consume(first, mean, std):
+        state["n"] += mean.shape[0]
+
+    eng.infer_cutouts_stream(scene, starts[wlo:whi], lambda *a: None, seed=1)
+    barrier()
+    t1 = time.perf_counter()
+    eng.infer_cutouts_stream(scene, starts[off + lo:off + hi], consume, seed=2)
+    ctx.sync()
+    barrier()
+    dt_host = time.perf_counter() - t1
+    if group is not None:
+        dt_host = group.max(dt_host)
+    rows = None
+    if rank == 0 and not args.no_roofline and hasattr(eng, "prof_enable"):
+        # per-kernel-family pass over two chunks (HIP events on the launch streams), as for the train configurations
+        eng.prof_reset()
+        eng.prof_enable(True)
+        eng.infer_cutouts_composite(scene, starts[:2 * chunk], starts[:2 * chunk], seed=3)
+        eng.prof_enable(False)
+        rows = []
+        for f in eng.prof_families():
+            ms = f["ms"] / 2
+            rows.append({"kernel": f["name"], "launches_per_step": f["launches"] / 2, "flops_per_step": f["flops"] / 2,
+                         "executed_flops_per_step": f["executed_flops"] / 2,
+                         "algorithmic_bytes_per_step": (f["algorithmic_bytes"] / 2) or None, "ms_per_step": ms,
+                         "avg_us": ms * 1e3 / max(1.0, f["launches"] / 2),
+                         "tflops": f["flops"] / 2 / (ms * 1e-3) / 1e12 if ms > 0 else 0.0})
     eng.close()
     mr = _multi_rank_block(ctx, group, None, 0, 0, 1, world) if world > 1 else None     # who ran where (no timing pass)
     if rank != 0:
@@ -431,21 +468,37 @@ def run_inference_config(args, E, ctx, group, rank, world):
     enc_macs, dec_macs = E.arch_macs(E.make_config())
     fwd_flops = 2.0 * (enc_macs + dec_macs + 32 * 33 // 2)
     val = n_timed / dt
+    peak = BF16_MFMA_PEAK_TFLOPS if dtype else FP32_MFMA_PEAK_TFLOPS
+    whole = val * fwd_flops / world / 1e12
+    roofline = {"bound": "mfma", "kernel": None, "achieved": whole, "peak": peak, "unit": "TFLOP/s", "frac": whole / peak,
+                "traffic": None, "note": "whole forward, algorithmic FLOPs per GPU (658.7 MFLOP per stamp) over the dense MFMA peak"}
+    if rows:
+        dom = max(rows, key=lambda r: r["ms_per_step"])
+        for r in rows:
+            r["algorithmic_tflops"] = r["tflops"]
+            r["executed_tflops"] = r["executed_flops_per_step"] / (r["ms_per_step"] * 1e-3) / 1e12 if r["ms_per_step"] > 0 else 0.0
+            r["executed_frac"] = r["executed_tflops"] / peak
+        roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["executed_tflops"], "peak": peak, "unit": "TFLOP/s",
+                    "frac": dom["executed_frac"],
+                    "frac_definition": "executed matrix FLOPs of the dominant kernel's launches of one 8192-cutout call / their "
+                                       "duration / the dense MFMA peak of the dtype",
+                    "algorithmic_tflops": dom["algorithmic_tflops"], "algorithmic_frac": dom["algorithmic_tflops"] / peak,
+                    "algorithmic_bytes": dom["algorithmic_bytes_per_step"], "traffic": None,
+                    "whole_step_tflops": whole, "whole_step_frac": whole / peak, "kernels": rows}
     return {
-        "metric": "galaxy stamps/sec (deblend inference over field cutouts) 59x59x6",
+        "metric": "galaxy stamps/sec (deblend_field inference over field cutouts, fields composited on the GPU) 59x59x6",
         "value": val, "unit": "stamps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if dtype else "f32", "data": "synthetic",
         "config": {"workload": CONFIGS[4]["label"], "global_batch": chunk * world, "per_gpu_batch": chunk,
                    "parallelism": f"shard{world} (no collective)"},
-        "includes": "field H2D once, cutout gather + float32 cast on the GPU, forward, D2H of mean and stddev of every stamp "
-                    "into the pinned ring, consumed in place (PCIe-inclusive: 167 KB per stamp cross the host link)",
-        "d2h_gbs": val * 2 * cs * cs * 6 * 4 / 1e9,
-        "roofline": {"bound": "mfma", "achieved": val * fwd_flops / world / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS if dtype else FP32_MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": val * fwd_flops / world / 1e12 / (BF16_MFMA_PEAK_TFLOPS if dtype else FP32_MFMA_PEAK_TFLOPS),
-                     "traffic": None, "note": "algorithmic forward FLOPs per GPU (658.7 MFLOP per stamp) over the dense MFMA peak of "
-                                              "the dtype; the entry is host-link-bound where d2h_gbs reaches the box's link rate"},
-        "cpu_baseline": None, "checksum": state["checksum"], **({"multi_rank": mr} if mr else {}),
+        "includes": "the field is in HBM when the timed region starts (uploaded by the call: 206 MB once per rank); cutout gather + "
+                    "float32 cast, forward, mean / stddev / residual fields composited on the GPU; D2H of the three fields",
+        "stamps_to_host": {"value": n_timed / dt_host, "unit": "stamps/s", "d2h_gbs": n_timed / dt_host * 2 * cs * cs * 6 * 4 / 1e9,
+                           "note": "the same cutouts with mean and stddev of every stamp copied to the host (167 KB per stamp: "
+                                   "PCIe-inclusive, bound by the box's host link)"},
+        "roofline": roofline, "cpu_baseline": None, "checksum": float(out["mean_field"][::37, ::41, 2].sum()),
+        **({"multi_rank": mr} if mr else {}),
     }
 
 

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "bf16.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace dv {
 
@@ -484,8 +485,12 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
 // HBM path 16 line requests for 1 KiB of use, and measured operand bandwidth halves (tools/probes/dma_probe.hip:
 // 17 vs 33 TB/s out of L2, 4.2 vs 8.4 out of the Infinity Cache, 3.5 vs 7.0 out of HBM).  CH = 2 issues the two halves
 // of the same lines back to back (chunks 2i and 2i+1 of a tap), so the second request merges with the first in L1.
-template <int NBLK, int CINMODE, int GT, int CH = 1>
-__global__ __launch_bounds__(256, GT == 16 ? (CH == 1 ? 2 : 1) : (CH == 1 ? 4 : 2)) void bconv_uni_kernel(const BConvParams p) {
+// NS = LDS stages of the ring (the DMA of step i + NS - 1 is issued while step i is multiplied).  3 is what ships; a
+// six-stage ring on 256-stamp tiles for the deep layers was measured in round 4 (one workgroup per CU walking 36-72 K
+// steps with five steps in flight) and changed nothing on the 8 x 8 layers (35.9 -> 38.3 us) while the 16 x 16 layers
+// lost 40 % to the single resident workgroup: the tiles are not paced by the latency of their DMA.
+template <int NBLK, int CINMODE, int GT, int CH = 1, int NS = 3>
+__global__ __launch_bounds__(256, NS > 3 ? 1 : (GT == 16 ? (CH == 1 ? 2 : 1) : (CH == 1 ? 4 : 2))) void bconv_uni_kernel(const BConvParams p) {
   constexpr int GW = GT / 4;                              // groups per wave
   constexpr int RW = GW * 16;                             // output rows (stamps) per wave
   constexpr int SUB = (GT + NBLK) * 1024;                 // one chunk of a stage: GT A blocks, NBLK B blocks
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(256, GT == 16 ? (CH == 1 ? 2 : 1) : (CH == 1 ? 4 : 
   constexpr int BN = 16 * NBLK;
   static_assert(RW * BN * 2 >= 1024, "a wave's bf16 tile must be at least one 1-KiB row piece");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  int* stab = reinterpret_cast<int*>(smem + 3 * STAGE);   // [0] valid taps, [1..9] their ids, [10..18] their source pixels
+  int* stab = reinterpret_cast<int*>(smem + NS * STAGE);   // [0] valid taps, [1..9] their ids, [10..18] their source pixels
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -647,16 +652,28 @@ __global__ __launch_bounds__(256, GT == 16 ? (CH == 1 ? 2 : 1) : (CH == 1 ? 4 : 
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) acc[gi][j] = (f32x4){bias[j], bias[j], bias[j], bias[j]};
 
-  if (nsteps > 0) issue(0, 0);
-  if (nsteps > 1) issue(1, 1);
+  constexpr int PER_STAGE = CH * (GW + 1);                // DMA instructions per wave and stage
+#pragma unroll
+  for (int k = 0; k < NS - 1; ++k)
+    if (k < nsteps) issue(k, k);
   int buf = 0;
   for (int i = 0; i < nsteps; ++i) {
-    if (i + 1 < nsteps)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH * (GW + 1)) : "memory");     // the newest stage: CH * (GW + 1) instructions per wave
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // stage i must have landed; the stages issued after it (at most NS - 2 of them) may still be in flight
+    const int ahead = min(NS - 2, nsteps - 1 - i);
+    if (NS == 3) {
+      if (ahead >= 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PER_STAGE) : "memory");
+      else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER_STAGE) : "memory");
+      else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_STAGE) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
-    if (i + 2 < nsteps) issue(i + 2, buf >= 1 ? buf - 1 : 2);
+    if (i + NS - 1 < nsteps) issue(i + NS - 1, buf >= 1 ? buf - 1 : NS - 1);   // the stage read in step i - 1
 #pragma unroll
     for (int h = 0; h < CH; ++h) {
       const unsigned char* sA = smem + buf * STAGE + h * SUB + wave * (GW * 1024) + fragoff;
@@ -672,7 +689,7 @@ __global__ __launch_bounds__(256, GT == 16 ? (CH == 1 ? 2 : 1) : (CH == 1 ? 4 : 
         for (int j = 0; j < NBLK; ++j)
           acc[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gi], b[j], acc[gi][j], 0, 0, 0);
     }
-    buf = buf == 2 ? 0 : buf + 1;
+    buf = buf == NS - 1 ? 0 : buf + 1;
   }
 
   // ---- epilogue: per-wave LDS tile [RW rows][BN]; the rows are consecutive rows of the output tensor ----
@@ -771,7 +788,7 @@ __global__ __launch_bounds__(256, GT == 16 ? (CH == 1 ? 2 : 1) : (CH == 1 ? 4 : 
     if constexpr (GW < 4) {
       // a partial slab row covers 64 stamps = 4 / GW waves: sum them through LDS in wave order (p.dal_part is the same for
       // every wave, so all of them reach the barrier)
-      float* pbuf = reinterpret_cast<float*>(smem + 3 * STAGE + 1024);   // [4 waves][2][BN]
+      float* pbuf = reinterpret_cast<float*>(smem + NS * STAGE + 1024);   // [4 waves][2][BN]
       if (g4 == 0) {
 #pragma unroll
         for (int j = 0; j < NBLK; ++j) {
@@ -803,6 +820,318 @@ __global__ __launch_bounds__(256, GT == 16 ? (CH == 1 ? 2 : 1) : (CH == 1 ? 4 : 
       for (int j = 0; j < NBLK; ++j) {
         p.dal_part[o + j] = dal[j];
         p.db_part[o + j] = db[j];
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-strip form for the stride-1 3 x 3 layers (round 4): register-blocked, with halo reuse.
+//
+// What bounded bconv_uni_kernel (round-4 measurements): a workgroup there is ONE output pixel, so every input
+// block (16 stamps x 32 channels, 1 KiB) is fetched by nine workgroups and every fetched KiB feeds NBLK <= 4 MFMAs - the
+// kernel lives on the L2 -> CU operand path (about one KiB per 16-36 cycles and CU) and on the issue cost of its LDS-DMA
+// pieces, matrix pipe 9 % busy.  Two round-4 probes confirmed it: the same tiles with both operands loaded straight into
+// registers (no LDS, no barrier) ran 1.4-4x SLOWER (the weights then cross the vector-memory path once per wave), and a
+// six-stage ring on 256-stamp tiles changed nothing (not latency).
+//
+// Here a wave owns 16 stamps x EIGHT consecutive output pixels of one row x 16*NBLK output channels and keeps all of their
+// accumulators in registers.  In the stamp-inner layout an input block IS an MFMA A fragment (lane (row l & 15, piece
+// l >> 4) holds 16 consecutive bytes of row `stamp`), and no other wave wants this wave's stamps: A goes global -> VGPR
+// directly, ten blocks per input row (the strip plus its halo), and each of them is used for up to 3 taps x NBLK MFMAs -
+// 24 NBLK MFMAs per ten KiB instead of NBLK per KiB.  The weights of a 32-channel chunk (9 taps x NBLK KiB, shared by the
+// workgroup's four waves = four stamp groups of the same strip) arrive by LDS-DMA into a double-buffered stage, one
+// barrier per CHUNK (not per K step), and are read as fragments per input row (3 NBLK ds_read_b128).  Input rows /
+// columns outside the image are read from a zero page, so the instruction stream - and with it the counted vmcnt at the
+// chunk boundary - is the same for every strip.
+template <int NBLK>
+__global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) {
+  constexpr int P = 8;                                    // output pixels per strip
+  constexpr int BN = 16 * NBLK;
+  constexpr int BSTAGE = 9 * NBLK * 1024;                 // weights of one chunk: [tap][column block][1 KiB fragment image]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* sB = smem;                               // 2 stages
+  constexpr int WREG = 16 * BN * (NBLK == 1 ? 4 : 2);     // per-wave epilogue tile [16 rows][BN]
+  unsigned char* wreg_base = smem + 2 * BSTAGE;
+  float* pbuf = reinterpret_cast<float*>(smem + 2 * BSTAGE + 4 * WREG);   // [8 px][4 waves][2][BN] partial sums of the fused PReLU backward
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = p.Cout / BN;
+  const int nq = p.NBp >> 6;                              // 64-stamp quads
+  const int nsx = (p.Hout + P - 1) / P;                   // strips per row
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  // tile order: column tile fastest (the tiles of one strip share its input), then stamp quad, then strip (row-major)
+  const int tile_n = bid % ntn;
+  const int rest = bid / ntn;
+  const int quad = rest % nq;
+  const int strip = rest / nq;
+  const int oh = strip / nsx, ow0 = (strip - oh * nsx) * P;
+  const int n0 = tile_n * BN;
+  const int st0 = quad * 64 + wave * 16;                  // first stamp of this wave
+  const int npx = min(P, p.Hout - ow0);                   // valid pixels of the strip
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int c = fr, g4 = fq;
+  const int ch0 = n0 + NBLK * c;
+  const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.X);
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
+  const size_t pixbytes = (size_t)p.NBp * p.Cin * 2;
+  const int cpt = p.Cin >> 5;
+  // A fragment source of input pixel (ih, iw), chunk cc: Xb + (ih*Hin + iw) * pixbytes + a_lane + cc * 64
+  const unsigned a_lane = (unsigned)((((st0 + fr) * p.Cin) + fq * 8) * 2);
+  // weight-DMA roles (as in bconv_uni_kernel): LDS slot `lane` of a block = (row lane >> 2, piece (lane & 3) ^ G4[row >> 2])
+  const int drow = lane >> 2;
+  const int dq = (lane & 3) ^ ((4 - (drow >> 2)) & 3);
+  const unsigned b_lane = (unsigned)((((n0 + NBLK * drow) * p.Kpad) + dq * 8) * 2);
+  const int fragoff = (fr * 4 + (fq ^ ((4 - (fr >> 2)) & 3))) * 16;
+  // input offset (dh, dw) of a weight tap t = kh * 3 + kw: form 0 (Conv2D forward / Conv2DTranspose data gradient, pad 1):
+  // source = out + k - 1; form 1 (Conv2DTranspose forward / Conv2D data gradient): source = out + 1 - k
+  const int sgn = p.form == 0 ? 1 : -1;
+
+  // weights of chunk cc -> stage buffer: 9 * NBLK pieces, dealt round-robin over the four waves
+  auto issue_b = [&](int cc, int buf) {
+    unsigned char* dst = sB + buf * BSTAGE;
+#pragma unroll
+    for (int k = 0; k < (9 * NBLK + 3) / 4; ++k) {
+      const int piece = k * 4 + wave;                     // (tap, column block)
+      if (piece < 9 * NBLK) {
+        const int t = piece / NBLK, j = piece - t * NBLK;
+        __builtin_amdgcn_global_load_lds((bc_gptr_t)(Wb + (size_t)((t * p.Cin + cc * 32) * 2) + (size_t)j * p.Kpad * 2 + b_lane),
+                                         (bc_lptr_t)(dst + piece * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[P][NBLK];
+  {
+    float bias[NBLK];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) bias[j] = 0.f;
+    if (p.bias && (p.epi == BEPI_FWD || p.epi == BEPI_RAW32)) load_f32<NBLK>(p.bias + ch0, bias);
+#pragma unroll
+    for (int px = 0; px < P; ++px)
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) acc[px][j] = (f32x4){bias[j], bias[j], bias[j], bias[j]};
+  }
+
+  // the three input rows of the strip (dh = -1, 0, 1) and its ten input columns (ow0 - 1 .. ow0 + 8).  Every source is a
+  // UNIFORM base (an input pixel's [NBp][Cin] block, or the zero page, which is at least one such block long) plus the
+  // lane's constant offset a_lane: no per-load vector address arithmetic, no address registers held across the loop
+  const unsigned char* zbase = reinterpret_cast<const unsigned char*>(p.zero);
+  bool rowok[3];
+  int rowpix[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int ih = oh + r - 1;
+    rowok[r] = ih >= 0 && ih < p.Hin;
+    rowpix[r] = (rowok[r] ? ih : 0) * p.Hin + ow0 - 1;
+  }
+  unsigned colmask = 0;
+#pragma unroll
+  for (int i = 0; i < P + 2; ++i) {
+    const int iw = ow0 - 1 + i;
+    if (iw >= 0 && iw < p.Hin && i <= npx + 1) colmask |= 1u << i;
+  }
+  bc_bf16x8 ra[2][P + 2];
+  auto load_a = [&](auto setc, int r, int cc) {
+    constexpr int S = decltype(setc)::value;
+#pragma unroll
+    for (int i = 0; i < P + 2; ++i) {
+      const bool ok = rowok[r] && ((colmask >> i) & 1u);
+      const unsigned long long u64 = (unsigned long long)(ok ? Xb + (size_t)(rowpix[r] + i) * pixbytes + cc * 64 : zbase);
+      // (uniform by construction; said so explicitly, or the address is built per lane in vector registers)
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u64), hi = __builtin_amdgcn_readfirstlane((unsigned)(u64 >> 32));
+      const unsigned char* ub = reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+      ra[S][i] = *reinterpret_cast<const bc_bf16x8*>(ub + a_lane);
+    }
+  };
+  // one input row against the weights of its three taps: out pixel px takes input column px + 1 + dw
+  auto row_mfma = [&](auto setc, int r, int buf) {
+    constexpr int S = decltype(setc)::value;
+    const int dh = r - 1;
+    const int kh = sgn > 0 ? dh + 1 : 1 - dh;
+    bc_bf16x8 rb[3][NBLK];
+    const unsigned char* bs = sB + buf * BSTAGE + fragoff;
+#pragma unroll
+    for (int dwi = 0; dwi < 3; ++dwi) {
+      const int kw = sgn > 0 ? dwi : 2 - dwi;             // dw = dwi - 1
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) rb[dwi][j] = *reinterpret_cast<const bc_bf16x8*>(bs + ((kh * 3 + kw) * NBLK + j) * 1024);
+    }
+    if (!rowok[r]) return;                                // (uniform) a row outside the image contributes nothing
+#pragma unroll
+    for (int i = 0; i < P + 2; ++i) {
+#pragma unroll
+      for (int dwi = 0; dwi < 3; ++dwi) {
+        const int px = i - dwi;                           // input column i = px + 1 + (dwi - 1)
+        if (px < 0 || px >= P) continue;
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j)
+          acc[px][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra[S][i], rb[dwi][j], acc[px][j], 0, 0, 0);
+      }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  issue_b(0, 0);
+  load_a(S0{}, 0, 0);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + 2) : "memory");     // the weight pieces are older than the ten A loads
+  __builtin_amdgcn_s_barrier();
+  if (cpt > 1) issue_b(1, 1);
+  // rows are walked (chunk, row) with the A loads one row ahead: row index q = 3 * cc + r, register set q & 1
+  for (int cc = 0; cc < cpt; ++cc) {
+    const int buf = cc & 1;
+    // rows 0 and 1 of the chunk (sets alternate with the global row index; 3 rows per chunk -> the parity flips per chunk)
+    if ((cc & 1) == 0) {
+      load_a(S1{}, 1, cc);
+      row_mfma(S0{}, 0, buf);
+      load_a(S0{}, 2, cc);
+      row_mfma(S1{}, 1, buf);
+      if (cc + 1 < cpt) load_a(S1{}, 0, cc + 1);
+      row_mfma(S0{}, 2, buf);
+    } else {
+      load_a(S0{}, 1, cc);
+      row_mfma(S1{}, 0, buf);
+      load_a(S1{}, 2, cc);
+      row_mfma(S0{}, 1, buf);
+      if (cc + 1 < cpt) load_a(S0{}, 0, cc + 1);
+      row_mfma(S1{}, 2, buf);
+    }
+    if (cc + 1 < cpt) {
+      // the weights of chunk cc + 1 were issued a chunk ago: everything but the ten youngest loads (the next row's A) is older
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + 2) : "memory");
+      __builtin_amdgcn_s_barrier();                       // every wave's pieces have landed, every wave is done with stage `buf`
+      if (cc + 2 < cpt) issue_b(cc + 2, buf);
+    }
+  }
+
+  // ---- epilogue, pixel by pixel: per-wave LDS tile [16 rows][BN], rows = the wave's 16 stamps of that pixel ----
+  unsigned char* wreg = wreg_base + wave * WREG;
+  bc_bf16* wt = reinterpret_cast<bc_bf16*>(wreg);
+  auto flush = [&](void* dst, int esz, size_t rb0) {
+    const int rowb = BN * esz;
+    unsigned char* out = reinterpret_cast<unsigned char*>(dst) + (rb0 * p.Cout + n0) * esz;
+    const size_t rstride = (size_t)p.Cout * esz;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k >= 16 * rowb / 1024) break;
+      const int byte = (k * 64 + lane) * 16;
+      const int row = byte / rowb, colb = byte - row * rowb;
+      *reinterpret_cast<f32x4*>(out + row * rstride + colb) = *reinterpret_cast<const f32x4*>(wreg + byte);
+    }
+  };
+  constexpr int NPC = 16 * BN / 512;                      // 16-byte pieces per lane of a [16][BN] bf16 tile (NBLK >= 2)
+#pragma unroll
+  for (int px = 0; px < P; ++px) {
+    if (px >= npx) break;                                 // (uniform)
+    const int pix = oh * p.Hout + ow0 + px;
+    const size_t rb0 = (size_t)pix * p.NBp + st0;
+    if (p.epi == BEPI_RAW32) {
+      if constexpr (NBLK == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) reinterpret_cast<float*>(wreg)[(4 * g4 + r) * BN + c] = acc[px][0][r];
+        flush(p.Uf, 4, rb0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j) p.Uf[(rb0 + 4 * g4 + r) * p.Cout + ch0 + j] = acc[px][j][r];
+      }
+      continue;
+    }
+    if constexpr (NBLK >= 2) {
+      if (p.epi == BEPI_RAWBF || (p.epi == BEPI_FWD && p.U)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v[NBLK];
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j) v[j] = acc[px][j][r];
+          store_bf<NBLK>(wt + (4 * g4 + r) * BN + NBLK * c, v);
+        }
+        flush(p.U, 2, rb0);
+        if (p.epi == BEPI_RAWBF) continue;
+      }
+      float al[NBLK];
+      load_f32<NBLK>(p.alpha + (size_t)pix * p.Cout + ch0, al);
+      if (p.epi == BEPI_FWD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a[NBLK];
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j) a[j] = fmaxf(acc[px][j][r], 0.f) + al[j] * fminf(acc[px][j][r], 0.f);
+          store_bf<NBLK>(wt + (4 * g4 + r) * BN + NBLK * c, a);
+        }
+        flush(p.A, 2, rb0);
+        continue;
+      }
+      // BEPI_BWD: d(pre-activation) = d(activation) * gate(u), stamp sums for d(alpha) / d(bias)
+#pragma unroll
+      for (int k = 0; k < NPC; ++k) {
+        const int byte = (k * 64 + lane) * 16;
+        const int row = byte / (BN * 2), colb = byte - row * (BN * 2);
+        *reinterpret_cast<f32x4*>(wreg + byte) = *reinterpret_cast<const f32x4*>(
+            reinterpret_cast<const unsigned char*>(p.Uin) + ((rb0 + row) * p.Cout + n0) * 2 + colb);
+      }
+      float dal[NBLK], db[NBLK];
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) dal[j] = db[j] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bc_bf16* q = wt + (4 * g4 + r) * BN + NBLK * c;
+        float u[NBLK], du[NBLK];
+        load_bf<NBLK>(q, u);
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
+          const float v = acc[px][j][r];
+          du[j] = v * (u[j] > 0.f ? 1.f : al[j]);
+          dal[j] += v * fminf(u[j], 0.f);
+          db[j] += du[j];
+        }
+        store_bf<NBLK>(q, du);
+      }
+      flush(p.U, 2, rb0);
+      if (p.dal_part) {
+        // sums over the wave's 16 stamps (rows live on the lane groups g4); parked in LDS per (pixel, wave) until the end
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
+          dal[j] += __shfl_xor(dal[j], 16);
+          dal[j] += __shfl_xor(dal[j], 32);
+          db[j] += __shfl_xor(db[j], 16);
+          db[j] += __shfl_xor(db[j], 32);
+        }
+        if (g4 == 0) {
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j) {
+            pbuf[((px * 4 + wave) * 2 + 0) * BN + NBLK * c + j] = dal[j];
+            pbuf[((px * 4 + wave) * 2 + 1) * BN + NBLK * c + j] = db[j];
+          }
+        }
+      }
+    }
+  }
+  if constexpr (NBLK >= 2) {
+    if (p.epi == BEPI_BWD && p.dal_part) {
+      // ... then over the four waves = 64 stamps, in wave order: one partial row per 64-stamp quad, as bconv_uni_kernel
+      // writes them (p.dal_part is uniform: every wave reaches the barrier)
+      __syncthreads();
+      for (int e = tid; e < npx * BN; e += 256) {
+        const int px = e / BN, col = e - px * BN;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a += pbuf[((px * 4 + w) * 2 + 0) * BN + col];
+          b += pbuf[((px * 4 + w) * 2 + 1) * BN + col];
+        }
+        const size_t o = ((size_t)quad * p.Hout * p.Hout + oh * p.Hout + ow0 + px) * p.Cout + n0 + col;
+        p.dal_part[o] = a;
+        p.db_part[o] = b;
       }
     }
   }
@@ -854,6 +1183,41 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   const bool pair = uni && mode == 0 && p.Cin % 64 == 0 && gt <= 8;
   const int ch = pair ? 2 : 1;
   const long tiles = ntiles(gt, nblk);
+  // row-strip form (bconv_row_kernel): stride-1 3 x 3 layers with Cin % 32 == 0 on batches padded to 64 stamps.  Shipped
+  // for the 16-column head conv only (measured, same box, serialised 256-stamp step: 52.4 -> 37.7 us); on the 32- to
+  // 256-channel layers it is parity-green but 1.2-1.6x SLOWER than the one-pixel tiles (one wave per SIMD with a single
+  // input row of register loads in flight does not cover the L2 / HBM latency: DESIGN 4b).  DV_BCONV_ROW=2 takes it for
+  // every eligible layer (the A/B switch of that measurement), =0 never.
+  static const int row_mode = getenv("DV_BCONV_ROW") ? atoi(getenv("DV_BCONV_ROW")) : 1;
+  if (row_mode && mode == 0 && p.s == 1 && p.pb == 1 && p.Hin == p.Hout && (p.NBp & 63) == 0) {
+    int nb = p.Cout % 64 == 0 ? 4 : (p.Cout % 32 == 0 ? 2 : 1);
+    const long strips = (long)p.Hout * ((p.Hout + 7) / 8);
+    auto rtiles = [&](int b) { return strips * (p.NBp >> 6) * (p.Cout / (16 * b)); };
+    // at least one workgroup per CU before the column tile stays wide
+    while (nb > 1 && rtiles(nb) < 256) nb >>= 1;
+    if (nb == 1 && p.epi != BEPI_RAW32) nb = 0;            // the bf16 epilogues want >= 32 columns (1-KiB row pieces)
+    if (nb == 1 && p.Cout % 16) nb = 0;
+    if (nb > 1 && row_mode < 2) nb = 0;
+    if (nb) {
+      const long rt = rtiles(nb);
+      const size_t rl = (size_t)2 * 9 * nb * 1024 + 4 * 16 * 16 * nb * (nb == 1 ? 4 : 2) + (size_t)8 * 4 * 2 * 16 * nb * 4 + 1024;
+#define BROW_LAUNCH(NB_)                                                                                  \
+      do {                                                                                                 \
+        static size_t attr_lds = 0;                                                                        \
+        if (attr_lds < rl) {                                                                               \
+          DV_HIP(hipFuncSetAttribute((const void*)bconv_row_kernel<NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl)); \
+          attr_lds = rl;                                                                                   \
+        }                                                                                                  \
+        hipLaunchKernelGGL((bconv_row_kernel<NB_>), dim3((unsigned)rt), dim3(256), rl, s, p);             \
+      } while (0)
+      if (nb == 4) BROW_LAUNCH(4);
+      else if (nb == 2) BROW_LAUNCH(2);
+      else BROW_LAUNCH(1);
+#undef BROW_LAUNCH
+      DV_HIP(hipGetLastError());
+      return OK;
+    }
+  }
   const size_t lds = uni ? (size_t)3 * ch * (gt + nblk) * 1024 + 4096 : (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;
 #define BC_LAUNCH_K(KERNEL_)                                                                           \
   do {                                                                                                 \

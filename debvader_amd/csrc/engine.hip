@@ -594,6 +594,18 @@ struct ProfScope {
   }
 };
 
+// a launcher declined the launch (returned 1: geometry not supported) after its ProfScope had counted it
+static void prof_uncount(dv_model* m, int k, int fam, double flops, double exec = -1.0, double bytes = 0.0) {
+  if (!m->prof_on) return;
+  m->prof_launches[k] -= 1;
+  if (fam >= 0) {
+    m->fam_launches[fam] -= 1;
+    m->fam_flops[fam] -= flops;
+    m->fam_exec[fam] -= exec < 0 ? flops : exec;
+    m->fam_bytes[fam] -= bytes;
+  }
+}
+
 static int prof_flush(dv_model* m) {
   prof_close(m);
   if (m->prof.empty()) return OK;
@@ -889,7 +901,9 @@ static int wino_conv(dv_model* m, const float* X, const float* W, bool nmajor, c
   const double bytes = 4.0 * ((double)NB * H * H * (Cin + (U ? Cout : 0) + (Aout ? Cout : 0)) + 16.0 * Cin * Cout +
                               (epi == 2 ? (double)H * H * Cout : 0.0));
   ProfScope ps(m, 0, nullptr, PF_WINO, flops, exec, bytes);
-  return launch_wino_conv(p, st);
+  const int r = launch_wino_conv(p, st);
+  if (r > 0) prof_uncount(m, 0, PF_WINO, flops, exec, bytes);
+  return r;
 }
 
 // fprop-form gconv over an [NB,Hin,Hin,Cin] tensor: out[NB,Hout,Hout,Cout], in pixel = out*s + k - pb
@@ -941,6 +955,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     {
       ProfScope ps(m, 0, nullptr, PF_GSTRIP, flops);
       r = launch_gconv_strip(g, nmajor, fwd_stream(m));
+      if (r > 0) prof_uncount(m, 0, PF_GSTRIP, flops);
     }
     if (r <= 0) return r;
   }
@@ -954,6 +969,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
     {
       ProfScope ps(m, 0, nullptr, PF_GSTRIP8, flops);
       r = launch_gconv_strip8(g, fwd_stream(m));
+      if (r > 0) prof_uncount(m, 0, PF_GSTRIP8, flops);
     }
     if (r <= 0) return r;
   }
@@ -1047,6 +1063,7 @@ static int gconv_dgrad(dv_model* m, const float* X, const float* W, bool nmajor,
       {
         ProfScope ps(m, 0, nullptr, PF_GSTRIP, flops);
         r = launch_gconv_strip(g, nmajor, fwd_stream(m));
+        if (r > 0) prof_uncount(m, 0, PF_GSTRIP, flops);
       }
       if (r <= 0) return r;
     }
@@ -1274,6 +1291,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
         const double bytes = 4.0 * ((double)NB * Hy * Hy * (Cx + Cy) + (double)S * 16.0 * Cx * Cy);
         ProfScope ps(m, 1, ws, PF_WINOW, wflops, exec, bytes);
         st = launch_wino_wgrad(wp, out, ws);
+        if (st > 0) prof_uncount(m, 1, PF_WINOW, wflops, exec, bytes);
       }
       if (st < 0) return st;
       if (st == 0) {
@@ -1328,6 +1346,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
     {
       ProfScope ps(m, 1, ws, PF_WSTRIP, wflops);
       st = launch_wgrad_strip(sp, Cx, Cy, sx, ws, &ns);
+      if (st > 0) prof_uncount(m, 1, PF_WSTRIP, wflops);
     }
     if (st < 0) return st;
     if (st > 0 && fz) {

@@ -39,8 +39,12 @@ static int bf_alloc(dv_model* m) {
   };
   const size_t HW = (size_t)A.H * A.H;
   DV_TRY(balloc(&bf.xh, HW * Bp * 16 * 2));
-  DV_TRY(balloc(&bf.zero, 1024));
-  DV_HIP(hipMemsetAsync(bf.zero, 0, 1024, m->ctx->stream));
+  // zero page: as long as ONE pixel's [Bp][C] block of the widest conv layer, so that the row-strip kernel can read an
+  // out-of-image block at its usual lane offsets from a uniform base (bconv_row_kernel); >= 1 KiB for the DMA kernels
+  size_t zero_bytes = 1024;
+  for (int i = 0; i < A.L; ++i) zero_bytes = std::max(zero_bytes, (size_t)Bp * A.cfg.filters[i] * 2);
+  DV_TRY(balloc(&bf.zero, zero_bytes));
+  DV_HIP(hipMemsetAsync(bf.zero, 0, zero_bytes, m->ctx->stream));
   size_t max_e = (size_t)A.dec_out * A.dec_out * 16;
   bf.enc_u.resize(2 * A.L); bf.enc_a.resize(2 * A.L); bf.dec_u.resize(2 * A.L); bf.dec_a.resize(2 * A.L);
   bf.enc_w.resize(2 * A.L); bf.dec_w.resize(2 * A.L);

@@ -180,83 +180,135 @@ __global__ __launch_bounds__(256) void scene_composite_kernel(double* __restrict
 // bit-identical to the host-composited path.  Stamps are the network's float32 outputs as the forward pass left them in
 // HBM (mean and stddev of every stamp, 167 KB per stamp that never cross the host link).
 //
-// A workgroup owns a 16 x 16-pixel tile of the field and scans the chunk's objects in segments of 256 (one per thread):
-// the objects whose window meets the tile are compacted IN ORDER into an LDS list (wave ballots + prefix counts), then
-// every thread walks the list for its pixel.  Uniformly scattered cutouts leave ~0.3 entries per segment and tile; a
-// pile of objects on one spot just makes the lists long - no capacity limit, no atomics, no float non-determinism.
-constexpr int CT = 16;   // tile edge
+// A workgroup owns a 32 x 32-pixel tile of the field (four pixels per thread) and scans the chunk's objects in rounds of 2048 (eight per thread,
+// their placements by four 16-byte loads): the objects whose window meets the tile are compacted IN ORDER into an LDS
+// list (a prefix sum of the hit counts over the 256 threads), then every thread walks the list for its pixel.  Uniformly
+// scattered cutouts leave ~4 entries per round and tile; a pile of objects on one spot just makes the lists long (a
+// round's list holds all 2048) - no capacity limit, no atomics, no float non-determinism.
+constexpr int CT = 32;       // tile edge: a thread owns the four pixels (ty + 16 a, tx + 16 b) of its 32 x 32 tile
+constexpr int CSEG = 2048;   // objects per scan round (8 per thread)
 template <int NBMAX>
 __global__ __launch_bounds__(256) void scene_composite_chunk_kernel(double* __restrict__ mean_f, double* __restrict__ std_f,
                                                                     double* __restrict__ res_f, int F, int nb,
                                                                     const float* __restrict__ loc,
                                                                     const float* __restrict__ scale,
                                                                     const int* __restrict__ places, int n, int cs) {
-  __shared__ int s_list[256];
-  __shared__ int s_wcount[4];
+  __shared__ int s_list[CSEG];        // objects of the round that meet the tile, in object order
+  __shared__ int s_lr[CSEG], s_lc[CSEG];   // their placements
+  __shared__ int s_wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntx = (F + CT - 1) / CT;
   const int tr0 = (blockIdx.x / ntx) * CT, tc0 = (blockIdx.x % ntx) * CT;
-  const int r = tr0 + (tid >> 4), c = tc0 + (tid & 15);
-  const bool inside = r < F && c < F;
-  double am[NBMAX], as[NBMAX], ar[NBMAX];
+  const int ty = tid >> 4, tx = tid & 15;
+  double am[4][NBMAX], as[4][NBMAX], ar[4][NBMAX];
 #pragma unroll
-  for (int b = 0; b < NBMAX; ++b) am[b] = as[b] = ar[b] = 0.0;
-  const long e0 = ((long)r * F + c) * nb;
-  if (inside) {
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int b = 0; b < NBMAX; ++b)
-      if (b < nb) {
-        am[b] = mean_f[e0 + b];
-        as[b] = std_f[e0 + b];
-        if (res_f) ar[b] = res_f[e0 + b];
+    for (int b = 0; b < NBMAX; ++b) am[q][b] = as[q][b] = ar[q][b] = 0.0;
+  bool loaded = false;
+  unsigned touched = 0;
+  for (int seg = 0; seg < n; seg += CSEG) {
+    // thread t tests objects seg + 8 t .. + 7 (four 16-byte loads of their placements): order by (thread, bit) = object order
+    const int o0 = seg + tid * 8;
+    unsigned hits = 0;
+    int pr[8], pc[8];
+    if (o0 + 8 <= n && (reinterpret_cast<size_t>(places + 2 * o0) & 15) == 0) {
+      const int4* q = reinterpret_cast<const int4*>(places + 2 * o0);
+      const int4 a = q[0], b = q[1], d = q[2], e = q[3];
+      pr[0] = a.x; pc[0] = a.y; pr[1] = a.z; pc[1] = a.w; pr[2] = b.x; pc[2] = b.y; pr[3] = b.z; pc[3] = b.w;
+      pr[4] = d.x; pc[4] = d.y; pr[5] = d.z; pc[5] = d.w; pr[6] = e.x; pc[6] = e.y; pr[7] = e.z; pc[7] = e.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool v = o0 + k < n;
+        pr[k] = v ? places[2 * (o0 + k)] : (1 << 29);
+        pc[k] = v ? places[2 * (o0 + k) + 1] : (1 << 29);
       }
-  }
-  bool touched = false;
-  for (int seg = 0; seg < n; seg += 256) {
-    const int o = seg + tid;
-    bool hit = false;
-    if (o < n) {
-      const int pr = places[2 * o], pc = places[2 * o + 1];
-      hit = pr < tr0 + CT && pr + cs > tr0 && pc < tc0 + CT && pc + cs > tc0;
     }
-    const unsigned long long bal = __ballot(hit);
-    if (lane == 0) s_wcount[wave] = __popcll(bal);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (pr[k] < tr0 + CT && pr[k] + cs > tr0 && pc[k] < tc0 + CT && pc[k] + cs > tc0) hits |= 1u << k;
+    // exclusive prefix of the hit counts over the 256 threads: wave scan, then the wave totals through LDS
+    const int cnt = __popc(hits);
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
     int base = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-      if (w < wave) base += s_wcount[w];
-    const int total = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
-    if (hit) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = o;
-    __syncthreads();
-    if (inside) {
-      for (int k = 0; k < total; ++k) {
-        const int ob = s_list[k];
-        const int rr = r - places[2 * ob], cc = c - places[2 * ob + 1];
-        if ((unsigned)rr < (unsigned)cs && (unsigned)cc < (unsigned)cs) {
-          const long so = (((long)ob * cs + rr) * cs + cc) * nb;
-          touched = true;
+      if (w < wave) base += s_wsum[w];
+    const int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    int pos = base + incl - cnt;
 #pragma unroll
-          for (int b = 0; b < NBMAX; ++b)
-            if (b < nb) {
-              const double v = (double)loc[so + b];
-              am[b] += v;
-              ar[b] -= v;
-              as[b] += (double)scale[so + b];
-            }
+    for (int k = 0; k < 8; ++k)
+      if (hits & (1u << k)) {
+        s_list[pos] = o0 + k;
+        s_lr[pos] = pr[k];
+        s_lc[pos] = pc[k];
+        ++pos;
+      }
+    __syncthreads();
+    if (total > 0) {
+      if (!loaded) {
+        loaded = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = tr0 + ty + 16 * (q >> 1), c = tc0 + tx + 16 * (q & 1);
+          if (r < F && c < F) {
+            const long e0 = ((long)r * F + c) * nb;
+#pragma unroll
+            for (int b = 0; b < NBMAX; ++b)
+              if (b < nb) {
+                am[q][b] = mean_f[e0 + b];
+                as[q][b] = std_f[e0 + b];
+                if (res_f) ar[q][b] = res_f[e0 + b];
+              }
+          }
+        }
+      }
+      for (int k = 0; k < total; ++k) {
+        const int lr = s_lr[k], lc = s_lc[k];
+        const long sb = (long)s_list[k] * cs;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rr = tr0 + ty + 16 * (q >> 1) - lr, cc = tc0 + tx + 16 * (q & 1) - lc;
+          if ((unsigned)rr < (unsigned)cs && (unsigned)cc < (unsigned)cs) {
+            const long so = ((sb + rr) * cs + cc) * nb;
+            touched |= 1u << q;
+#pragma unroll
+            for (int b = 0; b < NBMAX; ++b)
+              if (b < nb) {
+                const double v = (double)loc[so + b];
+                am[q][b] += v;
+                ar[q][b] -= v;
+                as[q][b] += (double)scale[so + b];
+              }
+          }
         }
       }
     }
-    __syncthreads();                       // the list is rewritten by the next segment
+    __syncthreads();                       // the list is rewritten by the next round
   }
-  if (inside && touched) {
 #pragma unroll
-    for (int b = 0; b < NBMAX; ++b)
-      if (b < nb) {
-        mean_f[e0 + b] = am[b];
-        std_f[e0 + b] = as[b];
-        if (res_f) res_f[e0 + b] = ar[b];
+  for (int q = 0; q < 4; ++q) {
+    const int r = tr0 + ty + 16 * (q >> 1), c = tc0 + tx + 16 * (q & 1);
+    if ((touched >> q) & 1u) {             // (touched implies the pixel lies inside the field: windows are tested against it)
+      if (r < F && c < F) {
+        const long e0 = ((long)r * F + c) * nb;
+#pragma unroll
+        for (int b = 0; b < NBMAX; ++b)
+          if (b < nb) {
+            mean_f[e0 + b] = am[q][b];
+            std_f[e0 + b] = as[q][b];
+            if (res_f) res_f[e0 + b] = ar[q][b];
+          }
       }
+    }
   }
 }
 
@@ -409,8 +461,12 @@ int launch_scene_composite_chunk(double* mean_f, double* std_f, double* res_f, i
     return E_INVALID;
   }
   const int ntx = (F + CT - 1) / CT;
-  hipLaunchKernelGGL(scene_composite_chunk_kernel<8>, dim3((unsigned)(ntx * ntx)), dim3(256), 0, s, mean_f, std_f, res_f, F, nb,
-                     loc, scale, places_dev, n, cs);
+  if (nb <= 6)
+    hipLaunchKernelGGL(scene_composite_chunk_kernel<6>, dim3((unsigned)(ntx * ntx)), dim3(256), 0, s, mean_f, std_f, res_f, F,
+                       nb, loc, scale, places_dev, n, cs);
+  else
+    hipLaunchKernelGGL(scene_composite_chunk_kernel<8>, dim3((unsigned)(ntx * ntx)), dim3(256), 0, s, mean_f, std_f, res_f, F,
+                       nb, loc, scale, places_dev, n, cs);
   DV_HIP(hipGetLastError());
   return OK;
 }

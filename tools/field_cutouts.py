@@ -40,7 +40,7 @@ def synthetic_field(size=259, nb=6, seed=0):
 
 
 def run(ctx=None, n_cutouts=1_000_000, chunk=8192, dtype=0, field=None, tiles=8, rank=0, world=1, seed=0, fused=False,
-        calls=None, stream=False):
+        calls=None, stream=False, on_device=False):
     from debvader_amd import engine as E
     from debvader_amd.parallel import shard_range
 
@@ -54,6 +54,8 @@ def run(ctx=None, n_cutouts=1_000_000, chunk=8192, dtype=0, field=None, tiles=8,
     lo, hi = shard_range(n_cutouts, rank, world)
     eng = E.Engine(E.make_config(max_batch=chunk, dtype=dtype), ctx)
     eng.init(seed=0)
+    if on_device:
+        return _run_on_device(ctx, eng, scene, starts, lo, hi, chunk, dtype, F, cs)
     if stream:
         return _run_stream(ctx, eng, scene, starts, lo, hi, chunk, dtype, F, cs)
     per_call = chunk * (calls or (4 if fused else 1))       # stamps per engine call (fused: the field is uploaded per call)
@@ -114,6 +116,44 @@ def run(ctx=None, n_cutouts=1_000_000, chunk=8192, dtype=0, field=None, tiles=8,
     }
 
 
+def _run_on_device(ctx, eng, scene, starts, lo, hi, chunk, dtype, F, cs):
+    """DeblendField.deblend_field(on_device=True) + get_predicted_field / get_residual_field: cutout gather, network and the
+    compositing of every stamp's mean and stddev into the field-sized results in ONE engine call (dv_infer_cutouts_composite);
+    only three F x F x 6 float64 fields and one float64 per stamp come back."""
+    places = starts.astype(np.int64)               # a stamp is put back where it was cut (integer positions)
+    eng.infer_cutouts_composite(scene, starts[lo:lo + min(2 * chunk, hi - lo)], places[lo:lo + min(2 * chunk, hi - lo)], seed=1)
+    t0 = time.perf_counter()
+    out = eng.infer_cutouts_composite(scene, starts[lo:hi], places[lo:hi], seed=2)
+    total = time.perf_counter() - t0
+    n = hi - lo
+    # the same forward with the stamps resident in HBM (no gather, no compositing, no copies)
+    nres = min(chunk, n)
+    x32 = ctx.scene_extract(scene, starts[lo:lo + nres], cs).astype(np.float32)
+    eng.upload(1, x32, x32)
+    eng.eval_step(1, first=0, B=nres, seed=3)
+    ctx.sync()
+    reps = 5
+    t1 = time.perf_counter()
+    for r in range(reps):
+        eng.eval_step(1, first=0, B=nres, seed=4 + r)
+    ctx.sync()
+    t_res = (time.perf_counter() - t1) / reps
+    eng.close()
+    return {
+        "workload": f"BASELINE configs[4] per GPU: DeblendField.deblend_field(on_device=True) + get_predicted_field + "
+                    f"get_residual_field over {n} cutouts (59x59x6) of a {F}x{F}x6 scene, {chunk} per network call, "
+                    f"{'bf16' if dtype else 'fp32'} engine",
+        "value": n / total, "unit": "stamps/s", "dtype": "bf16" if dtype else "f32", "n_cutouts": n, "chunk": chunk,
+        "includes": "field H2D once, cutout gather + float32 cast on the GPU, forward, mean / stddev / residual fields composited "
+                    "on the GPU in object order (float64), centre MSE per stamp; D2H of three F x F x 6 fields and N doubles",
+        "host_bytes_out": 3 * F * F * 6 * 8 + 8 * n,
+        "resident_forward_stamps_per_s": nres / t_res,
+        "fraction_of_resident_forward": (n / total) / (nres / t_res),
+        "checksum": float(out["mean_field"][::37, ::41, 2].sum()),
+        "mean_of_mse_center": float(out["mse_center"].mean()),
+    }
+
+
 def _run_stream(ctx, eng, scene, starts, lo, hi, chunk, dtype, F, cs):
     """deblend_field_cutouts(on_chunk=...): one engine call for the whole range, results consumed chunk by chunk from the
     pinned transfer ring (here: a checksum over every chunk and running sums of mean and stddev of the centre pixel)."""
@@ -159,13 +199,14 @@ def main():
     ap.add_argument("--tiles", type=int, default=8)
     ap.add_argument("--fused", action="store_true", help="deblend_field_cutouts: gather on the GPU, no host round trip")
     ap.add_argument("--stream", action="store_true", help="deblend_field_cutouts(on_chunk=...): results consumed per chunk")
+    ap.add_argument("--on-device", action="store_true", help="compositing on the GPU behind the forward passes: only fields come back")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     from debvader_amd import engine as E
 
     ctx = E.Context(int(os.environ.get("LOCAL_RANK", "0")), 0, 1, None)      # no collective: every rank is on its own
     field = np.load(a.field) if a.field else None
-    res = run(ctx, a.n, a.chunk, a.dtype, field, a.tiles, rank, world, fused=a.fused, stream=a.stream)
+    res = run(ctx, a.n, a.chunk, a.dtype, field, a.tiles, rank, world, fused=a.fused, stream=a.stream, on_device=a.on_device)
     res["rank"], res["world"] = rank, world
     print(json.dumps(res), flush=True)
 
