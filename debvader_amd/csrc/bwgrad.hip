@@ -8,15 +8,21 @@
 // which ds_read_b64_tr_b16 delivers from the row-major LDS image (4 stamps x 16 channels per 16-lane group).
 //
 // Every WAVE is a pipeline of its own (no workgroup barrier in the loop): it owns a 32 x 32 channel tile for all nine
-// taps (9 x 16 accumulator registers, v_mfma_f32_32x32x16_bf16), 16 stamps, and a range of Y rows.  It walks a row
-// pixel by pixel with a SLIDING WINDOW of X blocks in its private LDS (3 rows x 8 column slots of 1 KiB): a step
-// brings in only the s new columns (3*s blocks) and the next Y block by LDS-DMA, issued one step ahead of their use
-// (four pixels ahead at stride 1, two at stride 2; counted vmcnt), and multiplies the Y block with the nine X blocks
-// of the window - 4 KiB of DMA per 18 kFLOP x 16 instead of 10 KiB.  Taps outside the image are skipped (uniform per pixel).  The four waves of a workgroup are four
-// consecutive 16-stamp chunks; they sum their tiles through LDS in a fixed order and write one fp32 slab
-// [9][Cx][Cy] per workgroup, which reduce_partials adds up (deterministic).
+// taps (9 x 16 accumulator registers, v_mfma_f32_32x32x16_bf16), 16 stamps, and a range of Y rows.  It walks the pixels
+// of its rows as ONE stream with a SLIDING WINDOW of X blocks in its private LDS (3 rows x a ring of 10 column slots of
+// 1 KiB): a step brings in only the s new columns (3*s blocks; three columns at a row start) and the next Y block by
+// LDS-DMA, issued four to six pixels ahead of their use (counted vmcnt), and multiplies the Y block with the nine X
+// blocks of the window - 4 KiB of DMA per 18 kFLOP x 16 instead of 10 KiB.  Blocks outside the image come from the zero
+// page (scalar address arithmetic), so the loop has no branch; the operands of pixel t + 1 are read from LDS into a
+// second register set between the MFMAs of pixel t.  The four waves of a workgroup are four consecutive 16-stamp
+// chunks; each parks its tile in its own LDS region, the workgroup sums them in wave order and writes one fp32 slab
+// [9][Cx][Cy], which reduce_partials adds up (deterministic).
 // Operands with 16 channels (the first conv's padded input, the head's gradient) fill half of the 32-wide tile; the
-// lanes of the other half read a zeroed LDS region.
+// lanes of the other half are zeroed by a select.
+//
+// Round-4 measurements behind this form: with one wave per SIMD the loop is bound by the LDS-DMA path
+// (about 16 B/clk/CU with four waves in flight: a launch without its DMA takes 60 % of the time, without its MFMAs or
+// without its LDS reads 95 %), and 9 us of every launch are fixed (launch, accumulator reduction, slab).
 #include "common.h"
 #include "bf16.h"
 #include <algorithm>
@@ -33,15 +39,17 @@ typedef float bw_f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) bw_bf16x4* bw_l4ptr_t;
 
 namespace {
-constexpr int BW_NCS = 8;                              // column slots of the X window
+constexpr int BW_NCS = 10;                             // column slots of the X window (a ring, allocated column by column)
 constexpr int BW_NYS = 8;                              // Y slots
 constexpr int BW_WAVE_LDS = (3 * BW_NCS + BW_NYS) * 1024;
 constexpr int BW_RED_BYTES = 9 * 16 * 64 * 4;          // one wave's accumulators
+static_assert(BW_RED_BYTES <= BW_WAVE_LDS, "a wave parks its accumulators in its own window region");
 
 struct BWGeom {
   int ntx, nty;        // 32-channel tiles
   int nrseg, rows_per; // Y row segments
   int nsc4;            // groups of four 16-stamp chunks
+  int D;               // prefetch distance in pixels (launcher: the window ring must hold pixels t+1 .. t+D)
 };
 
 // Transposed LDS reads go through inline asm: for the builtin (an LDS read with no alias information) hipcc waits
@@ -60,9 +68,26 @@ __device__ __forceinline__ bw_bf16x8 tr_join(bw_u32x2 lo, bw_u32x2 hi) {
   const u32x4 q = {lo[0], lo[1], hi[0], hi[1]};
   return __builtin_bit_cast(bw_bf16x8, q);
 }
+// One pixel's operands: the Y block and the nine X blocks of the window, as the transposed reads deliver them.
+struct BWOps {
+  bw_u32x2 b0, b1, a0[9], a1[9];
+};
+// "The reads of this set have landed": the wait carries the registers as in/out operands, so that nothing that uses
+// them (not even a register copy) can be scheduled in front of it.
+__device__ __forceinline__ void tr_wait(BWOps& o) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(o.b0), "+v"(o.b1), "+v"(o.a0[0]), "+v"(o.a1[0]), "+v"(o.a0[1]), "+v"(o.a1[1]), "+v"(o.a0[2]),
+                 "+v"(o.a1[2]), "+v"(o.a0[3]), "+v"(o.a1[3]));
+  asm volatile("" : "+v"(o.a0[4]), "+v"(o.a1[4]), "+v"(o.a0[5]), "+v"(o.a1[5]), "+v"(o.a0[6]), "+v"(o.a1[6]),
+               "+v"(o.a0[7]), "+v"(o.a1[7]), "+v"(o.a0[8]), "+v"(o.a1[8]));
+}
+__device__ __forceinline__ int bw_wrap(int x) { return x >= BW_NCS ? x - BW_NCS : x; }
 }  // namespace
 
-template <bool XC16, bool YC16>
+// S = stride.  WAIT = DMA instructions of the D - 2 youngest issued pixels, (D - 2) * (3 * S + 1): the immediate of the
+// counted vmcnt at the top of a step (pixels up to t + D - 1 are in flight there, pixel t + 1 is needed).  A pixel that
+// starts a row issues more (three columns instead of S), which only makes the wait conservative.
+template <bool XC16, bool YC16, int S, int WAIT>
 __global__ __launch_bounds__(256, 1) void bwgrad_kernel(const BWgradParams p, const BWGeom gm) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -89,33 +114,23 @@ __global__ __launch_bounds__(256, 1) void bwgrad_kernel(const BWgradParams p, co
 
   const bw_bf16* Xb = reinterpret_cast<const bw_bf16*>(p.X);
   const bw_bf16* Yb = reinterpret_cast<const bw_bf16*>(p.Y);
-  const unsigned char* zlane = reinterpret_cast<const unsigned char*>(p.zero) + lane * 16;
 
   // DMA of one pixel block (16 stamps): 32-channel tile of a C-channel tensor, or a whole 16-channel tensor row set.
-  // The per-lane part of the source address is computed once; a block adds a scalar pixel offset.
-  const unsigned char* xlane = XC16 ? (lane < 32 ? reinterpret_cast<const unsigned char*>(Xb + ((size_t)st0 + (lane >> 1)) * 16 + (lane & 1) * 8) : zlane)
-                                    : reinterpret_cast<const unsigned char*>(Xb + ((size_t)st0 + (lane >> 2)) * p.Cx + cx0 + (lane & 3) * 8);
-  const unsigned char* ylane = YC16 ? (lane < 32 ? reinterpret_cast<const unsigned char*>(Yb + ((size_t)st0 + (lane >> 1)) * 16 + (lane & 1) * 8) : zlane)
-                                    : reinterpret_cast<const unsigned char*>(Yb + ((size_t)st0 + (lane >> 2)) * p.Cy + cy0 + (lane & 3) * 8);
-  const size_t xps = (size_t)p.NBp * p.Cx * 2, yps = (size_t)p.NBp * p.Cy * 2;   // bytes per pixel
-  const size_t xps_l = (XC16 && lane >= 32) ? 0 : xps, yps_l = (YC16 && lane >= 32) ? 0 : yps;
-  // A block that lies outside the image (or past the end of the row) is never multiplied - its taps are skipped - so
-  // its DMA needs no zero page and no select: the indices are clamped to some valid pixel and whatever lands is ignored.
-  auto dma = [&](bool isx, int pix, unsigned char* dst) {
-    const void* src = isx ? (const void*)(xlane + (size_t)pix * xps_l) : (const void*)(ylane + (size_t)pix * yps_l);
-    __builtin_amdgcn_global_load_lds((bw_gptr_t)src, (bw_lptr_t)dst, 16, 0, 0);
-  };
-  // column xc of the three window rows of Y row r (image rows r*s - pb + {0,1,2})
-  auto load_col = [&](int r, int xc) {
-    const int xcc = min(max(xc, 0), p.Hx - 1);
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int xr = min(max(r * p.s - p.pb + kh, 0), p.Hx - 1);
-      dma(true, xr * p.Hx + xcc, xwin + (kh * BW_NCS + (xc & (BW_NCS - 1))) * 1024);
-    }
-  };
-  auto load_y = [&](int r, int w) {
-    dma(false, r * p.Hy + min(w, p.Hy - 1), ywin + (w & (BW_NYS - 1)) * 1024);
+  // Source address = a SCALAR base (tensor + stamp chunk + channel tile + pixel, or the zero page for a block outside
+  // the image) + a per-lane offset computed once: the choice between the two is scalar arithmetic, no branch and no
+  // per-lane select.  The zero page is at least one pixel's [NBp][C] block long, i.e. longer than any lane offset.
+  // 16-channel tensors: a block is 512 B, lanes 32..63 fetch the same rows again into the unused half of the slot.
+  typedef unsigned long long bw_u64;
+  const bw_u64 zu = (bw_u64)p.zero;
+  const bw_u64 xu = (bw_u64)(Xb + (size_t)st0 * (XC16 ? 16 : p.Cx) + (XC16 ? 0 : cx0));
+  const bw_u64 yu = (bw_u64)(Yb + (size_t)st0 * (YC16 ? 16 : p.Cy) + (YC16 ? 0 : cy0));
+  const unsigned xoff_l = XC16 ? ((lane & 31) >> 1) * 32 + (lane & 1) * 16 : (lane >> 2) * p.Cx * 2 + (lane & 3) * 16;
+  const unsigned yoff_l = YC16 ? ((lane & 31) >> 1) * 32 + (lane & 1) * 16 : (lane >> 2) * p.Cy * 2 + (lane & 3) * 16;
+  const bw_u64 xps = (bw_u64)p.NBp * p.Cx * 2, yps = (bw_u64)p.NBp * p.Cy * 2;   // bytes per pixel
+  auto dma = [&](bw_u64 base, bw_u64 pixoff, bool ok, unsigned off_l, unsigned char* dst) {
+    const bw_u64 m = (bw_u64)0 - (bw_u64)ok;
+    const bw_u64 ub = zu + (m & (base - zu + pixoff));
+    __builtin_amdgcn_global_load_lds((bw_gptr_t)(ub + off_l), (bw_lptr_t)dst, 16, 0, 0);
   };
 
   // transposed-read lane roles for a [16 stamps][32 ch] block: 16-lane group g = (channel half g & 1, stamp half g >> 1)
@@ -140,101 +155,140 @@ __global__ __launch_bounds__(256, 1) void bwgrad_kernel(const BWgradParams p, co
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   if (active) {
-    // prefetch distance in pixels: the window's 8 column slots hold the 3 live columns and D*s incoming ones
-    const int D = p.s == 1 ? 4 : 2;
-    // loads of pixel w: its new columns (three for pixel 0) and its Y block; past the row's end the same number of
-    // DMA instructions is issued from the zero page (the counted waits below rely on fixed counts)
-    auto load_pixel = [&](int r, int w) {
-      const int nc = w * p.s - p.pb + 2;
-      if (w == 0) {
-        load_col(r, nc - 2);
-        load_col(r, nc - 1);
-      } else if (p.s == 2) {
-        load_col(r, nc - 1);
+    // The Y pixels of the row segment are ONE stream t = 0 .. T-1 (rows back to back): no drain and refill per row.
+    // A pixel's three window columns sit in consecutive slots of the column ring, first slot base(t); base advances by
+    // s inside a row and by 3 at a row start (whose pixel brings three new columns instead of s).  X blocks outside the
+    // image come from the zero page, so every pixel multiplies all nine taps - no branch in the loop - and adding an
+    // exact zero product leaves the sums what skipping the tap left them.
+    const int T = (r1 - r0) * p.Hy;
+    const int D = gm.D;
+    int l_t = 0, l_r = r0, l_w = 0, l_base = 0;         // loader: next pixel, its row / column, its first column slot
+    auto load_col = [&](int j, bool real) {            // column j (0..2) of the loader's pixel: three window rows
+      const int xc = l_w * S - p.pb + j;
+      unsigned char* dst = xwin + bw_wrap(l_base + j) * 1024;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int xr = l_r * S - p.pb + kh;
+        const bool ok = real & ((unsigned)xr < (unsigned)p.Hx) & ((unsigned)xc < (unsigned)p.Hx);
+        dma(xu, (bw_u64)(unsigned)(xr * p.Hx + xc) * xps, ok, xoff_l, dst + kh * BW_NCS * 1024);
       }
-      load_col(r, nc);
-      load_y(r, w);
     };
-    for (int r = r0; r < r1; ++r) {
-      for (int w = 0; w < D; ++w) load_pixel(r, w);
-      for (int w = 0; w < p.Hy; ++w) {
-        load_pixel(r, w + D);
-        // everything but the D youngest pixels' loads (3*s + 1 each) has landed
-        if (p.s == 2)
-          asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        // all twenty transposed reads of the step are issued back to back (taps outside the image read blocks that no
-        // MFMA consumes), then one wait.  One vector add per window column; rows and second reads are immediates.
-        const unsigned ya = yl_addr + (w & (BW_NYS - 1)) * 1024;
-        bw_u32x2 b0 = tr_read<0>(ya), b1 = tr_read<YSECOND>(ya);
-        const int xc0 = w * p.s - p.pb;
-        bw_u32x2 a0[9], a1[9];
+    auto load_pixel = [&]() {
+      const bool real = l_t < T;                        // past the end: the same instructions from the zero page
+      if (l_w == 0) {                                   // (the counted waits rely on their number)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const unsigned xa = xl_addr + ((xc0 + kw) & (BW_NCS - 1)) * 1024;
-          a0[0 + kw] = tr_read<0>(xa);
-          a1[0 + kw] = tr_read<XSECOND>(xa);
-          a0[3 + kw] = tr_read<BW_NCS * 1024>(xa);
-          a1[3 + kw] = tr_read<BW_NCS * 1024 + XSECOND>(xa);
-          a0[6 + kw] = tr_read<2 * BW_NCS * 1024>(xa);
-          a1[6 + kw] = tr_read<2 * BW_NCS * 1024 + XSECOND>(xa);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // 16-channel operands: the lanes of the absent channel half read the present half's rows (the transposed read
-        // wants every lane active with an address of its own) and are zeroed here, by a select, not a branch
-        if (YC16) {
-          b0 = yzero ? (bw_u32x2){0u, 0u} : b0;
-          b1 = yzero ? (bw_u32x2){0u, 0u} : b1;
-        }
-        if (XC16) {
-#pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            a0[t] = xzero ? (bw_u32x2){0u, 0u} : a0[t];
-            a1[t] = xzero ? (bw_u32x2){0u, 0u} : a1[t];
-          }
-        }
-        const bw_bf16x8 b = tr_join(b0, b1);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int xr = r * p.s - p.pb + kh;
-          if (xr < 0 || xr >= p.Hx) continue;
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int xc = xc0 + kw;
-            if (xc < 0 || xc >= p.Hx) continue;
-            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(a0[kh * 3 + kw], a1[kh * 3 + kw]), b,
-                                                                       acc[kh * 3 + kw], 0, 0, 0);
-          }
-        }
+        for (int j = 0; j < 3 - S; ++j) load_col(j, real);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing zero-page loads, before the next row reuses the slots
+#pragma unroll
+      for (int j = 3 - S; j < 3; ++j) load_col(j, real);
+      dma(yu, (bw_u64)(unsigned)(l_r * p.Hy + l_w) * yps, real, yoff_l, ywin + (l_t & (BW_NYS - 1)) * 1024);
+      ++l_t;
+      if (++l_w == p.Hy) {
+        l_w = 0;
+        ++l_r;
+        l_base = bw_wrap(l_base + 3);
+      } else {
+        l_base = bw_wrap(l_base + S);
+      }
+    };
+    int c_t = 0, c_w = 0, c_base = 0;                   // reader: next pixel to fetch from LDS
+    // One step: fetch pixel t + 1's operands from LDS into the other register set WHILE the nine MFMAs of pixel t run
+    // (one wave per SIMD: nobody else would hide the reads) - a pair of transposed reads behind every MFMA, pinned there
+    // by scheduling barriers - and bring pixel t + D in from memory in the shadow of the third MFMA.
+    auto step = [&](BWOps& cur, BWOps& nxt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");   // pixel t + 1 has landed (pixels .. t+D-1 are issued)
+      const unsigned ya = yl_addr + (c_t & (BW_NYS - 1)) * 1024;
+      unsigned xa[3];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) xa[kw] = xl_addr + bw_wrap(c_base + kw) * 1024;
+      __builtin_amdgcn_sched_barrier(0);
+      nxt.b0 = tr_read<0>(ya);
+      nxt.b1 = tr_read<YSECOND>(ya);
+      // 16-channel operands: the lanes of the absent channel half read the present half's rows (the transposed read
+      // wants every lane active with an address of its own) and are zeroed here, by a select, not a branch
+      if (YC16) {
+        cur.b0 = yzero ? (bw_u32x2){0u, 0u} : cur.b0;
+        cur.b1 = yzero ? (bw_u32x2){0u, 0u} : cur.b1;
+      }
+      const bw_bf16x8 b = tr_join(cur.b0, cur.b1);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (XC16) {
+          cur.a0[t] = xzero ? (bw_u32x2){0u, 0u} : cur.a0[t];
+          cur.a1[t] = xzero ? (bw_u32x2){0u, 0u} : cur.a1[t];
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(cur.a0[t], cur.a1[t]), b, acc[t], 0, 0, 0);
+        const int kh = t / 3, kw = t % 3;
+        if (kh == 0) {
+          nxt.a0[t] = tr_read<0>(xa[kw]);
+          nxt.a1[t] = tr_read<XSECOND>(xa[kw]);
+        } else if (kh == 1) {
+          nxt.a0[t] = tr_read<BW_NCS * 1024>(xa[kw]);
+          nxt.a1[t] = tr_read<BW_NCS * 1024 + XSECOND>(xa[kw]);
+        } else {
+          nxt.a0[t] = tr_read<2 * BW_NCS * 1024>(xa[kw]);
+          nxt.a1[t] = tr_read<2 * BW_NCS * 1024 + XSECOND>(xa[kw]);
+        }
+        if (t == 2) load_pixel();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ++c_t;
+      if (++c_w == p.Hy) {
+        c_w = 0;
+        c_base = bw_wrap(c_base + 3);
+      } else {
+        c_base = bw_wrap(c_base + S);
+      }
+      tr_wait(nxt);
+    };
+    BWOps A, B;
+    for (int w = 0; w < D; ++w) load_pixel();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
+    {                                                  // operands of pixel 0
+      const unsigned ya = yl_addr;
+      A.b0 = tr_read<0>(ya);
+      A.b1 = tr_read<YSECOND>(ya);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const unsigned xa = xl_addr + kw * 1024;
+        A.a0[0 + kw] = tr_read<0>(xa);
+        A.a1[0 + kw] = tr_read<XSECOND>(xa);
+        A.a0[3 + kw] = tr_read<BW_NCS * 1024>(xa);
+        A.a1[3 + kw] = tr_read<BW_NCS * 1024 + XSECOND>(xa);
+        A.a0[6 + kw] = tr_read<2 * BW_NCS * 1024>(xa);
+        A.a1[6 + kw] = tr_read<2 * BW_NCS * 1024 + XSECOND>(xa);
+      }
+      c_t = 1;
+      c_w = p.Hy == 1 ? 0 : 1;
+      c_base = p.Hy == 1 ? 3 : S;
+      tr_wait(A);
     }
+    for (int t = 0; t < T; t += 2) {
+      step(A, B);
+      if (t + 1 < T) step(B, A);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing zero-page loads, before the region is reused below
   }
 
-  // ---- sum the four waves' tiles through LDS in wave order, then one slab per workgroup ----
-  float* red = reinterpret_cast<float*>(smem);         // reuses wave 0's window (all DMA has been waited for)
-  for (int wv = 0; wv < 4; ++wv) {
-    __syncthreads();
-    if (wave == wv) {
+  // ---- every wave parks its tile in its own window region; sums in wave order, one slab per workgroup ----
+  {
+    float* mine = reinterpret_cast<float*>(wl);
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float* q = red + (t * 16 + i) * 64 + lane;
-          *q = wv == 0 ? acc[t][i] : *q + acc[t][i];
-        }
-    }
+      for (int i = 0; i < 16; ++i) mine[(t * 16 + i) * 64 + lane] = acc[t][i];
   }
   __syncthreads();
   float* slab = p.part + (size_t)(sc4 * gm.nrseg + rseg) * 9 * p.Cx * p.Cy;
+  const float* red0 = reinterpret_cast<const float*>(smem);
+  constexpr int WSTRIDE = BW_WAVE_LDS / 4;
   for (int e = tid; e < 9 * 16 * 64; e += 256) {
     const int ln = e & 63, ti = e >> 6;
     const int i = ti & 15, t = ti >> 4;
     const int cx = cx0 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);
     const int cy = cy0 + (ln & 31);
-    if (cx < p.Cx && cy < p.Cy) slab[((size_t)t * p.Cx + cx) * p.Cy + cy] = red[e];
+    const float v = ((red0[e] + red0[WSTRIDE + e]) + red0[2 * WSTRIDE + e]) + red0[3 * WSTRIDE + e];
+    if (cx < p.Cx && cy < p.Cy) slab[((size_t)t * p.Cx + cx) * p.Cy + cy] = v;
   }
 }
 
@@ -270,22 +324,33 @@ int launch_bwgrad(const BWgradParams& p, hipStream_t s, int* nsplit_out) {
   if (nsplit_out) *nsplit_out = gm.nrseg * gm.nsc4;
   const unsigned grid = (unsigned)((long)gm.nsc4 * gm.nrseg * gm.ntx * gm.nty);
   const size_t lds = (size_t)4 * BW_WAVE_LDS;
-  static_assert(BW_RED_BYTES <= 4 * BW_WAVE_LDS, "reduction scratch must fit the windows");
-#define BW_LAUNCH(XC, YC)                                                                                       \
+  // prefetch distance D: pixel t + D is issued during step t, so the column ring holds the windows of pixels t+1 .. t+D:
+  // (D-1)*s + (3-s)*ceil((D-1)/Hy) + 3 <= BW_NCS (a row start inside the span brings 3 columns instead of s)
+  gm.D = p.s == 2 ? (p.Hy >= 3 ? 4 : 3) : (p.Hy >= 5 ? 6 : p.Hy == 4 ? 5 : 3);
+#define BW_LAUNCH_W(XC, YC, S_, W)                                                                              \
   do {                                                                                                          \
     static bool attr = false;                                                                                   \
     if (!attr) {                                                                                                \
-      DV_HIP(hipFuncSetAttribute((const void*)bwgrad_kernel<XC, YC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                 (int)lds));                                                                    \
+      DV_HIP(hipFuncSetAttribute((const void*)bwgrad_kernel<XC, YC, S_, W>,                                     \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
       attr = true;                                                                                              \
     }                                                                                                           \
-    hipLaunchKernelGGL((bwgrad_kernel<XC, YC>), dim3(grid), dim3(256), lds, s, p, gm);                          \
+    hipLaunchKernelGGL((bwgrad_kernel<XC, YC, S_, W>), dim3(grid), dim3(256), lds, s, p, gm);                   \
+  } while (0)
+#define BW_LAUNCH(XC, YC)                                                                                       \
+  do {                                                                                                          \
+    if (p.s == 2 && gm.D == 4) BW_LAUNCH_W(XC, YC, 2, 14);                                                      \
+    else if (p.s == 2) BW_LAUNCH_W(XC, YC, 2, 7);                                                               \
+    else if (gm.D == 6) BW_LAUNCH_W(XC, YC, 1, 16);                                                             \
+    else if (gm.D == 5) BW_LAUNCH_W(XC, YC, 1, 12);                                                             \
+    else BW_LAUNCH_W(XC, YC, 1, 4);                                                                             \
   } while (0)
   if (xc16 && yc16) BW_LAUNCH(true, true);
   else if (xc16) BW_LAUNCH(true, false);
   else if (yc16) BW_LAUNCH(false, true);
   else BW_LAUNCH(false, false);
 #undef BW_LAUNCH
+#undef BW_LAUNCH_W
   DV_HIP(hipGetLastError());
   return OK;
 }

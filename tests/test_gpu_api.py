@@ -487,7 +487,8 @@ def test_tiny_inference_calls_slice_k_and_match_the_same_stamps_in_a_large_call(
     eng.close()
 
 
-def test_on_device_compositing_is_bit_identical_to_the_host_composited_path():
+@pytest.mark.parametrize("dtype", ["float32", "bf16"])
+def test_on_device_compositing_is_bit_identical_to_the_host_composited_path(dtype):
     """DeblendField.deblend_field(on_device=True): cutout gather, network and the compositing of get_predicted_field /
     get_residual_field (field_deblender.py:99-189, :46-97) in ONE engine call with every stamp staying in HBM
     (dv_infer_cutouts_composite) against the default path - stamps to the host, then dv_scene_composite on them.  Same
@@ -500,7 +501,7 @@ def test_on_device_compositing_is_bit_identical_to_the_host_composited_path():
     from debvader_amd.model import model
     from debvader_amd.training.metrics import mse
 
-    net, _, _, _ = model.create_model_vae(**ARCH, max_batch=64, seed=3)
+    net, _, _, _ = model.create_model_vae(**ARCH, max_batch=64, seed=3, dtype=dtype)
     rng = np.random.default_rng(23)
     for F in (160, 131):
         field = rng.normal(0, 0.4, size=(1, F, F, 6))
