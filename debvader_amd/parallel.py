@@ -422,6 +422,19 @@ def make_context(rank: int, world: int, local_rank: Optional[int] = None, group=
         # so the gradients are NOT summed - the launch line, the rendezvous, the multi-rank event scopes and the step
         # structure run for real, the numbers mean nothing)
         local_rank = 0
+    else:
+        # launchers that pin one GPU per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set per process) leave every rank
+        # with a single visible device, which is then device 0 whatever LOCAL_RANK says
+        try:
+            visible = E.device_count()
+        except Exception:
+            visible = 0
+        if visible == 1:
+            local_rank = 0
+        elif 1 < visible <= local_rank:
+            print(f"[debvader_amd] WARNING: LOCAL_RANK {local_rank} but only {visible} visible GPUs; using device "
+                  f"{local_rank % visible}", file=sys.stderr, flush=True)
+            local_rank %= visible
     if world == 1:
         ctx = E.Context(local_rank, 0, 1, None)
         ctx.group = group
