@@ -280,15 +280,17 @@ __global__ __launch_bounds__(256, 1) void bwgrad_kernel(const BWgradParams p, co
   }
   __syncthreads();
   float* slab = p.part + (size_t)(sc4 * gm.nrseg + rseg) * 9 * p.Cx * p.Cy;
-  const float* red0 = reinterpret_cast<const float*>(smem);
-  constexpr int WSTRIDE = BW_WAVE_LDS / 4;
-  for (int e = tid; e < 9 * 16 * 64; e += 256) {
-    const int ln = e & 63, ti = e >> 6;
+  typedef float bw_f32x4 __attribute__((ext_vector_type(4)));
+  const bw_f32x4* red0 = reinterpret_cast<const bw_f32x4*>(smem);
+  constexpr int WSTRIDE = BW_WAVE_LDS / 16;
+  // four consecutive lanes = four consecutive cy of one (tap, cx): 16-byte LDS reads and slab stores
+  for (int q = tid; q < 9 * 16 * 16; q += 256) {
+    const int l4 = q & 15, ti = q >> 4;
     const int i = ti & 15, t = ti >> 4;
-    const int cx = cx0 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);
-    const int cy = cy0 + (ln & 31);
-    const float v = ((red0[e] + red0[WSTRIDE + e]) + red0[2 * WSTRIDE + e]) + red0[3 * WSTRIDE + e];
-    if (cx < p.Cx && cy < p.Cy) slab[((size_t)t * p.Cx + cx) * p.Cy + cy] = v;
+    const int cx = cx0 + (i & 3) + 8 * (i >> 2) + 4 * (l4 >> 3);
+    const int cy = cy0 + (l4 & 7) * 4;
+    const bw_f32x4 v = ((red0[q] + red0[WSTRIDE + q]) + red0[2 * WSTRIDE + q]) + red0[3 * WSTRIDE + q];
+    if (cx < p.Cx && cy < p.Cy) *reinterpret_cast<bw_f32x4*>(slab + ((size_t)t * p.Cx + cx) * p.Cy + cy) = v;
   }
 }
 
