@@ -489,8 +489,19 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
 // six-stage ring on 256-stamp tiles for the deep layers was measured in round 4 (one workgroup per CU walking 36-72 K
 // steps with five steps in flight) and changed nothing on the 8 x 8 layers (35.9 -> 38.3 us) while the 16 x 16 layers
 // lost 40 % to the single resident workgroup: the tiles are not paced by the latency of their DMA.
+// workgroups per CU the uniform kernel is compiled for (register budget): what its LDS footprint admits
+constexpr int bconv_uni_occupancy(int nblk, int gt, int ch, int ns) {
+  if (ns > 3) return 1;
+  if (ns == 2) {
+    if (gt == 16) return nblk <= 2 ? 4 : 3;
+    if (gt == 8) return ch == 2 ? 3 : 4;
+    return 4;
+  }
+  return gt == 16 ? (ch == 1 ? 2 : 1) : (ch == 1 ? 4 : 2);
+}
+
 template <int NBLK, int CINMODE, int GT, int CH = 1, int NS = 3>
-__global__ __launch_bounds__(256, NS > 3 ? 1 : (GT == 16 ? (CH == 1 ? 2 : 1) : (CH == 1 ? 4 : 2))) void bconv_uni_kernel(const BConvParams p) {
+__global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bconv_uni_kernel(const BConvParams p) {
   constexpr int GW = GT / 4;                              // groups per wave
   constexpr int RW = GW * 16;                             // output rows (stamps) per wave
   constexpr int SUB = (GT + NBLK) * 1024;                 // one chunk of a stage: GT A blocks, NBLK B blocks
@@ -1218,7 +1229,15 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
       return OK;
     }
   }
-  const size_t lds = uni ? (size_t)3 * ch * (gt + nblk) * 1024 + 4096 : (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;
+  // TWO ring stages instead of three (round 4): half of a launch's time is prologue and epilogue (HBM-bound stores on
+  // the 64 x 64 layers; launch, tap table and tile sums on the deep ones), which only ANOTHER resident workgroup can
+  // overlap with a K loop - 36-48 KB per workgroup instead of 54-76 put three to five on a CU instead of two.  Same box,
+  // alternating runs, 256-stamp step: three stages everywhere 2.04 ms; two stages for the 256-stamp tiles of <= 32
+  // columns 1.97; also for the 128- / 64-stamp tiles 1.95 (the default); also for the 256-stamp x 64-column tile
+  // (64 accumulators: three workgroups per CU spill) 1.99.  DV_BCONV_NS2=0|1|2|3 selects these (read per call: tests).
+  const int ns2_mode = getenv("DV_BCONV_NS2") ? atoi(getenv("DV_BCONV_NS2")) : 2;
+  const bool ns2 = uni && ((ns2_mode >= 1 && gt == 16 && nblk <= 2) || (ns2_mode >= 2 && gt < 16) || (ns2_mode >= 3 && gt == 16));
+  const size_t lds = uni ? (size_t)(ns2 ? 2 : 3) * ch * (gt + nblk) * 1024 + 4096 : (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;
 #define BC_LAUNCH_K(KERNEL_)                                                                           \
   do {                                                                                                 \
     static size_t attr_lds = 0;                                                                        \
@@ -1231,14 +1250,21 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
 #define BC_LAUNCH(NB_, MODE_)                                                                          \
   do {                                                                                                 \
     if (!uni) BC_LAUNCH_K((bconv_kernel<NB_, MODE_>));                                                 \
-    else if constexpr (MODE_ == 1) BC_LAUNCH_K((bconv_uni_kernel<NB_, 1, 16, 1>));                     \
-    else if (gt == 16) {                                                                               \
-      BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 16, 1>));                                                  \
+    else if constexpr (MODE_ == 1) {                                                                   \
+      if (ns2) BC_LAUNCH_K((bconv_uni_kernel<NB_, 1, 16, 1, 2>));                                      \
+      else BC_LAUNCH_K((bconv_uni_kernel<NB_, 1, 16, 1>));                                             \
+    } else if (gt == 16) {                                                                             \
+      if (ns2) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 16, 1, 2>));                                      \
+      else BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 16, 1>));                                             \
     } else if (gt == 8) {                                                                              \
-      if (pair) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 8, 2>));                                         \
+      if (pair && ns2) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 8, 2, 2>));                               \
+      else if (pair) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 8, 2>));                                    \
+      else if (ns2) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 8, 1, 2>));                                  \
       else BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 8, 1>));                                              \
     } else if constexpr (NB_ >= 2) {                                                                   \
-      if (pair) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 4, 2>));                                         \
+      if (pair && ns2) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 4, 2, 2>));                               \
+      else if (pair) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 4, 2>));                                    \
+      else if (ns2) BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 4, 1, 2>));                                  \
       else BC_LAUNCH_K((bconv_uni_kernel<NB_, 0, 4, 1>));                                              \
     }                                                                                                  \
   } while (0)

@@ -46,10 +46,14 @@ ARCHS = {
 }
 
 
-@pytest.mark.parametrize("arch_name,B", [("59px", 256), ("59px", 64), ("59px", 48), ("128px", 16)])
-def test_every_conv_layer_alone_against_the_oracle_primitives(arch_name, B):
+@pytest.mark.parametrize("arch_name,B,stages", [("59px", 256, 2), ("59px", 256, 3), ("59px", 64, 2), ("59px", 64, 3),
+                                                 ("59px", 48, 2), ("128px", 16, 2)])
+def test_every_conv_layer_alone_against_the_oracle_primitives(arch_name, B, stages, monkeypatch):
     from debvader_amd import engine as E
     from debvader_amd.data import synthetic_stamps
+
+    # uniform conv tiles with two ring stages (the default since round 4) or three (DV_BCONV_NS2=0, read per launch)
+    monkeypatch.setenv("DV_BCONV_NS2", "2" if stages == 2 else "0")
 
     arch = vo.Arch(**ARCHS[arch_name])
     L2 = 2 * len(arch.filters)
