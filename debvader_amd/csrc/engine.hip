@@ -2529,15 +2529,6 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
       DV_TRY(st);
     }
     if (m->normalise && (loc || sink || comp)) DV_TRY(launch_normalise(p->dloc[b], (long)nb * stamp, true, s));
-    if (comp) {
-      // the consumer that follows in the reference (field_deblender.py:99-189) runs here, on the chunk as it lies in HBM
-      ProfScope ps(m, 2, s);
-      DV_TRY(launch_scene_composite_chunk(comp->mean_f, comp->std_f, comp->res_f, cut->F, cut->nb, p->dloc[b], p->dscale[b],
-                                          comp->places + 2 * o, nb, cut->cs, s));
-      if (comp->mse)
-        DV_TRY(launch_scene_center_mse(cut->field, cut->F, cut->nb, cut->starts + 2 * o, p->dloc[b], nb, cut->cs,
-                                       comp->mse + o, s));
-    }
     if (mu)
       DV_HIP(hipMemcpy2DAsync(p->dsmall[b], d * sizeof(float), m->t, A.tw * sizeof(float), d * sizeof(float), nb,
                               hipMemcpyDeviceToDevice, s));
@@ -2551,6 +2542,18 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
     const int h = (int)(k % 3);
     DV_HIP(hipStreamWaitEvent(p->s_out, p->ev_comp[b], 0));
     if (trace) DV_HIP(hipEventRecord(tev[6 * k + 4], p->s_out));
+    if (comp) {
+      // the consumer that follows in the reference (field_deblender.py:99-189) takes the place of the D2H stage: it runs on
+      // the chunk as it lies in HBM, on the output stream, under the NEXT chunk's forward pass (an HBM-bound kernel beside
+      // latency-bound ones); chunks composite in order because they share this stream, and the forward of chunk k + 2
+      // waits for ev_d2h below before it overwrites the outputs this launch reads
+      ProfScope ps(m, 2, p->s_out);
+      DV_TRY(launch_scene_composite_chunk(comp->mean_f, comp->std_f, comp->res_f, cut->F, cut->nb, p->dloc[b], p->dscale[b],
+                                          comp->places + 2 * o, nb, cut->cs, p->s_out));
+      if (comp->mse)
+        DV_TRY(launch_scene_center_mse(cut->field, cut->F, cut->nb, cut->starts + 2 * o, p->dloc[b], nb, cut->cs,
+                                       comp->mse + o, p->s_out));
+    }
     if (loc || sink) DV_HIP(hipMemcpyAsync(p->hloc[h], p->dloc[b], nb * stamp * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
     if (scale || sink) DV_HIP(hipMemcpyAsync(p->hscale[h], p->dscale[b], nb * stamp * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
     if (mu || zstd || z)
