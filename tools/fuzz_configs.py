@@ -17,13 +17,20 @@ for size, bands, filters, latent in [(32, 2, (16, 32), 8), (45, 4, (32, 64, 128)
                                      (10, 6, (16, 32), 8), (8, 2, (32, 32, 32), 8), (59, 6, (32, 64, 128, 256, 256), 32),
                                      (9, 4, (32,), 8)]:
     for B in (1, 7, 64, 100, 256, 300):
-        cases.append((size, bands, filters, latent, B))
+        cases.append((size, bands, filters, latent, B, (3,) * len(filters)))
+# round 4: any band count, kernel sizes 1 .. 5 per level (general gather-GEMM / tiled weight gradient; fp32 engine only)
+for size, bands, filters, latent, kernels in [(20, 5, (32, 64), 8, (5, 5)), (32, 1, (16, 32), 8, (3, 5)),
+                                              (27, 3, (24, 48), 8, (1, 3)), (45, 7, (32, 64, 128), 16, (5, 3, 1)),
+                                              (59, 6, (32, 64, 128, 256), 32, (5, 3, 5, 3)), (16, 2, (32,), 8, (4,)),
+                                              (30, 6, (16, 32), 8, (2, 4))]:
+    for B in (1, 7, 64, 100):
+        cases.append((size, bands, filters, latent, B, kernels))
 bad = 0
 for dtype in (0, 1):
-    for size, bands, filters, latent, B in cases:
-        tag = f"dtype {dtype} size {size} bands {bands} filters {filters} latent {latent} B {B}"
+    for size, bands, filters, latent, B, kernels in cases:
+        tag = f"dtype {dtype} size {size} bands {bands} filters {filters} kernels {kernels} latent {latent} B {B}"
         try:
-            cfg = E.make_config((size, size, bands), latent, filters, (3,) * len(filters), max_batch=B, dtype=dtype)
+            cfg = E.make_config((size, size, bands), latent, filters, kernels, max_batch=B, dtype=dtype)
             eng = E.Engine(cfg)
         except (DvError, ValueError) as e:
             if B == 1:
