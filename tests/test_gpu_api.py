@@ -529,6 +529,9 @@ def test_on_device_compositing_is_bit_identical_to_the_host_composited_path(dtyp
             assert "output_images_mean" not in rb.dtype.names and "cutout_images" not in rb.dtype.names
     with pytest.raises(ValueError):
         b.deblend_field(np.array([[0.5, 1.0]]), on_device=True)                     # fractional positions: default path
+    # no galaxy inside the field: the reference's dictionary of None entries (field_deblender.py:262-266), no engine call
+    none = b.deblend_field(np.array([[1000.0, -1000.0]]), on_device=True)
+    assert isinstance(none, dict) and none["list_idx"] is None and none["output_images_mean"] is None
 
 
 def test_deblend_field_cutouts_equals_extract_then_deblend_bit_for_bit():
