@@ -1,5 +1,43 @@
 """debvader_amd — MI355X-native engine behind debvader's create_model_vae / train / deblend() surface.
 
 Python host code over a C-ABI HIP library (debvader_amd/lib/libdebvader_hip.so, include/debvader_hip.h).
+
+The package root exports what the reference's does (src/debvader/__init__.py:1-2), so `from debvader import DeblendField`
+becomes `from debvader_amd import DeblendField`.  The names resolve on first use (PEP 562): importing the package alone
+loads neither pandas nor the HIP library, which host-only tools and the CPU tests rely on.
 """
 __version__ = "0.1.0"
+
+_LAZY = {
+    # reference: src/debvader/__init__.py:1
+    "DeblendField": ("debvader_amd.deblend.field_deblender", "DeblendField"),
+    # the call surface of SURVEY section 8(b), one import away for users of the reference's sub-modules (`deblend` the
+    # function is not among them: `debvader_amd.deblend` is the sub-package, as `debvader.deblend` is in the reference)
+    "create_model_vae": ("debvader_amd.model.model", "create_model_vae"),
+    "load_deblender": ("debvader_amd.model.model", "load_deblender"),
+    "train_deblender": ("debvader_amd.training.train", "train_deblender"),
+    "extract_cutouts": ("debvader_amd.extract.extraction", "extract_cutouts"),
+}
+# reference: src/debvader/__init__.py:2 - the iterative procedure needs `sep` source detection (detect/detection.py), which is
+# outside this engine's scope; the name is answered with the reason instead of an AttributeError
+_OUT_OF_SCOPE = {"IterativeDeblendField": "the iterative procedure of deblend_iterative/ drives `sep` source detection, which this "
+                                          "engine does not provide; run the reference's loop around debvader_amd.DeblendField"}
+
+__all__ = ["__version__"] + sorted(_LAZY)
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+
+        mod, attr = _LAZY[name]
+        value = getattr(importlib.import_module(mod), attr)
+        globals()[name] = value
+        return value
+    if name in _OUT_OF_SCOPE:
+        raise NotImplementedError(f"debvader_amd.{name}: {_OUT_OF_SCOPE[name]}")
+    raise AttributeError(f"module 'debvader_amd' has no attribute {name!r}")
+
+
+def __dir__():
+    return sorted(list(globals()) + list(_LAZY))

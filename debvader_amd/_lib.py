@@ -75,6 +75,7 @@ SIGNATURES = {
     "dv_arch_buckets": (C.c_int, [C.POINTER(DvConfig), C.POINTER(C.c_int64)]),
     "dv_arch_offset": (C.c_int, [C.POINTER(DvConfig), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dv_device_count": (C.c_int, [_i32]),
+    "dv_device_bus_id": (C.c_int, [C.c_int32, C.c_char_p, C.c_size_t]),
     "dv_comm_unique_id": (C.c_int, [_p]),
     "dv_ctx_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _p, C.POINTER(_p)]),
     "dv_ctx_destroy": (C.c_int, [_p]),
@@ -109,6 +110,7 @@ SIGNATURES = {
     "dv_infer": (C.c_int, [_p, _f, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
     "dv_infer_f64": (C.c_int, [_p, _d, C.c_int64, _f, C.c_uint64, _f, _f, _f, _f, _f]),
     "dv_infer_cutouts": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_uint64, _f, _f, _f, _f, _f]),
+    "dv_infer_cutouts_keep": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_uint64, _f, _f, _d]),
     "dv_infer_cutouts_stream": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_uint64,
                                           C.c_void_p, C.c_void_p]),
     "dv_infer_cutouts_composite": (C.c_int, [_p, _d, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64,

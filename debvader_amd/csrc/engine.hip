@@ -2340,11 +2340,21 @@ static int pipe_host_buffers(dv_model* m, InferPipe* p) {
   if (p->host_ok) return OK;
   const Arch& A = m->A;
   const size_t img = (size_t)p->cap * A.H * A.H * A.C * sizeof(float);
-  for (int b = 0; b < 3; ++b) {
-    DV_HIP(hipHostMalloc((void**)&p->hloc[b], img, hipHostMallocDefault));
-    DV_HIP(hipHostMalloc((void**)&p->hscale[b], img, hipHostMallocDefault));
+  // a failed allocation frees what this call got so far and leaves the slots null, so that a retry on a reused pipe neither
+  // leaks pinned memory (several GB at 8192 stamps per chunk) nor overwrites live pointers
+  float** slots[8] = {&p->hloc[0], &p->hscale[0], &p->hloc[1], &p->hscale[1], &p->hloc[2], &p->hscale[2], &p->hin[0], &p->hin[1]};
+  for (int i = 0; i < 8; ++i) {
+    if (*slots[i]) continue;
+    hipError_t e = hipHostMalloc((void**)slots[i], img, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      *slots[i] = nullptr;
+      for (int j = 0; j < 8; ++j) {
+        if (*slots[j]) (void)hipHostFree(*slots[j]);
+        *slots[j] = nullptr;
+      }
+      return hip_fail(e, "hipHostMalloc(pinned transfer ring)", __FILE__, __LINE__);
+    }
   }
-  for (int b = 0; b < 2; ++b) DV_HIP(hipHostMalloc((void**)&p->hin[b], img, hipHostMallocDefault));
   p->host_ok = true;
   return OK;
 }
@@ -2419,6 +2429,42 @@ static void host_copy(float* dst, const void* src, size_t n, bool src_f64, int t
   for (auto& th : pool) th.join();
 }
 
+// out[i] = field[x_i : x_i + cs, y_i : y_i + cs, :] for n windows of a float64 field that lies in HOST memory, split over
+// `threads` host threads: cs row copies of cs * nb doubles per window (what numpy's slice assignment does in
+// extract/extraction.py:26-32).  Used for the float64 cutout_images the reference's recarray carries: the windows are exact
+// copies of host data, so they are assembled on the host beside the GPU's forward passes and never cross the host link.
+static void host_gather_cutouts(double* out, const double* field, int F, int nb, const int32_t* starts, int64_t n, int cs,
+                                int threads) {
+  auto work = [=](int64_t lo, int64_t hi) {
+    const size_t row = (size_t)cs * nb;
+    for (int64_t i = lo; i < hi; ++i) {
+      const double* src = field + ((size_t)starts[2 * i] * F + starts[2 * i + 1]) * nb;
+      double* dst = out + (size_t)i * cs * row;
+      for (int r = 0; r < cs; ++r) memcpy(dst + r * row, src + (size_t)r * F * nb, row * sizeof(double));
+    }
+  };
+  if (threads <= 1 || n < 64) {
+    work(0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const int64_t per = (n + threads - 1) / threads;
+  for (int t = 1; t < threads; ++t) {
+    const int64_t lo = std::min(n, per * t), hi = std::min(n, per * (t + 1));
+    if (lo < hi) pool.emplace_back(work, lo, hi);
+  }
+  work(0, std::min(n, per));
+  for (auto& th : pool) th.join();
+}
+
+// the float64 cutouts themselves, wanted by the caller beside the network's outputs (dv_infer_cutouts_keep): host copies of
+// the field and of the window starts, and where the windows go
+struct CutoutKeep {
+  const double* field;   // host, [F][F][nb]
+  const int32_t* starts; // host, [N][2]
+  double* out;           // host, [N][cs][cs][nb]
+};
+
 // input of the pipeline when the stamps are cutouts of a field that already sits in HBM (dv_infer_cutouts)
 struct CutoutSrc {
   const double* field;   // device, [F][F][nb]
@@ -2436,7 +2482,8 @@ struct CompositeSink {
 
 static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, const float* eps, uint64_t seed,
                            float* loc, float* scale, float* mu, float* zstd, float* z, const CutoutSrc* cut = nullptr,
-                           dv_chunk_fn sink = nullptr, void* sink_user = nullptr, const CompositeSink* comp = nullptr) {
+                           dv_chunk_fn sink = nullptr, void* sink_user = nullptr, const CompositeSink* comp = nullptr,
+                           const CutoutKeep* keep = nullptr) {
   const Arch& A = m->A;
   hipStream_t s = m->ctx->stream;
   const size_t stamp = (size_t)A.H * A.H * A.C;
@@ -2451,6 +2498,8 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
     const int b = (int)(k % 3);
     const int64_t o = k * chunk;
     const int nb = (int)std::min<int64_t>(chunk, N - o);
+    // the caller's float64 cutouts of this chunk: host work that needs nothing from the GPU, done before the wait
+    if (keep) host_gather_cutouts(keep->out + o * stamp, keep->field, cut->F, cut->nb, keep->starts + 2 * o, nb, cut->cs, p->threads);
     DV_HIP(hipEventSynchronize(p->ev_d2h[b]));
     if (sink) {
       // streaming consumer: it reads the pinned transfer buffers in place (valid until it returns), nothing is copied
@@ -2724,6 +2773,19 @@ int dv_device_count(int32_t* n) {
     return DV_OK;
   }
   *n = c;
+  return DV_OK;
+}
+
+int dv_device_bus_id(int32_t device, char* bus_id, size_t bus_len) {
+  if (!bus_id || bus_len < 16) return DV_E_INVALID;
+  bus_id[0] = 0;
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess || device < 0 || device >= c) {
+    (void)hipGetLastError();
+    set_error("dv_device_bus_id: device %d of %d visible", device, c);
+    return DV_E_NODEVICE;
+  }
+  DV_HIP(hipDeviceGetPCIBusId(bus_id, (int)bus_len, device));
   return DV_OK;
 }
 
@@ -3583,7 +3645,7 @@ int dv_infer_f64(dv_model* m, const double* x, int64_t N, const float* eps, uint
 
 static int infer_cutouts_impl(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
                               uint64_t seed, float* loc, float* scale, float* mu, float* zstd, float* z, dv_chunk_fn sink,
-                              void* sink_user) {
+                              void* sink_user, double* cutouts = nullptr) {
   if (!m || !field || !starts || N < 0 || F < 1) return DV_E_INVALID;
   const Arch& A = m->A;
   const int cs = A.H;
@@ -3622,7 +3684,9 @@ static int infer_cutouts_impl(dv_model* m, const double* field, int32_t F, int32
   const double t_up = since();
   if (st == OK) {
     CutoutSrc cut{fdev, sdev, F, nb, cs};
-    st = infer_pipelined(m, nullptr, false, N, nullptr, seed, loc, scale, mu, zstd, z, &cut, sink, sink_user);
+    CutoutKeep keep{field, starts, cutouts};
+    st = infer_pipelined(m, nullptr, false, N, nullptr, seed, loc, scale, mu, zstd, z, &cut, sink, sink_user, nullptr,
+                         cutouts ? &keep : nullptr);
   }
   (void)hipStreamSynchronize(s);
   const double t_pipe = since();
@@ -3671,11 +3735,12 @@ int dv_infer_cutouts_composite(dv_model* m, const double* field, int32_t F, int3
   double *fdev = nullptr, *mf = nullptr, *sf = nullptr, *rf = nullptr, *mse = nullptr;
   int *sdev = nullptr, *pdev = nullptr;
   const size_t sb = (size_t)N * 2 * sizeof(int);
+  int st = OK;
   auto cleanup = [&]() {
+    if (st != OK && m->pipe && m->pipe->s_out) (void)hipStreamSynchronize(m->pipe->s_out);   // nothing may still read these
     (void)hipFree(fdev); (void)hipFree(mf); (void)hipFree(sf); (void)hipFree(rf); (void)hipFree(mse);
     (void)hipFree(sdev); (void)hipFree(pdev);
   };
-  int st = OK;
 #define CC_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { st = hip_fail(e__, #call, __FILE__, __LINE__); cleanup(); return st; } } while (0)
   CC_HIP(hipMalloc((void**)&fdev, fb));
   CC_HIP(hipMalloc((void**)&mf, fb));
@@ -3703,7 +3768,13 @@ int dv_infer_cutouts_composite(dv_model* m, const double* field, int32_t F, int3
     if (rf) CC_HIP(hipMemcpyAsync(residual_field, rf, fb, hipMemcpyDeviceToHost, s));
     if (mse) CC_HIP(hipMemcpyAsync(mse_center, mse, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, s));
   }
-  (void)hipStreamSynchronize(s);
+  // the results are only defined once the copies have landed: a failed synchronise is this call's error.  On any failure
+  // the pipeline's output stream may still hold compositing launches that read the buffers freed below - drain it first.
+  {
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess && st == OK) st = hip_fail(e, "hipStreamSynchronize(result fields)", __FILE__, __LINE__);
+  }
+  if (st != OK && m->pipe && m->pipe->s_out) (void)hipStreamSynchronize(m->pipe->s_out);
 #undef CC_HIP
   cleanup();
   if (st != OK) return st;
@@ -3713,6 +3784,12 @@ int dv_infer_cutouts_composite(dv_model* m, const double* field, int32_t F, int3
 int dv_infer_cutouts(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
                      uint64_t seed, float* loc, float* scale, float* mu, float* zstd, float* z) {
   return infer_cutouts_impl(m, field, F, nb, starts, N, seed, loc, scale, mu, zstd, z, nullptr, nullptr);
+}
+
+int dv_infer_cutouts_keep(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
+                          uint64_t seed, float* loc, float* scale, double* cutouts) {
+  if (!cutouts) return DV_E_INVALID;
+  return infer_cutouts_impl(m, field, F, nb, starts, N, seed, loc, scale, nullptr, nullptr, nullptr, nullptr, nullptr, cutouts);
 }
 
 int dv_infer_cutouts_stream(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,

@@ -11,8 +11,8 @@ import pandas as pd
 
 from debvader_amd import engine as E
 from debvader_amd.deblend_cutout.deblender import deblend, deblend_epistemic
-from debvader_amd.extract.extraction import extract_cutouts
-from debvader_amd.training.metrics import mse
+from debvader_amd.extract.extraction import cutout_windows, extract_cutouts  # noqa: F401  (extract_cutouts: re-exported as in the reference)
+from debvader_amd.training.metrics import mse  # noqa: F401  (the reference's module imports it; the cut below is its vector form)
 
 
 class DeblendField:
@@ -39,7 +39,7 @@ class DeblendField:
         self.res_deblend = None
         self.mse = []
         self._ctx = getattr(getattr(net, "_core", None), "ctx", None) or E.default_context()
-        self._device_fields = None      # fields composited on the GPU by deblend_field(on_device=True)
+        self._device_fields = None      # (recarray, fields composited on the GPU) of the last deblend_field(on_device=True)
 
     # -- compositing -------------------------------------------------------------------------------
     @staticmethod
@@ -48,14 +48,29 @@ class DeblendField:
                           row["galaxy_distances_to_center_y"] + row["shifts"][1]] for row in res_deblend],
                         dtype=np.float64).reshape(-1, 2)
 
+    def _own_device_fields(self, res_deblend):
+        """The fields an on-device pass composited, if `res_deblend` (None: self.res_deblend) is that pass's recarray."""
+        if self._device_fields is None:
+            return None
+        rec, fields = self._device_fields
+        if rec is self.res_deblend and (res_deblend is None or res_deblend is rec):
+            return fields
+        return None
+
     def _stack(self, res_deblend, key):
+        names = getattr(getattr(res_deblend, "dtype", None), "names", None)
+        if names is not None and key not in names:
+            raise ValueError(f"this recarray has no {key!r} column: it comes from deblend_field(on_device=True), whose stamps "
+                             "stayed on the GPU - only the object that made it can return its fields, and only until its next "
+                             "pass; run the default path to composite from stamps")
         return np.array([np.asarray(row[key], dtype=np.float64) for row in res_deblend], dtype=np.float64).reshape(
             -1, self.cutout_size, self.cutout_size, self.nb_of_bands)
 
     def get_residual_field(self, res_deblend=None):
         """Field minus every predicted galaxy at its position (field_deblender.py:46-97); shape of the input field."""
-        if res_deblend is None and self._device_fields is not None:
-            return self._device_fields["residual_field"][None].copy()
+        dev = self._own_device_fields(res_deblend)
+        if dev is not None:
+            return dev["residual_field"][None].copy()
         if res_deblend is None:
             res_deblend = self.res_deblend
         deblended_image = self.field_image.copy()
@@ -66,11 +81,11 @@ class DeblendField:
 
     def get_predicted_field(self, res_deblend=None):
         """Predicted mean / stddev / epistemic fields (field_deblender.py:99-189), each (size, size, bands)."""
-        if res_deblend is None and self._device_fields is not None:
+        dev = self._own_device_fields(res_deblend)
+        if dev is not None:
             # deblend_field(on_device=True) composited them on the GPU behind the forward passes
-            return {"predicted_mean_field": self._device_fields["mean_field"].copy(),
-                    "predicted_stddev_field": self._device_fields["stddev_field"].copy(),
-                    "predicted_epistemic_field": np.zeros_like(self._device_fields["mean_field"])}
+            return {"predicted_mean_field": dev["mean_field"].copy(), "predicted_stddev_field": dev["stddev_field"].copy(),
+                    "predicted_epistemic_field": np.zeros_like(dev["mean_field"])}
         if res_deblend is None:
             res_deblend = self.res_deblend
         zeros = np.zeros((self.field_size, self.field_size, self.nb_of_bands))
@@ -100,66 +115,93 @@ class DeblendField:
         shifts, list_idx, galaxy_distances_to_center_x/_y, epistemic_uncertainty, passed_cuts
         (a dict of None entries when no galaxy could be extracted, as the reference does).
 
+        Default path (the reference's call sequence extract_cutouts -> deblend, :260-274): ONE engine call
+        (dv_infer_cutouts_keep) - the field goes to the GPU once, every chunk's cutouts are gathered and cast to float32
+        there, straight into the network's input, mean and stddev come back through the pinned transfer ring, and the
+        float64 `cutout_images` the recarray carries are assembled on the host from the field (they are copies of host
+        data) while the GPU works.  Same numbers, bit for bit, as extract_cutouts followed by deblend.
+
         on_device=True (engine-specific): the whole chain - cutout gather, network, and the compositing that
         get_predicted_field / get_residual_field do afterwards - runs on the GPU in one engine call
         (dv_infer_cutouts_composite) and only the field-sized results come back: BASELINE configs[4]'s million cutouts are
         167 GB of mean and stddev stamps that no longer cross the host link.  The recarray then carries the per-galaxy
         scalars (list_idx, positions, shifts, passed_cuts, mse_center) but no stamp images, and get_predicted_field() /
         get_residual_field() return the fields composited on the GPU - the same sums in the same order, bit for bit, as
-        compositing the stamps of the default path.  Needs integer positions (no optimise_positions), no epistemic pass.
+        compositing the stamps of the default path.  Needs integer positions, the object's own field, no caller-supplied
+        cutouts and no epistemic pass (each raises with a message otherwise).
         """
-        if on_device:
-            return self._deblend_field_on_device(galaxy_distances_to_center, mse_criterion, field_image)
-        self._device_fields = None
         if optimise_positions:
             raise NotImplementedError("optimise_positions=True needs the scipy.optimize position fit of "
                                       "deblend_cutout/optimization.py, which is outside this engine's scope")
+        if on_device:
+            if isinstance(cutout_images, np.ndarray):
+                raise ValueError("on_device=True cuts the stamps out of the field on the GPU; caller-supplied cutout_images "
+                                 "need the default path")
+            return self._deblend_field_on_device(galaxy_distances_to_center, mse_criterion, field_image)
         res_deblend = {"cutout_images": None, "output_images_mean": None, "output_images_stddev": None,
                        "shifts": None, "list_idx": None}
         if field_image is None:
-            field_image = self.field_image.copy()
+            field_image = self.field_image
+        field_image = np.asarray(field_image)
         field_size = field_image.shape[1]
+        cs, nb = self.cutout_size, self.nb_of_bands
 
         if isinstance(cutout_images, np.ndarray):
             output_images_mean, dist = deblend(self.net, cutout_images, normalise=self.normalise)
+            output_images_stddev = dist.stddev().numpy()
             list_idx = list(range(0, len(output_images_mean)))
+            cutouts = cutout_images                  # rows of list_idx
         else:
-            cutout_images, list_idx = extract_cutouts(field_image, field_size, galaxy_distances_to_center,
-                                                      self.cutout_size, self.nb_of_bands, ctx=self._ctx)
+            # extract_cutouts (extraction.py:4-43): which windows fit the field ...
+            n = len(galaxy_distances_to_center)
+            starts, ok = cutout_windows(field_size, galaxy_distances_to_center, cs) if n else (np.zeros((0, 2), np.int32), np.zeros(0, bool))
+            if field_image.ndim != 4 or field_image.shape[3] != nb:
+                ok[:] = False                        # the reference's slice assignment raises for every galaxy (caught, flagged)
+            list_idx = [int(i) for i in np.nonzero(ok)[0]]
+            if n and not ok.all():
+                print("Some galaxies are too close from the border of the field to be considered here.")
             if list_idx == []:
                 print("No galaxy deblended. End of the iterative procedure.")
                 return res_deblend
-            output_images_mean, dist = deblend(self.net, cutout_images[list_idx], normalise=self.normalise)
+            # ... and deblend(net, cutout_images[list_idx]) (deblender.py:18) on them, gathered on the GPU
+            core = self.net._core
+            eng = core.engine
+            eng.set_normalise(bool(self.normalise))
+            try:
+                r = eng.infer_cutouts_keep(field_image[0], starts[ok], seed=core.next_seed())
+            finally:
+                eng.set_normalise(False)
+            output_images_mean, output_images_stddev, cutouts = r["loc"], r["scale"], r["cutouts"]
         if list_idx == []:
             print("No galaxy deblended. End of the iterative procedure.")
             return res_deblend
+        rows = cutouts if len(cutouts) == len(list_idx) else cutouts[list_idx]   # stamp of galaxy list_idx[i] in row i
 
         if self.epistemic_uncertainty_estimation:
             # reference: np.std(deblend(net, [cutout] * 100)[0], axis=0) per object (field_deblender.py:303-313)
-            _, eps_std = deblend_epistemic(self.net, cutout_images[list_idx], n_samples=100, normalise=self.normalise)
+            _, eps_std = deblend_epistemic(self.net, rows, n_samples=100, normalise=self.normalise)
             epistemic_uncertainty = [e.astype(np.float64) for e in eps_std]
+            eps_norm = np.array([np.sum(e[:, :, 2]) for e in epistemic_uncertainty]) / \
+                np.array([np.sum(m[:, :, 2]) for m in output_images_mean])
         else:
-            epistemic_uncertainty = list(np.zeros((len(list_idx), self.cutout_size, self.cutout_size, self.nb_of_bands)))
+            epistemic_uncertainty = list(np.zeros((len(list_idx), cs, cs, nb)))
+            eps_norm = np.zeros(len(list_idx))
 
-        shifts, gx, gy, passed_cuts = [], [], [], []
-        c0, c1 = int(self.cutout_size / 2) - 5, int(self.cutout_size / 2) + 5
-        for i, k in enumerate(list_idx):
-            if self.epistemic_uncertainty_estimation:
-                eps_norm = np.sum(epistemic_uncertainty[i][:, :, 2]) / np.sum(output_images_mean[i, :, :, 2])
-            else:
-                eps_norm = 0
-            gx.append(galaxy_distances_to_center[k][0])
-            gy.append(galaxy_distances_to_center[k][1])
-            mse_center = mse(cutout_images[k, c0:c1, c0:c1], output_images_mean[i, c0:c1, c0:c1])
-            shifts.append(np.array([0, 0]))
-            passed_cuts.append(not (eps_norm > epistemic_criterion or mse_center > mse_criterion))
+        # the reference's per-galaxy loop (:320-352), over all galaxies at once: mse() of the centre 10 x 10 pixels
+        c0, c1 = int(cs / 2) - 5, int(cs / 2) + 5
+        diff = rows[:, c0:c1, c0:c1] - output_images_mean[:, c0:c1, c0:c1]
+        mse_center = np.mean(np.square(diff).reshape(len(diff), -1), axis=1)          # metrics.mse per galaxy
+        passed_cuts = [bool(v) for v in ~((eps_norm > epistemic_criterion) | (mse_center > mse_criterion))]
+        gx = [galaxy_distances_to_center[k][0] for k in list_idx]
+        gy = [galaxy_distances_to_center[k][1] for k in list_idx]
+        shifts = [np.array([0, 0]) for _ in list_idx]
 
         self.nb_of_detected_objects += [len(list(galaxy_distances_to_center))]
         self.nb_of_deblended_galaxies += [len(list_idx)]
 
-        res_deblend["cutout_images"] = list(cutout_images[list_idx])
+        res_deblend["cutout_images"] = list(rows)
         res_deblend["output_images_mean"] = list(output_images_mean)
-        res_deblend["output_images_stddev"] = list(dist.stddev().numpy())
+        res_deblend["output_images_stddev"] = list(output_images_stddev)
         res_deblend["shifts"] = shifts
         res_deblend["list_idx"] = list_idx
         res_deblend["galaxy_distances_to_center_x"] = gx
@@ -167,17 +209,20 @@ class DeblendField:
         res_deblend["epistemic_uncertainty"] = epistemic_uncertainty
         res_deblend["passed_cuts"] = passed_cuts
         self.res_deblend = pd.DataFrame(res_deblend).to_records(index=False)
+        self._device_fields = None          # the composited fields of an earlier on-device pass belonged to ITS recarray
         return self.res_deblend
 
     def _deblend_field_on_device(self, galaxy_distances_to_center, mse_criterion, field_image):
-        from debvader_amd.extract.extraction import cutout_windows
-
         if self.epistemic_uncertainty_estimation:
             raise NotImplementedError("on_device=True composites the mean and stddev fields; the epistemic estimate needs the "
                                       "default path")
-        if field_image is None:
-            field_image = self.field_image
-        field = np.ascontiguousarray(np.asarray(field_image, dtype=np.float64)[0])
+        # the reference's get_residual_field always subtracts from self.field_image (:60), whatever field the stamps were cut
+        # from: the device-composited residual can only stand in for it when both are the same field
+        if field_image is not None and field_image is not self.field_image and not (
+                np.shape(field_image) == self.field_image.shape and np.array_equal(field_image, self.field_image)):
+            raise ValueError("on_device=True composites the residual against the field it cuts the stamps from, which must be "
+                             "the object's own field_image; a different field_image needs the default path")
+        field = np.ascontiguousarray(self.field_image[0])
         F, cs = field.shape[0], self.cutout_size
         d = np.asarray(galaxy_distances_to_center, dtype=np.float64).reshape(-1, 2)
         starts, ok = cutout_windows(F, d, cs)
@@ -186,7 +231,7 @@ class DeblendField:
                "list_idx": None}
         if not list_idx:
             print("No galaxy deblended. End of the iterative procedure.")
-            return res
+            return res                       # res_deblend and the fields that belong to it stay as they were (as the reference)
         if not ok.all():
             print("Some galaxies are too close from the border of the field to be considered here.")
         dd = d[ok]
@@ -202,7 +247,6 @@ class DeblendField:
             out = eng.infer_cutouts_composite(field, starts[ok], places, seed=core.next_seed())
         finally:
             eng.set_normalise(False)
-        self._device_fields = out
         self.nb_of_detected_objects += [len(d)]
         self.nb_of_deblended_galaxies += [len(list_idx)]
         n = len(list_idx)
@@ -211,4 +255,5 @@ class DeblendField:
             "galaxy_distances_to_center_x": list(dd[:, 0]), "galaxy_distances_to_center_y": list(dd[:, 1]),
             "mse_center": list(out["mse_center"]), "passed_cuts": list(~(out["mse_center"] > mse_criterion)),
         }).to_records(index=False)
+        self._device_fields = (self.res_deblend, out)      # the fields and the recarray they belong to, set together
         return self.res_deblend

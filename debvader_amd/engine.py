@@ -71,6 +71,14 @@ def device_count() -> int:
     return n.value
 
 
+def device_bus_id(device: int) -> str:
+    """PCI bus id of visible device `device` ("" when it cannot be had: no GPU, index not visible)."""
+    buf = C.create_string_buffer(32)
+    if lib.dv_device_bus_id(int(device), buf, 32) != 0:
+        return ""
+    return buf.value.decode()
+
+
 def _fp(a: Optional[np.ndarray]):
     if a is None:
         return None
@@ -449,6 +457,23 @@ class Engine:
                                    starts.ctypes.data_as(C.POINTER(C.c_int32)), N, int(seed), _fp(bufs["loc"]),
                                    _fp(bufs["scale"]), _fp(bufs["mu"]), _fp(bufs["zstd"]), _fp(bufs["z"])))
         return {k: v for k, v in bufs.items() if v is not None}
+
+    def infer_cutouts_keep(self, field, starts, seed=0) -> Dict[str, np.ndarray]:
+        """infer_cutouts() for a caller that also needs the float64 cutouts (dv_infer_cutouts_keep): returns
+        {"loc", "scale" (float32), "cutouts" (float64)}, all (N,) + stamp shape.  The cutouts are assembled on the host from the
+        field the caller holds while the GPU runs the forward passes - bit-identical to ctx.scene_extract(field, starts, H) -
+        and mean / stddev are bit-identical to infer(cutouts) with the same seed."""
+        field = np.ascontiguousarray(field, dtype=np.float64)
+        starts = _i32_rows(starts, "cutout starts")
+        if field.ndim != 3 or field.shape[0] != field.shape[1]:
+            raise ValueError(f"expected a square field (F, F, bands), got {field.shape}")
+        N = starts.shape[0]
+        out = {"loc": np.empty((N,) + self.stamp_shape, np.float32), "scale": np.empty((N,) + self.stamp_shape, np.float32),
+               "cutouts": np.empty((N,) + self.stamp_shape, np.float64)}
+        check(lib.dv_infer_cutouts_keep(self._h, field.ctypes.data_as(C.POINTER(C.c_double)), field.shape[0], field.shape[2],
+                                        starts.ctypes.data_as(C.POINTER(C.c_int32)), N, int(seed), _fp(out["loc"]),
+                                        _fp(out["scale"]), out["cutouts"].ctypes.data_as(C.POINTER(C.c_double))))
+        return out
 
     def infer_cutouts_composite(self, field, starts, places, seed=0, residual=True, mse_center=True) -> Dict[str, np.ndarray]:
         """infer_cutouts() with the compositing that follows it in the reference done on the GPU (dv_infer_cutouts_composite):

@@ -405,6 +405,32 @@ def exchange_unique_id(rank: int, group) -> bytes:
     return group.broadcast(mine, src=0)
 
 
+def _check_one_gpu_per_rank(group, rank: int, world: int, local_rank: int):
+    """Every rank tells the others which physical GPU it is about to open - (host name, PCI bus id) - and ALL ranks raise
+    when two of them name the same one: e.g. a launcher that starts N ranks with a single visible, un-pinned GPU sends every
+    rank to device 0.  Done before the communicator exists, so nobody is left waiting inside ncclCommInitRank.  The one-GPU
+    rehearsal switches (DV_DEBUG_SAME_GPU / DV_DEBUG_FAKE_PEERS) and groups without a byte all-gather skip it."""
+    if os.environ.get("DV_DEBUG_SAME_GPU") or os.environ.get("DV_DEBUG_FAKE_PEERS"):
+        return
+    if not hasattr(group, "allgather") or hasattr(group, "get_backend"):
+        return
+    bus = getattr(E, "device_bus_id", lambda d: "")(local_rank)
+    mine = f"{socket.gethostname()}|{bus}".encode()
+    seen = {}
+    clash = None
+    for r, who in enumerate(group.allgather(mine)):
+        who = bytes(who).decode()
+        if who.endswith("|"):
+            continue                       # that rank could not name its device (no GPU visible): nothing to compare
+        if who in seen and clash is None:
+            clash = (seen[who], r, who)
+        seen.setdefault(who, r)
+    if clash:
+        raise RuntimeError(f"ranks {clash[0]} and {clash[1]} of {world} would both open GPU {clash[2].split('|')[1]} on host "
+                           f"{clash[2].split('|')[0]}: RCCL needs one GPU per rank - check LOCAL_RANK and the per-rank "
+                           f"HIP_VISIBLE_DEVICES pinning of the launcher")
+
+
 def make_context(rank: int, world: int, local_rank: Optional[int] = None, group=None) -> E.Context:
     """The engine context of this rank: GPU `local_rank`, RCCL communicator over `world` ranks.  With world > 1 and no
     `group` the ranks meet through HostGroup(rank, world) (MASTER_ADDR / MASTER_PORT); the group stays attached to the
@@ -432,9 +458,9 @@ def make_context(rank: int, world: int, local_rank: Optional[int] = None, group=
         if visible == 1:
             local_rank = 0
         elif 1 < visible <= local_rank:
-            print(f"[debvader_amd] WARNING: LOCAL_RANK {local_rank} but only {visible} visible GPUs; using device "
-                  f"{local_rank % visible}", file=sys.stderr, flush=True)
-            local_rank %= visible
+            # (a modulo here would put two ranks on one GPU; RCCL then fails late, inside ncclCommInitRank, or stalls its peers)
+            raise RuntimeError(f"LOCAL_RANK {local_rank} but only {visible} GPUs are visible to this process: launch at most "
+                               f"{visible} ranks per node, or pin one GPU per rank (HIP_VISIBLE_DEVICES)")
     if world == 1:
         ctx = E.Context(local_rank, 0, 1, None)
         ctx.group = group
@@ -442,6 +468,7 @@ def make_context(rank: int, world: int, local_rank: Optional[int] = None, group=
     own = group is None
     if own:
         group = HostGroup(rank, world)
+    _check_one_gpu_per_rank(group, rank, world, local_rank)
     uid = exchange_unique_id(rank, group)
     ctx = E.Context(local_rank, rank, world, uid)
     ctx.group = group

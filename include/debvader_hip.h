@@ -86,6 +86,10 @@ int dv_arch_macs(const dv_config* cfg, int64_t* encoder_macs, int64_t* decoder_m
 
 /* ---- context: one per process / GPU -------------------------------------------------------- */
 int dv_device_count(int32_t* n);
+/* PCI bus id of visible device `device` (>= 16 bytes), without creating a context: the ranks of a job compare
+ * (host, bus id) BEFORE they build the communicator, so that two ranks mapped onto one GPU fail fast with a clear message
+ * instead of inside ncclCommInitRank (debvader_amd.parallel.make_context).  DV_E_NODEVICE when the index is not visible. */
+int dv_device_bus_id(int32_t device, char* bus_id, size_t bus_len);
 int dv_comm_unique_id(void* out_id /* DV_UNIQUE_ID_BYTES */);
 /* world == 1: id may be NULL.  world > 1: every rank passes rank 0's id (exchanged by the host). */
 int dv_ctx_create(int32_t device, int32_t rank, int32_t world, const void* unique_id, dv_ctx** out);
@@ -194,6 +198,16 @@ int dv_infer_f64(dv_model* m, const double* x, int64_t N, const float* eps, uint
  * must lie inside the field (DV_E_INVALID otherwise); engine-drawn noise only. */
 int dv_infer_cutouts(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
                      uint64_t seed, float* loc, float* scale, float* mu, float* zstd, float* z);
+
+/* The same call for a caller that also needs the cutouts themselves: DeblendField.deblend_field's recarray carries
+ * `cutout_images` (float64, field_deblender.py:360) and its quality cut compares them with the predicted means (:323-327).
+ * `cutouts` [N][H][H][nb] receives field[x:x+H, y:y+H, :] for every start - exact copies of host data, so the library
+ * assembles them on the host (the reference's numpy slice assignment, extraction.py:26-32, over the pipeline's copy threads)
+ * while the GPU runs the forward passes; they never cross the host link.  loc / scale as in dv_infer_cutouts.  Replaces the
+ * reference's sequence extract_cutouts -> deblend (field_deblender.py:260-274) without the float64 D2H -> host cast -> H2D
+ * loop that sequence implies on a GPU. */
+int dv_infer_cutouts_keep(dv_model* m, const double* field, int32_t F, int32_t nb, const int32_t* starts, int64_t N,
+                          uint64_t seed, float* loc, float* scale, double* cutouts);
 
 /* The same, streaming: instead of filling N-stamp result arrays (167 KB per stamp - a million cutouts do not belong on one
  * host) the library hands every finished chunk to `consumer(user, first, count, mean, stddev)`, stamps

@@ -19,6 +19,11 @@ def _log(rank, **kw):
         fh.write(json.dumps(kw) + "\n")
 
 
+def device_bus_id(device):
+    """What the real engine reads with hipDeviceGetPCIBusId; $DV_STUB_BUS forces one id on every rank (two ranks on one GPU)."""
+    return os.environ.get("DV_STUB_BUS", f"0000:{int(device):02x}:00.0")
+
+
 class Context:
     def __init__(self, device=0, rank=0, world=1, unique_id=None):
         self.device, self.rank, self.world = device, rank, world

@@ -25,10 +25,13 @@ def _free_port():
     return p
 
 
-def test_two_rank_bench_launch_with_a_stub_engine(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_multi_rank_bench_launch_with_a_stub_engine(tmp_path, world):
+    """world 2, and world 8 - the node the driver's scaling run uses: rendezvous of eight ranks beside
+    torchrun's store, eight communicator reports gathered into `multi_rank`, `verified` true, MAX over eight ranks."""
     log = str(tmp_path / "stub")
     env = dict(os.environ, DV_BENCH_STUB_ENGINE="tests.stub_engine", DV_STUB_LOG=log, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
-    steps, warmup, world = 4, 2, 2
+    steps, warmup = 4, 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps),
            "--warmup", str(warmup)]
@@ -38,25 +41,25 @@ def test_two_rank_bench_launch_with_a_stub_engine(tmp_path):
     assert len(lines) == 1, r.stdout                         # one JSON line, from rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "weak"
-    assert d["config"]["global_batch"] == 256 * world and d["config"]["parallelism"] == "dp2"
-    # the slow rank (rank 1: 25 ms per step) sets the time: MAX over ranks, not rank 0's own 5 ms per step
-    assert d["ms_per_step"] >= 24.0, d["ms_per_step"]
+    assert d["config"]["global_batch"] == 256 * world and d["config"]["parallelism"] == f"dp{world}"
+    # the slowest rank (rank world-1: 5 + 20 ms per rank index and step) sets the time: MAX over ranks, not rank 0's own 5 ms
+    assert d["ms_per_step"] >= 4.0 + 20.0 * (world - 1), d["ms_per_step"]
     assert abs(d["value"] - 256 * world * steps / (d["ms_per_step"] * 1e-3 * steps)) <= 1e-6 * d["value"]
     # the N > 1 line is self-verifying: what RCCL reports for the communicator on EVERY rank, which
     # device each rank drives, the communication of a step and its exposed part, and a whole-step fraction
     mr = d["multi_rank"]
-    assert mr["world"] == world and mr["rccl_ranks"] == [world] * world and mr["rccl_rank_ids"] == [0, 1]
-    assert [v["rank"] for v in mr["devices"]] == [0, 1] and mr["distinct_devices"] == world
+    assert mr["world"] == world and mr["rccl_ranks"] == [world] * world and mr["rccl_rank_ids"] == list(range(world))
+    assert [v["rank"] for v in mr["devices"]] == list(range(world)) and mr["distinct_devices"] == world
     assert len({v["pci_bus_id"] for v in mr["devices"]}) == world and mr["verified"] is True and mr["rehearsal"] is False
     assert mr["collectives_per_step"] == 5 and abs(mr["comm_ms_per_step"] - 0.4) < 1e-9
-    assert abs(mr["exposed_comm_ms_per_step"] - 0.1) < 1e-9          # MAX over ranks (rank 1: 0.05 * 2)
+    assert abs(mr["exposed_comm_ms_per_step"] - 0.05 * world) < 1e-9          # MAX over ranks (rank r: 0.05 * (r + 1))
     assert d["roofline"]["whole_step_frac"] > 0 and d["roofline"]["bound"] == "mfma" and "rehearsal" not in d
     logs = {}
     for f in glob.glob(log + ".*"):
         logs[int(f.rsplit(".", 1)[1])] = [json.loads(ln) for ln in open(f)]
-    assert sorted(logs) == [0, 1]
+    assert sorted(logs) == list(range(world))
     uids = {rk: next(e["uid"] for e in ev if e["event"] == "ctx") for rk, ev in logs.items()}
-    assert uids[0] == uids[1] and len(uids[0]) == 256         # rank 0's 128 bytes on both ranks
+    assert len(set(uids.values())) == 1 and len(uids[0]) == 256         # rank 0's 128 bytes on every rank
     for rk, ev in logs.items():
         ts = [e for e in ev if e["event"] == "train_steps"]
         assert [t["steps"] for t in ts] == [warmup, steps, steps]       # warm-up, the timed region, the comm-timing pass

@@ -194,17 +194,20 @@ def _shard_worker_hostgroup(rank, world, port, q):
             group.close()
 
 
-def test_deblend_sharded_gathers_through_the_host_group_world2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_deblend_sharded_gathers_through_the_host_group(world):
     """Round 3: deblend_sharded(dist=ctx.group) called HostGroup.gather_object with torch.distributed's signature and
-    failed with a TypeError the first time it ran with two real ranks (tools/fit_multirank_rehearsal.py on a GPU box)."""
+    failed with a TypeError the first time it ran with two real ranks (tools/fit_multirank_rehearsal.py on a GPU box).
+    World 8 is the node the driver's scaling run uses: eight index-range shards (some of them empty for the 1- and
+    7-stamp inputs) gathered on rank 0 in input order."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_shard_worker_hostgroup, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_shard_worker_hostgroup, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in procs)
+    res = dict(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert res == {0: "ok", 1: "ok"}, res
+    assert res == {r: "ok" for r in range(world)}, res
 

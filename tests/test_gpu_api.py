@@ -534,6 +534,98 @@ def test_on_device_compositing_is_bit_identical_to_the_host_composited_path(dtyp
     assert isinstance(none, dict) and none["list_idx"] is None and none["output_images_mean"] is None
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bf16"])
+def test_default_deblend_field_is_one_engine_call_with_the_reference_sequences_bits(dtype, monkeypatch):
+    """DeblendField.deblend_field() as the reference's caller invokes it (field_deblender.py:219-383, no engine keyword): the
+    recarray of the one-call path (dv_infer_cutouts_keep: gather + cast on the GPU, float64 cutout_images assembled on the
+    host beside the forward passes) against the reference's own sequence spelled out - extract_cutouts, then deblend on the
+    float64 cutouts, then the per-galaxy loop with mse() - column by column, bit for bit; several chunks, galaxies the
+    reference drops, both normalise modes, a non-default quality cut.  Also: the default path makes no dv_scene_extract
+    call (no float64 D2H -> host cast -> H2D loop)."""
+    from debvader_amd.deblend import field_deblender as fd
+    from debvader_amd.deblend_cutout.deblender import deblend
+    from debvader_amd.extract.extraction import extract_cutouts
+    from debvader_amd.model import model
+    from debvader_amd.training.metrics import mse
+
+    net, _, _, _ = model.create_model_vae(**ARCH, max_batch=64, seed=5, dtype=dtype)
+    rng = np.random.default_rng(31)
+    F = 173
+    field = rng.normal(0, 0.4, size=(1, F, F, 6))
+    half = F // 2 - 30
+    d = rng.integers(-half - 5, half + 6, size=(200, 2)).astype(np.float64)
+    calls = []
+    real = type(net._core.ctx).scene_extract
+    for normalise in (False, True):
+        a = fd.DeblendField(net, field, normalise=normalise)
+        net._core.seed_counter = 400
+        monkeypatch.setattr(type(net._core.ctx), "scene_extract", lambda self, *k, **kw: calls.append(1) or real(self, *k, **kw))
+        res = a.deblend_field(d, mse_criterion=0.5)
+        monkeypatch.undo()
+        assert calls == []
+        # the reference's sequence
+        net._core.seed_counter = 400
+        cut, list_idx = extract_cutouts(field, F, d, 59, 6, ctx=net._core.ctx)
+        mean, dist = deblend(net, cut[list_idx], normalise=normalise)
+        std = dist.stddev().numpy()
+        assert 150 < len(list_idx) < 200 and list(res["list_idx"]) == list_idx
+        c0, c1 = 59 // 2 - 5, 59 // 2 + 5
+        for i, k in enumerate(list_idx):
+            np.testing.assert_array_equal(res["cutout_images"][i], cut[k])
+            np.testing.assert_array_equal(res["output_images_mean"][i], mean[i])
+            np.testing.assert_array_equal(res["output_images_stddev"][i], std[i])
+            assert res["galaxy_distances_to_center_x"][i] == d[k][0] and res["galaxy_distances_to_center_y"][i] == d[k][1]
+            assert bool(res["passed_cuts"][i]) == (not mse(cut[k, c0:c1, c0:c1], mean[i, c0:c1, c0:c1]) > 0.5)
+            assert np.array_equal(res["shifts"][i], [0, 0]) and not np.any(res["epistemic_uncertainty"][i])
+        assert res["cutout_images"][0].dtype == np.float64 and res["output_images_mean"][0].dtype == np.float32
+        assert a.nb_of_detected_objects == [200] and a.nb_of_deblended_galaxies == [len(list_idx)]
+    # caller-supplied cutouts keep the reference's branch (:254-258): every row is deblended, list_idx counts them
+    rb = a.deblend_field(d[:7], cutout_images=cut[list_idx][:7])
+    assert list(rb["list_idx"]) == list(range(7)) and rb["output_images_mean"][0].shape == (59, 59, 6)
+
+
+def test_on_device_pass_refuses_what_it_cannot_honour_and_keeps_fields_and_recarray_together():
+    """deblend_field(on_device=True) must not silently drop arguments of the reference's signature, and the
+    device-composited fields must never be served for a recarray they do not belong to."""
+    from debvader_amd.deblend.field_deblender import DeblendField
+    from debvader_amd.model import model
+
+    net, _, _, _ = model.create_model_vae(**ARCH, max_batch=32, seed=2)
+    rng = np.random.default_rng(5)
+    F = 140
+    field = rng.normal(0, 0.3, size=(1, F, F, 6))
+    d = np.array([[0.0, 0.0], [10.0, -12.0], [-20.0, 5.0]])
+    a = DeblendField(net, field)
+    with pytest.raises(NotImplementedError):
+        a.deblend_field(d, on_device=True, optimise_positions=True)
+    with pytest.raises(ValueError, match="cutout_images"):
+        a.deblend_field(d, on_device=True, cutout_images=np.zeros((3, 59, 59, 6)))
+    with pytest.raises(ValueError, match="field_image"):
+        a.deblend_field(d, on_device=True, field_image=field + 1.0)
+    assert a.res_deblend is None
+    ra = a.deblend_field(d, on_device=True, field_image=field.copy())          # an equal field is the object's own field
+    dev_mean = a.get_predicted_field()["predicted_mean_field"]
+    assert np.abs(dev_mean).max() > 0
+    # (1) a default-path call that returns early leaves recarray AND fields of the on-device pass in place
+    assert a.deblend_field(np.array([[1000.0, 1000.0]]))["list_idx"] is None
+    assert a.res_deblend is ra
+    np.testing.assert_array_equal(a.get_predicted_field()["predicted_mean_field"], dev_mean)
+    np.testing.assert_array_equal(a.get_residual_field(), a.get_residual_field(ra))
+    # (2) an on-device early return does the same
+    assert a.deblend_field(np.array([[1000.0, 1000.0]]), on_device=True)["list_idx"] is None
+    np.testing.assert_array_equal(a.get_predicted_field()["predicted_mean_field"], dev_mean)
+    # (3) a default-path pass replaces both: the fields now come from ITS stamps
+    net._core.seed_counter = 77
+    rd = a.deblend_field(d[:2])
+    assert a.res_deblend is rd and "output_images_mean" in rd.dtype.names
+    assert not np.array_equal(a.get_predicted_field()["predicted_mean_field"], dev_mean)
+    # (4) an on-device recarray without its object: a clear error instead of a KeyError inside the compositing
+    with pytest.raises(ValueError, match="on_device"):
+        a.get_predicted_field(ra)
+    with pytest.raises(ValueError, match="on_device"):
+        DeblendField(net, field).get_residual_field(ra)
+
+
 def test_deblend_field_cutouts_equals_extract_then_deblend_bit_for_bit():
     """DeblendField's extract_cutouts -> deblend pair (field_deblender.py:260-274) as one engine call with the gather and
     the float32 cast on the GPU (dv_infer_cutouts): same cast, same kernels, same noise numbering - identical results,

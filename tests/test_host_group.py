@@ -103,10 +103,11 @@ def _ctx_worker(rank, world, env, log, q):
         q.put((rank, repr(e)))
 
 
-def test_make_context_hands_rank0s_id_to_every_rank(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_make_context_hands_rank0s_id_to_every_rank(tmp_path, world):
     import json
 
-    world, log = 2, str(tmp_path / "stub")
+    log = str(tmp_path / "stub")
     env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "TORCHELASTIC_USE_AGENT_STORE": ""}
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -116,12 +117,64 @@ def test_make_context_hands_rank0s_id_to_every_rank(tmp_path):
     res = sorted(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(30)
-    assert [e for _, e in res] == [None, None], res
-    uids = []
+    assert [e for _, e in res] == [None] * world, res
+    uids, devs = [], []
     for r in range(world):
         ev = [json.loads(ln) for ln in open(f"{log}.{r}")]
         uids.append(next(e["uid"] for e in ev if e["event"] == "ctx"))
-    assert uids[0] == uids[1] and len(uids[0]) == 256
+        devs.append(next(e["device"] for e in ev if e["event"] == "ctx"))
+    assert len(set(uids)) == 1 and len(uids[0]) == 256 and devs == list(range(world))
+
+
+def _clash_worker(rank, world, env, log, q):
+    try:
+        os.environ.update(env, DV_STUB_LOG=log, DV_STUB_BUS="0000:05:00.0")       # every rank names the same GPU
+        import importlib
+
+        from debvader_amd import parallel
+
+        parallel.E = importlib.import_module("tests.stub_engine")
+        try:
+            parallel.make_context(rank, world, local_rank=0)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    except Exception as e:                                  # pragma: no cover
+        q.put((rank, repr(e)))
+
+
+def test_two_ranks_mapped_onto_one_gpu_fail_fast_on_every_rank(tmp_path):
+    """LOCAL_RANK beyond the visible devices used to wrap around (two ranks on one GPU, an error or a stall inside
+    ncclCommInitRank later).  Now the ranks compare (host, PCI bus id) through the host group BEFORE the communicator is built
+    and every rank raises with the same message; no engine context is created."""
+    import json
+
+    world, log = 2, str(tmp_path / "stub")
+    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "TORCHELASTIC_USE_AGENT_STORE": ""}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_clash_worker, args=(r, world, env, log, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    for _, msg in res:
+        assert "ranks 0 and 1" in msg and "0000:05:00.0" in msg and "one GPU per rank" in msg, res
+    assert not any(os.path.exists(f"{log}.{r}") for r in range(world))         # no Context was ever constructed
+
+
+def test_local_rank_beyond_the_visible_gpus_is_an_error_not_a_modulo(monkeypatch):
+    from debvader_amd import parallel
+
+    class _E:
+        @staticmethod
+        def device_count():
+            return 4
+
+    monkeypatch.setattr(parallel, "E", _E)
+    with pytest.raises(RuntimeError, match="only 4 GPUs are visible"):
+        parallel.make_context(5, 8, local_rank=5)
 
 
 def _hub_only(port, q):
