@@ -201,7 +201,9 @@ def secondary_entries(E, ctx, synthetic_stamps, quick: bool):
     fwd_flops = 2.0 * (enc_macs + dec_macs + 32 * 33 // 2)
     # ---- BASELINE configs[2]: the same model with bf16 storage / bf16 MFMA operands (per-GPU batch 256) ----
     B = 256
-    x, y = synthetic_stamps(4 * B, seed=1000)
+    from debvader_amd.data import bench_stamps
+
+    x, y, _ = bench_stamps(4 * B, seed=1000)
     steps = 20 if quick else 60
     _progress("secondary: bf16 train step")
     eng = E.Engine(E.make_config(max_batch=B, dtype=1), ctx)
@@ -260,8 +262,13 @@ def secondary_entries(E, ctx, synthetic_stamps, quick: bool):
     out["deblend_field_on_device_bf16"] = cutouts_run(ctx, n_cutouts=131072 if quick else 1000000, chunk=8192, dtype=1,
                                                       on_device=True)
     _progress("secondary: deblend over field cutouts (fp32, then bf16)")
-    out["deblend_cutouts"] = cutouts_run(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=0)
-    out["deblend_cutouts_bf16"] = cutouts_run(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=1)
+    # the reference's own call sequence (DeblendField.deblend_field with its defaults): one engine call per deblend_field
+    from tools.field_cutouts import run_drop_in
+
+    out["deblend_cutouts"] = run_drop_in(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=0,
+                                         per_call=16384 if quick else 32768)
+    out["deblend_cutouts_bf16"] = run_drop_in(ctx, n_cutouts=32768 if quick else 131072, chunk=8192, dtype=1,
+                                              per_call=16384 if quick else 32768)
     # ---- BASELINE configs[3]: 128 x 128 x 6 stamps, six levels (per-GPU share of the global batch 512: 64) ----
     _progress("secondary: 128-pixel architecture")
     B3 = 64
@@ -575,8 +582,12 @@ def main():
         x = rng.normal(0, 0.3, size=(2 * B, H, H, C)).astype(np.float32)
         y = np.abs(x) * 0.5
         pool = 2 * B
+        data_desc = "synthetic (Gaussian noise stamps of the 128-px geometry); random-init weights"
     else:
-        x, y = synthetic_stamps(pool, seed=1000 + rank)
+        # the real DC2 sample stamps tiled + the config-1 generator to fill the resident pool
+        from debvader_amd.data import bench_stamps
+
+        x, y, data_desc = bench_stamps(pool, seed=1000 + rank)
     eng.upload(0, x, y)
     eng.optimizer_reset(1e-4)
     Bg = B * world
@@ -673,7 +684,7 @@ def main():
             # the launch line and the step structure; its throughput means nothing and is not reported as a value
             "value": None if rehearsal else value, "unit": "stamps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": data_desc,
             "config": {"workload": conf["label"], "global_batch": Bg, "per_gpu_batch": B, "parallelism": f"dp{world}"},
             "last_loss": last_loss,
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,

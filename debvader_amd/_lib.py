@@ -28,6 +28,7 @@ class DvConfig(C.Structure):
         ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("bn_moving_var_unbiased", C.c_int32),
         ("sigma_floor", C.c_float), ("diag_shift", C.c_float),
         ("dtype", C.c_int32),
+        ("infer_graph", C.c_int32),
     ]
 
 

@@ -501,7 +501,8 @@ struct dv_model {
   // hipGraph at its second use and replayed afterwards; the noise seed lives in device memory
   unsigned long long* seed_dev = nullptr;
   bool use_seed_dev = false;
-  bool infer_graph = false;
+  bool infer_graph = false;      // dv_config.infer_graph
+  uint64_t graph_epoch = ~(uint64_t)0;   // parameter epoch the captured graphs belong to
   // set by dv_infer / dv_encode / dv_decode for calls of at most 16 stamps: the deep layers slice K over workgroups
   // (gconv2_small_splitk).  Decided per CALL, not per launch, so that how a longer input is chunked never changes bits.
   bool tiny_call = false;
@@ -3065,6 +3066,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   const Arch& A = m->A;
   const size_t Bc = (size_t)cfg->max_batch;
   m->Bc = cfg->max_batch;
+  m->infer_graph = cfg->infer_graph != 0;
   if (cfg->dtype == DV_DTYPE_F32) {
     // The fp32 weight-gradient and tiled kernels address a layer's tensors with 32-bit ELEMENT offsets.  A training step
     // has no lanes, so a max_batch whose largest activation reaches 2^31 elements would fail inside the first step, with
@@ -3553,10 +3555,19 @@ static int infer_entry(dv_model* m, const void* x, bool x_f64, int64_t N, const 
     // Launch-bound sizes (one forward lane, a single chunk, engine-drawn noise): replay a captured graph.  The first
     // call of a size runs eagerly (kernel attributes and other one-time host work must not fall into a capture), the
     // second is captured.
-    // Opt-in (dv_model_set_infer_graph): measured on MI355X a replay takes exactly as long as the
+    // Opt-in (dv_config.infer_graph): measured on MI355X a replay takes exactly as long as the
     // eager launches (0.600 vs 0.603 ms for one stamp, 0.806 vs 0.803 ms for 32) - the chain of ~45 dependent
     // few-microsecond kernels is bound by the GPU's dispatch-to-dispatch latency, not by host submission.
     const bool graphable = m->infer_graph && nb < 64 && N <= m->Bc && !eps && m->seed_dev != nullptr;
+    if (graphable && m->graph_epoch != m->param_epoch) {
+      // a parameter changed since the graphs were captured: the derived weights (Winograd transforms, bf16 casts, padded
+      // head) are re-made at the head of an EAGER forward pass, which a replay does not contain - drop the graphs; the
+      // next call of a size runs eagerly (and refreshes), the one after it is captured again
+      for (auto& kv : m->infer_graphs) (void)hipGraphExecDestroy(kv.second);
+      m->infer_graphs.clear();
+      m->infer_seen.clear();
+      m->graph_epoch = m->param_epoch;
+    }
     if (graphable) {
       const int key = nb | (zstd ? 1 << 20 : 0) | (m->normalise ? 1 << 21 : 0) | (loc ? 1 << 22 : 0);
       m->use_seed_dev = true;
@@ -3611,14 +3622,6 @@ int dv_model_set_keep_outputs(dv_model* m, int32_t on) {
   m->keep_outputs = on != 0;
   return DV_OK;
 }
-
-#ifdef DV_DEBUG_EXPORTS      // libdebvader_hip_debug.so only (include/debvader_hip_debug.h)
-int dv_model_set_infer_graph(dv_model* m, int32_t on) {
-  if (!m) return DV_E_INVALID;
-  m->infer_graph = on != 0;
-  return DV_OK;
-}
-#endif
 
 
 int dv_model_set_mse_sample(dv_model* m, int32_t on) {

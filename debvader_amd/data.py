@@ -43,3 +43,33 @@ def synthetic_stamps(n: int, seed: int = 0, size: int = 59, nb: int = 6, dtype=n
         Y[i] = (lab[..., None] * sed).astype(dtype)
         X[i] = (img[..., None] * sed + noise).astype(dtype)
     return X, Y
+
+
+def dc2_sample_stamps(path=None):
+    """The reference's real sample stamps this repository carries: the first four 59x59x6 DC2 stamps of
+    src/debvader/data/dc2_imgs/imgs_dc2.npy, float32, kept as the inputs of the golden fixture tests/golden/dc2_b4.npz.
+    Returns (x, y) or None when the fixture is not there (an installed package without the test tree)."""
+    import os
+
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dc2_b4.npz")
+    if not os.path.exists(path):
+        return None
+    with np.load(path) as d:
+        return np.asarray(d["x"], np.float32), np.asarray(d["y"], np.float32)
+
+
+def bench_stamps(n: int, seed: int = 0, real_fraction: float = 0.125):
+    """real DC2 stamps tiled + the config-1 generator to fill the batch.  Every 1/real_fraction-th
+    row is one of the four real stamps (cycled), the others come from synthetic_stamps(seed).  Returns (x, y, description);
+    the kernels' run time does not depend on the values, the description says what the rows were."""
+    x, y = synthetic_stamps(n, seed=seed)
+    real = dc2_sample_stamps()
+    if real is None or real[0].shape[1:] != x.shape[1:]:
+        return x, y, "synthetic"
+    step = max(1, int(round(1.0 / real_fraction)))
+    rows = np.arange(0, n, step)
+    x[rows] = real[0][np.arange(rows.size) % real[0].shape[0]]
+    y[rows] = real[1][np.arange(rows.size) % real[1].shape[0]]
+    return x, y, (f"synthetic Gaussian-blob stamps (SURVEY 8(d) config 1 generator) with the 4 real DC2 stamps of "
+                  f"tests/golden/dc2_b4.npz (from the reference's imgs_dc2.npy) tiled into every {step}th row; random-init weights")

@@ -56,6 +56,12 @@ typedef struct dv_config {
   int32_t dtype;                     /* DV_DTYPE_F32 (0, the reference's precision) or DV_DTYPE_BF16 (1): bf16 storage and
                                         bf16 MFMA operands for the conv / conv-transpose stacks (model.py:79-98,112-137),
                                         fp32 accumulation, fp32 master weights / Adam / dense trunk / sampler / head */
+  int32_t infer_graph;               /* 0 (default) / 1: dv_infer / dv_infer_f64 calls of fewer than 64 stamps in one chunk with
+                                        engine-drawn noise replay a captured hipGraph of their forward pass (the ~45 launches of
+                                        BASELINE configs[4]'s "hipGraph-captured decode", deblender.py:18) instead of launching
+                                        them one by one: first call of a size eager, second captured, then replayed; graphs are
+                                        dropped when a parameter changes.  Same bits either way.  Off by default: on MI355X a
+                                        one-stamp forward is bound by the duration of its kernels, not by submission */
 } dv_config;
 #define DV_DTYPE_F32 0
 #define DV_DTYPE_BF16 1

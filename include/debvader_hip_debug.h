@@ -33,12 +33,6 @@ int dv_debug_winograd(int32_t on);
 /* weight gradient of a stride-1 3x3 layer X [NB,H,H,Cx] x Y [NB,H,H,Cy] through the Winograd-domain kernel and through the
  * direct kernels on the same pseudo-random operands: out2 = {max |difference|, max |reference|} */
 int dv_debug_wgrad_check(dv_ctx* ctx, int32_t NB, int32_t H, int32_t Cx, int32_t Cy, float* out2);
-/* Replay a captured hipGraph for the forward pass of small inference batches (< 64 stamps, one chunk, engine-drawn
- * noise) instead of launching its ~45 kernels one by one: BASELINE configs[4] "hipGraph-captured decode" /
- * SURVEY row A10.  Kept as an experiment (no caller in debvader_amd/), off by default: on MI355X the replay takes exactly as long as the eager launches - a one-stamp forward
- * is bound by the DURATION of its kernels (a handful of workgroups per layer walking K serially: 27 kernels, 520 us of
- * kernel time inside a 668 us span), not by host submission or dispatch.  Same results either way. */
-int dv_model_set_infer_graph(dv_model* m, int32_t on);
 /* process-wide, read when a model is created: the fp32 engine's PReLU backward inside the data-gradient epilogue
  * (batch-major tiles) instead of the separate pass.  Measured slower at every batch size; kept for the A/B and for the
  * summation-order test of tests/test_gpu_api.py. */

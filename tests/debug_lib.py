@@ -32,7 +32,6 @@ DEBUG_SIGNATURES = {
     "dv_debug_fuse_prelu_bwd": (C.c_int, [C.c_int32]),
     "dv_debug_wgrad_check": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "dv_debug_wgrad": (C.c_int, [_p] + [C.c_int32] * 9 + [_f]),
-    "dv_model_set_infer_graph": (C.c_int, [_p, C.c_int32]),
 }
 
 _dlib = None

@@ -51,7 +51,7 @@ def test_the_product_library_exports_the_boundary_and_nothing_else():
     assert exported == _declared_symbols("debvader_hip.h"), set(exported) ^ set(_declared_symbols("debvader_hip.h"))
     assert not [n for n in exported if "debug" in n]
     dbg = _declared_symbols("debvader_hip_debug.h")
-    assert len(dbg) >= 9 and sorted(debug_lib.DEBUG_SIGNATURES) == dbg
+    assert len(dbg) >= 8 and sorted(debug_lib.DEBUG_SIGNATURES) == dbg
     exported_dbg = _exported_symbols(debug_lib.DEBUG_LIB_PATH)
     assert sorted(set(exported) | set(dbg)) == exported_dbg
     for d, _, files in os.walk(os.path.join(ROOT, "debvader_amd")):
@@ -71,7 +71,8 @@ def test_config_struct_matches_header_defaults():
     assert abs(cfg.kl_weight - 0.01) < 1e-9 and cfg.kl_multiplicity == 2
     assert abs(cfg.bn_eps - 1e-3) < 1e-9 and abs(cfg.sigma_floor - 1e-4) < 1e-10 and abs(cfg.diag_shift - 1e-5) < 1e-11
     assert cfg.dtype == _lib.DV_DTYPE_F32                       # the reference computes in float32
-    assert C.sizeof(_lib.DvConfig) == 4 * (5 + 8 + 8 + 1 + 7 + 1)
+    assert cfg.infer_graph == 0                                 # hipGraph replay of small inference calls: opt-in
+    assert C.sizeof(_lib.DvConfig) == 4 * (5 + 8 + 8 + 1 + 7 + 1 + 1)
 
 
 def test_arch_queries_match_reference_summary_and_oracle():
@@ -97,6 +98,24 @@ def test_arch_queries_match_reference_summary_and_oracle():
     head = 64 * 64 * 9 * 32 * 12                                  # the head conv stays 3x3 (model.py:137)
     dense = 4096 * 560 + 32 * 560 + 560 * 4096
     assert (e5 + d5 - head - dense) * 9 == (enc + dec - head - dense) * 25
+
+
+def test_package_root_exports_what_the_reference_root_exports():
+    """src/debvader/__init__.py:1-2: `from debvader import DeblendField` has a one-line counterpart; the names resolve
+    lazily (importing the package loads neither pandas nor the HIP library), and the out-of-scope name says why."""
+    import subprocess
+    import sys
+
+    code = ("import sys, debvader_amd\n"
+            "assert 'pandas' not in sys.modules and 'debvader_amd._lib' not in sys.modules\n"
+            "from debvader_amd import DeblendField, create_model_vae, load_deblender, train_deblender, extract_cutouts\n"
+            "from debvader_amd.deblend.field_deblender import DeblendField as D2\n"
+            "assert DeblendField is D2 and callable(create_model_vae) and 'DeblendField' in dir(debvader_amd)\n"
+            "try:\n    debvader_amd.IterativeDeblendField\n    raise SystemExit('no error')\n"
+            "except NotImplementedError as e:\n    assert 'sep' in str(e)\n"
+            "try:\n    debvader_amd.nonsense\n    raise SystemExit('no error')\nexcept AttributeError:\n    pass\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
 
 
 def test_bad_architectures_are_rejected_with_a_message():

@@ -1,6 +1,6 @@
 """Per-layer parity of the fp32 engine at the REAL layer shapes and the quoted batch (VERDICT r3 "what's weak" #2 (iii)):
 every Conv2D / Conv2DTranspose layer of the 59 x 59 x 6 net (model.py:79-98,112-137) at 256 stamps, and of the
-128 x 128 x 6 / six-level net at 32, re-computed ALONE by the oracle's float64 primitives from the ENGINE's stored input
+128 x 128 x 6 / six-level net at its per-GPU batch of 64 (BASELINE configs[3]), re-computed ALONE by the oracle's float64 primitives from the ENGINE's stored input
 of that layer (teacher forcing: nothing cascades, a failing layer is named), forward and backward:
 
   forward   u = conv(engine's activation below) + bias, a = PReLU(u)          (Winograd / strip / stride-2 / gather-GEMM kernels)
@@ -43,7 +43,7 @@ ARCHS = {
 }
 
 
-@pytest.mark.parametrize("arch_name,B", [("59px", 256), ("128px", 32), ("59px-5x5", 24)])
+@pytest.mark.parametrize("arch_name,B", [("59px", 256), ("128px", 64), ("59px-5x5", 24)])
 def test_every_conv_layer_alone_against_the_oracle_primitives_fp32(arch_name, B):
     from debvader_amd import engine as E
     from debvader_amd.data import synthetic_stamps
@@ -176,6 +176,11 @@ def test_every_conv_layer_alone_against_the_oracle_primitives_fp32(arch_name, B)
     _check(report, "enc/bn/gamma", eng.get_grad("enc/bn/gamma"), (dwf[:, :, :C, :] * W0).sum((0, 1, 3)), 2e-3)
     _check(report, "enc/bn/beta", eng.get_grad("enc/bn/beta"), (dwf[:, :, C:C + 1, :] * W0).sum((0, 1, 3)), 2e-3)
     eng.close()
+    from tests import margins
+    tol_of = lambda n: (TOL_ACT if ("_u" in n or "_du" in n or "_da" in n or n == "head_pre") else 1e-6 if "_a" in n else
+                        2e-3 if "/bn/" in n else TOL_BIAS if n.endswith("bias") else TOL_ALPHA if n.endswith("alpha") else TOL_W)
+    margins.record(f"fp32 engine, every conv layer ALONE (teacher-forced) vs float64 primitives: {arch_name}, B={B}",
+                   [(n, e, None, tol_of(n), "") for n, e in report])
     worst = sorted(report, key=lambda r: -r[1])[:8]
     print(f"\n{arch_name} B={B}: {len(report)} per-layer fp32 checks, largest relative errors: " +
           ", ".join(f"{n} {e:.2e}" for n, e in worst))

@@ -388,28 +388,37 @@ def test_monte_carlo_sample_batching_is_invisible():
     assert (outs[0][1] > 0).any()
 
 
-def test_graph_replayed_small_batch_inference_equals_eager_launches():
-    """BASELINE configs[4] "hipGraph-captured decode": the forward of a small batch replayed from a captured graph
-    (third call onwards) returns what the eager launches return for the same seed, and the seed - read from device
-    memory by the replayed sampler - still changes the noise."""
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_graph_replayed_small_batch_inference_equals_eager_launches(dtype):
+    """BASELINE configs[4] "hipGraph-captured decode" as a product switch (dv_config.infer_graph, default off): the forward of
+    a small batch replayed from a captured graph (third call of a size onwards) returns what the eager launches of a
+    second engine return for the same seed; the seed - read from device memory by the replayed sampler - still changes the
+    noise; and a parameter change drops the graphs (their derived weights - Winograd transforms, bf16 casts - are made by
+    eager passes only), so the replay never serves stale weights."""
     from debvader_amd import engine as E
-    from debvader_amd._lib import check
-    from tests import debug_lib
 
     x, _ = _data(5, 21)
-    with debug_lib.debug_build() as lib:   # the switch is an export of libdebvader_hip_debug.so (debvader_hip_debug.h)
-        eng = E.Engine(E.make_config(max_batch=64))
-        eng.init(seed=2)
-        eager = [eng.infer(x, seed=s, want=("loc", "scale", "z")) for s in (7, 8)]
-        check(lib.dv_model_set_infer_graph(eng._h, 1))      # kept as a measured experiment
-        for s in (1, 2):                   # eager warm-up of this size, then the capture
-            eng.infer(x, seed=s, want=("loc", "scale", "z"))
-        replay = [eng.infer(x, seed=s, want=("loc", "scale", "z")) for s in (7, 8)]
-        for a, b in zip(eager, replay):
-            for k in ("loc", "scale", "z"):
+    eager = E.Engine(E.make_config(max_batch=64, dtype=dtype))
+    graph = E.Engine(E.make_config(max_batch=64, dtype=dtype, infer_graph=1))
+    eager.init(seed=2)
+    graph.init(seed=2)
+    want = ("loc", "scale", "z")
+    for s in (1, 2):                       # eager warm-up of this size, then the capture
+        graph.infer(x, seed=s, want=want)
+    for rnd in range(2):
+        ref = [eager.infer(x, seed=s, want=want) for s in (7, 8)]
+        rep = [graph.infer(x, seed=s, want=want) for s in (7, 8)]
+        for a, b in zip(ref, rep):
+            for k in want:
                 np.testing.assert_array_equal(a[k], b[k])
-        assert np.abs(replay[0]["z"] - replay[1]["z"]).max() > 0
-        eng.close()
+        assert np.abs(rep[0]["z"] - rep[1]["z"]).max() > 0
+        # second round: new weights in both engines - the replaying engine must notice
+        k = eager.get_param("dec/convt3/kernel") * 1.5 + 0.01
+        for e in (eager, graph):
+            e.set_param("dec/convt3/kernel", k)
+            e.set_param("enc/conv2/kernel", e.get_param("enc/conv2/kernel") * 0.5)
+    eager.close()
+    graph.close()
 
 
 def test_deblend_sharded_single_rank_equals_deblend():

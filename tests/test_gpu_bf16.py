@@ -20,6 +20,7 @@ import pytest
 
 from oracle import vae_oracle as vo
 from oracle import vae_oracle_bf16 as vb
+from tests import margins
 
 pytestmark = pytest.mark.gpu
 
@@ -92,12 +93,22 @@ def _run(arch, B, seed, data=None, train_decoder=True, tol_out=1e-2, tol_grad_b=
         assert abs(out[k] - rb[k]) <= 5e-4 * abs(rb[k]) + 1e-9, ("bf16 oracle", k, out[k], rb[k])
         assert abs(out[k] - r[k]) <= tol_scal_64 * abs(r[k]) + 1e-9, ("fp64 oracle", k, out[k], r[k])
     assert set(gb) == set(g)
+    rows = [(k, abs(out[k] - rb[k]) / (abs(rb[k]) + 1e-30), abs(out[k] - r[k]) / (abs(r[k]) + 1e-30), 5e-4,
+             f"ELBO scalar, relative; other = vs float64 oracle (bound {tol_scal_64:g})") for k in ("loss", "nll_mean", "kl_reg")]
+    failed = []
     for name in g:
         gg = eng.get_grad(name)
-        assert _relmax(gg, gb[name]) <= tol_grad_b, ("bf16 oracle", name, _relmax(gg, gb[name]))
-        if check_fp64_grads:
-            assert _cos(gg, g[name]) >= min_cos, ("fp64 oracle, cosine", name, _cos(gg, g[name]))
-            assert _relmax(gg, g[name]) <= tol_grad_64, ("fp64 oracle", name, _relmax(gg, g[name]))
+        eb, e64, cs = _relmax(gg, gb[name]), _relmax(gg, g[name]), _cos(gg, g[name])
+        rows.append((name, eb, e64, tol_grad_b, f"gradient; other = vs float64 oracle (bound {tol_grad_64:g}), cosine {cs:.4f} "
+                                                f"(bound {min_cos:g}); bf16 oracle vs float64: {_relmax(gb[name], g[name]):.3e}"))
+        if eb > tol_grad_b:
+            failed.append(("bf16 oracle", name, eb))
+        if check_fp64_grads and (cs < min_cos or e64 > tol_grad_64):
+            failed.append(("fp64 oracle", name, e64, cs))
+    margins.record(f"bf16 engine vs bf16-rounding oracle and float64 oracle: {'x'.join(map(str, arch.input_shape))}, "
+                   f"{len(arch.filters)} levels, B={B}, {'stage 1' if train_decoder else 'decoder frozen'}, head scale bias +0.3",
+                   rows, "engine = vs the bf16-rounding oracle (same storage roundings); errors are max|a - ref| / max|ref| per tensor")
+    assert not failed, failed
     if not train_decoder:
         for name, _, tr in arch.param_specs():
             if name.startswith("dec/"):
@@ -183,6 +194,20 @@ def test_full_arch_64_stamps():
 
     x, y = synthetic_stamps(64, seed=6)
     _run(vo.Arch(), B=64, seed=3, data=(x, y), tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25)
+
+
+def test_full_arch_at_the_quoted_batch_of_256_stamps():
+    """BASELINE configs[2]'s per-GPU batch (VERDICT r4 "what's weak" #3): the WHOLE bf16 step of the 59 x 59 x 6 net at 256
+    stamps - the 256-stamp uniform tiles, the 128- / 64-stamp forms of the deep layers, paired chunks, the fused
+    PReLU-backward epilogues - against the bf16-rounding oracle (ELBO scalars <= 5e-4 relative, outputs <= 1e-2 * max) and
+    the float64 oracle (ELBO <= 5e-3 relative, outputs <= 2e-2 * max).  Gradients per tensor: <= 0.25 * max against the
+    bf16 oracle and against float64, cosine >= 0.97 - the bounds of the 64-stamp case; every flipped bf16 rounding of an
+    activation seeds a difference that 17 layers carry on, and the two bf16 evaluations sit as far from each other as
+    each sits from float64 (the measured numbers per tensor: profiles/r05_parity_margins.txt)."""
+    from debvader_amd.data import synthetic_stamps
+
+    x, y = synthetic_stamps(256, seed=9)
+    _run(vo.Arch(), B=256, seed=5, data=(x, y), tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25)
 
 
 def test_inference_matches_the_bf16_oracle_and_other_entry_points():

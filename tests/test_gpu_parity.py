@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import vae_oracle as vo
+from tests import margins
 
 pytestmark = pytest.mark.gpu
 
@@ -108,13 +109,23 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True, sigma_bias=0.0, f3
     for k in ("loss", "nll_mean", "kl_reg", "mse"):
         assert abs(out[k] - ref[k]) <= 1e-4 * abs(ref[k]) + 1e-12, (k, out[k], ref[k])
     worst = ("", 0.0)
+    rows = [(k, _relmax(acts[k], c[k]), None, 2e-4, "activation / output") for k in acts]
+    rows += [(k, abs(out[k] - ref[k]) / (abs(ref[k]) + 1e-30), None, 1e-4, "ELBO scalar, relative") for k in ("loss", "nll_mean", "kl_reg")]
+    failed = []
     for name, _, tr in arch.param_specs():
         if name not in g:
             continue
         e = _relmax(eng.get_grad(name), g[name])
         if e > worst[1]:
             worst = (name, e)
-        assert e <= tol(name), (name, e, tol(name))
+        rows.append((name, e, floor.get(name), tol(name),
+                     "gradient" + ("" if tol(name) <= _grad_tol(name) else "  [bound above 1e-3: float32's own distance]")))
+        if e > tol(name):
+            failed.append((name, e, tol(name)))
+    margins.record(f"fp32 engine vs float64 oracle: {'x'.join(map(str, arch.input_shape))}, {len(arch.filters)} levels, B={B}, "
+                   f"{'stage 1' if train_decoder else 'stage 2 (decoder frozen)'}, head scale bias +{sigma_bias}", rows,
+                   "errors are max|a - oracle| / max|oracle| per tensor; 'other impl' = the numpy float32 evaluation of the same step")
+    assert not failed, failed
 
     # the production form of the step: no loc / scale stores in the head kernel
     eng.keep_outputs(False)

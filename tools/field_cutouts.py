@@ -116,6 +116,82 @@ def run(ctx=None, n_cutouts=1_000_000, chunk=8192, dtype=0, field=None, tiles=8,
     }
 
 
+def run_drop_in(ctx=None, n_cutouts=131072, chunk=8192, dtype=0, field=None, tiles=8, per_call=32768, seed=0):
+    """The reference's OWN call sequence, nothing engine-specific in it: `DeblendField(net, field).deblend_field(distances)`
+    (deblend/field_deblender.py:219-383 with its defaults) on a net from create_model_vae, `per_call` galaxies per call,
+    the recarray with float64 cutout_images and float32 mean / stddev stamps per galaxy coming back every time.  Since round 5
+    that is one engine call per deblend_field (dv_infer_cutouts_keep); before, extract_cutouts -> deblend with a float64 D2H,
+    a host cast and an H2D per chunk."""
+    from debvader_amd import engine as E
+    from debvader_amd.deblend.field_deblender import DeblendField
+    from debvader_amd.model import model
+
+    ctx = ctx or E.default_context()
+    if field is None:
+        field = synthetic_field()
+    field = np.asarray(field, np.float64).reshape(field.shape[-3:])
+    scene = np.ascontiguousarray(np.tile(field, (tiles, tiles, 1)))
+    F, cs = scene.shape[0], 59
+    starts = np.random.default_rng(seed).integers(0, F - cs + 1, size=(n_cutouts, 2))
+    dist = (starts + cs // 2 - F // 2).astype(np.float64)        # extraction.py:26-30 read backwards: start -> distance to centre
+    net, _, _, _ = model.create_model_vae((cs, cs, 6), 32, [32, 64, 128, 256], [3, 3, 3, 3], max_batch=chunk, ctx=ctx, seed=0,
+                                          dtype="bf16" if dtype else "float32")
+    db = DeblendField(net, scene[None])
+    eng = net._core.engine
+    t_eng = [0.0]
+    real = eng.infer_cutouts_keep
+
+    def timed(*a, **k):
+        t = time.perf_counter()
+        r = real(*a, **k)
+        t_eng[0] += time.perf_counter() - t
+        return r
+
+    eng.infer_cutouts_keep = timed
+    res = db.deblend_field(dist[:min(2 * chunk, n_cutouts)])     # warm-up: kernel attributes, the pinned transfer ring
+    assert len(res) == min(2 * chunk, n_cutouts)
+    del res
+    t_eng[0] = 0.0
+    checksum, n_pass = 0.0, 0
+    t0 = time.perf_counter()
+    for b in range(0, n_cutouts, per_call):
+        res = db.deblend_field(dist[b:b + per_call])
+        checksum += float(res["output_images_mean"][0][29, 29, 2]) + float(res["cutout_images"][-1][29, 29, 2])
+        n_pass += int(np.sum(res["passed_cuts"]))
+        del res
+    total = time.perf_counter() - t0
+    # the same forward with the stamps resident in HBM (no host copies)
+    nres = min(chunk, n_cutouts)
+    x32 = ctx.scene_extract(scene, starts[:nres], cs).astype(np.float32)
+    eng.upload(1, x32, x32)
+    eng.eval_step(1, first=0, B=nres, seed=3)
+    ctx.sync()
+    reps = 5
+    t1 = time.perf_counter()
+    for r in range(reps):
+        eng.eval_step(1, first=0, B=nres, seed=4 + r)
+    ctx.sync()
+    t_res = (time.perf_counter() - t1) / reps
+    eng.close()
+    n = n_cutouts
+    return {
+        "workload": f"BASELINE configs[4] per GPU, the reference's own call sequence: DeblendField(net, field).deblend_field("
+                    f"distances) over {n} galaxies of a {F}x{F}x6 scene tiled from a 259x259x6 field, {per_call} per call, "
+                    f"{chunk} per network pass, {'bf16' if dtype else 'fp32'} engine",
+        "value": n / total, "unit": "stamps/s", "dtype": "bf16" if dtype else "f32", "n_cutouts": n, "chunk": chunk,
+        "per_call": per_call,
+        "includes": "per call: field H2D, cutout gather + float32 cast on the GPU, forward, D2H of mean and stddev through the "
+                    "pinned ring into fresh arrays, the float64 cutout_images assembled on the host from the field beside the "
+                    "forward passes (dv_infer_cutouts_keep), the centre-MSE quality cut and the pandas recarray of the reference",
+        "engine_call_stamps_per_s": n / t_eng[0] if t_eng[0] > 0 else None,
+        "python_side_s": total - t_eng[0],
+        "host_bytes_per_stamp": cs * cs * 6 * (8 + 4 + 4), "link_bytes_per_stamp": cs * cs * 6 * 8,
+        "resident_forward_stamps_per_s": nres / t_res,
+        "resident_forward_note": "same forward + head on a chunk already in HBM (dv_eval_step), no host copies",
+        "passed_cuts": n_pass, "checksum": checksum,
+    }
+
+
 def _run_on_device(ctx, eng, scene, starts, lo, hi, chunk, dtype, F, cs):
     """DeblendField.deblend_field(on_device=True) + get_predicted_field / get_residual_field: cutout gather, network and the
     compositing of every stamp's mean and stddev into the field-sized results in ONE engine call (dv_infer_cutouts_composite);
@@ -200,12 +276,17 @@ def main():
     ap.add_argument("--fused", action="store_true", help="deblend_field_cutouts: gather on the GPU, no host round trip")
     ap.add_argument("--stream", action="store_true", help="deblend_field_cutouts(on_chunk=...): results consumed per chunk")
     ap.add_argument("--on-device", action="store_true", help="compositing on the GPU behind the forward passes: only fields come back")
+    ap.add_argument("--drop-in", action="store_true", help="DeblendField.deblend_field(distances), the reference's call sequence")
+    ap.add_argument("--per-call", type=int, default=32768)
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     from debvader_amd import engine as E
 
     ctx = E.Context(int(os.environ.get("LOCAL_RANK", "0")), 0, 1, None)      # no collective: every rank is on its own
     field = np.load(a.field) if a.field else None
+    if a.drop_in:
+        print(json.dumps(run_drop_in(ctx, a.n, a.chunk, a.dtype, field, a.tiles, a.per_call)), flush=True)
+        return
     res = run(ctx, a.n, a.chunk, a.dtype, field, a.tiles, rank, world, fused=a.fused, stream=a.stream, on_device=a.on_device)
     res["rank"], res["world"] = rank, world
     print(json.dumps(res), flush=True)
