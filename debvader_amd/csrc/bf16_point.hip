@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void bf_input_kernel(const float* __restrict__
     if (b < NB) {
 #pragma unroll
       for (int c = 0; c < BI_MAXC; ++c)
-        if (c < C) lo[c] = (bp_bf16)((tile[sr][pp * C + c] - bn[2 * 8 + c]) * bn[3 * 8 + c]);   // bnstate rows are 8 wide
+        if (c < C) lo[c] = (bp_bf16)((tile[sr][pp * C + c] - bn[2 * DV_BN_MAXC + c]) * bn[3 * DV_BN_MAXC + c]);   // bnstate rows are DV_BN_MAXC wide
 #pragma unroll
       for (int c = 0; c < 8; ++c)
         if (c == C) lo[c] = (bp_bf16)1.f;

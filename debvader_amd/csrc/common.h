@@ -330,6 +330,9 @@ struct HeadParams {
 #define DV_MSE_STREAM 0x4D534500u   /* + rank */
 int launch_head(const HeadParams& p, hipStream_t s, int* nblocks_out);
 
+// input BatchNorm: the per-band state / sum rows are DV_BN_MAXC wide (bands 1 .. 15: the folded first conv reads bands + 1
+// channels of an 8- or 16-channel row)
+constexpr int DV_BN_MAXC = 16;
 int launch_bn_stats(const float* x, const int* idx, int first, int NB, int HW, int C, float* part, int* nblocks,
                     hipStream_t s);
 // out[c] = scale * sum_r part[r*ld + c] for c < ncols (ld = row stride, 0: ncols)
@@ -341,9 +344,6 @@ int launch_bn_finalize(const float* sums, float count, int C, const float* gamma
                        int training, int update_moving, float* bnstate, hipStream_t s);
 int launch_bn_apply(const float* x, const int* idx, int first, int NB, int HW, int C, int Cpad, const float* bnstate,
                     float* xn, hipStream_t s);
-int launch_bn_bwd(const float* dxn, const float* x, const int* idx, int first, int NB, int HW, int C, int Cpad,
-                  const float* bnstate, float* part, int* nblocks, hipStream_t s);
-
 int launch_prelu_fwd(const float* u, const float* alpha, float* a, long NB, int E, hipStream_t s);
 // da -> du in place; dalpha partials [nsplit][E]; dbias partials (mode by HW): see pointwise.hip
 int launch_prelu_bwd(float* da, const float* u, const float* alpha, int NB, int E, int C, int nsplit,
@@ -360,6 +360,7 @@ struct SamplerParams {
   float* kl;           // [NB]
   float* stddev;       // [NB, d] or null
   int NB, d;
+  int ldt, ldz;        // row strides of t and of eps / z / stddev (>= d + d(d+1)/2 and >= d; pad columns are written as zeros)
   float diag_shift;
   int gen;             // 1: generate eps with Philox(seed, stream, row0 + b)
   unsigned long long seed;
@@ -369,8 +370,9 @@ struct SamplerParams {
   const unsigned long long* seed_ptr;   // non-null: the seed is read from device memory (replayed hipGraphs)
 };
 int launch_sampler_fwd(const SamplerParams& p, hipStream_t s);
+// ldt: row stride of t and dt, ldz: of eps, z and dz (pad columns of dt are written as zeros)
 int launch_sampler_bwd(const float* t, const float* eps, const float* z, const float* dz, float* dt, int NB, int d,
-                       float diag_shift, float kls, hipStream_t s);
+                       int ldt, int ldz, float diag_shift, float kls, hipStream_t s);
 
 int launch_adam(float* w, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps,
                 hipStream_t s);

@@ -75,7 +75,11 @@ struct Arch {
   dv_config cfg;
   int H = 0, C = 0, d = 0, L = 0;
   int tw = 0, dec_hidden = 0, w0 = 0, flat = 0, dec_out = 0, crop0 = 0;
+  // row strides of the latent-sized tensors (t, d(t): twp; eps, z, stddev, the decoder's input: dp): tw and d padded to
+  // multiples of 4 floats for the 16-byte accesses of the dense kernels; the pad columns carry zeros
+  int twp = 0, dp = 0;
   int C2p = 0;  // head output channels as stored: 2*bands padded to a multiple of 16
+  int C0p = 8;  // channels of the normalised input as stored: bands + the constant 1 that carries the BatchNorm shift, padded to 8 or 16
   std::vector<int> enc_sizes;
   std::vector<Spec> specs;
   size_t n_enc_train = 0, n_train = 0, n_total = 0;  // flat counts incl. alignment padding
@@ -129,8 +133,12 @@ struct Arch {
       set_error("only square stamps are supported (reference uses input_shape[0] for both axes)");
       return E_INVALID;
     }
-    if (L < 1 || L > DV_MAX_LEVELS || C < 1 || C > 7 || d < 1 || d > 64 || H < 4) {
+    if (L < 1 || L > DV_MAX_LEVELS || C < 1 || C > 15 || d < 1 || d > 64 || H < 4) {
       set_error("unsupported architecture (levels=%d bands=%d latent=%d size=%d)", L, C, d, H);
+      return E_INVALID;
+    }
+    if (C > 7 && c->dtype == DV_DTYPE_BF16) {
+      set_error("the bf16 engine takes 1 .. 7 bands (bands=%d): use dtype f32 for 8 .. 15", C);
       return E_INVALID;
     }
     for (int i = 0; i < L; ++i) {
@@ -148,6 +156,8 @@ struct Arch {
       }
     }
     tw = d + d * (d + 1) / 2;
+    twp = (tw + 3) & ~3;
+    dp = (d + 3) & ~3;
     dec_hidden = 32 + 32 * 33 / 2;  // hard-coded params_size(32), model.py:114
     enc_sizes.assign(1, H);
     for (int i = 0; i < L; ++i) enc_sizes.push_back((enc_sizes.back() + 1) / 2);
@@ -162,6 +172,7 @@ struct Arch {
     }
     D0 = 7 + 6 * L;
     C2p = ((2 * C + 15) / 16) * 16;
+    C0p = C < 8 ? 8 : 16;
     specs.clear();
     auto add = [&](const std::string& n, std::vector<int64_t> sh, bool tr) {
       Spec s;
@@ -215,10 +226,6 @@ struct Arch {
     add("dec/head/bias", {2 * C}, true);
     // (any band count 1 .. 7: the first conv reads bands + 1 of 8 folded channels, the head stores 2*bands of C2p
     // columns, and the label / output rows of the head kernels are addressed per element unless bands == 6)
-    if (tw & 3 || dec_hidden & 3 || d & 3) {
-      set_error("latent_dim must be a multiple of 4 for the vectorised kernels");
-      return E_INVALID;
-    }
     // flat layout: [encoder trainables | decoder trainables | non-trainables], every tensor 16-byte aligned
     size_t off = 0;
     n_enc_params = n_dec_params = n_trainable_params = 0;
@@ -425,6 +432,10 @@ struct dv_model {
   float* W1p = nullptr;  // first conv kernel with the input BatchNorm folded in, 8 input channels
   float* G0s = nullptr;  // gradient w.r.t. W1p (scratch)
   float *Whp = nullptr, *bhp = nullptr, *Ghs = nullptr;  // head kernel/bias padded to C2p output channels, grad scratch
+  // latent sizes that are not multiples of 4 (model.py:164 takes any latent_dim): the encoder's Dense kernel / bias with their
+  // tw columns padded to twp (zeros), the decoder's first Dense kernel with its d rows padded to dp (zeros), and the scratch
+  // their weight gradients are written to; null when no padding is needed
+  float *Wdp = nullptr, *bdp = nullptr, *Gdp = nullptr, *W0p = nullptr, *G0p = nullptr;
   bool enc_trainable = true, dec_trainable = true;
   bool opt_enc = true, opt_dec = true;  // what the current optimizer updates (fixed at dv_optimizer_reset)
   float lr = 1e-4f, b1 = 0.9f, b2 = 0.999f, aeps = 1e-7f;
@@ -1546,11 +1557,39 @@ static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int 
   return launch_reduce_rows_f64(m->ws3, nr, ncols_out, m->G + m->A.specs[bias_spec].off, 1.0f, m->ctx->stream, C);
 }
 
+// the operands the dense trunk reads (the parameters themselves unless the latent sizes needed padding)
+static const float* enc_dense_w(const dv_model* m) { return m->Wdp ? m->Wdp : m->P + m->A.specs[m->A.enc_dk()].off; }
+static const float* enc_dense_b(const dv_model* m) { return m->bdp ? m->bdp : m->P + m->A.specs[m->A.enc_db()].off; }
+static float* enc_dense_g(dv_model* m) { return m->Gdp ? m->Gdp : m->G + m->A.specs[m->A.enc_dk()].off; }
+static const float* dec_dense0_w(const dv_model* m) { return m->W0p ? m->W0p : m->P + m->A.specs[m->A.D0 + 1].off; }
+static float* dec_dense0_g(dv_model* m) { return m->G0p ? m->G0p : m->G + m->A.specs[m->A.D0 + 1].off; }
+// the gradient a padded weight-gradient launch left in its scratch -> the parameter's gradient, on the weight-gradient
+// stream behind the launch's slab sum
+static int wgrad_result_ready(dv_model* m, hipStream_t ws);
+static int take_padded_grad(dv_model* m, const float* scratch, float* dst, int rows, int nsrc, int ndst) {
+  hipStream_t ws = m->wstream ? m->wstream : m->ctx->stream;
+  DV_TRY(wgrad_result_ready(m, ws));
+  ProfScope ps(m, 2, ws);
+  return launch_take_cols(scratch, dst, rows, nsrc, ndst, ws);
+}
+// rows of `width` floats between buffers whose row strides may differ (the padded latent tensors <-> the caller's dense arrays)
+static int copy_rows(float* dst, size_t dst_ld, const float* src, size_t src_ld, size_t width, size_t rows, hipMemcpyKind kind,
+                     hipStream_t s) {
+  if (rows == 0) return OK;
+  if (dst_ld == width && src_ld == width)
+    DV_HIP(hipMemcpyAsync(dst, src, rows * width * sizeof(float), kind, s));
+  else
+    DV_HIP(hipMemcpy2DAsync(dst, dst_ld * sizeof(float), src, src_ld * sizeof(float), width * sizeof(float), rows, kind, s));
+  return OK;
+}
+
 static int refresh_head_pad(dv_model* m, hipStream_t st = nullptr) {
   const Arch& A = m->A;
   m->bf.dirty = true;
   m->param_epoch++;
   if (!st) st = m->ctx->stream;
+  if (m->W0p)      // decoder Dense 0 [d, hidden] -> [dp, hidden]: as one row of d * hidden floats padded to dp * hidden
+    DV_TRY(launch_pad_cols(m->P + A.specs[A.D0 + 1].off, m->W0p, 1, A.d * A.dec_hidden, A.dp * A.dec_hidden, st));
   DV_TRY(launch_pad_cols(m->P + A.specs[A.head_k()].off, m->Whp, 9 * A.cfg.filters[0], 2 * A.C, A.C2p, st));
   return launch_pad_cols(m->P + A.specs[A.head_b()].off, m->bhp, 1, 2 * A.C, A.C2p, st);
 }
@@ -1559,8 +1598,12 @@ static int refresh_w1p(dv_model* m) {
   const Arch& A = m->A;
   m->bf.dirty = true;
   m->param_epoch++;
+  if (m->Wdp) {
+    DV_TRY(launch_pad_cols(m->P + A.specs[A.enc_dk()].off, m->Wdp, A.flat, A.tw, A.twp, m->ctx->stream));
+    DV_TRY(launch_pad_cols(m->P + A.specs[A.enc_db()].off, m->bdp, 1, A.tw, A.twp, m->ctx->stream));
+  }
   return launch_pad_w1(m->P + A.specs[A.enc_k(0)].off, m->P + A.specs[0].off, m->P + A.specs[1].off, m->W1p,
-                       A.enc_ksz(0) * A.enc_ksz(0), A.C, 8, A.cfg.filters[0], m->ctx->stream);
+                       A.enc_ksz(0) * A.enc_ksz(0), A.C, A.C0p, A.cfg.filters[0], m->ctx->stream);
 }
 
 // ---- forward ----------------------------------------------------------------------------------
@@ -1587,13 +1630,13 @@ static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first,
       int nblk = 0;
       ProfScope ps(m, 2, s);
       // one 16-float partial row per 1024 pixels (pointwise.hip BN_PIX_PER_BLOCK): checked BEFORE the launch writes them
-      if (((size_t)NB * HW + 1023) / 1024 * 16 > m->ws3_elems) {
+      if (((size_t)NB * HW + 1023) / 1024 * (2 * DV_BN_MAXC) > m->ws3_elems) {
         set_error("BN statistics workspace too small for %d stamps", NB);
         return E_STATE;
       }
       DV_TRY(launch_bn_stats(xsrc, idx, first, NB, HW, A.C, m->ws3, &nblk, s));
-      DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 16, m->bnsums, 1.0f, s));
-      DV_TRY(allreduce_small(m->ctx, m->bnsums, 16));
+      DV_TRY(launch_reduce_rows_f64(m->ws3, nblk, 2 * DV_BN_MAXC, m->bnsums, 1.0f, s));
+      DV_TRY(allreduce_small(m->ctx, m->bnsums, 2 * DV_BN_MAXC));
     }
     m->bn_pre_valid = false;
   }
@@ -1627,10 +1670,10 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
   hipStream_t s = fwd_stream(m);
   const int HW = A.H * A.H;
   float* P = m->P;
-  float* xn = LANE(m->xn, (size_t)HW * 8);
+  float* xn = LANE(m->xn, (size_t)HW * A.C0p);
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_bn_apply(xsrc, idx ? idx + m->b0 : nullptr, first + m->b0, NB, HW, A.C, 8, m->bnstate, xn, s));
+    DV_TRY(launch_bn_apply(xsrc, idx ? idx + m->b0 : nullptr, first + m->b0, NB, HW, A.C, A.C0p, m->bnstate, xn, s));
   }
   const float* in = xn;
   for (int j = 0; j < 2 * A.L; ++j) {
@@ -1639,7 +1682,7 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
     const int ksz = A.enc_ksz(j);
     int pb = same_pad_before(hin, ksz, st, nullptr);
     const float* W = j == 0 ? m->W1p : P + A.specs[A.enc_k(j)].off;
-    int cin_phys = j == 0 ? 8 : cin;
+    int cin_phys = j == 0 ? A.C0p : cin;
     const size_t e_out = (size_t)hout * hout * cout;
     DV_TRY(gconv_fprop(m, in, W, false, P + A.specs[A.enc_b(j)].off, P + A.specs[A.enc_al(j)].off,
                        keep_u ? LANE(m->enc_u[j], e_out) : nullptr, LANE(m->enc_a[j], e_out), 2, NB, hin, cin_phys,
@@ -1650,8 +1693,8 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
     ProfScope ps(m, 2);
     DV_TRY(launch_prelu_fwd(in, P + A.specs[A.enc_flat_al()].off, LANE(m->flat_a, A.flat), NB, A.flat, s));
   }
-  return gconv_fprop(m, LANE(m->flat_a, A.flat), P + A.specs[A.enc_dk()].off, false, P + A.specs[A.enc_db()].off,
-                     nullptr, LANE(m->t, A.tw), nullptr, 1, NB, 1, A.flat, 1, A.tw, 1, 0, true);
+  return gconv_fprop(m, LANE(m->flat_a, A.flat), enc_dense_w(m), false, enc_dense_b(m),
+                     nullptr, LANE(m->t, A.twp), nullptr, 1, NB, 1, A.flat, 1, A.twp, 1, 0, true);
 }
 
 static int decoder_forward(dv_model* m, int NB, bool keep_u) {
@@ -1661,11 +1704,12 @@ static int decoder_forward(dv_model* m, int NB, bool keep_u) {
   float* P = m->P;
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_prelu_fwd(LANE(m->z, A.d), P + A.specs[A.D0].off, LANE(m->dec_ain, A.d), NB, A.d, s));
+    // (dp > d: the slopes' 16-byte aligned slot is read past its d values; z's pad columns are zero, so are theirs)
+    DV_TRY(launch_prelu_fwd(LANE(m->z, A.dp), P + A.specs[A.D0].off, LANE(m->dec_ain, A.dp), NB, A.dp, s));
   }
-  DV_TRY(gconv_fprop(m, LANE(m->dec_ain, A.d), P + A.specs[A.D0 + 1].off, false, P + A.specs[A.D0 + 2].off,
+  DV_TRY(gconv_fprop(m, LANE(m->dec_ain, A.dp), dec_dense0_w(m), false, P + A.specs[A.D0 + 2].off,
                      P + A.specs[A.D0 + 3].off, keep_u ? LANE(m->dec_uh, A.dec_hidden) : nullptr,
-                     LANE(m->dec_ah, A.dec_hidden), 2, NB, 1, A.d, 1, A.dec_hidden, 1, 0, true));
+                     LANE(m->dec_ah, A.dec_hidden), 2, NB, 1, A.dp, 1, A.dec_hidden, 1, 0, true));
   int r = A.w0 * A.w0 * A.cfg.filters[A.L - 1];
   DV_TRY(gconv_fprop(m, LANE(m->dec_ah, A.dec_hidden), P + A.specs[A.D0 + 4].off, false, P + A.specs[A.D0 + 5].off,
                      P + A.specs[A.D0 + 6].off, keep_u ? LANE(m->dec_ur, r) : nullptr, LANE(m->dec_ar, r), 2, NB, 1,
@@ -1693,11 +1737,13 @@ static int sampler_forward(dv_model* m, int NB, bool gen, uint64_t seed, unsigne
   const Arch& A = m->A;
   SamplerParams sp;
   memset(&sp, 0, sizeof sp);
-  sp.t = LANE(m->t, A.tw);
-  sp.eps = LANE(m->eps, A.d);
-  sp.z = LANE(m->z, A.d);
+  sp.t = LANE(m->t, A.twp);
+  sp.eps = LANE(m->eps, A.dp);
+  sp.z = LANE(m->z, A.dp);
+  sp.ldt = A.twp;
+  sp.ldz = A.dp;
   sp.kl = LANE(m->kl, 1);
-  sp.stddev = want_std ? LANE(m->zstd, A.d) : nullptr;
+  sp.stddev = want_std ? LANE(m->zstd, A.dp) : nullptr;
   sp.NB = NB;
   sp.d = A.d;
   sp.diag_shift = A.cfg.diag_shift;
@@ -1761,8 +1807,7 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
   m->cur_seed = seed;
   if (!m->bf.on) DV_TRY(wino_refresh_all(m, s));   // before the lanes split: both read the same transformed weights
   if (run_encoder) DV_TRY(bn_prepare(m, xsrc, idx, first, NB, Bg, training, upd_moving));
-  if (eps_host)
-    DV_HIP(hipMemcpyAsync(m->eps, eps_host, (size_t)NB * A.d * sizeof(float), hipMemcpyHostToDevice, s));
+  if (eps_host) DV_TRY(copy_rows(m->eps, A.dp, eps_host, A.d, A.d, NB, hipMemcpyHostToDevice, s));
   const long head_blocks_total = ((long)NB * A.dec_out * A.dec_out + 255) / 256 + 2;
   if ((size_t)head_blocks_total * 2 > m->ws3_elems) {
     set_error("head workspace too small");
@@ -1974,14 +2019,15 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   advance();
   DV_TRY(prelu_bwd(m, cur, m->dec_uh, A.D0 + 3, A.D0 + 2, NB, A.dec_hidden, A.dec_hidden, dg));
   if (dg) {
-    DV_TRY(wgrad(m, m->dec_ain, 1, A.d, cur, 1, A.dec_hidden, NB, 1, 0, true, G + A.specs[A.D0 + 1].off, 1, 1));
+    DV_TRY(wgrad(m, m->dec_ain, 1, A.dp, cur, 1, A.dec_hidden, NB, 1, 0, true, dec_dense0_g(m), 1, 1));
+    if (m->G0p) DV_TRY(take_padded_grad(m, m->G0p, G + A.specs[A.D0 + 1].off, 1, A.dp * A.dec_hidden, A.d * A.dec_hidden));
     DV_TRY(wgrad_read());
   }
   DV_NEXT_OUT();
-  DV_TRY(gconv_fprop(m, cur, P + A.specs[A.D0 + 1].off, true, nullptr, nullptr, oth, nullptr, 0, NB, 1, A.dec_hidden,
-                     1, A.d, 1, 0, true));
+  DV_TRY(gconv_fprop(m, cur, dec_dense0_w(m), true, nullptr, nullptr, oth, nullptr, 0, NB, 1, A.dec_hidden,
+                     1, A.dp, 1, 0, true));
   advance();
-  DV_TRY(prelu_bwd(m, cur, m->z, A.D0, -1, NB, A.d, A.d, dg));
+  DV_TRY(prelu_bwd(m, cur, m->z, A.D0, -1, NB, A.dp, A.dp, dg));
   // every decoder gradient is final here and no later kernel of the step reads a decoder parameter: the bucket is
   // all-reduced on the comm stream while the encoder backward runs, and (early_adam) updated there right behind it
   const bool early = m->early_adam && ovl;
@@ -2008,15 +2054,16 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   {
     ProfScope ps(m, 2);
     DV_NEXT_OUT();
-    DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, cur, oth, NB, A.d, A.cfg.diag_shift, kls, s));
+    DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, cur, oth, NB, A.d, A.twp, A.dp, A.cfg.diag_shift, kls, s));
   }
-  advance();  // cur = d(t) [NB, tw]
+  advance();  // cur = d(t) [NB, twp]
   // encoder dense
-  DV_TRY(bias_grad_colsum(m, cur, NB, A.tw, A.tw, A.enc_db()));
-  DV_TRY(wgrad(m, m->flat_a, 1, A.flat, cur, 1, A.tw, NB, 1, 0, true, G + A.specs[A.enc_dk()].off, 1, 1));
+  DV_TRY(bias_grad_colsum(m, cur, NB, A.twp, A.tw, A.enc_db()));
+  DV_TRY(wgrad(m, m->flat_a, 1, A.flat, cur, 1, A.twp, NB, 1, 0, true, enc_dense_g(m), 1, 1));
+  if (m->Gdp) DV_TRY(take_padded_grad(m, m->Gdp, G + A.specs[A.enc_dk()].off, A.flat, A.twp, A.tw));
   DV_TRY(wgrad_read());
   DV_NEXT_OUT();
-  DV_TRY(gconv_fprop(m, cur, P + A.specs[A.enc_dk()].off, true, nullptr, nullptr, oth, nullptr, 0, NB, 1, A.tw, 1,
+  DV_TRY(gconv_fprop(m, cur, enc_dense_w(m), true, nullptr, nullptr, oth, nullptr, 0, NB, 1, A.twp, 1,
                      A.flat, 1, 0, true));
   advance();
   DV_TRY(prelu_bwd(m, cur, m->enc_a[2 * A.L - 1], A.enc_flat_al(), -1, NB, A.flat, A.flat, true));
@@ -2028,13 +2075,13 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     int pb = same_pad_before(hin, ksz, st, nullptr);
     // first layer: its PReLU backward is folded into the weight-gradient kernel (no data gradient follows it)
     const bool fuse0 = j == 0 && !cur_is_du && m->fuse_first && cout == 32 && st == 1 && pb == 1 && ksz == 3 && !g_no_special &&
-                       wgrad_strip8_fusable(hout, hout);
+                       A.C0p == 8 && wgrad_strip8_fusable(hout, hout);     // (the fused strip form reads 8-channel input rows)
     if (!cur_is_du && !fuse0)
       DV_TRY(prelu_bwd(m, cur, m->enc_u[j], A.enc_al(j), A.enc_b(j), NB, hout * hout * cout, cout, true));
     m->du_enc[j] = fuse0 ? nullptr : cur;      // (fused first layer: d(pre-activation) is never materialised,
     if (j == 0) m->da_enc0 = fuse0 ? cur : nullptr;   //  its d(activation) is what the pass leaves)
     const float* xin = j == 0 ? m->xn : m->enc_a[j - 1];
-    int cin_phys = j == 0 ? 8 : cin;
+    int cin_phys = j == 0 ? A.C0p : cin;
     if (j == 0) {
       // first conv + input BatchNorm: the gradient w.r.t. the folded 8-channel kernel gives d(kernel), d(gamma) and
       // d(beta) directly (bn_conv0_grads_kernel), so this layer needs no data-gradient pass at all
@@ -2043,13 +2090,13 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
       const bool last_on_main = true;
       hipStream_t ws = (m->wstream && !last_on_main) ? m->wstream : s;
       FuseBwd f0{m->enc_u[0], A.enc_al(0), A.enc_b(0), true};
-      DV_TRY(wgrad(m, xin, hin, 8, cur, hout, cout, NB, st, pb, false, m->G0s, 8, 8, fuse0 ? &f0 : nullptr,
+      DV_TRY(wgrad(m, xin, hin, A.C0p, cur, hout, cout, NB, st, pb, false, m->G0s, A.C0p, A.C0p, fuse0 ? &f0 : nullptr,
                    last_on_main, ksz));
       DV_TRY(wgrad_result_ready(m, ws));
       ProfScope ps(m, 2, ws);
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
                                    G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, ksz * ksz, A.C,
-                                   8, cout, ws));
+                                   A.C0p, cout, ws));
       DV_TRY(wgrad_read());
       break;
     }
@@ -2177,13 +2224,13 @@ static int bn_prefetch(dv_model* m, const float* x, int64_t first, int NB, int* 
   DV_HIP(hipStreamWaitEvent(c->comm_stream, m->ev_bnpre_go, 0));
   if (idx_host)
     DV_HIP(hipMemcpyAsync(idx_dev, idx_host, (size_t)NB * sizeof(int), hipMemcpyHostToDevice, c->comm_stream));
-  if (((size_t)NB * HW + 1023) / 1024 * 16 > m->bn_pre_part_elems) {      // before the launch, not after it has written
+  if (((size_t)NB * HW + 1023) / 1024 * (2 * DV_BN_MAXC) > m->bn_pre_part_elems) {      // before the launch, not after it has written
     set_error("bn prefetch workspace too small");
     return E_STATE;
   }
   DV_TRY(launch_bn_stats(x, idx_dev, (int)first, NB, HW, A.C, m->bn_pre_part, &nblk, c->comm_stream));
-  DV_TRY(launch_reduce_rows_f64(m->bn_pre_part, nblk, 16, m->bn_pre_sums, 1.0f, c->comm_stream));
-  if (c->comm) DV_TRY(comm_allreduce(c, m->bn_pre_sums, 16));
+  DV_TRY(launch_reduce_rows_f64(m->bn_pre_part, nblk, 2 * DV_BN_MAXC, m->bn_pre_sums, 1.0f, c->comm_stream));
+  if (c->comm) DV_TRY(comm_allreduce(c, m->bn_pre_sums, 2 * DV_BN_MAXC));
   DV_HIP(hipEventRecord(m->ev_bnpre, c->comm_stream));
   m->bn_pre_valid = true;
   m->bn_pre_x = x;
@@ -2373,7 +2420,7 @@ static int pipe_get(dv_model* m, int cap, InferPipe** out, bool need_host = true
   m->pipe = nullptr;
   InferPipe* p = new InferPipe();
   p->cap = cap;
-  const size_t img = (size_t)cap * A.H * A.H * A.C * sizeof(float), small = (size_t)cap * 3 * A.d * sizeof(float);
+  const size_t img = (size_t)cap * A.H * A.H * A.C * sizeof(float), small = (size_t)cap * 3 * A.d * sizeof(float);   // (dense rows of d: the strided device rows are packed on the way)
   int st = OK;
 #define PP_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { st = hip_fail(e__, #call, __FILE__, __LINE__); pipe_free(p); return st; } } while (0)
   for (int b = 0; b < 3; ++b) {
@@ -2580,12 +2627,12 @@ static int infer_pipelined(dv_model* m, const void* x, bool x_f64, int64_t N, co
     }
     if (m->normalise && (loc || sink || comp)) DV_TRY(launch_normalise(p->dloc[b], (long)nb * stamp, true, s));
     if (mu)
-      DV_HIP(hipMemcpy2DAsync(p->dsmall[b], d * sizeof(float), m->t, A.tw * sizeof(float), d * sizeof(float), nb,
+      DV_HIP(hipMemcpy2DAsync(p->dsmall[b], d * sizeof(float), m->t, A.twp * sizeof(float), d * sizeof(float), nb,
                               hipMemcpyDeviceToDevice, s));
     if (zstd)
-      DV_HIP(hipMemcpyAsync(p->dsmall[b] + (size_t)chunk * d, m->zstd, (size_t)nb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+      DV_TRY(copy_rows(p->dsmall[b] + (size_t)chunk * d, d, m->zstd, A.dp, d, nb, hipMemcpyDeviceToDevice, s));
     if (z)
-      DV_HIP(hipMemcpyAsync(p->dsmall[b] + (size_t)2 * chunk * d, m->z, (size_t)nb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+      DV_TRY(copy_rows(p->dsmall[b] + (size_t)2 * chunk * d, d, m->z, A.dp, d, nb, hipMemcpyDeviceToDevice, s));
     if (trace) DV_HIP(hipEventRecord(tev[6 * k + 3], s));
     DV_HIP(hipEventRecord(p->ev_comp[b], s));
     // stage C: device -> pinned (three-deep ring) on the second copy stream
@@ -3071,7 +3118,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
     // The fp32 weight-gradient and tiled kernels address a layer's tensors with 32-bit ELEMENT offsets.  A training step
     // has no lanes, so a max_batch whose largest activation reaches 2^31 elements would fail inside the first step, with
     // half of it queued (and, with several ranks, peers left inside collectives): refuse it here.
-    size_t per_stamp = (size_t)A.H * A.H * 8;
+    size_t per_stamp = (size_t)A.H * A.H * A.C0p;
     for (int j = 0; j < 2 * A.L; ++j) {
       int hin, cin, hout, cout, s;
       A.enc_layer(j, &hin, &cin, &hout, &cout, &s);
@@ -3109,12 +3156,12 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   ALLOC(m->Mm, A.n_total);
   ALLOC(m->Vv, A.n_total);
   const size_t k0sq = (size_t)cfg->kernels[0] * cfg->kernels[0];
-  ALLOC(m->W1p, k0sq * 8 * cfg->filters[0]);
-  ALLOC(m->G0s, k0sq * 8 * cfg->filters[0]);
+  ALLOC(m->W1p, k0sq * A.C0p * cfg->filters[0]);
+  ALLOC(m->G0s, k0sq * A.C0p * cfg->filters[0]);
   ALLOC(m->Whp, 9 * cfg->filters[0] * A.C2p);
   ALLOC(m->Ghs, 9 * cfg->filters[0] * A.C2p);
   ALLOC(m->bhp, A.C2p);
-  size_t in_e = (size_t)A.H * A.H * 8;
+  size_t in_e = (size_t)A.H * A.H * A.C0p;
   ALLOC(m->xn, Ba * in_e);
   track(in_e);
   ALLOC(m->stage_x, Bc * A.H * A.H * A.C);
@@ -3134,13 +3181,22 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   }
   track(A.flat);
   ALLOC(m->flat_a, Bc * A.flat);
-  ALLOC(m->t, Bc * A.tw);
-  track(A.tw);
-  ALLOC(m->eps, Bc * A.d);
-  ALLOC(m->z, Bc * A.d);
-  ALLOC(m->zstd, Bc * A.d);
+  ALLOC(m->t, Bc * A.twp);
+  track(A.twp);
+  ALLOC(m->eps, Bc * A.dp);
+  ALLOC(m->z, Bc * A.dp);
+  ALLOC(m->zstd, Bc * A.dp);
+  if (A.twp != A.tw) {
+    ALLOC(m->Wdp, (size_t)A.flat * A.twp);
+    ALLOC(m->Gdp, (size_t)A.flat * A.twp);
+    ALLOC(m->bdp, A.twp);
+  }
+  if (A.dp != A.d) {
+    ALLOC(m->W0p, (size_t)A.dp * A.dec_hidden);
+    ALLOC(m->G0p, (size_t)A.dp * A.dec_hidden);
+  }
   ALLOC(m->kl, Bc);
-  ALLOC(m->dec_ain, Bc * A.d);
+  ALLOC(m->dec_ain, Bc * A.dp);
   ALLOC(m->dec_uh, Bc * A.dec_hidden);
   ALLOC(m->dec_ah, Bc * A.dec_hidden);
   size_t r = (size_t)A.w0 * A.w0 * cfg->filters[A.L - 1];
@@ -3175,7 +3231,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   size_t max_w = 0;
   for (auto& s : A.specs)
     if (s.ndim >= 2) max_w = std::max(max_w, s.count);
-  max_w = std::max(max_w, k0sq * 8 * cfg->filters[0]);
+  max_w = std::max(max_w, k0sq * A.C0p * cfg->filters[0]);
   m->ws1_elems = std::max((size_t)32 << 20, (max_w + 1024) * 3);   // three rotating regions, each at least one slab
   ALLOC(m->ws1, m->ws1_elems);
   m->ws4_elems = (size_t)4 * 16 * Bc * std::max((size_t)A.flat, (size_t)A.tw);
@@ -3196,14 +3252,14 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   m->ws3_elems = std::max(m->ws3_elems, (size_t)64 * std::max((size_t)A.flat, r));
   // BN statistics / BN backward partials: one 16-float row per 1024 pixels of the batch (the capacity used to
   // be derived from other users of the buffer and overran silently above ~19k stamps of 59 px)
-  m->ws3_elems = std::max(m->ws3_elems, ((Bc * (size_t)A.H * A.H + 1023) / 1024 + 1) * 16);
+  m->ws3_elems = std::max(m->ws3_elems, ((Bc * (size_t)A.H * A.H + 1023) / 1024 + 1) * (2 * DV_BN_MAXC));
   ALLOC(m->ws3, m->ws3_elems);
   ALLOC(m->scal, 16);
   ALLOC(m->zero_page, 64);
-  ALLOC(m->bnstate, 32);
-  ALLOC(m->bnsums, 16);
-  ALLOC(m->bn_pre_sums, 16);
-  m->bn_pre_part_elems = (size_t)16 * (((size_t)Bc * A.H * A.H + 1023) / 1024 + 16);
+  ALLOC(m->bnstate, 4 * DV_BN_MAXC);
+  ALLOC(m->bnsums, 2 * DV_BN_MAXC);
+  ALLOC(m->bn_pre_sums, 2 * DV_BN_MAXC);
+  m->bn_pre_part_elems = (size_t)(2 * DV_BN_MAXC) * (((size_t)Bc * A.H * A.H + 1023) / 1024 + 16);
   ALLOC(m->bn_pre_part, m->bn_pre_part_elems);
   for (int k = 0; k < 3; ++k)
     if (hipEventCreateWithFlags(&m->ev_wk[k], sync_event_flags()) != hipSuccess ||
@@ -3232,8 +3288,16 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
       hipMemsetAsync(m->Vv, 0, A.n_total * sizeof(float), s) != hipSuccess ||
       hipMemsetAsync(m->scal, 0, 16 * sizeof(float), s) != hipSuccess ||
       hipMemsetAsync(m->zero_page, 0, 64 * sizeof(float), s) != hipSuccess ||
-      hipMemsetAsync(m->bnsums, 0, 16 * sizeof(float), s) != hipSuccess)
+      hipMemsetAsync(m->bnsums, 0, 2 * DV_BN_MAXC * sizeof(float), s) != hipSuccess)
     return fail(E_HIP);
+  if (A.dp != A.d || A.twp != A.tw) {                // pad columns of the latent-sized rows: zero from the start
+    if (hipMemsetAsync(m->eps, 0, Bc * A.dp * sizeof(float), s) != hipSuccess ||
+        hipMemsetAsync(m->z, 0, Bc * A.dp * sizeof(float), s) != hipSuccess ||
+        hipMemsetAsync(m->zstd, 0, Bc * A.dp * sizeof(float), s) != hipSuccess ||
+        hipMemsetAsync(m->dec_ain, 0, Bc * A.dp * sizeof(float), s) != hipSuccess ||
+        hipMemsetAsync(m->t, 0, Bc * A.twp * sizeof(float), s) != hipSuccess)
+      return fail(E_HIP);
+  }
   if (bf16) {
     st = bf_alloc(m);
     if (st != OK) return fail(st);
@@ -3355,7 +3419,11 @@ int dv_model_set_param(dv_model* m, int32_t i, const float* host, size_t nbytes)
     DV_TRY(refresh_head_pad(m));
     DV_HIP(hipStreamSynchronize(m->ctx->stream));
   }
-  if (i == m->A.enc_k(0) || i == 0 || i == 1) {
+  if (i == m->A.D0 + 1 && m->W0p) {
+    DV_TRY(refresh_head_pad(m));
+    DV_HIP(hipStreamSynchronize(m->ctx->stream));
+  }
+  if (i == m->A.enc_k(0) || i == 0 || i == 1 || ((i == m->A.enc_dk() || i == m->A.enc_db()) && m->Wdp)) {
     DV_TRY(refresh_w1p(m));
     DV_HIP(hipStreamSynchronize(m->ctx->stream));
   }
@@ -3607,10 +3675,10 @@ static int infer_entry(dv_model* m, const void* x, bool x_f64, int64_t N, const 
     if (scale)
       DV_HIP(hipMemcpyAsync(scale + o * stamp, m->scale, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
     if (mu)
-      DV_HIP(hipMemcpy2DAsync(mu + o * A.d, A.d * sizeof(float), m->t, A.tw * sizeof(float), A.d * sizeof(float), nb,
+      DV_HIP(hipMemcpy2DAsync(mu + o * A.d, A.d * sizeof(float), m->t, A.twp * sizeof(float), A.d * sizeof(float), nb,
                               hipMemcpyDeviceToHost, s));
-    if (zstd) DV_HIP(hipMemcpyAsync(zstd + o * A.d, m->zstd, (size_t)nb * A.d * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (z) DV_HIP(hipMemcpyAsync(z + o * A.d, m->z, (size_t)nb * A.d * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (zstd) DV_TRY(copy_rows(zstd + o * A.d, A.d, m->zstd, A.dp, A.d, nb, hipMemcpyDeviceToHost, s));
+    if (z) DV_TRY(copy_rows(z + o * A.d, A.d, m->z, A.dp, A.d, nb, hipMemcpyDeviceToHost, s));
     DV_HIP(hipStreamSynchronize(s));
     m->lastB = nb;
   }
@@ -3859,7 +3927,7 @@ int dv_encode(dv_model* m, const float* x, int64_t N, float* t) {
     DV_TRY(stage_host_batch(m, x + o * stamp, nb));
     DV_TRY(bn_prepare(m, m->stage_x, nullptr, 0, nb, nb, false, false));
     DV_TRY(encoder_forward(m, m->stage_x, nullptr, 0, nb, false));
-    DV_HIP(hipMemcpyAsync(t + o * A.tw, m->t, (size_t)nb * A.tw * sizeof(float), hipMemcpyDeviceToHost, s));
+    DV_TRY(copy_rows(t + o * A.tw, A.tw, m->t, A.twp, A.tw, nb, hipMemcpyDeviceToHost, s));
     DV_HIP(hipStreamSynchronize(s));
   }
   return prof_flush(m);
@@ -3874,7 +3942,7 @@ int dv_decode(dv_model* m, const float* z, int64_t N, float* loc, float* scale) 
   const size_t stamp = (size_t)A.H * A.H * A.C;
   for (int64_t o = 0; o < N; o += m->Bc) {
     int nb = (int)std::min<int64_t>(m->Bc, N - o);
-    DV_HIP(hipMemcpyAsync(m->z, z + o * A.d, (size_t)nb * A.d * sizeof(float), hipMemcpyHostToDevice, s));
+    DV_TRY(copy_rows(m->z, A.dp, z + o * A.d, A.d, A.d, nb, hipMemcpyHostToDevice, s));   // (the pad columns stay zero)
     DV_TRY(forward_all(m, nullptr, nullptr, nullptr, 0, nb, nb, false, false, false, nullptr, 0, 0u, 0u, false, false,
                        true, /*run_encoder=*/false));
     if (loc) DV_HIP(hipMemcpyAsync(loc + o * stamp, m->loc, nb * stamp * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -3892,9 +3960,18 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
   const float* src = nullptr;
   size_t elems = 0;
   std::string n(name);
-  if (n == "t") { src = m->t; elems = B * A.tw; }
-  else if (n == "z") { src = m->z; elems = B * A.d; }
-  else if (n == "eps") { src = m->eps; elems = B * A.d; }
+  if (n == "t" || n == "z" || n == "eps") {        // rows of tw / d values, stored with the padded strides twp / dp
+    const size_t w = n == "t" ? A.tw : A.d, ld = n == "t" ? A.twp : A.dp;
+    src = n == "t" ? m->t : n == "z" ? m->z : m->eps;
+    if (nbytes != B * w * sizeof(float)) {
+      set_error("activation %s holds %zu bytes, caller passed %zu", name, B * w * sizeof(float), nbytes);
+      return DV_E_INVALID;
+    }
+    DV_HIP(hipSetDevice(m->ctx->device));
+    DV_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (B) DV_HIP(hipMemcpy2D(host, w * sizeof(float), src, ld * sizeof(float), w * sizeof(float), B, hipMemcpyDeviceToHost));
+    return DV_OK;
+  }
   else if (n == "kl") { src = m->kl; elems = B; }
   else if (n == "loc") { src = m->loc; elems = B * A.H * A.H * A.C; }
   else if (n == "scale") { src = m->scale; elems = B * A.H * A.H * A.C; }
@@ -3970,7 +4047,7 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
         }
     return DV_OK;
   }
-  else if (n == "xn") { src = m->xn; elems = B * A.H * A.H * 8; }
+  else if (n == "xn") { src = m->xn; elems = B * A.H * A.H * A.C0p; }
   else if (n == "dec_in") { src = m->dec_ar; elems = B * A.w0 * A.w0 * A.cfg.filters[A.L - 1]; }
   else if (n == "d_head_pre" || n == "enc_da0" || n.rfind("enc_du", 0) == 0 || n.rfind("dec_du", 0) == 0) {
     // gradients the last backward pass left in its per-step buffer pool (tests/test_gpu_layers.py)

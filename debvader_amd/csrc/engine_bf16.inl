@@ -68,7 +68,7 @@ static int bf_alloc(dv_model* m) {
   DV_TRY(balloc(&bf.dt, (size_t)A.dec_out * A.dec_out * Bp * 16 * 2));
   DV_TRY(balloc((void**)&bf.flat_in, (size_t)m->Bc * A.flat * 4));
   {
-    const size_t w[5] = {r, (size_t)A.dec_hidden, (size_t)A.d, (size_t)A.tw, (size_t)A.flat};
+    const size_t w[5] = {r, (size_t)A.dec_hidden, (size_t)A.dp, (size_t)A.twp, (size_t)A.flat};
     for (int k = 0; k < 5; ++k) DV_TRY(balloc((void**)&bf.trunk[k], (size_t)m->Bc * w[k] * 4));
   }
   bf.gpool.resize(4 * A.L + 4);
@@ -183,8 +183,8 @@ static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, in
     DV_TRY(launch_bf_to_rows(in, bf.flat_in, NB, bf.NBp, sl * sl, fl, s));
     DV_TRY(launch_prelu_fwd(bf.flat_in, P + A.specs[A.enc_flat_al()].off, m->flat_a, NB, A.flat, s));
   }
-  return gconv_fprop(m, m->flat_a, P + A.specs[A.enc_dk()].off, false, P + A.specs[A.enc_db()].off, nullptr, m->t,
-                     nullptr, 1, NB, 1, A.flat, 1, A.tw, 1, 0, true);
+  return gconv_fprop(m, m->flat_a, enc_dense_w(m), false, enc_dense_b(m), nullptr, m->t,
+                     nullptr, 1, NB, 1, A.flat, 1, A.twp, 1, 0, true);
 }
 
 static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
@@ -196,10 +196,10 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
   DV_TRY(bf_refresh_weights(m, s));
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_prelu_fwd(m->z, P + A.specs[A.D0].off, m->dec_ain, NB, A.d, s));
+    DV_TRY(launch_prelu_fwd(m->z, P + A.specs[A.D0].off, m->dec_ain, NB, A.dp, s));
   }
-  DV_TRY(gconv_fprop(m, m->dec_ain, P + A.specs[A.D0 + 1].off, false, P + A.specs[A.D0 + 2].off,
-                     P + A.specs[A.D0 + 3].off, keep_u ? m->dec_uh : nullptr, m->dec_ah, 2, NB, 1, A.d, 1, A.dec_hidden,
+  DV_TRY(gconv_fprop(m, m->dec_ain, dec_dense0_w(m), false, P + A.specs[A.D0 + 2].off,
+                     P + A.specs[A.D0 + 3].off, keep_u ? m->dec_uh : nullptr, m->dec_ah, 2, NB, 1, A.dp, 1, A.dec_hidden,
                      1, 0, true));
   const int fl = A.cfg.filters[A.L - 1];
   const int r = A.w0 * A.w0 * fl;
@@ -460,10 +460,13 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   DV_TRY(gconv_fprop(m, tr0, P + A.specs[A.D0 + 4].off, true, nullptr, nullptr, tr1, nullptr, 0, NB, 1, r, 1,
                      A.dec_hidden, 1, 0, true));
   DV_TRY(prelu_bwd(m, tr1, m->dec_uh, A.D0 + 3, A.D0 + 2, NB, A.dec_hidden, A.dec_hidden, dg));
-  if (dg) DV_TRY(wgrad(m, m->dec_ain, 1, A.d, tr1, 1, A.dec_hidden, NB, 1, 0, true, G + A.specs[A.D0 + 1].off, 1, 1));
-  DV_TRY(gconv_fprop(m, tr1, P + A.specs[A.D0 + 1].off, true, nullptr, nullptr, tr2, nullptr, 0, NB, 1, A.dec_hidden, 1,
-                     A.d, 1, 0, true));
-  DV_TRY(prelu_bwd(m, tr2, m->z, A.D0, -1, NB, A.d, A.d, dg));
+  if (dg) {
+    DV_TRY(wgrad(m, m->dec_ain, 1, A.dp, tr1, 1, A.dec_hidden, NB, 1, 0, true, dec_dense0_g(m), 1, 1));
+    if (m->G0p) DV_TRY(take_padded_grad(m, m->G0p, G + A.specs[A.D0 + 1].off, 1, A.dp * A.dec_hidden, A.d * A.dec_hidden));
+  }
+  DV_TRY(gconv_fprop(m, tr1, dec_dense0_w(m), true, nullptr, nullptr, tr2, nullptr, 0, NB, 1, A.dec_hidden, 1,
+                     A.dp, 1, 0, true));
+  DV_TRY(prelu_bwd(m, tr2, m->z, A.D0, -1, NB, A.dp, A.dp, dg));
   const bool trunk_red = ws != s && m->arena_reduce && m->ctx->red_stream != nullptr;   // sums on the reduction stream
   // Every decoder gradient has been queued and no later kernel of the step reads a decoder parameter: finish the
   // decoder's reductions now (slab sums and d(alpha) / d(bias) partials, one launch each, on the weight-gradient
@@ -509,12 +512,13 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   const float kls = (float)((double)A.cfg.kl_multiplicity * A.cfg.kl_weight / ((double)Bg * (double)Bg));
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, tr2, tr3, NB, A.d, A.cfg.diag_shift, kls, s));
+    DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, tr2, tr3, NB, A.d, A.twp, A.dp, A.cfg.diag_shift, kls, s));
   }
   m->main_marked = false;   // (the record prelu_bwd left behind predates the sampler: the dense weight gradient below needs its own)
-  DV_TRY(bias_grad_colsum(m, tr3, NB, A.tw, A.tw, A.enc_db()));
-  DV_TRY(wgrad(m, m->flat_a, 1, A.flat, tr3, 1, A.tw, NB, 1, 0, true, G + A.specs[A.enc_dk()].off, 1, 1));
-  DV_TRY(gconv_fprop(m, tr3, P + A.specs[A.enc_dk()].off, true, nullptr, nullptr, tr4, nullptr, 0, NB, 1, A.tw, 1, A.flat,
+  DV_TRY(bias_grad_colsum(m, tr3, NB, A.twp, A.tw, A.enc_db()));
+  DV_TRY(wgrad(m, m->flat_a, 1, A.flat, tr3, 1, A.twp, NB, 1, 0, true, enc_dense_g(m), 1, 1));
+  if (m->Gdp) DV_TRY(take_padded_grad(m, m->Gdp, G + A.specs[A.enc_dk()].off, A.flat, A.twp, A.tw));
+  DV_TRY(gconv_fprop(m, tr3, enc_dense_w(m), true, nullptr, nullptr, tr4, nullptr, 0, NB, 1, A.twp, 1, A.flat,
                      1, 0, true));
   DV_TRY(prelu_bwd(m, tr4, bf.flat_in, A.enc_flat_al(), -1, NB, A.flat, A.flat, true));
   m->wstream = s;

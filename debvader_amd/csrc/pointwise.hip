@@ -52,7 +52,7 @@ int launch_reduce_rows_f64(const float* part, int nrows, int ncols, float* out, 
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm over the band axis
-constexpr int BN_MAXC = 8;
+constexpr int BN_MAXC = DV_BN_MAXC;   // 16
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int BN_PIX_PER_BLOCK = 1024;
 
@@ -184,6 +184,7 @@ int launch_bn_finalize(const float* sums, float count, int C, const float* gamma
   return OK;
 }
 
+template <int CP>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const int* __restrict__ idx,
                                                        int first, int NB, int HW, int C, const float* __restrict__ st,
                                                        float* __restrict__ xn) {
@@ -195,73 +196,28 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   const float* px = x + (row * HW + pix) * C;
   // channels [0,C): xhat = (x - mean) * inv_std; channel C: 1 (carries beta through the folded first conv, see
   // fold_bn_w1_kernel); remaining pad channels: 0.  gamma/beta live in the folded weights, not here.
-  float o[BN_MAXC];
+  float o[CP];
 #pragma unroll
-  for (int c = 0; c < BN_MAXC; ++c)
+  for (int c = 0; c < CP; ++c)
     o[c] = (c < C) ? (px[c] - st[2 * BN_MAXC + c]) * st[3 * BN_MAXC + c] : (c == C ? 1.f : 0.f);
-  f32x4* dst = reinterpret_cast<f32x4*>(xn + pp * BN_MAXC);
-  dst[0] = (f32x4){o[0], o[1], o[2], o[3]};
-  dst[1] = (f32x4){o[4], o[5], o[6], o[7]};
+  f32x4* dst = reinterpret_cast<f32x4*>(xn + pp * CP);
+#pragma unroll
+  for (int q = 0; q < CP / 4; ++q) dst[q] = (f32x4){o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
 }
 
 int launch_bn_apply(const float* x, const int* idx, int first, int NB, int HW, int C, int Cpad, const float* bnstate,
                     float* xn, hipStream_t s) {
-  if (Cpad != BN_MAXC || C >= BN_MAXC) {
-    set_error("bn_apply: needs Cpad == %d and at most %d bands (one pad channel carries the BN shift)", BN_MAXC,
-              BN_MAXC - 1);
+  if ((Cpad != 8 && Cpad != 16) || C >= Cpad) {
+    set_error("bn_apply: needs Cpad 8 or 16 and fewer bands than that (one pad channel carries the BN shift)");
     return E_INVALID;
   }
   long total = (long)NB * HW;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, idx, first, NB, HW, C,
-                     bnstate, xn);
-  DV_HIP(hipGetLastError());
-  return OK;
-}
-
-// d(gamma)_c = sum dxn_c * xhat_c ; d(beta)_c = sum dxn_c   -> part[block][16]
-__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ x,
-                                                     const int* __restrict__ idx, int first, int NB, int HW, int C,
-                                                     const float* __restrict__ st, float* __restrict__ part) {
-  __shared__ float sh[4];
-  const long total = (long)NB * HW;
-  const long p0 = (long)blockIdx.x * BN_PIX_PER_BLOCK;
-  float dg[BN_MAXC], db[BN_MAXC];
-#pragma unroll
-  for (int c = 0; c < BN_MAXC; ++c) dg[c] = db[c] = 0.f;
-  for (long pp = p0 + threadIdx.x; pp < min(total, p0 + BN_PIX_PER_BLOCK); pp += 256) {
-    int b = (int)(pp / HW);
-    int pix = (int)(pp - (long)b * HW);
-    long row = idx ? idx[b] : first + b;
-    const float* px = x + (row * HW + pix) * C;
-    const f32x4* g = reinterpret_cast<const f32x4*>(dxn + pp * BN_MAXC);
-    f32x4 g0 = g[0], g1 = g[1];
-    float gv[BN_MAXC] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-#pragma unroll
-    for (int c = 0; c < BN_MAXC; ++c)
-      if (c < C) {
-        float xh = (px[c] - st[2 * BN_MAXC + c]) * st[3 * BN_MAXC + c];
-        dg[c] += gv[c] * xh;
-        db[c] += gv[c];
-      }
-  }
-#pragma unroll
-  for (int c = 0; c < BN_MAXC; ++c) {
-    float a = block_sum(dg[c], sh);
-    float b = block_sum(db[c], sh);
-    if (threadIdx.x == 0) {
-      part[blockIdx.x * 2 * BN_MAXC + c] = a;
-      part[blockIdx.x * 2 * BN_MAXC + BN_MAXC + c] = b;
-    }
-  }
-}
-
-int launch_bn_bwd(const float* dxn, const float* x, const int* idx, int first, int NB, int HW, int C, int Cpad,
-                  const float* bnstate, float* part, int* nblocks, hipStream_t s) {
-  if (Cpad != BN_MAXC || C > BN_MAXC) return E_INVALID;
-  long total = (long)NB * HW;
-  int nb = (int)((total + BN_PIX_PER_BLOCK - 1) / BN_PIX_PER_BLOCK);
-  *nblocks = nb;
-  hipLaunchKernelGGL(bn_bwd_kernel, dim3(nb), dim3(256), 0, s, dxn, x, idx, first, NB, HW, C, bnstate, part);
+  if (Cpad == 8)
+    hipLaunchKernelGGL(bn_apply_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, idx, first, NB, HW, C,
+                       bnstate, xn);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, idx, first, NB, HW, C,
+                       bnstate, xn);
   DV_HIP(hipGetLastError());
   return OK;
 }
@@ -473,7 +429,7 @@ int launch_colsum(const float* x, long rows, int C, float* part, int* nrows_part
 
 // ------------------------------------------------------------------------------------------------
 // relu + crop + Normal(loc, floor + scale) head: loss partial sums, outputs and d(loss)/d(tpre)
-constexpr int HEAD_MAXNB = 8;
+constexpr int HEAD_MAXNB = 16;
 __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
   __shared__ float sh[4];
   const long total = (long)p.NB * p.Hd * p.Hd;
@@ -674,7 +630,8 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
   const int bs = p.rep_nb > 0 ? b % p.rep_nb : b;
   const unsigned long long seed =
       (p.seed_ptr ? *p.seed_ptr : p.seed) + (p.rep_nb > 0 ? (unsigned long long)(b / p.rep_nb) : 0ull);
-  const float* t = p.t + (size_t)bs * tw;
+  const float* t = p.t + (size_t)bs * p.ldt;
+  const size_t zo = (size_t)b * p.ldz;
   // the row of t goes through LDS (coalesced): the lower-triangle gather below would otherwise be a chain of
   // d dependent, divergent global loads per stamp (31 us per step at d = 32)
   __shared__ float st_all[4][64 + 64 * 65 / 2];
@@ -695,10 +652,12 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
       float sn, cs;
       sincosf(6.283185307179586f * u2, &sn, &cs);
       e = (a & 1) ? rad * sn : rad * cs;
-      p.eps[(size_t)b * d + lane] = e;
+      p.eps[zo + lane] = e;
     } else {
-      e = p.eps[(size_t)b * d + lane];
+      e = p.eps[zo + lane];
     }
+  } else if (lane < p.ldz && p.gen) {
+    p.eps[zo + lane] = 0.f;
   }
   float z = 0.f, logd = 0.f, l2 = 0.f, ldiag = 0.f;
   if (lane < d) {
@@ -718,16 +677,16 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
   }
   float k = (lane < d) ? (0.5f * z * z - 0.5f * e * e - logd) : 0.f;
   k = wave_sum(k);
-  if (lane < d) {
-    p.z[(size_t)b * d + lane] = z;
-    if (p.stddev) p.stddev[(size_t)b * d + lane] = sqrtf(l2);
+  if (lane < p.ldz) {                                 // (pad columns d .. ldz - 1: zeros)
+    p.z[zo + lane] = lane < d ? z : 0.f;
+    if (p.stddev) p.stddev[zo + lane] = lane < d ? sqrtf(l2) : 0.f;
   }
   if (lane == 0) p.kl[b] = k;
 }
 
 int launch_sampler_fwd(const SamplerParams& p, hipStream_t s) {
-  if (p.d > 64 || p.d < 1) {
-    set_error("sampler: latent_dim must be in [1,64]");
+  if (p.d > 64 || p.d < 1 || p.ldz < p.d || p.ldz > 64 || p.ldt < p.d + p.d * (p.d + 1) / 2) {
+    set_error("sampler: latent_dim must be in [1,64] (row strides %d / %d)", p.ldt, p.ldz);
     return E_INVALID;
   }
   if (p.NB == 0) return OK;
@@ -738,22 +697,23 @@ int launch_sampler_fwd(const SamplerParams& p, hipStream_t s) {
 
 __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restrict__ t, const float* __restrict__ eps,
                                                           const float* __restrict__ z, const float* __restrict__ dz,
-                                                          float* __restrict__ dt, int NB, int d, float diag_shift,
-                                                          float kls) {
+                                                          float* __restrict__ dt, int NB, int d, int ldt, int ldz,
+                                                          float diag_shift, float kls) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= NB) return;
   const int tw = d + d * (d + 1) / 2;
-  const float* tb = t + (size_t)b * tw;
-  float* dtb = dt + (size_t)b * tw;
+  const float* tb = t + (size_t)b * ldt;
+  float* dtb = dt + (size_t)b * ldt;
+  const size_t zo = (size_t)b * ldz;
   // the gradient row is assembled in LDS and written out coalesced (every element of the row is produced exactly
   // once: fill_triangular is a bijection between the d(d+1)/2 inputs and the lower triangle)
   __shared__ float st_all[4][64 + 64 * 65 / 2];
   float* st = st_all[threadIdx.x >> 6];
   float e = 0.f, g = 0.f, raw = 0.f;
   if (lane < d) {
-    e = eps[(size_t)b * d + lane];
-    g = dz[(size_t)b * d + lane] + kls * z[(size_t)b * d + lane];
+    e = eps[zo + lane];
+    g = dz[zo + lane] + kls * z[zo + lane];
     raw = tb[d + tril_src(d, lane, lane)];
     st[lane] = g;
   }
@@ -773,13 +733,13 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < tw; i += 64) dtb[i] = st[i];
+  for (int i = lane; i < ldt; i += 64) dtb[i] = i < tw ? st[i] : 0.f;
 }
 
 int launch_sampler_bwd(const float* t, const float* eps, const float* z, const float* dz, float* dt, int NB, int d,
-                       float diag_shift, float kls, hipStream_t s) {
+                       int ldt, int ldz, float diag_shift, float kls, hipStream_t s) {
   if (NB == 0) return OK;
-  hipLaunchKernelGGL(sampler_bwd_kernel, dim3((NB + 3) / 4), dim3(256), 0, s, t, eps, z, dz, dt, NB, d, diag_shift,
+  hipLaunchKernelGGL(sampler_bwd_kernel, dim3((NB + 3) / 4), dim3(256), 0, s, t, eps, z, dz, dt, NB, d, ldt, ldz, diag_shift,
                      kls);
   DV_HIP(hipGetLastError());
   return OK;
@@ -858,7 +818,7 @@ __global__ __launch_bounds__(256) void bn_conv0_grads_kernel(const float* __rest
                                                              const float* __restrict__ beta, float* __restrict__ dW,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              int taps, int cin, int cpad, int cout) {
-  __shared__ double sg[BN_MAXC][256], sb[BN_MAXC][256];
+  __shared__ double sg[BN_MAXC][256];              // (32 KB: the d(gamma) sums, then the d(beta) sums)
   double ag[BN_MAXC], ab[BN_MAXC];
 #pragma unroll
   for (int c = 0; c < BN_MAXC; ++c) ag[c] = ab[c] = 0.0;
@@ -879,17 +839,17 @@ __global__ __launch_bounds__(256) void bn_conv0_grads_kernel(const float* __rest
       }
   }
 #pragma unroll
-  for (int c = 0; c < BN_MAXC; ++c) {
-    sg[c][threadIdx.x] = ag[c];
-    sb[c][threadIdx.x] = ab[c];
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < 2 * cin) {
-    const int c = threadIdx.x % cin;
-    const bool isb = (int)threadIdx.x >= cin;
-    double acc = 0.0;
-    for (int k = 0; k < 256; ++k) acc += isb ? sb[c][k] : sg[c][k];
-    (isb ? dbeta : dgamma)[c] = (float)acc;
+  for (int round = 0; round < 2; ++round) {
+#pragma unroll
+    for (int c = 0; c < BN_MAXC; ++c) sg[c][threadIdx.x] = round ? ab[c] : ag[c];
+    __syncthreads();
+    if ((int)threadIdx.x < cin) {
+      const int c = threadIdx.x;
+      double acc = 0.0;
+      for (int k = 0; k < 256; ++k) acc += sg[c][k];
+      (round ? dbeta : dgamma)[c] = (float)acc;
+    }
+    __syncthreads();
   }
 }
 

@@ -18,7 +18,8 @@ _NOISE = np.array([0.02, 0.03, 0.05, 0.08, 0.10, 0.11, 0.11, 0.11])
 def synthetic_stamps(n: int, seed: int = 0, size: int = 59, nb: int = 6, dtype=np.float32):
     """Returns (blended inputs, isolated labels), each (n, size, size, nb)."""
     rng = np.random.default_rng(seed)
-    sed, sig_band = _SED[:nb], _NOISE[:nb]
+    # (more than six bands: the measured six-band SED / noise rows repeat)
+    sed, sig_band = np.resize(_SED, nb), np.resize(_NOISE, nb)
     yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
     c0 = (size - 1) / 2.0
 

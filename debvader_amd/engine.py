@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import atexit
 import ctypes as C
+import os
+import sys
 import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -97,6 +99,63 @@ def _i32_rows(a, what: str) -> np.ndarray:
     if a.size and (a.min() < -2 ** 31 or a.max() > 2 ** 31 - 1):
         raise ValueError(f"{what} outside the int32 range")
     return np.ascontiguousarray(a, dtype=np.int32).reshape(-1, 2)
+
+
+class _HostPool:
+    """Recycles the host memory of large result arrays across calls.
+
+    DeblendField.deblend_field returns 16 bytes per pixel and band and galaxy (float64 cutout, float32 mean and stddev): 11 GB
+    per 32 768 galaxies.  Fresh np.empty arrays cost a page fault per 4 KiB while the engine's copy threads fill them and
+    an munmap of the same size when the previous result is dropped - together more than the GPU work of the call
+    (tools/probes/df_lines.py: 0.21 s engine call, 0.25 - 0.5 s freeing the previous recarray).  The pool keeps the raw
+    blocks and hands out VIEWS of them; a block is handed out again only when nothing but the pool references it
+    (sys.getrefcount - every view a caller or a recarray still holds counts, numpy collapses view chains onto the owning
+    array), so a result somebody still has is never overwritten.  Bounded by $DV_HOST_POOL_GB (default 32, 0 disables);
+    arrays below 64 MB are plain np.empty."""
+
+    MIN_BYTES = 64 << 20
+
+    def __init__(self):
+        try:
+            self.cap = int(float(os.environ.get("DV_HOST_POOL_GB", "32")) * (1 << 30))
+        except ValueError:
+            self.cap = 32 << 30
+        self.blocks: List[np.ndarray] = []
+
+    def empty(self, shape, dtype) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if nbytes < self.MIN_BYTES or nbytes > self.cap:
+            return np.empty(shape, dtype)
+        pick = -1
+        for i in range(len(self.blocks)):
+            # 2 = the list's reference + getrefcount's argument: no view of this block is alive anywhere
+            if sys.getrefcount(self.blocks[i]) == 2 and self.blocks[i].nbytes >= nbytes and (
+                    pick < 0 or self.blocks[i].nbytes < self.blocks[pick].nbytes):
+                pick = i
+        if pick < 0:
+            total = sum(b.nbytes for b in self.blocks)
+            i = 0
+            while total + nbytes > self.cap and i < len(self.blocks):      # make room: drop idle blocks, oldest first
+                if sys.getrefcount(self.blocks[i]) == 2:
+                    total -= self.blocks[i].nbytes
+                    del self.blocks[i]
+                else:
+                    i += 1
+            if total + nbytes > self.cap:
+                return np.empty(shape, dtype)                                # everything pooled is in use: not tracked
+            self.blocks.append(np.empty(nbytes, np.uint8))
+            pick = len(self.blocks) - 1
+        else:
+            self.blocks.append(self.blocks.pop(pick))                        # most recently used last
+            pick = len(self.blocks) - 1
+        return self.blocks[pick][:nbytes].view(dtype).reshape(shape)
+
+    def clear(self):
+        self.blocks = []
+
+
+_host_pool = _HostPool()
 
 
 def _f32c(a, shape=None) -> np.ndarray:
@@ -422,7 +481,7 @@ class Engine:
                     raise ValueError(f"out[{k!r}] must be a C-contiguous float32 array of shape {shape}")
                 bufs[k] = out[k]
             else:
-                bufs[k] = np.empty(shape, np.float32)
+                bufs[k] = _host_pool.empty(shape, np.float32)
         if eps is not None:
             eps = _f32c(eps, (N, self.latent))
         if f64:
@@ -452,7 +511,7 @@ class Engine:
                     raise ValueError(f"out[{k!r}] must be a C-contiguous float32 array of shape {shape}")
                 bufs[k] = out[k]
             else:
-                bufs[k] = np.empty(shape, np.float32)
+                bufs[k] = _host_pool.empty(shape, np.float32)
         check(lib.dv_infer_cutouts(self._h, field.ctypes.data_as(C.POINTER(C.c_double)), field.shape[0], field.shape[2],
                                    starts.ctypes.data_as(C.POINTER(C.c_int32)), N, int(seed), _fp(bufs["loc"]),
                                    _fp(bufs["scale"]), _fp(bufs["mu"]), _fp(bufs["zstd"]), _fp(bufs["z"])))
@@ -468,8 +527,9 @@ class Engine:
         if field.ndim != 3 or field.shape[0] != field.shape[1]:
             raise ValueError(f"expected a square field (F, F, bands), got {field.shape}")
         N = starts.shape[0]
-        out = {"loc": np.empty((N,) + self.stamp_shape, np.float32), "scale": np.empty((N,) + self.stamp_shape, np.float32),
-               "cutouts": np.empty((N,) + self.stamp_shape, np.float64)}
+        out = {"loc": _host_pool.empty((N,) + self.stamp_shape, np.float32),
+               "scale": _host_pool.empty((N,) + self.stamp_shape, np.float32),
+               "cutouts": _host_pool.empty((N,) + self.stamp_shape, np.float64)}
         check(lib.dv_infer_cutouts_keep(self._h, field.ctypes.data_as(C.POINTER(C.c_double)), field.shape[0], field.shape[2],
                                         starts.ctypes.data_as(C.POINTER(C.c_int32)), N, int(seed), _fp(out["loc"]),
                                         _fp(out["scale"]), out["cutouts"].ctypes.data_as(C.POINTER(C.c_double))))

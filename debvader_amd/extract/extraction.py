@@ -12,14 +12,33 @@ def cutout_windows(field_size, galaxy_distances_to_center, cutout_size=59):
     is empty).
     """
     half = int(cutout_size / 2)
+    try:                                             # all galaxies at once; int() truncates towards zero
+        d = np.asarray(galaxy_distances_to_center, dtype=np.float64)
+        if d.ndim != 2 or d.shape[1] < 2 or not np.isfinite(d).all():
+            raise ValueError
+        start = -half + np.trunc(d[:, :2]).astype(np.int64) + int(field_size / 2)
+    except (ValueError, TypeError):
+        return _cutout_windows_loop(field_size, galaxy_distances_to_center, cutout_size)
+    end = start + 2 * half + 1
+    inside = (start >= 0) & (end <= field_size)
+    # numpy wraps negative indices: a window that lies entirely at negative indices (a galaxy more than half a field
+    # beyond the low edge) is a full-size slice counted from the far edge.  The reference accepts it.
+    wrapped = (start < 0) & (end < 0) & (field_size + start >= 0)
+    starts = np.where(inside, start, np.where(wrapped, field_size + start, 0))
+    ok = (inside | wrapped).all(axis=1) & (2 * half + 1 == cutout_size)
+    return starts.astype(np.int32).reshape(-1, 2), ok
+
+
+def _cutout_windows_loop(field_size, galaxy_distances_to_center, cutout_size=59):
+    """cutout_windows galaxy by galaxy (the form that follows extraction.py:26-30 line by line; the fallback for inputs
+    that are not a rectangular numeric table, and what tests compare the vector form with)."""
+    half = int(cutout_size / 2)
     starts, ok = [], []
 
     def axis(start):
         end = start + 2 * half + 1
         if start >= 0 and end <= field_size:
             return start, True
-        # numpy wraps negative indices: a window that lies entirely at negative indices (a galaxy more than half a
-        # field beyond the low edge) is a full-size slice counted from the far edge.  The reference accepts it.
         if start < 0 and end < 0 and field_size + start >= 0:
             return field_size + start, True
         return 0, False

@@ -126,12 +126,41 @@ def test_bad_architectures_are_rejected_with_a_message():
         E.arch_counts(E.make_config(kernels=(3, 7, 3, 3)))
     with pytest.raises(DvError, match="3x3"):                   # the bf16 engine: 3x3 only
         E.arch_counts(E.make_config(kernels=(3, 5, 3, 3), dtype=1))
+    with pytest.raises(DvError, match="bands"):                 # 1 .. 15 bands (fp32), 1 .. 7 (bf16)
+        E.arch_counts(E.make_config(input_shape=(59, 59, 16)))
     with pytest.raises(DvError, match="bands"):
-        E.arch_counts(E.make_config(input_shape=(59, 59, 8)))
+        E.arch_counts(E.make_config(input_shape=(59, 59, 8), dtype=1))
+    ten = E.make_config(input_shape=(59, 59, 10), latent_dim=10)   # 8 .. 15 bands and any latent size: accepted (fp32)
+    from oracle import vae_oracle as vo
+    assert E.arch_specs(ten) == vo.Arch((59, 59, 10), 10).param_specs() and E.arch_counts(ten)["tensors"] == 64
     with pytest.raises(DvError, match="square"):
         E.arch_counts(E.make_config(input_shape=(59, 60, 6)))
     with pytest.raises(ValueError):
         E.make_config(filters=(32, 64), kernels=(3,))
+
+
+def test_host_result_pool_never_hands_out_memory_somebody_still_holds():
+    """engine._HostPool: blocks go out again only when no view of them is alive; below the threshold and above the cap it is
+    plain np.empty."""
+    from debvader_amd.engine import _HostPool
+
+    p = _HostPool()
+    p.MIN_BYTES, p.cap = 1 << 20, 10 << 20
+    a = p.empty((4, 1 << 16), np.float64)                      # 2 MB
+    assert a.flags.c_contiguous and a.shape == (4, 1 << 16) and len(p.blocks) == 1
+    views = list(a)                                            # what a recarray column holds
+    del a
+    b = p.empty((1 << 18,), np.float64)
+    assert len(p.blocks) == 2 and not any(np.shares_memory(b, v) for v in views)
+    del views
+    c = p.empty((1 << 19,), np.float32)                        # the first block is idle again: reused, no third block
+    assert len(p.blocks) == 2 and not np.shares_memory(b, c)
+    d = p.empty((1 << 20,), np.float64)                        # 8 MB on top of 4 MB in use: over the cap, untracked
+    assert d.base is None and len(p.blocks) == 2
+    del b, c
+    e = p.empty((1 << 20,), np.float64)                        # idle blocks are dropped to make room
+    assert e.base is not None and sum(x.nbytes for x in p.blocks) <= p.cap
+    assert p.empty((3,), np.float32).base is None
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -20,7 +20,7 @@ from tests.test_gpu_parity import _run_parity
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("bands", [5, 3, 1, 7])
+@pytest.mark.parametrize("bands", [5, 3, 1, 7, 8, 10, 15])
 def test_band_counts_the_reference_api_accepts_toy_arch(bands):
     arch = vo.Arch(input_shape=(13, 13, bands), latent_dim=8, filters=(8, 16), kernels=(3, 3))
     _run_parity(arch, B=5, seed=40 + bands)
@@ -34,6 +34,71 @@ def test_five_bands_on_the_reference_architecture():
     arch = vo.Arch(input_shape=(59, 59, 5))
     x, y = synthetic_stamps(8, seed=15, nb=5)
     _run_parity(arch, B=8, seed=61, data=(x, y))
+
+
+def test_ten_bands_on_the_reference_architecture():
+    # (59, 59, 10): train.py:86,104-107 builds (59, 59, nb_of_bands) for any band count; 8 .. 15 bands take the 16-channel
+    # form of the folded first conv (bands + the constant 1 that carries the BatchNorm shift) and 32 head columns
+    from debvader_amd.data import synthetic_stamps
+
+    arch = vo.Arch(input_shape=(59, 59, 10))
+    x, y = synthetic_stamps(8, seed=16, nb=10)
+    _run_parity(arch, B=8, seed=62, data=(x, y))
+
+
+@pytest.mark.parametrize("latent", [10, 5, 30, 1, 63])
+def test_latent_sizes_that_are_not_multiples_of_four_toy_arch(latent):
+    # model.py:164 takes any latent_dim: params_size = d + d (d + 1) / 2 is then rarely a multiple of 4; the engine pads the
+    # rows of t / z / eps to 16-byte multiples and the two Dense kernels that touch them (zeros)
+    arch = vo.Arch(input_shape=(13, 13, 4), latent_dim=latent, filters=(8, 16), kernels=(3, 3))
+    _run_parity(arch, B=5, seed=140 + latent)
+    _run_parity(arch, B=9, seed=150 + latent, train_decoder=False)
+
+
+def test_latent_dim_ten_on_the_reference_architecture():
+    from debvader_amd.data import synthetic_stamps
+
+    arch = vo.Arch(latent_dim=10)
+    x, y = synthetic_stamps(8, seed=17)
+    _run_parity(arch, B=8, seed=63, data=(x, y))
+
+
+def test_latent_dim_ten_through_the_api_sub_models():
+    """encoder(x) -> (B, 65) rows, z(x).mean() / .stddev() -> (B, 10), decoder(z) and deblend over more stamps than one engine
+    batch: the strided device rows are packed on every way out and in (dv_encode, dv_decode, dv_infer's mu / zstd / z)."""
+    from debvader_amd.data import synthetic_stamps
+    from debvader_amd.deblend_cutout.deblender import deblend
+    from debvader_amd.model import model
+
+    arch = vo.Arch(input_shape=(13, 13, 4), latent_dim=10, filters=(8, 16), kernels=(3, 3))
+    net, encoder, decoder, z = model.create_model_vae((13, 13, 4), 10, [8, 16], [3, 3], max_batch=8, seed=4)
+    eng = net._core.engine
+    p = vo.init_params(arch, seed=11, perturb=0.05)
+    p = {k: v.astype(np.float32).astype(np.float64) for k, v in p.items()}
+    eng.set_params(p)
+    x, _ = synthetic_stamps(19, seed=18, size=13, nb=4)
+    t = encoder(x).numpy()
+    ref_t = vo.encoder_forward(arch, p, x.astype(np.float64), training=False)
+    assert t.shape == (19, 65)
+    np.testing.assert_allclose(t, ref_t, rtol=0, atol=2e-4 * np.abs(ref_t).max())
+    q = z(x)
+    np.testing.assert_array_equal(q.mean().numpy(), t[:, :10])
+    L = vo.sampler_forward(arch, ref_t, np.zeros((19, 10)))[1]
+    np.testing.assert_allclose(q.stddev().numpy(), np.sqrt((L ** 2).sum(-1)), rtol=2e-4)
+    zz = np.random.default_rng(5).normal(size=(19, 10)).astype(np.float32)
+    d = decoder(zz)
+    loc, _ = vo.decoder_forward(arch, p, zz.astype(np.float64))
+    np.testing.assert_allclose(d.mean().numpy(), loc, rtol=0, atol=2e-4 * np.abs(loc).max())
+    mean, dist = deblend(net, x.astype(np.float64))
+    assert mean.shape == (19, 13, 13, 4) and np.isfinite(mean).all() and (dist.stddev().numpy() >= 1e-4 * (1 - 1e-6)).all()
+    eng.close()
+
+
+def test_latent_dim_ten_on_the_bf16_engine():
+    from tests.test_gpu_bf16 import _run
+
+    arch = vo.Arch(input_shape=(13, 13, 4), latent_dim=10, filters=(16, 32), kernels=(3, 3))
+    _run(arch, B=5, seed=75, check_fp64_grads=False)
 
 
 @pytest.mark.parametrize("bands", [5, 3])

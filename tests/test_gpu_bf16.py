@@ -98,13 +98,13 @@ def _run(arch, B, seed, data=None, train_decoder=True, tol_out=1e-2, tol_grad_b=
     failed = []
     for name in g:
         gg = eng.get_grad(name)
-        eb, e64, cs = _relmax(gg, gb[name]), _relmax(gg, g[name]), _cos(gg, g[name])
-        rows.append((name, eb, e64, tol_grad_b, f"gradient; other = vs float64 oracle (bound {tol_grad_64:g}), cosine {cs:.4f} "
+        eb, ef, cs = _relmax(gg, gb[name]), _relmax(gg, g[name]), _cos(gg, g[name])
+        rows.append((name, eb, ef, tol_grad_b, f"gradient; other = vs float64 oracle (bound {tol_grad_64:g}), cosine {cs:.4f} "
                                                 f"(bound {min_cos:g}); bf16 oracle vs float64: {_relmax(gb[name], g[name]):.3e}"))
         if eb > tol_grad_b:
             failed.append(("bf16 oracle", name, eb))
-        if check_fp64_grads and (cs < min_cos or e64 > tol_grad_64):
-            failed.append(("fp64 oracle", name, e64, cs))
+        if check_fp64_grads and (cs < min_cos or ef > tol_grad_64):
+            failed.append(("fp64 oracle", name, ef, cs))
     margins.record(f"bf16 engine vs bf16-rounding oracle and float64 oracle: {'x'.join(map(str, arch.input_shape))}, "
                    f"{len(arch.filters)} levels, B={B}, {'stage 1' if train_decoder else 'decoder frozen'}, head scale bias +0.3",
                    rows, "engine = vs the bf16-rounding oracle (same storage roundings); errors are max|a - ref| / max|ref| per tensor")

@@ -41,6 +41,45 @@ def test_window_logic_matches_oracle():
         assert np.nonzero(ok)[0].tolist() == idx
 
 
+def test_vector_window_logic_equals_the_galaxy_by_galaxy_form():
+    from debvader_amd.extract.extraction import _cutout_windows_loop, cutout_windows
+    rng = np.random.default_rng(2)
+    for F, cs in ((41, 11), (15, 5), (259, 59), (60, 59), (30, 6)):
+        d = rng.uniform(-2 * F, 2 * F, size=(500, 2))
+        d[::3] = np.round(d[::3])
+        for table in (d, d.tolist(), [tuple(r) for r in d.astype(np.int64)]):
+            a, b = cutout_windows(F, table, cs), _cutout_windows_loop(F, table, cs)
+            assert a[0].dtype == b[0].dtype and a[1].dtype == b[1].dtype
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+    assert cutout_windows(15, [], 5)[0].shape == (0, 2)
+
+
+def test_recarray_built_directly_equals_the_pandas_one_of_the_reference():
+    """field_deblender.py:380 returns pd.DataFrame(res_deblend).to_records(index=False); _to_records builds the same recarray
+    without pandas inspecting the image columns."""
+    import pandas as pd
+
+    from debvader_amd.deblend.field_deblender import _to_records
+    rng = np.random.default_rng(3)
+    for n, dist in ((7, rng.uniform(-9, 9, (7, 2))), (1, np.array([[3, -4]])), (4, [(1, 2), (3, 4), (5, 6), (7, 8)])):
+        cols = {"cutout_images": list(rng.normal(size=(n, 5, 5, 2))),
+                "output_images_mean": list(rng.normal(size=(n, 5, 5, 2)).astype(np.float32)),
+                "output_images_stddev": list(rng.normal(size=(n, 5, 5, 2)).astype(np.float32)),
+                "shifts": [np.array([0, 0]) for _ in range(n)], "list_idx": list(range(n)),
+                "galaxy_distances_to_center_x": [dist[k][0] for k in range(n)],
+                "galaxy_distances_to_center_y": [dist[k][1] for k in range(n)],
+                "epistemic_uncertainty": list(np.zeros((n, 5, 5, 2))), "passed_cuts": [bool(k % 2) for k in range(n)]}
+        want = pd.DataFrame(cols).to_records(index=False)
+        got = _to_records(cols)
+        assert type(got) is type(want) and got.dtype == want.dtype and got.shape == want.shape
+        for k in cols:
+            for a, b in zip(got[k], want[k]):
+                np.testing.assert_array_equal(a, b)
+                assert type(a) is type(b)
+        assert got[0]["cutout_images"] is cols["cutout_images"][0]
+
+
 @pytest.mark.gpu
 def test_extract_cutouts_gpu_matches_reference_fixture(capsys):
     from debvader_amd.extract.extraction import extract_cutouts
