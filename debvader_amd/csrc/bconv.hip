@@ -33,7 +33,8 @@ constexpr int BC_GT = 16;      // groups per tile
 #define BC_NST_VALUE 3
 #endif
 constexpr int BC_NST = BC_NST_VALUE;   // LDS stages: 3 = DMA two steps ahead; 2 = one step ahead, but twice the workgroups per CU
-constexpr int BC_TABW = 12;    // table row: 9 tap offsets, output row base, pixel index, spare
+constexpr int BC_MAXT = 25;    // taps of the largest kernel (5 x 5)
+constexpr int BC_TABW = 28;    // table row: up to 25 tap offsets, output row base, pixel index, spare
 
 template <int N>
 struct BfVec;
@@ -81,8 +82,10 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
   constexpr int BN = 16 * NBLK;
   constexpr int NST = BC_NST;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  int* tab = reinterpret_cast<int*>(smem + NST * STAGE);   // [16][12]
-  int* anyv = tab + BC_GT * BC_TABW;                      // [16]
+  int* tab = reinterpret_cast<int*>(smem + NST * STAGE);   // [16][BC_TABW]
+  int* anyv = tab + BC_GT * BC_TABW;                      // [BC_MAXT + 1]
+  int* vlist = anyv + BC_MAXT + 1;                        // [BC_MAXT] valid taps in order
+  const int ksz = p.ksz, ntap = ksz * ksz;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
   };
   // source pixel of tap t for output pixel (oh, ow), -1 when outside the image (or, form 1, between the strides)
   auto src_pixel = [&](int oh, int ow, int t) -> int {
-    const int kh = (t * 11) >> 5, kw = t - kh * 3;       // t / 3 for t < 9
+    const int kh = ksz == 3 ? (t * 11) >> 5 : t / ksz, kw = t - kh * ksz;       // (t * 11) >> 5 = t / 3 for t < 9
     int ih, iw;
     bool ok = true;
     if (p.form == 0) {
@@ -127,7 +130,6 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
   // ---- which groups / taps: a tile that is ONE pixel (stamps padded to a multiple of 256) needs no table -------
   const bool uni = (NSB & 15) == 0;
   int u_oh = 0, u_ow = 0, u_sb0 = 0;                    // uniform tile: its pixel and first stamp block
-  unsigned long long vcode = 0;
   int nvalid = 0;
   if (uni) {
     const int tpp = NSB >> 4;
@@ -135,15 +137,17 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
     u_sb0 = (tile_m - vp * tpp) * 16;
     vpixel(vp, &u_oh, &u_ow);
     if (u_oh >= p.Hout || u_ow >= p.Hout) return;      // padding of the 8 x 8 blocks
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-      if (src_pixel(u_oh, u_ow, t) >= 0) {
-        vcode |= (unsigned long long)t << (4 * nvalid);
-        ++nvalid;
-      }
+    if (tid == 0) {
+      int n = 0;
+      for (int t = 0; t < ntap; ++t)
+        if (src_pixel(u_oh, u_ow, t) >= 0) vlist[n++] = t;
+      anyv[BC_MAXT] = n;
+    }
+    __syncthreads();
+    nvalid = anyv[BC_MAXT];
   } else {
-    if (tid < BC_GT * 9) {
-      const int g = tid / 9, t = tid - g * 9;
+    for (int e = tid; e < BC_GT * ntap; e += 256) {
+      const int g = e / ntap, t = e - g * ntap;
       const int m16 = tile_m * BC_GT + g;
       int off = -1;
       const int vp = m16 / NSB, sb = m16 - vp * NSB;
@@ -154,37 +158,35 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
         // offset of the group's [16][Cin] block in units of 8 elements (16 bytes)
         if (sp >= 0) off = (sp * p.NBp + sb * 16) * (p.Cin >> 3);
         if (t == 0) {
-          tab[g * BC_TABW + 9] = (oh * p.Hout + ow) * p.NBp + sb * 16;
-          tab[g * BC_TABW + 10] = oh * p.Hout + ow;
+          tab[g * BC_TABW + BC_MAXT] = (oh * p.Hout + ow) * p.NBp + sb * 16;
+          tab[g * BC_TABW + BC_MAXT + 1] = oh * p.Hout + ow;
         }
       } else if (t == 0) {
-        tab[g * BC_TABW + 9] = -1;
-        tab[g * BC_TABW + 10] = 0;
+        tab[g * BC_TABW + BC_MAXT] = -1;
+        tab[g * BC_TABW + BC_MAXT + 1] = 0;
       }
       tab[g * BC_TABW + t] = off;
     }
     __syncthreads();
-    if (tid < 10) {                                     // taps 0..8; 9: any group inside the image
+    if (tid <= ntap) {                                  // taps 0 .. ntap - 1; ntap: any group inside the image
       int a = 0;
 #pragma unroll
-      for (int g = 0; g < BC_GT; ++g) a |= tab[g * BC_TABW + tid] >= 0 ? 1 : 0;
-      anyv[tid] = a;
+      for (int g = 0; g < BC_GT; ++g) a |= tab[g * BC_TABW + (tid < ntap ? tid : BC_MAXT)] >= 0 ? 1 : 0;
+      anyv[tid < ntap ? tid : BC_MAXT] = a;
     }
     __syncthreads();
-    if (!anyv[9]) return;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-      if (anyv[t]) {
-        vcode |= (unsigned long long)t << (4 * nvalid);
-        ++nvalid;
-      }
+    if (!anyv[BC_MAXT]) return;
+    __syncthreads();
+    if (tid == 0) {
+      int n = 0;
+      for (int t = 0; t < ntap; ++t)
+        if (anyv[t]) vlist[n++] = t;
+      anyv[BC_MAXT] = n;
+    }
+    __syncthreads();
+    nvalid = anyv[BC_MAXT];
   }
   nvalid = __builtin_amdgcn_readfirstlane(nvalid);
-  {
-    const unsigned vlo = __builtin_amdgcn_readfirstlane((unsigned)vcode);
-    const unsigned vhi = __builtin_amdgcn_readfirstlane((unsigned)(vcode >> 32));
-    vcode = ((unsigned long long)vhi << 32) | vlo;
-  }
   // block offset (units of 16 bytes) of group g for tap t, -1 outside; output row base and pixel of group g
   auto group_off = [&](int g, int t) -> int {
     if (uni) {
@@ -193,12 +195,12 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
     }
     return tab[g * BC_TABW + t];
   };
-  auto group_rb = [&](int g) -> int { return uni ? (u_oh * p.Hout + u_ow) * p.NBp + (u_sb0 + g) * 16 : tab[g * BC_TABW + 9]; };
-  auto group_pix = [&](int g) -> int { return uni ? u_oh * p.Hout + u_ow : tab[g * BC_TABW + 10]; };
+  auto group_rb = [&](int g) -> int { return uni ? (u_oh * p.Hout + u_ow) * p.NBp + (u_sb0 + g) * 16 : tab[g * BC_TABW + BC_MAXT]; };
+  auto group_pix = [&](int g) -> int { return uni ? u_oh * p.Hout + u_ow : tab[g * BC_TABW + BC_MAXT + 1]; };
 
   const int cpt = p.Cin >> 5;         // chunks per tap (CINMODE 0)
   const int ppt = p.Cin >> 3;         // 16-byte pieces per tap (CINMODE 1: 1 or 2)
-  const int nsteps = CINMODE == 0 ? nvalid * cpt : (9 * ppt + 3) >> 2;
+  const int nsteps = CINMODE == 0 ? nvalid * cpt : (ntap * ppt + 3) >> 2;
 
   // DMA lane roles: LDS slot `lane` of a block = (row, piece ^ G4[row>>2])
   const int drow = lane >> 2;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
       if (is_ti < 0 || is_cc + 1 == cpt) {
         ++is_ti;
         is_cc = 0;
-        is_tap = (int)((vcode >> (4 * is_ti)) & 15);
+        is_tap = __builtin_amdgcn_readfirstlane(vlist[is_ti]);
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
           const int off = group_off(wave * 4 + gi, is_tap);
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
       const int piece = step * 4 + dq;
       const int tap = ppt == 1 ? piece : piece >> 1;
       const int sub = ppt == 1 ? 0 : piece & 1;
-      const bool pv = piece < 9 * ppt;
+      const bool pv = piece < ntap * ppt;
       const int lo = arow + sub * 8;
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
@@ -510,7 +512,8 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
   constexpr int BN = 16 * NBLK;
   static_assert(RW * BN * 2 >= 1024, "a wave's bf16 tile must be at least one 1-KiB row piece");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  int* stab = reinterpret_cast<int*>(smem + NS * STAGE);   // [0] valid taps, [1..9] their ids, [10..18] their source pixels
+  int* stab = reinterpret_cast<int*>(smem + NS * STAGE);   // [0] valid taps, [1..25] their ids, [26..50] their source pixels
+  const int ksz = p.ksz, ntap = ksz * ksz;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
   const int pix = oh * p.Hout + ow;
 
   auto src_pixel = [&](int t) -> int {                   // t may be a lane value (CINMODE 1)
-    const int kh = (t * 11) >> 5, kw = t - kh * 3;
+    const int kh = ksz == 3 ? (t * 11) >> 5 : t / ksz, kw = t - kh * ksz;
     int ih, iw;
     bool ok = true;
     if (p.form == 0) {
@@ -550,12 +553,11 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
   if (CINMODE == 0) {
     if (tid == 0) {
       int n = 0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      for (int t = 0; t < ntap; ++t) {
         const int sp = src_pixel(t);
         if (sp >= 0) {
           stab[1 + n] = t;
-          stab[10 + n] = sp;
+          stab[1 + BC_MAXT + n] = sp;
           ++n;
         }
       }
@@ -564,8 +566,8 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
     __syncthreads();
   }
   const int cpt = p.Cin >> 5, ppt = p.Cin >> 3;
-  const int nvalid = CINMODE == 0 ? __builtin_amdgcn_readfirstlane(stab[0]) : 9;
-  const int nsteps = CINMODE == 0 ? nvalid * (cpt / CH) : (9 * ppt + 3) >> 2;      // (CH == 2: cpt is even)
+  const int nvalid = CINMODE == 0 ? __builtin_amdgcn_readfirstlane(stab[0]) : ntap;
+  const int nsteps = CINMODE == 0 ? nvalid * (cpt / CH) : (ntap * ppt + 3) >> 2;      // (CH == 2: cpt is even)
 
   const int drow = lane >> 2;
   const int dq = (lane & 3) ^ ((4 - (drow >> 2)) & 3);
@@ -580,19 +582,20 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
   const unsigned gstride = (unsigned)(16 * p.Cin * 2);   // one 16-stamp group
   const unsigned char* wbase = Wb + (size_t)(n0 + jb) * p.Kpad * 2;
 
-  // CINMODE 1: the (at most five) steps' lane sources, worked out once
-  const unsigned char* psrc[5] = {zlane, zlane, zlane, zlane, zlane};
-  bool pok[5] = {false, false, false, false, false};
+  // CINMODE 1: the lane source of step i (piece i * 4 + dq of the (tap, 8-channel piece) list); null = outside the image
+  auto piece_src = [&](int i) -> const unsigned char* {
+    const int piece = i * 4 + dq;
+    const int tap = ppt == 1 ? piece : piece >> 1;
+    const int sub = ppt == 1 ? 0 : piece & 1;
+    const int sp = piece < ntap * ppt ? src_pixel(tap) : -1;
+    return sp >= 0 ? Xb + (size_t)sp * pixbytes + (unsigned)((((st0 + wave * RW + drow) * p.Cin) + sub * 8) * 2) : nullptr;
+  };
+  // 3 x 3 kernels (at most five steps): worked out once; larger kernels (up to 13 steps) work them out at issue time
+  const unsigned char* psrc[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if constexpr (CINMODE == 1) {
+    if (ksz == 3) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int piece = i * 4 + dq;
-      const int tap = ppt == 1 ? piece : piece >> 1;
-      const int sub = ppt == 1 ? 0 : piece & 1;
-      const int sp = piece < 9 * ppt ? src_pixel(tap) : -1;
-      pok[i] = sp >= 0;
-      psrc[i] = Xb + (size_t)(sp >= 0 ? sp : 0) * pixbytes +
-                (unsigned)((((st0 + wave * RW + drow) * p.Cin) + sub * 8) * 2);
+      for (int i = 0; i < 5; ++i) psrc[i] = piece_src(i);
     }
   }
 
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
         ++is_ti;
         is_cc = 0;
         is_tap = __builtin_amdgcn_readfirstlane(stab[1 + is_ti]);
-        tsrc = Xb + (size_t)__builtin_amdgcn_readfirstlane(stab[10 + is_ti]) * pixbytes;
+        tsrc = Xb + (size_t)__builtin_amdgcn_readfirstlane(stab[1 + BC_MAXT + is_ti]) * pixbytes;
       } else {
         is_cc += CH;
       }
@@ -622,15 +625,19 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
         __builtin_amdgcn_global_load_lds((bc_gptr_t)(wbase + (is_tap * p.Cin + (is_cc + h) * 32) * 2 + b_lane),
                                          (bc_lptr_t)(sB + h * SUB + jb * 1024), 16, 0, 0);
     } else {
+      const unsigned char* ps = nullptr;
+      if (ksz == 3) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i)
-        if (i == step) {
+        for (int i = 0; i < 5; ++i)
+          if (i == step) ps = psrc[i];
+      } else {
+        ps = piece_src(step);
+      }
 #pragma unroll
-          for (int gi = 0; gi < GW; ++gi) {
-            const void* src = pok[i] ? (const void*)(psrc[i] + gi * gstride) : (const void*)zlane;
-            __builtin_amdgcn_global_load_lds((bc_gptr_t)src, (bc_lptr_t)(sA + (wave * GW + gi) * 1024), 16, 0, 0);
-          }
-        }
+      for (int gi = 0; gi < GW; ++gi) {
+        const void* src = ps ? (const void*)(ps + gi * gstride) : (const void*)zlane;
+        __builtin_amdgcn_global_load_lds((bc_gptr_t)src, (bc_lptr_t)(sA + (wave * GW + gi) * 1024), 16, 0, 0);
+      }
       __builtin_amdgcn_global_load_lds((bc_gptr_t)(wbase + step * 64 + b_lane), (bc_lptr_t)(sB + jb * 1024), 16, 0, 0);
     }
   };
@@ -1150,8 +1157,10 @@ __global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) 
 
 int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   BConvParams p = p_in;
-  if (p.NBp <= 0 || (p.NBp & 15) || p.Cout % 16 || p.Kpad % 32 || p.s < 1 || p.s > 2) {
-    set_error("bconv: bad geometry (NBp %d, Cout %d, Kpad %d)", p.NBp, p.Cout, p.Kpad);
+  if (p.ksz == 0) p.ksz = 3;
+  if (p.NBp <= 0 || (p.NBp & 15) || p.Cout % 16 || p.Kpad % 32 || p.s < 1 || p.s > 2 || p.ksz < 1 || p.ksz > 5 ||
+      p.Kpad < p.ksz * p.ksz * p.Cin) {
+    set_error("bconv: bad geometry (NBp %d, Cout %d, Kpad %d, kernel size %d)", p.NBp, p.Cout, p.Kpad, p.ksz);
     return E_INVALID;
   }
   const int mode = p.Cin % 32 == 0 ? 0 : ((p.Cin == 8 || p.Cin == 16) ? 1 : -1);
@@ -1200,7 +1209,7 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   // input row of register loads in flight does not cover the L2 / HBM latency: DESIGN 4b).  DV_BCONV_ROW=2 takes it for
   // every eligible layer (the A/B switch of that measurement), =0 never.
   static const int row_mode = getenv("DV_BCONV_ROW") ? atoi(getenv("DV_BCONV_ROW")) : 1;
-  if (row_mode && mode == 0 && p.s == 1 && p.pb == 1 && p.Hin == p.Hout && (p.NBp & 63) == 0) {
+  if (row_mode && mode == 0 && p.ksz == 3 && p.s == 1 && p.pb == 1 && p.Hin == p.Hout && (p.NBp & 63) == 0) {
     int nb = p.Cout % 64 == 0 ? 4 : (p.Cout % 32 == 0 ? 2 : 1);
     const long strips = (long)p.Hout * ((p.Hout + 7) / 8);
     auto rtiles = [&](int b) { return strips * (p.NBp >> 6) * (p.Cout / (16 * b)); };
@@ -1237,7 +1246,7 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   // (64 accumulators: three workgroups per CU spill) 1.99.  DV_BCONV_NS2=0|1|2|3 selects these (read per call: tests).
   const int ns2_mode = getenv("DV_BCONV_NS2") ? atoi(getenv("DV_BCONV_NS2")) : 2;
   const bool ns2 = uni && ((ns2_mode >= 1 && gt == 16 && nblk <= 2) || (ns2_mode >= 2 && gt < 16) || (ns2_mode >= 3 && gt == 16));
-  const size_t lds = uni ? (size_t)(ns2 ? 2 : 3) * ch * (gt + nblk) * 1024 + 4096 : (size_t)BC_NST * (BC_GT + nblk) * 1024 + 1024;
+  const size_t lds = uni ? (size_t)(ns2 ? 2 : 3) * ch * (gt + nblk) * 1024 + 4096 : (size_t)BC_NST * (BC_GT + nblk) * 1024 + 2048;
 #define BC_LAUNCH_K(KERNEL_)                                                                           \
   do {                                                                                                 \
     static size_t attr_lds = 0;                                                                        \

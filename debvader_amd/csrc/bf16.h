@@ -36,6 +36,7 @@ struct BConvParams {
   int form, s, pb;
   int Kpad;
   int epi;
+  int ksz;             // kernel size 1 .. 5 (0: 3); taps t = kh * ksz + kw, k = t * Cin + c
 };
 int launch_bconv(const BConvParams& p, hipStream_t s);
 // BWD epilogue is usable (a wave's four 16-stamp groups share one pixel)
@@ -106,10 +107,11 @@ int launch_bf_reduce_batch(const BRedBatch& b, hipStream_t s);
 
 // one weight matrix of the family, produced from the fp32 master tensor by bf_cast_weights
 struct BCastDesc {
-  const float* src;    // master tensor [9][A][B] (taps, then two channel axes), or null (descriptor unused)
+  const float* src;    // master tensor [taps][A][B] (taps, then two channel axes), or null (descriptor unused)
   void* dst;           // bf16 [N][Kpad]
   int A, B;            // master axes after the tap axis
   int n_is_b;          // 1: n = B index, c = A index (dst[n][tap*A + c] = src[tap][c][n]); 0: n = A, c = B
+  int taps;            // kernel taps (ksz * ksz; 0: 9)
   int N, Cin, Kpad;    // N rows written (>= real n count: extra rows zero), Cin = c extent in dst (>= real: zero)
   // first conv with the input BatchNorm folded in: c < nbands scaled by gamma[c], c == nbands = sum_c w*beta
   const float* gamma;

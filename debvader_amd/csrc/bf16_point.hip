@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void bf_cast_kernel(const BCastDesc* __restric
     const int n = (int)(e / d.Kpad), k = (int)(e - (long)n * d.Kpad);
     float v = 0.f;
     const int nreal = d.n_is_b ? d.B : d.A, creal = d.n_is_b ? d.A : d.B;
-    if (k < 9 * d.Cin && n < nreal) {
+    if (k < (d.taps ? d.taps : 9) * d.Cin && n < nreal) {
       const int tap = k / d.Cin, c = k - tap * d.Cin;
       if (d.gamma) {
         // first conv: master [9][nbands][B], n = B index; folded input BatchNorm

@@ -146,10 +146,6 @@ struct Arch {
         set_error("kernel sizes 1 .. 5 are implemented (kernels[%d]=%d)", i, c->kernels[i]);
         return E_INVALID;
       }
-      if (c->kernels[i] != 3 && c->dtype == DV_DTYPE_BF16) {
-        set_error("the bf16 engine implements 3x3 kernels only (kernels[%d]=%d): use dtype f32", i, c->kernels[i]);
-        return E_INVALID;
-      }
       if (c->filters[i] < 4 || (c->filters[i] & 3)) {
         set_error("filters must be multiples of 4");
         return E_INVALID;
@@ -404,6 +400,8 @@ struct BfState {
   std::vector<dv::BCastDesc> descs;
   dv::BCastDesc* descs_dev = nullptr;
   float* G0s16 = nullptr;        // not used directly: slabs of the first layer reduce into G0s
+  float *wx32 = nullptr, *wy32 = nullptr;   // fp32 [NB][pixels * channels] copies of the two operands of a weight gradient whose
+                                 // kernel size is not 3 (the bf16 weight-gradient kernel holds nine taps): see bf_wgrad_f32
   void* zero = nullptr;          // 1 KiB of zeros
   float* trunk[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // fp32 gradient rows of the dense trunk, one buffer per
                                  // stage of a backward pass (its weight gradients read them from the aux stream)

@@ -83,10 +83,11 @@ static int bf_alloc(dv_model* m) {
 
   // bf16 weight matrices and the descriptors the cast kernel walks
   float* P = m->P;
-  auto add = [&](const float* src, int Aax, int Bax, int n_is_b, int N, int Cin, void** dst, int* Kout) -> int {
+  auto add = [&](const float* src, int Aax, int Bax, int n_is_b, int N, int Cin, int ksz, void** dst, int* Kout) -> int {
     BCastDesc d;
     memset(&d, 0, sizeof d);
-    d.src = src; d.A = Aax; d.B = Bax; d.n_is_b = n_is_b; d.N = N; d.Cin = Cin; d.Kpad = bf_pad32(9 * Cin);
+    d.src = src; d.A = Aax; d.B = Bax; d.n_is_b = n_is_b; d.N = N; d.Cin = Cin; d.taps = ksz * ksz;
+    d.Kpad = bf_pad32(ksz * ksz * Cin);
     DV_TRY(balloc(dst, (size_t)N * d.Kpad * 2));
     d.dst = *dst;
     *Kout = d.Kpad;
@@ -98,25 +99,34 @@ static int bf_alloc(dv_model* m) {
     A.enc_layer(j, &hin, &cin, &hout, &cout, &s);
     const float* k = P + A.specs[A.enc_k(j)].off;           // HWIO [9][cin][cout]
     if (j == 0) {
-      DV_TRY(add(k, cin, cout, 1, cout, 16, &bf.enc_w[j].f, &bf.enc_w[j].Kf));
+      DV_TRY(add(k, cin, cout, 1, cout, 16, A.enc_ksz(j), &bf.enc_w[j].f, &bf.enc_w[j].Kf));
       BCastDesc& d = bf.descs.back();
       d.gamma = P + A.specs[0].off;
       d.beta = P + A.specs[1].off;
       d.nbands = A.C;
     } else {
-      DV_TRY(add(k, cin, cout, 1, cout, cin, &bf.enc_w[j].f, &bf.enc_w[j].Kf));
-      DV_TRY(add(k, cin, cout, 0, cin, cout, &bf.enc_w[j].d, &bf.enc_w[j].Kd));
+      DV_TRY(add(k, cin, cout, 1, cout, cin, A.enc_ksz(j), &bf.enc_w[j].f, &bf.enc_w[j].Kf));
+      DV_TRY(add(k, cin, cout, 0, cin, cout, A.enc_ksz(j), &bf.enc_w[j].d, &bf.enc_w[j].Kd));
     }
     A.dec_layer(j, &hin, &cin, &hout, &cout, &s);
     const float* kt = P + A.specs[A.dec_k(j)].off;           // (kh,kw,cout,cin)
-    DV_TRY(add(kt, cout, cin, 0, cout, cin, &bf.dec_w[j].f, &bf.dec_w[j].Kf));
-    DV_TRY(add(kt, cout, cin, 1, cin, cout, &bf.dec_w[j].d, &bf.dec_w[j].Kd));
+    DV_TRY(add(kt, cout, cin, 0, cout, cin, A.dec_ksz(j), &bf.dec_w[j].f, &bf.dec_w[j].Kf));
+    DV_TRY(add(kt, cout, cin, 1, cin, cout, A.dec_ksz(j), &bf.dec_w[j].d, &bf.dec_w[j].Kd));
   }
   {
     const int f0 = A.cfg.filters[0];
     const float* kh = P + A.specs[A.head_k()].off;           // HWIO [9][f0][2C]
-    DV_TRY(add(kh, f0, 2 * A.C, 1, 16, f0, &bf.head_w.f, &bf.head_w.Kf));
-    DV_TRY(add(kh, f0, 2 * A.C, 0, f0, 16, &bf.head_w.d, &bf.head_w.Kd));
+    DV_TRY(add(kh, f0, 2 * A.C, 1, 16, f0, 3, &bf.head_w.f, &bf.head_w.Kf));
+    DV_TRY(add(kh, f0, 2 * A.C, 0, f0, 16, 3, &bf.head_w.d, &bf.head_w.Kd));
+  }
+  {
+    bool any = false;
+    for (int i = 0; i < A.L; ++i) any = any || A.cfg.kernels[i] != 3;
+    if (any) {                     // operands of the fp32 weight-gradient kernels (bf_wgrad_f32)
+      max_e = std::max(max_e, (size_t)A.H * A.H * 16);
+      DV_TRY(balloc((void**)&bf.wx32, max_e * (size_t)m->Bc * 4));
+      DV_TRY(balloc((void**)&bf.wy32, max_e * (size_t)m->Bc * 4));
+    }
   }
   DV_TRY(balloc((void**)&bf.descs_dev, bf.descs.size() * sizeof(BCastDesc)));
   DV_HIP(hipMemcpyAsync(bf.descs_dev, bf.descs.data(), bf.descs.size() * sizeof(BCastDesc), hipMemcpyHostToDevice,
@@ -138,20 +148,20 @@ static int bf_refresh_weights(dv_model* m, hipStream_t s) {
 
 static int bf_conv(dv_model* m, const void* X, const void* W, int Kpad, int form, int Hin, int Cin, int Hout, int Cout,
                    int s, int pb, int epi, void* U, void* Aout, float* Uf, const float* bias, const float* alpha,
-                   const void* Uin, float* dalp, float* dbp) {
+                   const void* Uin, float* dalp, float* dbp, int ksz = 3) {
   BConvParams p;
   memset(&p, 0, sizeof p);
   p.X = X; p.W = W; p.zero = m->bf.zero; p.U = U; p.A = Aout; p.Uf = Uf; p.bias = bias; p.alpha = alpha; p.Uin = Uin;
   p.dal_part = dalp; p.db_part = dbp;
   p.Hin = Hin; p.Hout = Hout; p.Cin = Cin; p.Cout = Cout; p.NBp = m->bf.NBp;
-  p.form = form; p.s = s; p.pb = pb; p.Kpad = Kpad; p.epi = epi;
+  p.form = form; p.s = s; p.pb = pb; p.Kpad = Kpad; p.epi = epi; p.ksz = ksz;
   // algorithmic FLOPs: form 0 meets nine taps per output pixel, form 1 nine per source pixel; the folded
   // first conv and the padded head count their real channels
   const BfState& bf = m->bf;
   const double cin_alg = (W == bf.enc_w[0].f) ? m->A.C : (W == bf.head_w.d ? 2 * m->A.C : Cin);
   const double cout_alg = (W == bf.head_w.f) ? 2 * m->A.C : Cout;
   const double px = form == 0 ? (double)Hout * Hout : (double)Hin * Hin;
-  ProfScope ps(m, 0, nullptr, PF_BCONV, 2.0 * bf.NBp * px * 9.0 * cin_alg * cout_alg);
+  ProfScope ps(m, 0, nullptr, PF_BCONV, 2.0 * bf.NBp * px * (double)(ksz * ksz) * cin_alg * cout_alg);
   return launch_bconv(p, fwd_stream(m));
 }
 
@@ -171,10 +181,10 @@ static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, in
   for (int j = 0; j < 2 * A.L; ++j) {
     int hin, cin, hout, cout, st;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
-    const int pb = same_pad_before(hin, 3, st, nullptr);
+    const int pb = same_pad_before(hin, A.enc_ksz(j), st, nullptr);
     DV_TRY(bf_conv(m, in, bf.enc_w[j].f, bf.enc_w[j].Kf, 0, hin, j == 0 ? 16 : cin, hout, cout, st, pb, BEPI_FWD,
                    keep_u ? bf.enc_u[j] : nullptr, bf.enc_a[j], nullptr, P + A.specs[A.enc_b(j)].off,
-                   P + A.specs[A.enc_al(j)].off, nullptr, nullptr, nullptr));
+                   P + A.specs[A.enc_al(j)].off, nullptr, nullptr, nullptr, A.enc_ksz(j)));
     in = bf.enc_a[j];
   }
   const int sl = A.enc_sizes[A.L], fl = A.cfg.filters[A.L - 1];
@@ -214,10 +224,10 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
   for (int j = 0; j < 2 * A.L; ++j) {
     int hin, cin, hout, cout, st;
     A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
-    const int pb = same_pad_before(hout, 3, st, nullptr);
+    const int pb = same_pad_before(hout, A.dec_ksz(j), st, nullptr);
     DV_TRY(bf_conv(m, in, bf.dec_w[j].f, bf.dec_w[j].Kf, 1, hin, cin, hout, cout, st, pb, BEPI_FWD,
                    keep_u ? bf.dec_u[j] : nullptr, bf.dec_a[j], nullptr, P + A.specs[A.dec_b(j)].off,
-                   P + A.specs[A.dec_al(j)].off, nullptr, nullptr, nullptr));
+                   P + A.specs[A.dec_al(j)].off, nullptr, nullptr, nullptr, A.dec_ksz(j)));
     in = bf.dec_a[j];
   }
   return bf_conv(m, in, bf.head_w.f, bf.head_w.Kf, 0, A.dec_out, A.cfg.filters[0], A.dec_out, 16, 1, 1, BEPI_RAW32,
@@ -326,11 +336,47 @@ static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, i
   return OK;
 }
 
+// Weight gradient of a layer whose kernel size is not 3 (model.py:81-91 takes any kernels[i]): the bf16 weight-gradient
+// kernel keeps a 32 x 32 x NINE-tap accumulator per wave, so these layers take the fp32 engine's table-driven kernel on fp32
+// copies of the two bf16 operands (exact: every bf16 value is an fp32 value, products and sums in fp32 as on the bf16 matrix
+// cores).  Everything runs on the MAIN stream - copies, kernel, slab sum - after the weight-gradient and reduction streams
+// have been joined (their launches rotate through the same slab workspace): functional, not tuned, like the fp32 engine's
+// own k != 3 path.
+static int bf_wgrad_f32(dv_model* m, const void* X, int Hx, int Cx, const void* Y, int Hy, int Cy, int NB, int s, int pb,
+                        float* out, int cpad, int creal, int ksz) {
+  BfState& bf = m->bf;
+  dv_ctx* cx = m->ctx;
+  hipStream_t st = cx->stream;
+  if (!bf.wx32 || !bf.wy32) {
+    set_error("bf16 engine: no fp32 operand buffers for a %d x %d weight gradient", ksz, ksz);
+    return E_STATE;
+  }
+  hipStream_t ws = bf_wstream(m);
+  if (ws != st) {
+    DV_HIP(hipEventRecord(cx->ev_join, ws));
+    DV_HIP(hipStreamWaitEvent(st, cx->ev_join, 0));
+    if (cx->red_stream) {
+      DV_HIP(hipEventRecord(cx->ev_red, cx->red_stream));
+      DV_HIP(hipStreamWaitEvent(st, cx->ev_red, 0));
+    }
+  }
+  {
+    ProfScope ps(m, 2, st);
+    DV_TRY(launch_bf_to_rows(X, bf.wx32, NB, bf.NBp, Hx * Hx, Cx, st));
+    DV_TRY(launch_bf_to_rows(Y, bf.wy32, NB, bf.NBp, Hy * Hy, Cy, st));
+  }
+  hipStream_t keep = m->wstream;
+  m->wstream = st;                                   // kernel and slab sum on the main stream, the whole of ws1
+  const int r = wgrad(m, bf.wx32, Hx, Cx, bf.wy32, Hy, Cy, NB, s, pb, false, out, cpad, creal, nullptr, true, ksz);
+  m->wstream = keep;
+  return r;
+}
+
 // data gradient into `out` with the PReLU backward of the target layer (pre-activation u, slopes / bias specs) applied:
 // fused into the epilogue when the stamp padding allows it, else a separate pass
 static int bf_dgrad_prelu(dv_model* m, const void* X, const void* W, int Kpad, int form, int Hin, int Cin, int Hout,
                           int Cout, int s, int pb, void* out, const void* u, int alpha_spec, int bias_spec,
-                          bool want_grads) {
+                          bool want_grads, int ksz = 3) {
   const Arch& A = m->A;
   BfState& bf = m->bf;
   hipStream_t st = m->ctx->stream;
@@ -363,10 +409,10 @@ static int bf_dgrad_prelu(dv_model* m, const void* X, const void* W, int Kpad, i
       b.src = db; b.out = dbimg; b.final_out = m->G + A.specs[bias_spec].off; b.nparts = nparts; b.n = (int)E; b.cols = Cout;
     }
     return bf_conv(m, X, W, Kpad, form, Hin, Cin, Hout, Cout, s, pb, BEPI_BWD, out, nullptr, nullptr, nullptr, alpha, u, dal,
-                   db);
+                   db, ksz);
   }
   DV_TRY(bf_conv(m, X, W, Kpad, form, Hin, Cin, Hout, Cout, s, pb, BEPI_RAWBF, out, nullptr, nullptr, nullptr, nullptr,
-                 nullptr, nullptr, nullptr));
+                 nullptr, nullptr, nullptr, ksz));
   float* dbr = nullptr;
   if (want_grads) {
     if (m->arena_off + (size_t)E > m->arena_elems) {
@@ -424,17 +470,19 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   for (int j = 2 * A.L - 1; j >= 0; --j) {
     int hin, cin, hout, cout, st;
     A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
-    const int pb = same_pad_before(hout, 3, st, nullptr);
+    const int ksz = A.dec_ksz(j);
+    const int pb = same_pad_before(hout, ksz, st, nullptr);
     const void* xin = j == 0 ? bf.dec_in : bf.dec_a[j - 1];
     bf.du_dec[j] = cur;
-    if (dg) DV_TRY(bf_wgrad(m, cur, hout, cout, xin, hin, cin, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout));
+    if (dg && ksz == 3) DV_TRY(bf_wgrad(m, cur, hout, cout, xin, hin, cin, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout));
+    if (dg && ksz != 3) DV_TRY(bf_wgrad_f32(m, cur, hout, cout, xin, hin, cin, NB, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout, ksz));
     oth = next_buf();
     if (j > 0) {
       DV_TRY(bf_dgrad_prelu(m, cur, bf.dec_w[j].d, bf.dec_w[j].Kd, 0, hout, cout, hin, cin, st, pb, oth, bf.dec_u[j - 1],
-                            A.dec_al(j - 1), A.dec_b(j - 1), dg));
+                            A.dec_al(j - 1), A.dec_b(j - 1), dg, ksz));
     } else {
       DV_TRY(bf_conv(m, cur, bf.dec_w[j].d, bf.dec_w[j].Kd, 0, hout, cout, hin, cin, st, pb, BEPI_RAWBF, oth, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ksz));
     }
     cur = oth;
   }
@@ -552,20 +600,22 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   for (int j = 2 * A.L - 1; j >= 0; --j) {
     int hin, cin, hout, cout, st;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
-    const int pb = same_pad_before(hin, 3, st, nullptr);
+    const int ksz = A.enc_ksz(j);
+    const int pb = same_pad_before(hin, ksz, st, nullptr);
     bf.du_enc[j] = cur;
     if (j == 0) {
       // first conv with the folded input BatchNorm: the gradient w.r.t. the 16-channel folded kernel (channels
       // 0..C-1 = bands, C = the constant one) yields d(kernel), d(gamma), d(beta); no data gradient
       // last launch of the pass: on the (otherwise idle) main stream, slabs in the pool's tail region
-      const bool lm = ws != s && (size_t)((bf.NBp + 63) / 64) * 9 * 16 * cout <= bf.slab_tail / BF_MAIN_SLOTS;
-      DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8, lm));
+      const bool lm = ksz != 3 || (ws != s && (size_t)((bf.NBp + 63) / 64) * 9 * 16 * cout <= bf.slab_tail / BF_MAIN_SLOTS);
+      if (ksz == 3) DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8, lm));
+      else DV_TRY(bf_wgrad_f32(m, bf.xh, hin, 16, cur, hout, cout, NB, st, pb, m->G0s, 16, 8, ksz));
       for (int jd = 1; jd < BF_MAIN_SLOTS; ++jd) {       // the launches held back behind the last data gradient
         if (!deferred[jd]) continue;
         int h1, c1, ho1, co1, s1;
         A.enc_layer(jd, &h1, &c1, &ho1, &co1, &s1);
         DV_TRY(bf_wgrad(m, bf.enc_a[jd - 1], h1, c1, bf.du_enc[jd], ho1, co1, s1, same_pad_before(h1, 3, s1, nullptr),
-                        G + A.specs[A.enc_k(jd)].off, c1, c1, true, jd));
+                        G + A.specs[A.enc_k(jd)].off, c1, c1, true, jd));     // (only 3 x 3 layers are deferred)
       }
       if (lm || any_deferred) {                          // their slabs are summed on the weight-gradient stream
         DV_HIP(hipEventRecord(m->ctx->ev_ready, s));
@@ -576,11 +626,13 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       ProfScope ps(m, 2, ws);
       if (dg && !head_cols_taken) DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, ws));
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
-                                   G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, 9, A.C, 8, cout,
+                                   G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, ksz * ksz, A.C, 8, cout,
                                    ws));
       break;
     }
-    if (j <= want_defer && ws != s && j < BF_MAIN_SLOTS && j < A.L &&
+    if (ksz != 3) {
+      DV_TRY(bf_wgrad_f32(m, bf.enc_a[j - 1], hin, cin, cur, hout, cout, NB, st, pb, G + A.specs[A.enc_k(j)].off, cin, cin, ksz));
+    } else if (j <= want_defer && ws != s && j < BF_MAIN_SLOTS && j < A.L &&
         (size_t)((bf.NBp + 63) / 64) * 9 * cin * cout <= bf.slab_tail / BF_MAIN_SLOTS) {
       deferred[j] = any_deferred = true;                 // queued on the main stream behind the last data gradient
     } else {
@@ -588,7 +640,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     }
     oth = next_buf();
     DV_TRY(bf_dgrad_prelu(m, cur, bf.enc_w[j].d, bf.enc_w[j].Kd, 1, hout, cout, hin, cin, st, pb, oth, bf.enc_u[j - 1],
-                          A.enc_al(j - 1), A.enc_b(j - 1), true));
+                          A.enc_al(j - 1), A.enc_b(j - 1), true, ksz));
     cur = oth;
     if (j == A.L && A.L >= 2) {
       // Middle bucket, as in the fp32 backward: the deep half of the encoder (conv L .. conv 2L-1, their PReLUs, the

@@ -112,6 +112,27 @@ def test_band_counts_on_the_bf16_engine(bands):
     _run(arch, B=64, seed=80 + bands, tol_grad_b=5e-2, check_fp64_grads=False)
 
 
+@pytest.mark.parametrize("filters,kernels,size", [((16, 32), (5, 5), 13), ((16, 32, 64), (3, 5, 3), 20), ((32, 32), (1, 5), 13),
+                                                  ((16, 32), (2, 4), 13)])
+def test_kernel_sizes_other_than_three_on_the_bf16_engine(filters, kernels, size):
+    """model.py:81-91,121-134 takes kernels[i] freely.  bf16 engine: the one-pixel conv tiles walk a tap list of up to 25
+    entries (forward and data gradient, both stride-2 forms); the weight gradient of such a layer runs on the fp32
+    table-driven kernel over fp32 copies of its bf16 operands (exact).  Against the bf16-rounding oracle, for a ragged batch
+    (general tiles), 64 stamps (64-stamp uniform tiles) and 256 stamps (256-stamp tiles, first-layer form)."""
+    from tests.test_gpu_bf16 import _run
+
+    arch = vo.Arch(input_shape=(size, size, 4), latent_dim=8, filters=filters, kernels=kernels)
+    # (five stamps: a d(alpha) entry is a sum of five bf16-rounded products, so one flipped rounding - fp32 against float64
+    # accumulation over up to 25 taps - moves it by up to 2^-8; 1e-2 instead of the 3 x 3 toy case's 5e-3)
+    # (whole-step gradients of two bf16 evaluations differ by flipped roundings that the layers carry on: the bounds are
+    # those of tests/test_gpu_bf16.py for nets of this depth; tests/test_gpu_0_layers_bf16.py checks every layer of a
+    # k != 3 net ALONE at 1e-2 / 5e-3)
+    tol = 0.25 if len(filters) > 2 else 5e-2
+    _run(arch, B=5, seed=170 + kernels[0], tol_grad_b=tol, check_fp64_grads=False)
+    _run(arch, B=64, seed=180 + kernels[0], tol_grad_b=tol, check_fp64_grads=False)
+    _run(arch, B=256, seed=190 + kernels[0], tol_grad_b=tol, check_fp64_grads=False, train_decoder=False)
+
+
 @pytest.mark.parametrize("kernels", [(5, 5), (5, 3), (1, 5), (2, 4)])
 def test_kernel_sizes_other_than_three_toy_arch(kernels):
     arch = vo.Arch(input_shape=(13, 13, 4), latent_dim=8, filters=(8, 16), kernels=kernels)
@@ -128,12 +149,14 @@ def test_five_by_five_kernels_on_the_reference_architecture():
     _run_parity(arch, B=6, seed=62, data=(x, y))
 
 
-def test_bf16_engine_refuses_kernel_sizes_it_does_not_implement():
+def test_bf16_engine_refuses_what_it_does_not_implement_with_a_message():
     from debvader_amd import engine as E
     from debvader_amd._lib import DvError
 
-    with pytest.raises(DvError, match="3x3"):
-        E.Engine(E.make_config((13, 13, 4), 8, (16, 32), (5, 5), max_batch=4, dtype=1))
+    with pytest.raises(DvError, match="filters must be 16 or multiples of 32"):
+        E.Engine(E.make_config((13, 13, 4), 8, (8, 24), (3, 3), max_batch=4, dtype=1))
+    with pytest.raises(DvError, match="bands"):
+        E.Engine(E.make_config((13, 13, 9), 8, (16, 32), (3, 3), max_batch=4, dtype=1))
 
 
 def test_train_deblender_with_five_bands_like_the_reference_notebook():

@@ -43,11 +43,16 @@ def _check(report, what, got, ref, tol):
 ARCHS = {
     "59px": dict(),                                                             # train.py:104-107
     "128px": dict(input_shape=(128, 128, 6), latent_dim=32, filters=(32, 64, 128, 256, 512, 512), kernels=(3,) * 6),
+    # kernel sizes other than 3 (model.py:81-91,121-134; round 5): tap lists of up to 25 entries in the conv tiles, the
+    # weight gradient on the fp32 table-driven kernel over fp32 copies of the bf16 operands
+    "59px-k5314": dict(kernels=(5, 3, 1, 4)),
+    "29px-k55": dict(input_shape=(29, 29, 6), latent_dim=16, filters=(32, 64), kernels=(5, 5)),
 }
 
 
 @pytest.mark.parametrize("arch_name,B,stages", [("59px", 256, 2), ("59px", 256, 3), ("59px", 64, 2), ("59px", 64, 3),
-                                                 ("59px", 48, 2), ("128px", 16, 2)])
+                                                 ("59px", 48, 2), ("128px", 16, 2), ("59px-k5314", 64, 2), ("59px-k5314", 48, 2),
+                                                 ("29px-k55", 256, 2), ("29px-k55", 24, 3)])
 def test_every_conv_layer_alone_against_the_oracle_primitives(arch_name, B, stages, monkeypatch):
     from debvader_amd import engine as E
     from debvader_amd.data import synthetic_stamps

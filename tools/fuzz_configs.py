@@ -18,11 +18,13 @@ for size, bands, filters, latent in [(32, 2, (16, 32), 8), (45, 4, (32, 64, 128)
                                      (9, 4, (32,), 8)]:
     for B in (1, 7, 64, 100, 256, 300):
         cases.append((size, bands, filters, latent, B, (3,) * len(filters)))
-# round 4: any band count, kernel sizes 1 .. 5 per level (general gather-GEMM / tiled weight gradient; fp32 engine only)
+# round 4: any band count, kernel sizes 1 .. 5 per level (general gather-GEMM / tiled weight gradient); round 5: the bf16
+# engine takes them too, and both take latent sizes that are not multiples of 4; the fp32 engine 8 .. 15 bands
 for size, bands, filters, latent, kernels in [(20, 5, (32, 64), 8, (5, 5)), (32, 1, (16, 32), 8, (3, 5)),
                                               (27, 3, (24, 48), 8, (1, 3)), (45, 7, (32, 64, 128), 16, (5, 3, 1)),
                                               (59, 6, (32, 64, 128, 256), 32, (5, 3, 5, 3)), (16, 2, (32,), 8, (4,)),
-                                              (30, 6, (16, 32), 8, (2, 4))]:
+                                              (30, 6, (16, 32), 8, (2, 4)), (27, 10, (16, 32), 10, (3, 3)),
+                                              (20, 4, (32, 64), 5, (5, 3)), (59, 15, (32, 64), 30, (3, 3))]:
     for B in (1, 7, 64, 100):
         cases.append((size, bands, filters, latent, B, kernels))
 bad = 0
