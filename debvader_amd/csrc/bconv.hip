@@ -74,7 +74,7 @@ __device__ __forceinline__ void load_f32(const float* src, float* v) {
 }  // namespace
 
 // CINMODE 0: Cin % 32 == 0, a K step is one 32-channel chunk of one tap.
-// CINMODE 1: Cin == 8 or 16 (first conv, data gradient of the 16-channel head): a K step is four 16-byte pieces,
+// CINMODE 1: Cin % 8 == 0 but not % 32 (first conv, data gradient of the 16-channel head, 48- / 80-... channel layers): a K step is four 16-byte pieces,
 //            piece q of step i is channels (i*4+q) % (Cin/8) * 8.. of tap (i*4+q) / (Cin/8); all nine taps are walked.
 template <int NBLK, int CINMODE>
 __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const BConvParams p) {
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256, BC_NST == 3 ? 2 : 4) void bconv_kernel(const B
       __builtin_amdgcn_global_load_lds((bc_gptr_t)(wrow + is_tap * p.Cin + is_cc * 32), (bc_lptr_t)(sB + jb * 1024), 16, 0, 0);
     } else {
       const int piece = step * 4 + dq;
-      const int tap = ppt == 1 ? piece : piece >> 1;
-      const int sub = ppt == 1 ? 0 : piece & 1;
+      const int tap = ppt == 1 ? piece : ppt == 2 ? piece >> 1 : piece / ppt;
+      const int sub = piece - tap * ppt;
       const bool pv = piece < ntap * ppt;
       const int lo = arow + sub * 8;
 #pragma unroll
@@ -585,15 +585,16 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
   // CINMODE 1: the lane source of step i (piece i * 4 + dq of the (tap, 8-channel piece) list); null = outside the image
   auto piece_src = [&](int i) -> const unsigned char* {
     const int piece = i * 4 + dq;
-    const int tap = ppt == 1 ? piece : piece >> 1;
-    const int sub = ppt == 1 ? 0 : piece & 1;
+    const int tap = ppt == 1 ? piece : ppt == 2 ? piece >> 1 : piece / ppt;
+    const int sub = piece - tap * ppt;
     const int sp = piece < ntap * ppt ? src_pixel(tap) : -1;
     return sp >= 0 ? Xb + (size_t)sp * pixbytes + (unsigned)((((st0 + wave * RW + drow) * p.Cin) + sub * 8) * 2) : nullptr;
   };
-  // 3 x 3 kernels (at most five steps): worked out once; larger kernels (up to 13 steps) work them out at issue time
+  // at most five steps (3 x 3 kernels on 8 or 16 channels): worked out once; longer walks work them out at issue time
+  const bool ptab = nsteps <= 5;
   const unsigned char* psrc[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if constexpr (CINMODE == 1) {
-    if (ksz == 3) {
+    if (ptab) {
 #pragma unroll
       for (int i = 0; i < 5; ++i) psrc[i] = piece_src(i);
     }
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
                                          (bc_lptr_t)(sB + h * SUB + jb * 1024), 16, 0, 0);
     } else {
       const unsigned char* ps = nullptr;
-      if (ksz == 3) {
+      if (ptab) {
 #pragma unroll
         for (int i = 0; i < 5; ++i)
           if (i == step) ps = psrc[i];
@@ -1163,9 +1164,12 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
     set_error("bconv: bad geometry (NBp %d, Cout %d, Kpad %d, kernel size %d)", p.NBp, p.Cout, p.Kpad, p.ksz);
     return E_INVALID;
   }
-  const int mode = p.Cin % 32 == 0 ? 0 : ((p.Cin == 8 || p.Cin == 16) ? 1 : -1);
+  // mode 1 (K walked in 8-channel pieces across tap boundaries) was written for the 8- / 16-channel first conv and head
+  // gradient; it is what every other channel count that is a multiple of 8 but not of 32 takes too (filters 48, 80, ...:
+  // functional, the per-piece lane addressing is not tuned for long K)
+  const int mode = p.Cin % 32 == 0 ? 0 : (p.Cin % 8 == 0 ? 1 : -1);
   if (mode < 0) {
-    set_error("bconv: input channels must be 8, 16 or a multiple of 32 (got %d)", p.Cin);
+    set_error("bconv: input channels must be a multiple of 8 (got %d)", p.Cin);
     return E_INVALID;
   }
   if (p.epi == BEPI_BWD && p.dal_part && !bconv_bwd_fusable(p.NBp)) {

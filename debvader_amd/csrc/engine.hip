@@ -3576,11 +3576,19 @@ int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t 
   if (Bg <= 0) Bg = B;
   DV_HIP(hipSetDevice(m->ctx->device));
   int64_t span = std::max<int64_t>(1, m->slots[slot].n - B + 1);
+  // DV_TIME_ENQUEUE=1: host time spent queuing the steps (stderr) - when it approaches the steps' GPU time the host, not the
+  // GPU, paces the loop
+  static const bool time_enqueue = getenv("DV_TIME_ENQUEUE") != nullptr;
+  const auto tq0 = std::chrono::steady_clock::now();
   for (int k = 0; k < steps; ++k) {
     int64_t start = (first + (int64_t)k * B) % span;
     m->hint_next_first = k + 1 < steps ? (first + (int64_t)(k + 1) * B) % span : -1;   // lets step k prefetch k+1's BN sums
     DV_TRY(enqueue_step(m, MODE_TRAIN, slot, nullptr, start, B, Bg, nullptr, seed + (uint64_t)k));
     if (m->prof_on) DV_TRY(prof_flush(m));
+  }
+  if (time_enqueue) {
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count();
+    fprintf(stderr, "[dv] queued %d steps in %.1f us of host time (%.1f us per step)\n", steps, us, us / steps);
   }
   DV_TRY(fetch_scalars(m, Bg, out));
   return prof_flush(m);

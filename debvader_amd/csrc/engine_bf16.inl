@@ -15,8 +15,8 @@ static int bf_alloc(dv_model* m) {
   const size_t Bp = ((size_t)m->Bc + 15) & ~(size_t)15;
   for (int i = 0; i < A.L; ++i) {
     const int f = A.cfg.filters[i];
-    if (!(f == 16 || f % 32 == 0)) {
-      set_error("bf16 engine: filters must be 16 or multiples of 32 (filters[%d]=%d)", i, f);
+    if (f % 16) {
+      set_error("bf16 engine: filters must be multiples of 16 (filters[%d]=%d)", i, f);
       return E_INVALID;
     }
   }
@@ -121,7 +121,7 @@ static int bf_alloc(dv_model* m) {
   }
   {
     bool any = false;
-    for (int i = 0; i < A.L; ++i) any = any || A.cfg.kernels[i] != 3;
+    for (int i = 0; i < A.L; ++i) any = any || A.cfg.kernels[i] != 3 || !(A.cfg.filters[i] == 16 || A.cfg.filters[i] % 32 == 0);
     if (any) {                     // operands of the fp32 weight-gradient kernels (bf_wgrad_f32)
       max_e = std::max(max_e, (size_t)A.H * A.H * 16);
       DV_TRY(balloc((void**)&bf.wx32, max_e * (size_t)m->Bc * 4));
@@ -342,6 +342,7 @@ static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, i
 // cores).  Everything runs on the MAIN stream - copies, kernel, slab sum - after the weight-gradient and reduction streams
 // have been joined (their launches rotate through the same slab workspace): functional, not tuned, like the fp32 engine's
 // own k != 3 path.
+static bool bf_wgrad_takes(int c) { return c == 16 || c % 32 == 0; }   // channel counts of bwgrad_kernel's 32-wide tiles
 static int bf_wgrad_f32(dv_model* m, const void* X, int Hx, int Cx, const void* Y, int Hy, int Cy, int NB, int s, int pb,
                         float* out, int cpad, int creal, int ksz) {
   BfState& bf = m->bf;
@@ -455,7 +456,8 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   size_t enc_reduced = A.n_enc_train;                    // [enc_reduced, n_enc_train) all-reduced inside this pass
   // ---- head conv ----
   if (dg) {
-    DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, 1, 1, m->Ghs, f0, f0));   // (columns taken at the end)
+    if (bf_wgrad_takes(f0)) DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, 1, 1, m->Ghs, f0, f0));   // (columns taken at the end)
+    else DV_TRY(bf_wgrad_f32(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, NB, 1, 1, m->Ghs, f0, f0, 3));
     ProfScope ps(m, 2, s);
     int nr = 0;
     DV_TRY(launch_bf_colsum(bf.dt, (long)Hd * Hd * bf.NBp, 16, m->ws3, &nr, s));
@@ -474,8 +476,9 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     const int pb = same_pad_before(hout, ksz, st, nullptr);
     const void* xin = j == 0 ? bf.dec_in : bf.dec_a[j - 1];
     bf.du_dec[j] = cur;
-    if (dg && ksz == 3) DV_TRY(bf_wgrad(m, cur, hout, cout, xin, hin, cin, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout));
-    if (dg && ksz != 3) DV_TRY(bf_wgrad_f32(m, cur, hout, cout, xin, hin, cin, NB, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout, ksz));
+    const bool wg_bf = ksz == 3 && bf_wgrad_takes(cout) && bf_wgrad_takes(cin);
+    if (dg && wg_bf) DV_TRY(bf_wgrad(m, cur, hout, cout, xin, hin, cin, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout));
+    if (dg && !wg_bf) DV_TRY(bf_wgrad_f32(m, cur, hout, cout, xin, hin, cin, NB, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout, ksz));
     oth = next_buf();
     if (j > 0) {
       DV_TRY(bf_dgrad_prelu(m, cur, bf.dec_w[j].d, bf.dec_w[j].Kd, 0, hout, cout, hin, cin, st, pb, oth, bf.dec_u[j - 1],
@@ -607,8 +610,9 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       // first conv with the folded input BatchNorm: the gradient w.r.t. the 16-channel folded kernel (channels
       // 0..C-1 = bands, C = the constant one) yields d(kernel), d(gamma), d(beta); no data gradient
       // last launch of the pass: on the (otherwise idle) main stream, slabs in the pool's tail region
-      const bool lm = ksz != 3 || (ws != s && (size_t)((bf.NBp + 63) / 64) * 9 * 16 * cout <= bf.slab_tail / BF_MAIN_SLOTS);
-      if (ksz == 3) DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8, lm));
+      const bool wg0 = ksz == 3 && bf_wgrad_takes(cout);
+      const bool lm = !wg0 || (ws != s && (size_t)((bf.NBp + 63) / 64) * 9 * 16 * cout <= bf.slab_tail / BF_MAIN_SLOTS);
+      if (wg0) DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8, lm));
       else DV_TRY(bf_wgrad_f32(m, bf.xh, hin, 16, cur, hout, cout, NB, st, pb, m->G0s, 16, 8, ksz));
       for (int jd = 1; jd < BF_MAIN_SLOTS; ++jd) {       // the launches held back behind the last data gradient
         if (!deferred[jd]) continue;
@@ -630,7 +634,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
                                    ws));
       break;
     }
-    if (ksz != 3) {
+    if (ksz != 3 || !bf_wgrad_takes(cin) || !bf_wgrad_takes(cout)) {
       DV_TRY(bf_wgrad_f32(m, bf.enc_a[j - 1], hin, cin, cur, hout, cout, NB, st, pb, G + A.specs[A.enc_k(j)].off, cin, cin, ksz));
     } else if (j <= want_defer && ws != s && j < BF_MAIN_SLOTS && j < A.L &&
         (size_t)((bf.NBp + 63) / 64) * 9 * cin * cout <= bf.slab_tail / BF_MAIN_SLOTS) {

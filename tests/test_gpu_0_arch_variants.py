@@ -113,9 +113,11 @@ def test_band_counts_on_the_bf16_engine(bands):
 
 
 @pytest.mark.parametrize("filters,kernels,size", [((16, 32), (5, 5), 13), ((16, 32, 64), (3, 5, 3), 20), ((32, 32), (1, 5), 13),
-                                                  ((16, 32), (2, 4), 13)])
+                                                  ((16, 32), (2, 4), 13), ((48, 80), (3, 3), 13), ((16, 48), (3, 5), 13)])
 def test_kernel_sizes_other_than_three_on_the_bf16_engine(filters, kernels, size):
-    """model.py:81-91,121-134 takes kernels[i] freely.  bf16 engine: the one-pixel conv tiles walk a tap list of up to 25
+    """model.py:81-91,121-134 takes kernels[i] and filters[i] freely.  Filters that are multiples of 16 but not of 32 (48, 80)
+    walk K in 8-channel pieces across tap boundaries in the conv tiles, and their weight gradients take the fp32 kernel as
+    the k != 3 layers do.  bf16 engine: the one-pixel conv tiles walk a tap list of up to 25
     entries (forward and data gradient, both stride-2 forms); the weight gradient of such a layer runs on the fp32
     table-driven kernel over fp32 copies of its bf16 operands (exact).  Against the bf16-rounding oracle, for a ragged batch
     (general tiles), 64 stamps (64-stamp uniform tiles) and 256 stamps (256-stamp tiles, first-layer form)."""
@@ -153,7 +155,7 @@ def test_bf16_engine_refuses_what_it_does_not_implement_with_a_message():
     from debvader_amd import engine as E
     from debvader_amd._lib import DvError
 
-    with pytest.raises(DvError, match="filters must be 16 or multiples of 32"):
+    with pytest.raises(DvError, match="filters must be multiples of 16"):
         E.Engine(E.make_config((13, 13, 4), 8, (8, 24), (3, 3), max_batch=4, dtype=1))
     with pytest.raises(DvError, match="bands"):
         E.Engine(E.make_config((13, 13, 9), 8, (16, 32), (3, 3), max_batch=4, dtype=1))

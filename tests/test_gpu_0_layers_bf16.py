@@ -47,12 +47,13 @@ ARCHS = {
     # weight gradient on the fp32 table-driven kernel over fp32 copies of the bf16 operands
     "59px-k5314": dict(kernels=(5, 3, 1, 4)),
     "29px-k55": dict(input_shape=(29, 29, 6), latent_dim=16, filters=(32, 64), kernels=(5, 5)),
+    "29px-f48": dict(input_shape=(29, 29, 6), latent_dim=16, filters=(48, 80), kernels=(3, 5)),   # filters % 16 == 0 only
 }
 
 
 @pytest.mark.parametrize("arch_name,B,stages", [("59px", 256, 2), ("59px", 256, 3), ("59px", 64, 2), ("59px", 64, 3),
                                                  ("59px", 48, 2), ("128px", 16, 2), ("59px-k5314", 64, 2), ("59px-k5314", 48, 2),
-                                                 ("29px-k55", 256, 2), ("29px-k55", 24, 3)])
+                                                 ("29px-k55", 256, 2), ("29px-k55", 24, 3), ("29px-f48", 256, 2), ("29px-f48", 40, 2)])
 def test_every_conv_layer_alone_against_the_oracle_primitives(arch_name, B, stages, monkeypatch):
     from debvader_amd import engine as E
     from debvader_amd.data import synthetic_stamps
