@@ -250,8 +250,11 @@ def test_gradient_buckets_partition_the_trainable_buffer():
     import ctypes as C
     from debvader_amd import engine as E
     from debvader_amd._lib import lib, check
-    for args in ((), ((13, 13, 4), 8, (8, 16), (3, 3)), ((128, 128, 6), 32, (32, 64, 128, 256, 512, 512), (3,) * 6)):
-        cfg = E.make_config(*args)
+    for args, kw in (((), {}), ((), {"dtype": 1}), (((13, 13, 4), 8, (8, 16), (3, 3)), {}),
+                     (((128, 128, 6), 32, (32, 64, 128, 256, 512, 512), (3,) * 6), {}),
+                     (((128, 128, 6), 32, (32, 64, 128, 256, 512, 512), (3,) * 6), {"dtype": 1}),
+                     (((59, 59, 10), 10, (32, 64, 128, 256), (3, 5, 3, 3)), {})):      # bf16 / 128 px / 10 bands, latent 10, a 5 x 5 level
+        cfg = E.make_config(*args, **kw)
         out = (C.c_int64 * 4)()
         check(lib.dv_arch_buckets(C.byref(cfg), out))
         split, n_enc, n_train, n_total = list(out)
@@ -276,5 +279,5 @@ def test_gradient_buckets_partition_the_trainable_buffer():
                 assert hi <= split
                 sizes["last"] += cnt.value
         # the deep half holds the dense layer and the deep convolutions: most of the encoder
-        assert sizes["mid"] > 5 * sizes["last"] > 0
+        assert sizes["mid"] > 3 * sizes["last"] > 0
         assert any(n == "enc/dense/kernel" for n, _, _ in specs)
