@@ -155,7 +155,7 @@ def _git_head():
 def _pmc_traffic():
     """HBM bytes per step and kernel family from the committed rocprofv3 PMC passes of this round (FETCH_SIZE doubled as
     the micro-architecture guide prescribes for gfx950; tools/pmc_traffic.py spells out the collection)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as fh:
