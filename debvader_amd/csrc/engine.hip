@@ -1662,6 +1662,14 @@ struct TinyCall {          // scope of one public inference call of at most 16 s
   ~TinyCall() { m->tiny_call = false; }
 };
 
+// DV_EXP_NO_A=<min size> (a MEASUREMENT switch, results are wrong): training forwards of the layers at least that many
+// pixels wide store the pre-activation only (epilogue 1: no PReLU, no activation store) - the upper bound of what "store u
+// only"  can save before any consumer pays for applying PReLU on load
+static int exp_epi(bool keep_u, int hout) {
+  static const int min_h = getenv("DV_EXP_NO_A") ? atoi(getenv("DV_EXP_NO_A")) : 0;
+  return (min_h > 0 && keep_u && hout >= min_h) ? 1 : 2;
+}
+
 static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u) {
   if (m->bf.on) return bf_encoder_forward(m, xsrc, idx, first, NB, keep_u);
   const Arch& A = m->A;
@@ -1683,8 +1691,8 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
     int cin_phys = j == 0 ? A.C0p : cin;
     const size_t e_out = (size_t)hout * hout * cout;
     DV_TRY(gconv_fprop(m, in, W, false, P + A.specs[A.enc_b(j)].off, P + A.specs[A.enc_al(j)].off,
-                       keep_u ? LANE(m->enc_u[j], e_out) : nullptr, LANE(m->enc_a[j], e_out), 2, NB, hin, cin_phys,
-                       hout, cout, st, pb, false, nullptr, nullptr, ksz));
+                       keep_u ? LANE(m->enc_u[j], e_out) : nullptr, LANE(m->enc_a[j], e_out), exp_epi(keep_u, hout), NB, hin,
+                       cin_phys, hout, cout, st, pb, false, nullptr, nullptr, ksz));
     in = LANE(m->enc_a[j], e_out);
   }
   {
@@ -1722,7 +1730,7 @@ static int decoder_forward(dv_model* m, int NB, bool keep_u) {
     // Conv2DTranspose = data gradient of a SAME conv over the output grid; kernel (kh,kw,cout,cin) is n-major
     DV_TRY(gconv_dgrad(m, in, P + A.specs[A.dec_k(j)].off, true, P + A.specs[A.dec_b(j)].off,
                        P + A.specs[A.dec_al(j)].off, keep_u ? LANE(m->dec_u[j], e_out) : nullptr,
-                       LANE(m->dec_a[j], e_out), 2, NB, hin, cin, hout, cout, st, pb, nullptr, nullptr, ksz));
+                       LANE(m->dec_a[j], e_out), exp_epi(keep_u, hout), NB, hin, cin, hout, cout, st, pb, nullptr, nullptr, ksz));
     in = LANE(m->dec_a[j], e_out);
   }
   return gconv_fprop(m, in, m->Whp, false, m->bhp, nullptr, LANE(m->tpre, (size_t)A.dec_out * A.dec_out * A.C2p),
