@@ -182,7 +182,8 @@ static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, in
     int hin, cin, hout, cout, st;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
     const int pb = same_pad_before(hin, A.enc_ksz(j), st, nullptr);
-    DV_TRY(bf_conv(m, in, bf.enc_w[j].f, bf.enc_w[j].Kf, 0, hin, j == 0 ? 16 : cin, hout, cout, st, pb, BEPI_FWD,
+    DV_TRY(bf_conv(m, in, bf.enc_w[j].f, bf.enc_w[j].Kf, 0, hin, j == 0 ? 16 : cin, hout, cout, st, pb,
+                   exp_epi(keep_u, hout) == 1 ? BEPI_RAWBF : BEPI_FWD,   // (DV_EXP_NO_A: measurement only, see engine.hip)
                    keep_u ? bf.enc_u[j] : nullptr, bf.enc_a[j], nullptr, P + A.specs[A.enc_b(j)].off,
                    P + A.specs[A.enc_al(j)].off, nullptr, nullptr, nullptr, A.enc_ksz(j)));
     in = bf.enc_a[j];
@@ -225,7 +226,8 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
     int hin, cin, hout, cout, st;
     A.dec_layer(j, &hin, &cin, &hout, &cout, &st);
     const int pb = same_pad_before(hout, A.dec_ksz(j), st, nullptr);
-    DV_TRY(bf_conv(m, in, bf.dec_w[j].f, bf.dec_w[j].Kf, 1, hin, cin, hout, cout, st, pb, BEPI_FWD,
+    DV_TRY(bf_conv(m, in, bf.dec_w[j].f, bf.dec_w[j].Kf, 1, hin, cin, hout, cout, st, pb,
+                   exp_epi(keep_u, hout) == 1 ? BEPI_RAWBF : BEPI_FWD,
                    keep_u ? bf.dec_u[j] : nullptr, bf.dec_a[j], nullptr, P + A.specs[A.dec_b(j)].off,
                    P + A.specs[A.dec_al(j)].off, nullptr, nullptr, nullptr, A.dec_ksz(j)));
     in = bf.dec_a[j];
