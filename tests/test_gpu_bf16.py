@@ -73,19 +73,12 @@ def _run(arch, B, seed, data=None, train_decoder=True, tol_out=1e-2, tol_grad_b=
     eng.keep_outputs(True)
     x64, y64, e64 = x.astype(np.float64), y.astype(np.float64), eps.astype(np.float64)
     fused = ((B + 15) // 16 * 16) % 64 == 0
-    # the two oracles are independent: the float64 one runs beside the bf16-rounding one (numpy's BLAS calls drop the GIL)
-    from concurrent.futures import ThreadPoolExecutor
-
-    def _fp64():
-        c_ = vo.forward(arch, p, x64, e64, training=True)
-        return c_, vo.losses(arch, c_, y64), vo.backward(arch, p, c_, y64, train_decoder=train_decoder)
-
-    with ThreadPoolExecutor(1) as ex:
-        fut = ex.submit(_fp64)
-        cb = vb.forward(arch, p, x64, e64, training=True)
-        rb = vo.losses(arch, cb, y64)
-        gb = vb.backward(arch, p, cb, y64, train_decoder=train_decoder, fused=fused)
-        c, r, g = fut.result()
+    cb = vb.forward(arch, p, x64, e64, training=True)
+    rb = vo.losses(arch, cb, y64)
+    gb = vb.backward(arch, p, cb, y64, train_decoder=train_decoder, fused=fused)
+    c = vo.forward(arch, p, x64, e64, training=True)
+    r = vo.losses(arch, c, y64)
+    g = vo.backward(arch, p, c, y64, train_decoder=train_decoder)
 
     out = eng.grad_step(0, first=0, B=B, eps=eps)
     H, W, C = arch.input_shape

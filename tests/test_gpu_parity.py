@@ -62,14 +62,10 @@ def _f32_floor(arch, p, x, y, eps, g, train_decoder):
     """What float32 itself costs on this case: the SAME step evaluated by the numpy oracle in float32 (float32 parameters,
     activations, BLAS accumulation), per gradient tensor as |g32 - g64| / max|g64|.  An independent fp32 evaluation, not
     the engine: tests/test_gpu_0_fullsize_oracle.py uses it to tell float32's noise at 256 stamps from a kernel error."""
-    g32 = _f32_grads(arch, p, x, y, eps, train_decoder)
-    return {k: _relmax(g32[k], g[k]) for k in g}
-
-
-def _f32_grads(arch, p, x, y, eps, train_decoder):
     p32 = {k: v.astype(np.float32) for k, v in p.items()}
     c32 = vo.forward(arch, p32, x.astype(np.float32), eps.astype(np.float32), training=True)
-    return vo.backward(arch, p32, c32, y.astype(np.float32), train_decoder=train_decoder)
+    g32 = vo.backward(arch, p32, c32, y.astype(np.float32), train_decoder=train_decoder)
+    return {k: _relmax(g32[k], g[k]) for k in g}
 
 
 def _run_parity(arch, B, seed, data=None, train_decoder=True, sigma_bias=0.0, f32_floor=False):
@@ -89,14 +85,10 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True, sigma_bias=0.0, f3
     eng.upload(0, x, y)
 
     x64, y64, e64 = x.astype(np.float64), y.astype(np.float64), eps.astype(np.float64)
-    # the float32 evaluation runs beside the float64 one (numpy's BLAS calls drop the GIL; the two are independent)
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(1) as ex:
-        fut = ex.submit(_f32_grads, arch, p, x, y, eps, train_decoder) if f32_floor else None
-        c = vo.forward(arch, p, x64, e64, training=True)
-        ref = vo.losses(arch, c, y64)
-        g = vo.backward(arch, p, c, y64, train_decoder=train_decoder)
-        floor = {k: _relmax(v, g[k]) for k, v in fut.result().items() if k in g} if fut else {}
+    c = vo.forward(arch, p, x64, e64, training=True)
+    ref = vo.losses(arch, c, y64)
+    g = vo.backward(arch, p, c, y64, train_decoder=train_decoder)
+    floor = _f32_floor(arch, p, x, y, eps, g, train_decoder) if f32_floor else {}
 
     def tol(name):
         return max(_grad_tol(name), min(1.5 * floor.get(name, 0.0), 1e-2))

@@ -5,6 +5,8 @@ import sys
 
 cases, cur = [], None
 for ln in open(sys.argv[1]):
+    if ln.startswith("#   "):                      # the explanation / column header lines of a case
+        continue
     if ln.startswith("# "):
         cur = {"name": ln[2:].strip(), "rows": []}
         cases.append(cur)
