@@ -1223,6 +1223,11 @@ static int wgrad(dv_model* m, const float* X, int Hx, int Cx, const float* Y, in
 static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int Cx, const float* Y, int Hy, int Cy, int NB,
                       int sx, int pb, bool single_tap, float* out, int cpad, int creal, const FuseBwd* fz, int ksz) {
   const bool k3 = ksz == 3;
+  {   // DV_EXP_SKIP_WGRAD=2 (MEASUREMENT, wrong gradients): no conv weight-gradient work at all (all three families and their
+      // slab sums; the fused first layer and the dense layers stay) - what the whole weight-gradient stream costs the step
+    static const int exp_all = getenv("DV_EXP_SKIP_WGRAD") ? atoi(getenv("DV_EXP_SKIP_WGRAD")) : 0;
+    if (exp_all >= 2 && !single_tap && !fz) return OK;
+  }
   // slab region and the stream that sums the slabs: with the weight gradients on the aux stream the reduction goes to
   // the reduction stream and the slabs rotate through three regions of ws1
   dv_ctx* cx = m->ctx;
@@ -1430,7 +1435,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   p.pchunk = pchunk;
   // DV_EXP_SKIP_WGRAD=1 (a MEASUREMENT switch, gradients are wrong): the tiled weight-gradient launches of the conv layers
   // are left out, slab sums and stream hand-overs kept - the upper bound of what a faster wgrad_kernel can give the step
-  static const bool exp_skip = getenv("DV_EXP_SKIP_WGRAD") != nullptr;
+  static const bool exp_skip = getenv("DV_EXP_SKIP_WGRAD") != nullptr && atoi(getenv("DV_EXP_SKIP_WGRAD")) >= 1;
   if (!(exp_skip && !single_tap)) {
     ProfScope ps(m, 1, ws, PF_WGRAD, wflops);
     DV_TRY(launch_wgrad(p, ws));
