@@ -106,10 +106,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
         }
   }
 #pragma unroll
-  for (int c = 0; c < BN_MAXC; ++c) {
-    s[c] = wave_sum(s[c]);
-    ss[c] = wave_sum(ss[c]);
-  }
+  for (int c = 0; c < BN_MAXC; ++c)
+    if (c < C) {                                       // (C is uniform: bands beyond it hold zeros and need no shuffle)
+      s[c] = wave_sum(s[c]);
+      ss[c] = wave_sum(ss[c]);
+    }
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int c = 0; c < BN_MAXC; ++c) {
