@@ -64,6 +64,14 @@ struct Spec {
   size_t off;  // offset in the flat parameter buffer (floats)
 };
 
+// DV_EXP_SKIP_SMALL=1 (a MEASUREMENT switch, results are wrong): the elementwise neighbours of the dense trunk that a fused
+// trunk would absorb (split-K finish, the two PReLU forwards, the narrow dense data gradient, the bias column sums, the
+// bf16 seam conversions) are not launched - the upper bound of what merging them can give the step
+static bool exp_skip_small() {
+  static const bool v = getenv("DV_EXP_SKIP_SMALL") != nullptr;
+  return v;
+}
+
 static int same_pad_before(int n_in, int k, int s, int* n_out) {
   int o = (n_in + s - 1) / s;
   int tot = std::max((o - 1) * s + k - n_in, 0);
@@ -987,6 +995,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
       !g_no_special) {
     // narrow dense data gradient (hidden -> latent_dim): one wave per stamp instead of two serial 128 x 32 tiles
     ProfScope ps(m, 2);                                // (9 MFLOP per step: timed with the small kernels, not as a matrix family)
+    if (exp_skip_small()) return OK;
     return launch_dense_narrow(X, W, U, NB, Cin, Cout, fwd_stream(m));
   }
   // (dense operands whose width is a multiple of 4 but not of 32 - the 560-wide ones - take the ragged-K form of gconv2)
@@ -1019,6 +1028,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
           DV_TRY(launch_gconv2(q, fwd_stream(m)));
         }
         ProfScope ps(m, 2);
+        if (exp_skip_small()) return OK;
         return launch_splitk_finish(ws4, ks, MN, Cout, epi >= 1 ? bias : nullptr, epi == 2 ? alpha : nullptr,
                                     (long)Hout * Hout * Cout, U, epi == 2 ? Aout : nullptr, fwd_stream(m));
       }
@@ -1559,6 +1569,7 @@ static int bias_grad_colsum(dv_model* m, const float* dy, long rows, int C, int 
     return E_STATE;
   }
   ProfScope ps(m, 2);
+  if (exp_skip_small()) return OK;
   DV_TRY(launch_colsum(dy, rows, C, m->ws3, &nr, m->ctx->stream));
   return launch_reduce_rows_f64(m->ws3, nr, ncols_out, m->G + m->A.specs[bias_spec].off, 1.0f, m->ctx->stream, C);
 }
@@ -1705,7 +1716,7 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
   }
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_prelu_fwd(in, P + A.specs[A.enc_flat_al()].off, LANE(m->flat_a, A.flat), NB, A.flat, s));
+    if (!exp_skip_small()) DV_TRY(launch_prelu_fwd(in, P + A.specs[A.enc_flat_al()].off, LANE(m->flat_a, A.flat), NB, A.flat, s));
   }
   return gconv_fprop(m, LANE(m->flat_a, A.flat), enc_dense_w(m), false, enc_dense_b(m),
                      nullptr, LANE(m->t, A.twp), nullptr, 1, NB, 1, A.flat, 1, A.twp, 1, 0, true);
@@ -1719,7 +1730,7 @@ static int decoder_forward(dv_model* m, int NB, bool keep_u) {
   {
     ProfScope ps(m, 2);
     // (dp > d: the slopes' 16-byte aligned slot is read past its d values; z's pad columns are zero, so are theirs)
-    DV_TRY(launch_prelu_fwd(LANE(m->z, A.dp), P + A.specs[A.D0].off, LANE(m->dec_ain, A.dp), NB, A.dp, s));
+    if (!exp_skip_small()) DV_TRY(launch_prelu_fwd(LANE(m->z, A.dp), P + A.specs[A.D0].off, LANE(m->dec_ain, A.dp), NB, A.dp, s));
   }
   DV_TRY(gconv_fprop(m, LANE(m->dec_ain, A.dp), dec_dense0_w(m), false, P + A.specs[A.D0 + 2].off,
                      P + A.specs[A.D0 + 3].off, keep_u ? LANE(m->dec_uh, A.dec_hidden) : nullptr,

@@ -191,8 +191,8 @@ static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, in
   const int sl = A.enc_sizes[A.L], fl = A.cfg.filters[A.L - 1];
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_bf_to_rows(in, bf.flat_in, NB, bf.NBp, sl * sl, fl, s));
-    DV_TRY(launch_prelu_fwd(bf.flat_in, P + A.specs[A.enc_flat_al()].off, m->flat_a, NB, A.flat, s));
+    if (!exp_skip_small()) DV_TRY(launch_bf_to_rows(in, bf.flat_in, NB, bf.NBp, sl * sl, fl, s));
+    if (!exp_skip_small()) DV_TRY(launch_prelu_fwd(bf.flat_in, P + A.specs[A.enc_flat_al()].off, m->flat_a, NB, A.flat, s));
   }
   return gconv_fprop(m, m->flat_a, enc_dense_w(m), false, enc_dense_b(m), nullptr, m->t,
                      nullptr, 1, NB, 1, A.flat, 1, A.twp, 1, 0, true);
@@ -207,7 +207,7 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
   DV_TRY(bf_refresh_weights(m, s));
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_prelu_fwd(m->z, P + A.specs[A.D0].off, m->dec_ain, NB, A.dp, s));
+    if (!exp_skip_small()) DV_TRY(launch_prelu_fwd(m->z, P + A.specs[A.D0].off, m->dec_ain, NB, A.dp, s));
   }
   DV_TRY(gconv_fprop(m, m->dec_ain, dec_dense0_w(m), false, P + A.specs[A.D0 + 2].off,
                      P + A.specs[A.D0 + 3].off, keep_u ? m->dec_uh : nullptr, m->dec_ah, 2, NB, 1, A.dp, 1, A.dec_hidden,
@@ -219,7 +219,7 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
                      0, true));
   {
     ProfScope ps(m, 2);
-    DV_TRY(launch_bf_from_rows(m->dec_ar, bf.dec_in, NB, bf.NBp, A.w0 * A.w0, fl, s));
+    if (!exp_skip_small()) DV_TRY(launch_bf_from_rows(m->dec_ar, bf.dec_in, NB, bf.NBp, A.w0 * A.w0, fl, s));
   }
   const void* in = bf.dec_in;
   for (int j = 0; j < 2 * A.L; ++j) {
@@ -506,7 +506,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   m->wstream = ws;
   {
     ProfScope ps(m, 2, s);
-    DV_TRY(launch_bf_to_rows(cur, tr0, NB, bf.NBp, A.w0 * A.w0, fl, s));
+    if (!exp_skip_small()) DV_TRY(launch_bf_to_rows(cur, tr0, NB, bf.NBp, A.w0 * A.w0, fl, s));
   }
   DV_TRY(prelu_bwd(m, tr0, m->dec_ur, A.D0 + 6, A.D0 + 5, NB, r, r, dg));
   if (dg) DV_TRY(wgrad(m, m->dec_ah, 1, A.dec_hidden, tr0, 1, r, NB, 1, 0, true, G + A.specs[A.D0 + 4].off, 1, 1));
@@ -589,7 +589,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     float* dbr = m->arena + m->arena_off;
     m->arena_off += (size_t)E;
     ProfScope ps(m, 2, s);
-    DV_TRY(launch_bf_from_rows(c32, cur, NB, bf.NBp, (int)Pn, fl, s));
+    if (!exp_skip_small()) DV_TRY(launch_bf_from_rows(c32, cur, NB, bf.NBp, (int)Pn, fl, s));
     DV_TRY(launch_bf_prelu_bwd(cur, bf.enc_u[jl], P + A.specs[A.enc_al(jl)].off, cur, G + A.specs[A.enc_al(jl)].off, dbr,
                                bf.NBp, (int)Pn, fl, s));
     DV_TRY(launch_reduce_rows_f64(dbr, (int)Pn, fl, G + A.specs[A.enc_b(jl)].off, 1.0f, s));
