@@ -567,7 +567,8 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
   }
   const int cpt = p.Cin >> 5, ppt = p.Cin >> 3;
   const int nvalid = CINMODE == 0 ? __builtin_amdgcn_readfirstlane(stab[0]) : ntap;
-  const int nsteps = CINMODE == 0 ? nvalid * (cpt / CH) : (ntap * ppt + 3) >> 2;      // (CH == 2: cpt is even)
+  const int nsteps_all = CINMODE == 0 ? nvalid * (cpt / CH) : (ntap * ppt + 3) >> 2;      // (CH == 2: cpt is even)
+  const int nsteps = (p.exp == 1 || p.exp == 5) ? min(nsteps_all, 1) : nsteps_all;
 
   const int drow = lane >> 2;
   const int dq = (lane & 3) ^ ((4 - (drow >> 2)) & 3);
@@ -711,11 +712,13 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
     buf = buf == NS - 1 ? 0 : buf + 1;
   }
 
+  if (p.exp >= 4) return;                                 // (measurement: no epilogue at all; 5: after a one-step loop)
   // ---- epilogue: per-wave LDS tile [RW rows][BN]; the rows are consecutive rows of the output tensor ----
   __builtin_amdgcn_s_barrier();
   constexpr int WREG = RW * BN * (NBLK == 1 ? 4 : 2);
   unsigned char* wreg = smem + wave * WREG;
   auto flush = [&](void* dst, int esz) {
+    if (p.exp == 3) return;                               // (measurement: no epilogue stores)
     const int rowb = BN * esz;
     unsigned char* out = reinterpret_cast<unsigned char*>(dst) + (rb0 * p.Cout + n0) * esz;
     const size_t rstride = (size_t)p.Cout * esz;
@@ -1159,6 +1162,11 @@ __global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) 
 int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   BConvParams p = p_in;
   if (p.ksz == 0) p.ksz = 3;
+  {
+    static const int exp_mode = getenv("DV_EXP_BCONV") ? atoi(getenv("DV_EXP_BCONV")) : 0;   // measurement only (bf16.h)
+    p.exp = exp_mode;
+    if (exp_mode == 2) return OK;                       // (2: no conv launch at all)
+  }
   if (p.NBp <= 0 || (p.NBp & 15) || p.Cout % 16 || p.Kpad % 32 || p.s < 1 || p.s > 2 || p.ksz < 1 || p.ksz > 5 ||
       p.Kpad < p.ksz * p.ksz * p.Cin) {
     set_error("bconv: bad geometry (NBp %d, Cout %d, Kpad %d, kernel size %d)", p.NBp, p.Cout, p.Kpad, p.ksz);

@@ -347,6 +347,10 @@ int launch_bwgrad(const BWgradParams& p, hipStream_t s, int* nsplit_out) {
     else if (gm.D == 5) BW_LAUNCH_W(XC, YC, 1, 12);                                                             \
     else BW_LAUNCH_W(XC, YC, 1, 4);                                                                             \
   } while (0)
+  {   // DV_EXP_SKIP_WGRAD >= 1 (MEASUREMENT, wrong gradients): geometry and slab bookkeeping as usual, no kernel
+    static const bool exp_skip = getenv("DV_EXP_SKIP_WGRAD") != nullptr && atoi(getenv("DV_EXP_SKIP_WGRAD")) >= 1;
+    if (exp_skip) return OK;
+  }
   if (xc16 && yc16) BW_LAUNCH(true, true);
   else if (xc16) BW_LAUNCH(true, false);
   else if (yc16) BW_LAUNCH(false, true);
