@@ -71,6 +71,11 @@ static bool exp_skip_small() {
   static const bool v = getenv("DV_EXP_SKIP_SMALL") != nullptr;
   return v;
 }
+// DV_EXP_SKIP_SMALL=2: additionally none of the dense trunk's matrix launches (forward, data gradient, weight gradient)
+static bool exp_skip_dense() {
+  static const bool v = getenv("DV_EXP_SKIP_SMALL") != nullptr && atoi(getenv("DV_EXP_SKIP_SMALL")) >= 2;
+  return v;
+}
 
 static int same_pad_before(int n_in, int k, int s, int* n_out) {
   int o = (n_in + s - 1) / s;
@@ -931,6 +936,7 @@ static int gconv_fprop(dv_model* m, const float* X, const float* W, bool nmajor,
                        float* U, float* Aout, int epi, int NB, int Hin, int Cin, int Hout, int Cout, int s, int pb,
                        bool single_tap = false, const FuseBwd* fz = nullptr, bool* fused = nullptr, int ksz = 3) {
   if (fused) *fused = false;
+  if (single_tap && Hin == 1 && exp_skip_dense()) return OK;
   GConvParams p;
   memset(&p, 0, sizeof p);
   p.X = X;
@@ -1237,6 +1243,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
       // slab sums; the fused first layer and the dense layers stay) - what the whole weight-gradient stream costs the step
     static const int exp_all = getenv("DV_EXP_SKIP_WGRAD") ? atoi(getenv("DV_EXP_SKIP_WGRAD")) : 0;
     if (exp_all >= 2 && !single_tap && !fz) return OK;
+    if (single_tap && exp_skip_dense()) return OK;
   }
   // slab region and the stream that sums the slabs: with the weight gradients on the aux stream the reduction goes to
   // the reduction stream and the slabs rotate through three regions of ws1
