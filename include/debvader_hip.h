@@ -41,11 +41,12 @@ typedef struct dv_model dv_model;
 /* Architecture + numerics of create_model_vae(input_shape, latent_dim, filters, kernels)
  * (src/debvader/model/model.py:164-218; fixed values used by train_deblender: training/train.py:104-107). */
 typedef struct dv_config {
-  int32_t height, width, bands;      /* input_shape (59,59,6); square stamps, 1 .. 7 bands (train.py:86 nb_of_bands) */
-  int32_t latent_dim;                /* 32 */
+  int32_t height, width, bands;      /* input_shape (59,59,6); square stamps, 1 .. 15 bands (train.py:86 nb_of_bands; the bf16
+                                        engine 1 .. 7) */
+  int32_t latent_dim;                /* 32; any value 1 .. 64 (model.py:164) */
   int32_t n_levels;                  /* len(filters) */
-  int32_t filters[DV_MAX_LEVELS];    /* [32,64,128,256] */
-  int32_t kernels[DV_MAX_LEVELS];    /* [3,3,3,3]; 1 .. 5 per level (model.py:81-91,121-134); the bf16 engine: 3 only */
+  int32_t filters[DV_MAX_LEVELS];    /* [32,64,128,256]; multiples of 4 (bf16 engine: of 16) */
+  int32_t kernels[DV_MAX_LEVELS];    /* [3,3,3,3]; 1 .. 5 per level (model.py:81-91,121-134), both engines */
   int32_t max_batch;                 /* stamps per device step (workspace capacity) */
   float kl_weight;                   /* KLDivergenceRegularizer weight, model.py:213 (0.01) */
   int32_t kl_multiplicity;           /* times Keras adds the activity loss (2) */
