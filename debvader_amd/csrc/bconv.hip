@@ -554,12 +554,24 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
   if (CINMODE == 0) {
     if (tid == 0) {
       int n = 0;
-      for (int t = 0; t < ntap; ++t) {
-        const int sp = src_pixel(t);
-        if (sp >= 0) {
-          stab[1 + n] = t;
-          stab[1 + BC_MAXT + n] = sp;
-          ++n;
+      if (ksz == 3) {                                     // the form every BASELINE configuration takes: fully unrolled
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int sp = src_pixel(t);
+          if (sp >= 0) {
+            stab[1 + n] = t;
+            stab[1 + BC_MAXT + n] = sp;
+            ++n;
+          }
+        }
+      } else {
+        for (int t = 0; t < ntap; ++t) {
+          const int sp = src_pixel(t);
+          if (sp >= 0) {
+            stab[1 + n] = t;
+            stab[1 + BC_MAXT + n] = sp;
+            ++n;
+          }
         }
       }
       stab[0] = n;
