@@ -363,6 +363,12 @@ def _roofline_f32(rows, classes, pmc, src, B, dt, steps, train_flops):
     }
 
 
+def _same_gpu_rehearsal():
+    """DV_DEBUG_SAME_GPU is honoured by the development library only (parallel._rehearsal)"""
+    from debvader_amd import parallel
+    return parallel._rehearsal("DV_DEBUG_SAME_GPU")
+
+
 def _multi_rank_block(ctx, group, eng, B, Bg, steps, world):
     """What makes an N > 1 line checkable: the size RCCL itself reports for the communicator on every rank, the device
     each rank drives, and the communication of a step - time inside the collectives on the comm stream against the part
@@ -386,7 +392,7 @@ def _multi_rank_block(ctx, group, eng, B, Bg, steps, world):
         "rccl_rank_ids": [i.get("comm_rank") for i in infos],
         "devices": [{"rank": r, "hip_device": i.get("device"), "pci_bus_id": i.get("bus_id")} for r, i in enumerate(infos)],
         "distinct_devices": len({i.get("bus_id") for i in infos}),
-        "rehearsal": any(i.get("rehearsal") for i in infos) or bool(os.environ.get("DV_DEBUG_SAME_GPU")),
+        "rehearsal": any(i.get("rehearsal") for i in infos) or _same_gpu_rehearsal(),
     }
     if profs:
         blk.update({

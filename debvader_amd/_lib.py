@@ -67,6 +67,7 @@ CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_
 
 SIGNATURES = {
     "dv_version": (C.c_int, []),
+    "dv_build_kind": (C.c_int, []),
     "dv_crc32c": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     "dv_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
     "dv_config_default": (C.c_int, [C.POINTER(DvConfig)]),
@@ -139,6 +140,10 @@ def bind(handle, signatures):
 
 
 bind(lib, SIGNATURES)
+# dv_build_kind() == 1: a DEVELOPMENT build of the engine was selected with DEBVADER_AMD_LIB (it carries measurement
+# switches that give wrong results and the one-GPU rehearsal hooks).  The package honours DV_DEBUG_SAME_GPU /
+# DV_DEBUG_FAKE_PEERS only then; with the product library those variables do nothing.
+IS_DEBUG_LIB = lib.dv_build_kind() == 1
 
 
 def last_error() -> str:

@@ -504,7 +504,9 @@ constexpr int bconv_uni_occupancy(int nblk, int gt, int ch, int ns) {
 
 template <int NBLK, int CINMODE, int GT, int CH = 1, int NS = 3>
 __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bconv_uni_kernel(const BConvParams p) {
+#ifdef DV_DEBUG_EXPORTS
   if (p.exp == 6) return;                                 // (measurement: empty workgroups - launch and dispatch only)
+#endif
   constexpr int GW = GT / 4;                              // groups per wave
   constexpr int RW = GW * 16;                             // output rows (stamps) per wave
   constexpr int SUB = (GT + NBLK) * 1024;                 // one chunk of a stage: GT A blocks, NBLK B blocks
@@ -581,7 +583,11 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
   const int cpt = p.Cin >> 5, ppt = p.Cin >> 3;
   const int nvalid = CINMODE == 0 ? __builtin_amdgcn_readfirstlane(stab[0]) : ntap;
   const int nsteps_all = CINMODE == 0 ? nvalid * (cpt / CH) : (ntap * ppt + 3) >> 2;      // (CH == 2: cpt is even)
-  const int nsteps = (p.exp == 1 || p.exp == 5) ? min(nsteps_all, 1) : nsteps_all;
+#ifdef DV_DEBUG_EXPORTS
+  const int nsteps = (p.exp == 1 || p.exp == 5) ? min(nsteps_all, 1) : nsteps_all;   // (measurement)
+#else
+  const int nsteps = nsteps_all;
+#endif
 
   const int drow = lane >> 2;
   const int dq = (lane & 3) ^ ((4 - (drow >> 2)) & 3);
@@ -725,13 +731,17 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
     buf = buf == NS - 1 ? 0 : buf + 1;
   }
 
+#ifdef DV_DEBUG_EXPORTS
   if (p.exp >= 4) return;                                 // (measurement: no epilogue at all; 5: after a one-step loop)
+#endif
   // ---- epilogue: per-wave LDS tile [RW rows][BN]; the rows are consecutive rows of the output tensor ----
   __builtin_amdgcn_s_barrier();
   constexpr int WREG = RW * BN * (NBLK == 1 ? 4 : 2);
   unsigned char* wreg = smem + wave * WREG;
   auto flush = [&](void* dst, int esz) {
+#ifdef DV_DEBUG_EXPORTS
     if (p.exp == 3) return;                               // (measurement: no epilogue stores)
+#endif
     const int rowb = BN * esz;
     unsigned char* out = reinterpret_cast<unsigned char*>(dst) + (rb0 * p.Cout + n0) * esz;
     const size_t rstride = (size_t)p.Cout * esz;
@@ -1175,11 +1185,13 @@ __global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) 
 int launch_bconv(const BConvParams& p_in, hipStream_t s) {
   BConvParams p = p_in;
   if (p.ksz == 0) p.ksz = 3;
+#ifdef DV_DEBUG_EXPORTS
   {
-    static const int exp_mode = getenv("DV_EXP_BCONV") ? atoi(getenv("DV_EXP_BCONV")) : 0;   // measurement only (bf16.h)
+    static const int exp_mode = DV_EXP_SWITCH("DV_EXP_BCONV");   // measurement only, development library (bf16.h)
     p.exp = exp_mode;
     if (exp_mode == 2) return OK;                       // (2: no conv launch at all)
   }
+#endif
   if (p.NBp <= 0 || (p.NBp & 15) || p.Cout % 16 || p.Kpad % 32 || p.s < 1 || p.s > 2 || p.ksz < 1 || p.ksz > 5 ||
       p.Kpad < p.ksz * p.ksz * p.Cin) {
     set_error("bconv: bad geometry (NBp %d, Cout %d, Kpad %d, kernel size %d)", p.NBp, p.Cout, p.Kpad, p.ksz);

@@ -37,8 +37,10 @@ struct BConvParams {
   int Kpad;
   int epi;
   int ksz;             // kernel size 1 .. 5 (0: 3); taps t = kh * ksz + kw, k = t * Cin + c
+#ifdef DV_DEBUG_EXPORTS   // (development library only: every translation unit that sees this struct is built both ways)
   int exp;             // measurement switch (DV_EXP_BCONV; results are wrong): 1 = the K loop stops after one step,
                        // 2 = launch_bconv returns without launching, 3 = K loop as usual but no epilogue stores
+#endif
 };
 int launch_bconv(const BConvParams& p, hipStream_t s);
 // BWD epilogue is usable (a wave's four 16-stamp groups share one pixel)

@@ -348,7 +348,7 @@ int launch_bwgrad(const BWgradParams& p, hipStream_t s, int* nsplit_out) {
     else BW_LAUNCH_W(XC, YC, 1, 4);                                                                             \
   } while (0)
   {   // DV_EXP_SKIP_WGRAD >= 1 (MEASUREMENT, wrong gradients): geometry and slab bookkeeping as usual, no kernel
-    static const bool exp_skip = getenv("DV_EXP_SKIP_WGRAD") != nullptr && atoi(getenv("DV_EXP_SKIP_WGRAD")) >= 1;
+    static const bool exp_skip = DV_EXP_SWITCH("DV_EXP_SKIP_WGRAD") >= 1;
     if (exp_skip) return OK;
   }
   if (xc16 && yc16) BW_LAUNCH(true, true);

@@ -34,6 +34,17 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// MEASUREMENT switches (DV_EXP_*, DV_TIME_ENQUEUE) leave work out of a step to price it: they give WRONG results, so they
+// exist only in the development library (libdebvader_hip_debug.so, -DDV_DEBUG_EXPORTS), which announces every one that is
+// set on stderr.  In the product library DV_EXP_SWITCH(...) is the constant 0: the environment is not read, the names do
+// not appear in the binary (tests/test_abi_and_host.py checks `strings`), and the branches fold away.
+#ifdef DV_DEBUG_EXPORTS
+int exp_switch(const char* name);        // engine.hip: atoi of the variable (unset or "0": off), one warning per name
+#define DV_EXP_SWITCH(name) ::dv::exp_switch(name)
+#else
+#define DV_EXP_SWITCH(name) 0
+#endif
+
 #ifdef __HIPCC__
 // Philox4x32-10 and the standard normal the engine derives from it (pairs (0,1), (2,3) of a block are one
 // Box-Muller draw): shared by the sampler and the sampled-"mse" metric of the head kernels

@@ -20,6 +20,8 @@
 #include <string>
 #include <thread>
 #include <map>
+#include <mutex>
+#include <set>
 #include <vector>
 
 #include "../../include/debvader_hip.h"
@@ -67,13 +69,28 @@ struct Spec {
 // DV_EXP_SKIP_SMALL=1 (a MEASUREMENT switch, results are wrong): the elementwise neighbours of the dense trunk that a fused
 // trunk would absorb (split-K finish, the two PReLU forwards, the narrow dense data gradient, the bias column sums, the
 // bf16 seam conversions) are not launched - the upper bound of what merging them can give the step
+#ifdef DV_DEBUG_EXPORTS
+int exp_switch(const char* name) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  if (v != 0) {
+    static std::mutex mu;
+    static std::set<std::string> told;
+    std::lock_guard<std::mutex> g(mu);
+    if (told.insert(name).second)
+      fprintf(stderr, "[libdebvader_hip_debug] WARNING: %s=%d is a MEASUREMENT switch - work is left out, every result of "
+                      "this process is WRONG\n", name, v);
+  }
+  return v;
+}
+#endif
 static bool exp_skip_small() {
-  static const bool v = getenv("DV_EXP_SKIP_SMALL") != nullptr;
+  static const bool v = DV_EXP_SWITCH("DV_EXP_SKIP_SMALL") >= 1;
   return v;
 }
 // DV_EXP_SKIP_SMALL=2: additionally none of the dense trunk's matrix launches (forward, data gradient, weight gradient)
 static bool exp_skip_dense() {
-  static const bool v = getenv("DV_EXP_SKIP_SMALL") != nullptr && atoi(getenv("DV_EXP_SKIP_SMALL")) >= 2;
+  static const bool v = DV_EXP_SWITCH("DV_EXP_SKIP_SMALL") >= 2;
   return v;
 }
 
@@ -1241,7 +1258,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   const bool k3 = ksz == 3;
   {   // DV_EXP_SKIP_WGRAD=2 (MEASUREMENT, wrong gradients): no conv weight-gradient work at all (all three families and their
       // slab sums; the fused first layer and the dense layers stay) - what the whole weight-gradient stream costs the step
-    static const int exp_all = getenv("DV_EXP_SKIP_WGRAD") ? atoi(getenv("DV_EXP_SKIP_WGRAD")) : 0;
+    static const int exp_all = DV_EXP_SWITCH("DV_EXP_SKIP_WGRAD");
     if (exp_all >= 2 && !single_tap && !fz) return OK;
     if (single_tap && exp_skip_dense()) return OK;
   }
@@ -1452,7 +1469,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   p.pchunk = pchunk;
   // DV_EXP_SKIP_WGRAD=1 (a MEASUREMENT switch, gradients are wrong): the tiled weight-gradient launches of the conv layers
   // are left out, slab sums and stream hand-overs kept - the upper bound of what a faster wgrad_kernel can give the step
-  static const bool exp_skip = getenv("DV_EXP_SKIP_WGRAD") != nullptr && atoi(getenv("DV_EXP_SKIP_WGRAD")) >= 1;
+  static const bool exp_skip = DV_EXP_SWITCH("DV_EXP_SKIP_WGRAD") >= 1;
   if (!(exp_skip && !single_tap)) {
     ProfScope ps(m, 1, ws, PF_WGRAD, wflops);
     DV_TRY(launch_wgrad(p, ws));
@@ -1692,7 +1709,7 @@ struct TinyCall {          // scope of one public inference call of at most 16 s
 // pixels wide store the pre-activation only (epilogue 1: no PReLU, no activation store) - the upper bound of what "store u
 // only"  can save before any consumer pays for applying PReLU on load
 static int exp_epi(bool keep_u, int hout) {
-  static const int min_h = getenv("DV_EXP_NO_A") ? atoi(getenv("DV_EXP_NO_A")) : 0;
+  static const int min_h = DV_EXP_SWITCH("DV_EXP_NO_A");
   return (min_h > 0 && keep_u && hout >= min_h) ? 1 : 2;
 }
 
@@ -2719,6 +2736,13 @@ using namespace dv;
 extern "C" {
 
 int dv_version(void) { return 100; }
+int dv_build_kind(void) {
+#ifdef DV_DEBUG_EXPORTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 // CRC-32C (Castagnoli), slicing-by-8 on the host: the checksum TensorFlow tensor-bundle checkpoints carry per tensor
 // and per index block (debvader_amd/model/tf_checkpoint.py; reference call sites model.py:262-266, train.py:49-75).
@@ -2962,16 +2986,19 @@ static int ctx_build(dv_ctx* c, int world, int rank, const void* unique_id) {
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
     StdoutToStderr quiet;
-    if (getenv("DV_DEBUG_FAKE_PEERS")) {
-      // rehearsal hook (see parallel.make_context): a one-rank communicator per rank, so that several ranks can share the
-      // one GPU of a build box; everything else believes in `world` ranks
-      fprintf(stderr, "[libdebvader_hip] WARNING: DV_DEBUG_FAKE_PEERS is set: rank %d of %d gets a ONE-RANK communicator - "
+#ifdef DV_DEBUG_EXPORTS
+    if (getenv("DV_DEBUG_FAKE_PEERS") && atoi(getenv("DV_DEBUG_FAKE_PEERS")) != 0) {
+      // rehearsal hook of the DEVELOPMENT library (see parallel.make_context): a one-rank communicator per rank, so that
+      // several ranks can share the one GPU of a build box; everything else believes in `world` ranks
+      fprintf(stderr, "[libdebvader_hip_debug] WARNING: DV_DEBUG_FAKE_PEERS is set: rank %d of %d gets a ONE-RANK communicator - "
                       "gradients and BN statistics are NOT summed across ranks; this is a launch rehearsal, not a job\n",
               rank, world);
       c->fake_peers = true;
       DV_NCCL(ncclGetUniqueId(&id));
       DV_NCCL(ncclCommInitRank(&c->comm, 1, id, 0));
-    } else {
+    } else
+#endif
+    {
       DV_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
     }
   }
@@ -3612,7 +3639,7 @@ int dv_train_steps(dv_model* m, int32_t slot, int64_t first, int32_t B, int32_t 
   int64_t span = std::max<int64_t>(1, m->slots[slot].n - B + 1);
   // DV_TIME_ENQUEUE=1: host time spent queuing the steps (stderr) - when it approaches the steps' GPU time the host, not the
   // GPU, paces the loop
-  static const bool time_enqueue = getenv("DV_TIME_ENQUEUE") != nullptr;
+  static const bool time_enqueue = DV_EXP_SWITCH("DV_TIME_ENQUEUE") != 0;   // (development library only)
   const auto tq0 = std::chrono::steady_clock::now();
   for (int k = 0; k < steps; ++k) {
     int64_t start = (first + (int64_t)k * B) % span;

@@ -319,7 +319,7 @@ static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, i
   p.Hx = Hx; p.Cx = Cx; p.Hy = Hy; p.Cy = Cy; p.NBp = bf.NBp; p.s = s; p.pb = pb;
   int ns = 0;
   hipStream_t st = on_main ? m->ctx->stream : bf_wstream(m);
-  static const bool exp_no_events = getenv("DV_EXP_NO_WGRAD_EVENTS") != nullptr;   // MEASUREMENT only (races: use with DV_EXP_SKIP_WGRAD)
+  static const bool exp_no_events = DV_EXP_SWITCH("DV_EXP_NO_WGRAD_EVENTS") != 0;   // MEASUREMENT only (races: use with DV_EXP_SKIP_WGRAD)
   if (st != m->ctx->stream && !exp_no_events) {
     DV_HIP(hipEventRecord(m->ctx->ev_ready, m->ctx->stream));
     DV_HIP(hipStreamWaitEvent(st, m->ctx->ev_ready, 0));

@@ -405,48 +405,86 @@ def exchange_unique_id(rank: int, group) -> bytes:
     return group.broadcast(mine, src=0)
 
 
-def _check_one_gpu_per_rank(group, rank: int, world: int, local_rank: int):
-    """Every rank tells the others which physical GPU it is about to open - (host name, PCI bus id) - and ALL ranks raise
-    when two of them name the same one: e.g. a launcher that starts N ranks with a single visible, un-pinned GPU sends every
-    rank to device 0.  Done before the communicator exists, so nobody is left waiting inside ncclCommInitRank.  The one-GPU
-    rehearsal switches (DV_DEBUG_SAME_GPU / DV_DEBUG_FAKE_PEERS) and groups without a byte all-gather skip it."""
-    if os.environ.get("DV_DEBUG_SAME_GPU") or os.environ.get("DV_DEBUG_FAKE_PEERS"):
-        return
+def _rehearsal(var: str) -> bool:
+    """The one-GPU rehearsal hooks (DV_DEBUG_SAME_GPU: every rank opens device 0; DV_DEBUG_FAKE_PEERS: every rank gets a
+    one-rank communicator, gradients are NOT summed) exist in the DEVELOPMENT build of the engine only (selected with
+    DEBVADER_AMD_LIB; dv_build_kind() == 1).  With the product library the variables are not honoured - a stray one in a user's shell must
+    not turn a job into a rehearsal - and one line on stderr says so."""
+    v = os.environ.get(var)
+    if not v or v == "0":
+        return False
+    from . import _lib as L
+    if L.IS_DEBUG_LIB:
+        return True
+    if var not in _rehearsal.told:
+        _rehearsal.told.add(var)
+        print(f"[debvader_amd] {var} is set but the product library is loaded: ignored (the rehearsal hooks live in the "
+              f"development build of the engine, selected with DEBVADER_AMD_LIB)", file=sys.stderr, flush=True)
+    return False
+
+
+_rehearsal.told = set()
+
+
+def _agree_on_devices(group, rank: int, world: int, local_rank: int, problem: Optional[str]):
+    """Every rank tells the others which physical GPU it is about to open - (host name, PCI bus id) - together with any
+    problem it found on its own (LOCAL_RANK beyond the visible GPUs), and ALL ranks raise together when one of them has a
+    problem or two of them name the same GPU: e.g. a launcher that starts N ranks with a single visible, un-pinned GPU
+    sends every rank to device 0.  Done before the communicator exists, so nobody is left waiting inside
+    ncclCommInitRank or in the rendezvous for a rank that has already given up.  Every rank of a job takes part (the
+    decision to skip - a rehearsal, a group without a byte all-gather - depends only on things all ranks share: the
+    launcher's environment and the group's type)."""
     if not hasattr(group, "allgather") or hasattr(group, "get_backend"):
+        if problem:
+            raise RuntimeError(problem)
         return
-    bus = getattr(E, "device_bus_id", lambda d: "")(local_rank)
-    mine = f"{socket.gethostname()}|{bus}".encode()
+    rehearsal = _rehearsal("DV_DEBUG_SAME_GPU") or _rehearsal("DV_DEBUG_FAKE_PEERS")
+    bus = "" if problem else getattr(E, "device_bus_id", lambda d: "")(local_rank)
+    mine = f"{socket.gethostname()}|{bus}|{problem or ''}".encode()
     seen = {}
     clash = None
+    problems = []
     for r, who in enumerate(group.allgather(mine)):
-        who = bytes(who).decode()
-        if who.endswith("|"):
-            continue                       # that rank could not name its device (no GPU visible): nothing to compare
-        if who in seen and clash is None:
-            clash = (seen[who], r, who)
-        seen.setdefault(who, r)
+        host, bus_r, prob_r = bytes(who).decode().split("|", 2)
+        if prob_r:
+            problems.append(f"rank {r}: {prob_r}")
+            continue
+        if not bus_r or rehearsal:
+            continue                       # that rank could not name its device (no GPU visible) / ranks share on purpose
+        key = (host, bus_r)
+        if key in seen and clash is None:
+            clash = (seen[key], r, key)
+        seen.setdefault(key, r)
+    if problems:
+        raise RuntimeError("; ".join(problems))
     if clash:
-        raise RuntimeError(f"ranks {clash[0]} and {clash[1]} of {world} would both open GPU {clash[2].split('|')[1]} on host "
-                           f"{clash[2].split('|')[0]}: RCCL needs one GPU per rank - check LOCAL_RANK and the per-rank "
+        raise RuntimeError(f"ranks {clash[0]} and {clash[1]} of {world} would both open GPU {clash[2][1]} on host "
+                           f"{clash[2][0]}: RCCL needs one GPU per rank - check LOCAL_RANK and the per-rank "
                            f"HIP_VISIBLE_DEVICES pinning of the launcher")
 
 
 def make_context(rank: int, world: int, local_rank: Optional[int] = None, group=None) -> E.Context:
     """The engine context of this rank: GPU `local_rank`, RCCL communicator over `world` ranks.  With world > 1 and no
     `group` the ranks meet through HostGroup(rank, world) (MASTER_ADDR / MASTER_PORT); the group stays attached to the
-    context (ctx.group) for the caller's barriers and is closed with it."""
+    context (ctx.group) for the caller's barriers and is closed with it.  Order with world > 1: join the group FIRST, then
+    agree on the devices (a rank that cannot open its GPU says so to everybody and all ranks raise the same error - no
+    healthy peer is left blocking in the rendezvous), then the communicator; a group created here is closed again when
+    any of that fails."""
     if local_rank is None:
         local_rank = int(os.environ.get("LOCAL_RANK", rank))
-    for var in ("DV_DEBUG_SAME_GPU", "DV_DEBUG_FAKE_PEERS"):
-        if os.environ.get(var) and world > 1:
+    same_gpu = _rehearsal("DV_DEBUG_SAME_GPU")
+    fake_peers = _rehearsal("DV_DEBUG_FAKE_PEERS")
+    for var, on in (("DV_DEBUG_SAME_GPU", same_gpu), ("DV_DEBUG_FAKE_PEERS", fake_peers)):
+        if on and world > 1:
             print(f"[debvader_amd] WARNING: {var} is set - this is a REHEARSAL of a {world}-rank launch on one GPU; "
                   f"gradients are NOT summed across ranks and any throughput it prints means nothing", file=sys.stderr,
                   flush=True)
-    if os.environ.get("DV_DEBUG_SAME_GPU"):
+    problem = None
+    if same_gpu:
         # rehearsal of a multi-rank launch on a one-GPU box: every rank opens device 0 (a real RCCL communicator refuses
-        # two ranks on one device; with DV_DEBUG_FAKE_PEERS=1 the engine gives each rank a one-rank communicator instead,
-        # so the gradients are NOT summed - the launch line, the rendezvous, the multi-rank event scopes and the step
-        # structure run for real, the numbers mean nothing)
+        # two ranks on one device; with DV_DEBUG_FAKE_PEERS=1 the development library gives each rank a one-rank
+        # communicator instead, so the gradients are NOT summed - the launch line, the rendezvous, the multi-rank event
+        # scopes and the step structure run for real, the numbers mean nothing)
         local_rank = 0
     else:
         # launchers that pin one GPU per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set per process) leave every rank
@@ -459,18 +497,28 @@ def make_context(rank: int, world: int, local_rank: Optional[int] = None, group=
             local_rank = 0
         elif 1 < visible <= local_rank:
             # (a modulo here would put two ranks on one GPU; RCCL then fails late, inside ncclCommInitRank, or stalls its peers)
-            raise RuntimeError(f"LOCAL_RANK {local_rank} but only {visible} GPUs are visible to this process: launch at most "
-                               f"{visible} ranks per node, or pin one GPU per rank (HIP_VISIBLE_DEVICES)")
+            problem = (f"LOCAL_RANK {local_rank} but only {visible} GPUs are visible to this process: launch at most "
+                       f"{visible} ranks per node, or pin one GPU per rank (HIP_VISIBLE_DEVICES)")
     if world == 1:
+        if problem:
+            raise RuntimeError(problem)
         ctx = E.Context(local_rank, 0, 1, None)
         ctx.group = group
         return ctx
     own = group is None
     if own:
         group = HostGroup(rank, world)
-    _check_one_gpu_per_rank(group, rank, world, local_rank)
-    uid = exchange_unique_id(rank, group)
-    ctx = E.Context(local_rank, rank, world, uid)
+    try:
+        _agree_on_devices(group, rank, world, local_rank, problem)
+        uid = exchange_unique_id(rank, group)
+        ctx = E.Context(local_rank, rank, world, uid)
+    except BaseException:
+        if own:
+            try:
+                group.close()
+            except Exception:
+                pass
+        raise
     ctx.group = group
     ctx._owns_group = own
     return ctx

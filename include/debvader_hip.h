@@ -71,6 +71,11 @@ typedef struct dv_config {
 enum { DV_S_LOSS = 0, DV_S_NLL_MEAN = 1, DV_S_KL_REG = 2, DV_S_MSE = 3, DV_N_SCALARS = 4 };
 
 int dv_version(void);
+/* 0: the product library (this header is its whole exported surface; it reads no measurement or rehearsal switch);
+ * 1: the DEVELOPMENT build (same sources under -DDV_DEBUG_EXPORTS: include/debvader_hip_debug.h, the wrong-result
+ * measurement switches DV_EXP_*, the one-GPU rehearsal hook DV_DEBUG_FAKE_PEERS).  The Python package honours its own
+ * rehearsal variable (DV_DEBUG_SAME_GPU) only when this returns 1.  No counterpart in the reference (tooling). */
+int dv_build_kind(void);
 /* CRC-32C of `n` bytes continuing from `crc` (0 to start): the checksum of TensorFlow tensor-bundle checkpoints,
  * which load_weights / ModelCheckpoint read and write (model.py:262-266, train.py:49-75).  Host only. */
 uint32_t dv_crc32c(uint32_t crc, const void* data, size_t n);

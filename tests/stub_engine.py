@@ -24,6 +24,11 @@ def device_bus_id(device):
     return os.environ.get("DV_STUB_BUS", f"0000:{int(device):02x}:00.0")
 
 
+def device_count():
+    """GPUs visible to this process ($DV_STUB_VISIBLE; 0 = unknown, as on a box without a GPU)"""
+    return int(os.environ.get("DV_STUB_VISIBLE", "0"))
+
+
 class Context:
     def __init__(self, device=0, rank=0, world=1, unique_id=None):
         self.device, self.rank, self.world = device, rank, world

@@ -172,6 +172,75 @@ def test_no_gpu_means_loud_failure_not_fallback():
         E.Context()
 
 
+def _product_env_names():
+    """Every DV_* / DEBVADER_* name the product can read: string constants of the library + os.environ reads of the package."""
+    import re
+    import subprocess
+
+    from debvader_amd import _lib
+
+    out = subprocess.run(["strings", "-n", "6", os.path.join(ROOT, "debvader_amd", "lib", "libdebvader_hip.so")],
+                         capture_output=True, text=True, check=True).stdout
+    names = set(re.findall(r"^(DV_[A-Z][A-Z0-9_]+)$", out, flags=re.M))
+    names -= {n for n in names if n.startswith("DV_E_") or n.startswith("DV_S_") or n.startswith("DV_DTYPE")}
+    for d, _, files in os.walk(os.path.join(ROOT, "debvader_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                names |= set(re.findall(r"""environ(?:\.get|\.pop|\.setdefault)?[\[(]\s*["']((?:DV|DEBVADER)_[A-Z0-9_]+)""", src))
+                names |= set(re.findall(r"""_rehearsal\(["'](DV_[A-Z0-9_]+)""", src))
+                names |= set(re.findall(r"""for var(?:, on)? in \(+["'](DV_[A-Z0-9_]+)["']""", src))
+    return names, out
+
+
+def test_the_product_library_contains_no_measurement_or_rehearsal_switch():
+    """VERDICT r5 / ADVICE r5: DV_EXP_* (work left out: wrong results), DV_TIME_ENQUEUE and the rehearsal hook
+    DV_DEBUG_FAKE_PEERS used to be compiled into libdebvader_hip.so and read silently from the environment.  They are
+    code of the development build only (-DDV_DEBUG_EXPORTS); the product binary does not even contain the names, and
+    dv_build_kind() tells the two apart."""
+    import subprocess
+
+    from debvader_amd import _lib
+    from tests import debug_lib
+
+    if os.environ.get("DEBVADER_AMD_LIB"):
+        pytest.skip("another build of the library is selected")
+    _, out = _product_env_names()
+    bad = [ln for ln in out.splitlines() if "DV_EXP_" in ln or "DV_DEBUG_" in ln or "DV_TIME_ENQUEUE" in ln]
+    assert not bad, bad
+    dbg = subprocess.run(["strings", "-n", "6", debug_lib.DEBUG_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for name in ("DV_EXP_BCONV", "DV_EXP_NO_A", "DV_EXP_SKIP_WGRAD", "DV_EXP_SKIP_SMALL", "DV_EXP_NO_WGRAD_EVENTS",
+                 "DV_TIME_ENQUEUE", "DV_DEBUG_FAKE_PEERS"):
+        assert name in dbg, name                              # ... they live in the development build
+    assert _lib.lib.dv_build_kind() == 0 and _lib.IS_DEBUG_LIB is False
+    assert debug_lib.load().dv_build_kind() == 1
+
+
+def test_every_environment_variable_the_product_reads_is_documented():
+    """README's table of environment switches claims to be complete: every DV_* string constant of the product library and
+    every os.environ read of the package appears in it."""
+    names, _ = _product_env_names()
+    assert {"DV_NO_OVERLAP", "DV_EVENT_SCOPE", "DV_HOST_POOL_GB", "DV_RDZV_TOKEN", "DEBVADER_AMD_LIB"} <= names, names
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    table = readme[readme.index("## Environment switches of the engine"):]
+    missing = sorted(n for n in names if f"`{n}" not in table)
+    assert not missing, f"not in README's environment table: {missing}"
+
+
+def test_rehearsal_variables_do_nothing_with_the_product_library(monkeypatch, capsys):
+    from debvader_amd import parallel
+
+    monkeypatch.setenv("DV_DEBUG_SAME_GPU", "1")
+    monkeypatch.setenv("DV_DEBUG_FAKE_PEERS", "1")
+    parallel._rehearsal.told.clear()
+    if os.environ.get("DEBVADER_AMD_LIB"):
+        pytest.skip("another build of the library is selected")
+    assert parallel._rehearsal("DV_DEBUG_SAME_GPU") is False and parallel._rehearsal("DV_DEBUG_FAKE_PEERS") is False
+    err = capsys.readouterr().err
+    assert err.count("ignored") == 2 and "development build" in err
+    assert parallel._rehearsal("DV_DEBUG_SAME_GPU") is False and capsys.readouterr().err == ""     # told once
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "debvader_amd")
     for d, _, files in os.walk(pkg):

@@ -730,7 +730,10 @@ def test_multi_rank_bench_launch_rehearsed_on_one_gpu():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    env.update({"DV_DEBUG_SAME_GPU": "1", "DV_DEBUG_FAKE_PEERS": "1"})
+    # the rehearsal hooks exist in the DEVELOPMENT library only (round 6): with the product library the same variables are
+    # ignored (one line on stderr), so a stray one cannot turn a job into a rehearsal
+    env.update({"DV_DEBUG_SAME_GPU": "1", "DV_DEBUG_FAKE_PEERS": "1",
+                "DEBVADER_AMD_LIB": os.path.join(root, "debvader_amd", "lib", "libdebvader_hip_debug.so")})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3",
            "--no-roofline", "--no-secondary", "--no-cpu-baseline"]

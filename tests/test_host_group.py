@@ -174,7 +174,50 @@ def test_local_rank_beyond_the_visible_gpus_is_an_error_not_a_modulo(monkeypatch
 
     monkeypatch.setattr(parallel, "E", _E)
     with pytest.raises(RuntimeError, match="only 4 GPUs are visible"):
-        parallel.make_context(5, 8, local_rank=5)
+        parallel.make_context(0, 1, local_rank=5)
+
+
+def _beyond_worker(rank, world, env, log, q):
+    try:
+        os.environ.update(env, DV_STUB_LOG=log, DV_STUB_VISIBLE="4")
+        import importlib
+        import threading
+
+        from debvader_amd import parallel
+
+        parallel.E = importlib.import_module("tests.stub_engine")
+        try:
+            parallel.make_context(rank, world, local_rank=(5 if rank == 1 else 0))     # rank 1 cannot open its GPU
+            q.put((rank, "no error", 0))
+        except RuntimeError as e:
+            q.put((rank, str(e), sum(t.name.startswith("dv-hub") for t in threading.enumerate())))
+    except Exception as e:                                  # pragma: no cover
+        q.put((rank, repr(e), -1))
+
+
+def test_a_rank_that_cannot_open_its_gpu_fails_every_rank_together(tmp_path):
+    """the LOCAL_RANK >= visible-GPUs check used to raise on that rank alone, BEFORE it joined the host group -
+    its healthy peers then sat in the rendezvous until the timeout.  Now every rank joins first, the unlucky one says what
+    is wrong in the device all-gather, ALL ranks raise the same message within seconds, nobody builds an engine context
+    and a group that make_context created itself is closed again."""
+    import time
+
+    world, log = 2, str(tmp_path / "stub")
+    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "TORCHELASTIC_USE_AGENT_STORE": "",
+           "DV_RDZV_TIMEOUT": "60"}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    t0 = time.time()
+    procs = [ctx.Process(target=_beyond_worker, args=(r, world, env, log, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    assert time.time() - t0 < 50                                               # (nobody waited for the rendezvous timeout)
+    for _, msg, _ in res:
+        assert "rank 1: LOCAL_RANK 5 but only 4 GPUs are visible" in msg, res
+    assert not any(os.path.exists(f"{log}.{r}") for r in range(world))         # no Context was ever constructed
 
 
 def _hub_only(port, q):

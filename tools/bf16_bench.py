@@ -3,7 +3,13 @@ import sys
 import time
 
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the MEASUREMENT switches (DV_EXP_*, DV_TIME_ENQUEUE: work left out, wrong results) exist in the development build only;
+# when one is set this tool drives that build (the product library does not read them)
+if any(k.startswith("DV_EXP_") or k == "DV_TIME_ENQUEUE" for k in os.environ) and not os.environ.get("DEBVADER_AMD_LIB"):
+    os.environ["DEBVADER_AMD_LIB"] = os.path.join(ROOT, "debvader_amd", "lib", "libdebvader_hip_debug.so")
+    print("[bf16_bench] measurement switch set: using the development build of the engine", file=sys.stderr)
 from debvader_amd import engine as E
 from debvader_amd.data import synthetic_stamps
 

@@ -2,7 +2,7 @@
 DV_DEBUG_SAME_GPU=1 DV_DEBUG_FAKE_PEERS=1): the global batch is split over the ranks, every rank keeps only its rows
 resident, callbacks / checkpoints run on rank 0, validation runs every epoch.  Gradients are NOT summed across the fake
 peers, so the ranks' weights drift apart - the point is that the whole multi-rank host path runs and ends cleanly.
-  DV_DEBUG_SAME_GPU=1 DV_DEBUG_FAKE_PEERS=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \\
+  DEBVADER_AMD_LIB=$PWD/debvader_amd/lib/libdebvader_hip_debug.so DV_DEBUG_SAME_GPU=1 DV_DEBUG_FAKE_PEERS=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \\
       --master-addr 127.0.0.1 --master-port 29521 tools/fit_multirank_rehearsal.py"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
