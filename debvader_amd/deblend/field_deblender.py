@@ -59,8 +59,16 @@ class DeblendField:
         self.nb_of_deblended_galaxies = []
         self.res_deblend = None
         self.mse = []
-        self._ctx = getattr(getattr(net, "_core", None), "ctx", None) or E.default_context()
+        self._ctx_obj = getattr(getattr(net, "_core", None), "ctx", None)   # the compositing runs on the net's GPU context;
+                                                                            # a net without one gets the default context at
+                                                                            # the first get_*_field call (see _ctx)
         self._device_fields = None      # (recarray, fields composited on the GPU) of the last deblend_field(on_device=True)
+
+    @property
+    def _ctx(self):
+        if self._ctx_obj is None:
+            self._ctx_obj = E.default_context()
+        return self._ctx_obj
 
     # -- compositing -------------------------------------------------------------------------------
     @staticmethod
@@ -184,15 +192,39 @@ class DeblendField:
             if list_idx == []:
                 print("No galaxy deblended. End of the iterative procedure.")
                 return res_deblend
-            # ... and deblend(net, cutout_images[list_idx]) (deblender.py:18) on them, gathered on the GPU
-            core = self.net._core
-            eng = core.engine
-            eng.set_normalise(bool(self.normalise))
-            try:
-                r = eng.infer_cutouts_keep(field_image[0], starts[ok], seed=core.next_seed())
-            finally:
-                eng.set_normalise(False)
-            output_images_mean, output_images_stddev, cutouts = r["loc"], r["scale"], r["cutouts"]
+            core = getattr(self.net, "_core", None)
+            if core is None or getattr(core, "engine", None) is None or field_image.shape[1] != field_image.shape[2]:
+                # a wrapped or plain-callable net (anything deblend() accepts), or a field that is not square (the fused
+                # engine call gathers from square fields only): the reference's two steps as they stand,
+                # extract_cutouts (extraction.py:4-43) then deblend(net, cutout_images[list_idx]) (:260-274)
+                # (slices taken on the host: a window that fits field_size but not the shorter axis of a rectangular field
+                # comes out truncated - the reference's assignment raises for it and the galaxy is flagged, :36-41)
+                cut = [field_image[0, xs:xs + cs, ys:ys + cs] for xs, ys in starts[ok]]
+                fits = [c.shape == (cs, cs, nb) for c in cut]
+                if not all(fits):
+                    if ok.all():
+                        print("Some galaxies are too close from the border of the field to be considered here.")
+                    list_idx = [i for i, f in zip(list_idx, fits) if f]
+                    cut = [c for c, f in zip(cut, fits) if f]
+                    if list_idx == []:
+                        print("No galaxy deblended. End of the iterative procedure.")
+                        return res_deblend
+                cutouts = np.array(cut, dtype=np.float64)
+                output_images_mean, dist = deblend(self.net, cutouts, normalise=self.normalise)
+                output_images_stddev = dist.stddev().numpy()
+            else:
+                # ... and deblend(net, cutout_images[list_idx]) (deblender.py:18) on them, gathered on the GPU.  The
+                # previous pass's recarray is let go first: its 16 bytes per pixel go back to the result-array pool
+                # (engine._HostPool) and this call's arrays reuse them - unless the caller still holds that recarray
+                self.res_deblend = None
+                self._device_fields = None
+                eng = core.engine
+                eng.set_normalise(bool(self.normalise))
+                try:
+                    r = eng.infer_cutouts_keep(field_image[0], starts[ok], seed=core.next_seed())
+                finally:
+                    eng.set_normalise(False)
+                output_images_mean, output_images_stddev, cutouts = r["loc"], r["scale"], r["cutouts"]
         if list_idx == []:
             print("No galaxy deblended. End of the iterative procedure.")
             return res_deblend

@@ -6,9 +6,11 @@ sit on top of it.
 from __future__ import annotations
 
 import atexit
+import collections
 import ctypes as C
 import os
 import sys
+import threading
 import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -101,61 +103,140 @@ def _i32_rows(a, what: str) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.int32).reshape(-1, 2)
 
 
+class _Lease:
+    """Owner token of one hand-out of a pool block.  The array the caller receives is built on this object
+    (__array_interface__), so numpy makes it the END of the `base` chain of that array and of everything derived from it -
+    views, reshapes, the object columns of a recarray, a memoryview, np.frombuffer of one.  When the last of them dies the
+    token dies, and its weakref.finalize puts the block back on the pool's return queue."""
+
+    __slots__ = ("_mem", "__array_interface__", "__weakref__")
+
+    def __init__(self, mem: np.ndarray, nbytes: int):
+        self._mem = mem                                     # keeps the block alive while the lease is
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (mem.ctypes.data, False), "version": 3}
+
+
 class _HostPool:
     """Recycles the host memory of large result arrays across calls.
 
     DeblendField.deblend_field returns 16 bytes per pixel and band and galaxy (float64 cutout, float32 mean and stddev): 11 GB
     per 32 768 galaxies.  Fresh np.empty arrays cost a page fault per 4 KiB while the engine's copy threads fill them and
     an munmap of the same size when the previous result is dropped - together more than the GPU work of the call
-    (tools/probes/df_lines.py: 0.21 s engine call, 0.25 - 0.5 s freeing the previous recarray).  The pool keeps the raw
-    blocks and hands out VIEWS of them; a block is handed out again only when nothing but the pool references it
-    (sys.getrefcount - every view a caller or a recarray still holds counts, numpy collapses view chains onto the owning
-    array), so a result somebody still has is never overwritten.  Bounded by $DV_HOST_POOL_GB (default 32, 0 disables);
-    arrays below 64 MB are plain np.empty."""
+    (tools/probes/df_lines.py: 0.21 s engine call, 0.25 - 0.5 s freeing the previous recarray).
+
+    Ownership (round 6; until then the pool looked at sys.getrefcount of its blocks, without a lock).  A hand-out is an
+    array whose `base` chain ends in a _Lease token that only that array and its descendants reference; the pool itself
+    keeps no reference to the token, only a weakref.finalize on it.  A block goes back to the idle list when - and only when -
+    its token has been collected, i.e. when no array, view, recarray column, memoryview or np.frombuffer of the hand-out
+    is alive.  What Python cannot see it cannot protect: a RAW ADDRESS taken from a result (arr.ctypes.data, a pointer kept
+    by a C extension) does not keep the token alive - whoever holds one must keep the array too, or copy.
+    Thread safety: empty() runs under a lock from the scan to the finished view; finalizers (which may run on any thread,
+    also inside empty() through the garbage collector) only append to a deque, which empty() drains under the lock.
+    Bounds: the pool never tracks more than `cap` bytes (leased + idle; $DV_HOST_POOL_GB, default min(24 GB, a quarter
+    of the machine's RAM); 0 disables the pool) - beyond it a request gets a plain np.empty; idle blocks are kept only up
+    to the total of the last four requests (a deblend_field call asks for three arrays) and are dropped when they have
+    not been used for eight requests, so one large call does not pin its memory for the life of the process.
+    host_pool_clear() drops every idle block at once.  Arrays below 64 MB are plain np.empty."""
 
     MIN_BYTES = 64 << 20
+    KEEP_REQUESTS = 4          # idle bytes kept <= the total of this many most recent requests
+    MAX_IDLE_AGE = 8           # ... and an idle block older than this many requests is dropped
 
-    def __init__(self):
+    def __init__(self, cap_bytes: Optional[int] = None):
+        if cap_bytes is None:
+            try:
+                cap_bytes = int(float(os.environ["DV_HOST_POOL_GB"]) * (1 << 30))
+            except (KeyError, ValueError):
+                cap_bytes = min(24 << 30, self._ram_bytes() // 4)
+        self.cap = max(0, cap_bytes)
+        self._lock = threading.Lock()
+        self._idle: List[tuple] = []                       # (block, tick of its last use), least recently used first
+        self._returned = collections.deque()               # blocks whose lease has died, not yet back on the idle list
+        self._leased = 0                                   # bytes handed out and not yet returned
+        self._recent = collections.deque(maxlen=self.KEEP_REQUESTS)
+        self._tick = 0
+
+    @staticmethod
+    def _ram_bytes() -> int:
         try:
-            self.cap = int(float(os.environ.get("DV_HOST_POOL_GB", "32")) * (1 << 30))
-        except ValueError:
-            self.cap = 32 << 30
-        self.blocks: List[np.ndarray] = []
+            return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+        except (ValueError, OSError, AttributeError):
+            return 64 << 30
+
+    def _give_back(self, block: np.ndarray):
+        """finalizer of a lease (any thread, possibly inside empty() via the garbage collector): no lock taken here"""
+        self._returned.append(block)
+
+    def _drain(self):
+        while True:
+            try:
+                block = self._returned.popleft()
+            except IndexError:
+                return
+            self._leased -= block.nbytes
+            self._idle.append((block, self._tick))
+
+    def _trim(self, keep_bytes: int):
+        """drops idle blocks that are too old, then the least recently used ones until at most keep_bytes stay idle"""
+        self._idle = [(b, t) for b, t in self._idle if self._tick - t <= self.MAX_IDLE_AGE]
+        total = sum(b.nbytes for b, _ in self._idle)
+        while self._idle and total > keep_bytes:
+            total -= self._idle.pop(0)[0].nbytes
 
     def empty(self, shape, dtype) -> np.ndarray:
         dtype = np.dtype(dtype)
         nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
         if nbytes < self.MIN_BYTES or nbytes > self.cap:
             return np.empty(shape, dtype)
-        pick = -1
-        for i in range(len(self.blocks)):
-            # 2 = the list's reference + getrefcount's argument: no view of this block is alive anywhere
-            if sys.getrefcount(self.blocks[i]) == 2 and self.blocks[i].nbytes >= nbytes and (
-                    pick < 0 or self.blocks[i].nbytes < self.blocks[pick].nbytes):
-                pick = i
-        if pick < 0:
-            total = sum(b.nbytes for b in self.blocks)
-            i = 0
-            while total + nbytes > self.cap and i < len(self.blocks):      # make room: drop idle blocks, oldest first
-                if sys.getrefcount(self.blocks[i]) == 2:
-                    total -= self.blocks[i].nbytes
-                    del self.blocks[i]
-                else:
-                    i += 1
-            if total + nbytes > self.cap:
-                return np.empty(shape, dtype)                                # everything pooled is in use: not tracked
-            self.blocks.append(np.empty(nbytes, np.uint8))
-            pick = len(self.blocks) - 1
-        else:
-            self.blocks.append(self.blocks.pop(pick))                        # most recently used last
-            pick = len(self.blocks) - 1
-        return self.blocks[pick][:nbytes].view(dtype).reshape(shape)
+        with self._lock:
+            self._tick += 1
+            self._drain()
+            self._recent.append(nbytes)
+            pick = -1
+            for i, (b, _) in enumerate(self._idle):           # best fit among the idle blocks
+                if b.nbytes >= nbytes and (pick < 0 or b.nbytes < self._idle[pick][0].nbytes):
+                    pick = i
+            if pick >= 0:
+                block = self._idle.pop(pick)[0]
+            else:
+                idle = sum(b.nbytes for b, _ in self._idle)
+                if self._leased + idle + nbytes > self.cap:   # make room among the idle blocks first
+                    self._trim(max(0, self.cap - self._leased - nbytes))
+                    idle = sum(b.nbytes for b, _ in self._idle)
+                if self._leased + idle + nbytes > self.cap:
+                    return np.empty(shape, dtype)             # everything tracked is in use: a plain array, not tracked
+                block = np.empty(nbytes, np.uint8)
+            self._leased += block.nbytes
+            self._trim(sum(self._recent))
+            lease = _Lease(block, nbytes)
+            weakref.finalize(lease, self._give_back, block)
+            out = np.asarray(lease).view(dtype).reshape(shape)  # the only references to `lease` are out's base chain
+            del lease
+            return out
+
+    def stats(self) -> dict:
+        with self._lock:
+            self._drain()
+            return {"cap": self.cap, "leased_bytes": self._leased, "idle_bytes": sum(b.nbytes for b, _ in self._idle),
+                    "idle_blocks": len(self._idle)}
 
     def clear(self):
-        self.blocks = []
+        """drops every idle block (leased ones belong to their holders and are freed when those let go)"""
+        with self._lock:
+            self._drain()
+            self._idle = []
 
 
 _host_pool = _HostPool()
+
+
+def host_pool_clear():
+    """Frees the idle blocks of the result-array pool (see _HostPool) - e.g. after the last deblend_field of a session."""
+    _host_pool.clear()
+
+
+def host_pool_stats() -> dict:
+    return _host_pool.stats()
 
 
 def _f32c(a, shape=None) -> np.ndarray:

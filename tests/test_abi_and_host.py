@@ -138,28 +138,146 @@ def test_bad_architectures_are_rejected_with_a_message():
         E.make_config(filters=(32, 64), kernels=(3,))
 
 
-def test_host_result_pool_never_hands_out_memory_somebody_still_holds():
-    """engine._HostPool: blocks go out again only when no view of them is alive; below the threshold and above the cap it is
-    plain np.empty."""
+def _pool(cap_mb=10, min_mb=1):
     from debvader_amd.engine import _HostPool
 
-    p = _HostPool()
-    p.MIN_BYTES, p.cap = 1 << 20, 10 << 20
+    p = _HostPool(cap_bytes=cap_mb << 20)
+    p.MIN_BYTES = min_mb << 20
+    return p
+
+
+def test_host_result_pool_never_hands_out_memory_somebody_still_holds():
+    """engine._HostPool (ownership rebuilt in round 6): a hand-out is built on a lease token that ends the `base` chain of
+    the array and of everything derived from it; the block returns to the pool only when that token has been collected.
+    Below the threshold and above the cap a request is plain np.empty."""
+    import gc
+
+    p = _pool()
     a = p.empty((4, 1 << 16), np.float64)                      # 2 MB
-    assert a.flags.c_contiguous and a.shape == (4, 1 << 16) and len(p.blocks) == 1
+    assert a.flags.c_contiguous and a.flags.writeable and a.shape == (4, 1 << 16)
+    assert p.stats()["leased_bytes"] == 2 << 20 and p.stats()["idle_blocks"] == 0
     views = list(a)                                            # what a recarray column holds
     del a
+    gc.collect()
+    assert p.stats()["leased_bytes"] == 2 << 20                # the rows keep the lease alive
     b = p.empty((1 << 18,), np.float64)
-    assert len(p.blocks) == 2 and not any(np.shares_memory(b, v) for v in views)
+    assert not any(np.shares_memory(b, v) for v in views) and p.stats()["leased_bytes"] == 4 << 20
+    addr = views[0].ctypes.data
     del views
+    gc.collect()
+    assert p.stats() == {"cap": 10 << 20, "leased_bytes": 2 << 20, "idle_bytes": 2 << 20, "idle_blocks": 1}
     c = p.empty((1 << 19,), np.float32)                        # the first block is idle again: reused, no third block
-    assert len(p.blocks) == 2 and not np.shares_memory(b, c)
+    assert c.ctypes.data == addr and not np.shares_memory(b, c) and p.stats()["idle_blocks"] == 0
     d = p.empty((1 << 20,), np.float64)                        # 8 MB on top of 4 MB in use: over the cap, untracked
-    assert d.base is None and len(p.blocks) == 2
+    assert d.base is None and p.stats()["leased_bytes"] == 4 << 20
     del b, c
     e = p.empty((1 << 20,), np.float64)                        # idle blocks are dropped to make room
-    assert e.base is not None and sum(x.nbytes for x in p.blocks) <= p.cap
+    st = p.stats()
+    assert e.base is not None and st["leased_bytes"] + st["idle_bytes"] <= p.cap and st["idle_blocks"] <= 1
     assert p.empty((3,), np.float32).base is None
+
+
+def test_host_result_pool_sees_memoryviews_frombuffer_and_recarrays():
+    """Holders that are not ndarray views of the hand-out - a memoryview, np.frombuffer of it, a recarray whose object
+    column holds the rows - keep the block out of circulation until THEY die (sys.getrefcount of the block, the round-5
+    protocol, was blind to none of these by luck of numpy's base collapsing, and to raw addresses by construction: a raw
+    address is still invisible and its holder must keep the array - documented on the class)."""
+    import gc
+
+    import pandas as pd
+
+    p = _pool()
+    a = p.empty((1 << 18,), np.float64)
+    a[:] = 7.0
+    mv = memoryview(a)
+    fb = np.frombuffer(mv, dtype=np.uint8)
+    del a
+    gc.collect()
+    b = p.empty((1 << 18,), np.float64)
+    b[:] = 1.0
+    assert not np.shares_memory(b, fb) and fb[:8].view(np.float64)[0] == 7.0
+    del mv
+    gc.collect()
+    assert p.stats()["leased_bytes"] == 4 << 20                # np.frombuffer still holds it
+    del fb
+    gc.collect()
+    assert p.stats()["leased_bytes"] == 2 << 20 and p.stats()["idle_blocks"] == 1
+    r = p.empty((8, 1 << 15), np.float64)                      # the idle block, now as the image column of a recarray
+    r[:] = 3.0
+    rec = pd.DataFrame({"img": list(r), "k": range(8)}).to_records(index=False)
+    del r
+    gc.collect()
+    c = p.empty((1 << 18,), np.float64)
+    c[:] = 5.0
+    assert all((row == 3.0).all() for row in rec["img"])       # nobody wrote over the rows the recarray holds
+    del rec
+    gc.collect()
+    assert p.stats()["leased_bytes"] == 4 << 20                # b and c
+
+
+def test_host_result_pool_is_safe_with_two_threads():
+    """the scan-then-act of the old pool could hand one block to two threads (ctypes calls release the GIL).
+    Two threads take, fill, verify and drop arrays 300 times each: no array ever sees the other thread's pattern, and
+    at the end everything is back (nothing leased)."""
+    import gc
+    import threading
+
+    p = _pool(cap_mb=24)
+    errors = []
+
+    def worker(tag):
+        rng = np.random.default_rng(tag)
+        held = []
+        for it in range(300):
+            n = int(rng.integers(1 << 17, 1 << 18))
+            a = p.empty((n,), np.float64)
+            a[:] = tag * 1000 + it
+            held.append((a, tag * 1000 + it))
+            if len(held) > 3:
+                arr, want = held.pop(int(rng.integers(0, len(held))))
+                if not (arr == want).all():
+                    errors.append((tag, it))
+        for arr, want in held:
+            if not (arr == want).all():
+                errors.append((tag, -1))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in (1, 2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    gc.collect()
+    assert not errors, errors[:5]
+    assert p.stats()["leased_bytes"] == 0
+
+
+def test_host_result_pool_bounds_what_it_keeps_and_can_be_switched_off(monkeypatch):
+    """Idle memory is bounded by the last four requests and ages out after eight; DV_HOST_POOL_GB=0 switches the pool
+    off (every result a fresh array); host_pool_clear() drops the idle blocks."""
+    import gc
+
+    from debvader_amd import engine as E
+
+    p = _pool(cap_mb=64)
+    big = [p.empty((1 << 20,), np.float64) for _ in range(4)]  # 4 x 8 MB
+    del big
+    gc.collect()
+    assert p.stats()["idle_bytes"] == 32 << 20
+    small = p.empty((1 << 17,), np.float64)                    # 1 MB: reuses one 8 MB block; recent = 8 + 8 + 8 + 1
+    assert p.stats()["idle_bytes"] <= 25 << 20
+    for _ in range(9):                                         # nine small requests later the big blocks have aged out
+        small = p.empty((1 << 17,), np.float64)
+    assert p.stats()["idle_bytes"] <= 8 << 20
+    del small
+    p.clear()
+    assert p.stats()["idle_bytes"] == 0
+    monkeypatch.setenv("DV_HOST_POOL_GB", "0")
+    off = E._HostPool()
+    assert off.cap == 0 and off.empty((1 << 24,), np.float64).base is None and off.stats()["leased_bytes"] == 0
+    monkeypatch.delenv("DV_HOST_POOL_GB")
+    assert 0 < E._HostPool().cap <= 24 << 30                   # default: a quarter of the RAM, at most 24 GB
+    E.host_pool_clear()
+    assert E.host_pool_stats()["idle_bytes"] == 0
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

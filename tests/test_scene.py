@@ -166,3 +166,39 @@ def test_deblend_field_end_to_end():
     assert db.deblend_field([[128, 128]])["list_idx"] is None
     with pytest.raises(NotImplementedError):
         db.deblend_field(dists, optimise_positions=True)
+
+
+class _PlainNet:
+    """Anything deblend() accepts: a callable that returns a distribution-like object (no engine behind it)."""
+
+    def __call__(self, images):
+        from debvader_amd.distributions import Normal
+
+        x = np.asarray(images, dtype=np.float32)
+        return Normal(0.5 * x, 0.1 + np.abs(x))
+
+
+def test_deblend_field_falls_back_to_extract_then_deblend_for_a_plain_net_and_a_rectangular_field(capsys):
+    """the default deblend_field path had come to require net._core.engine and a square field.  The reference's
+    two steps (extract_cutouts then deblend(net, cutouts), field_deblender.py:260-274) take any callable net and slice
+    whatever field they are given; a window that field_size admits but the shorter axis truncates makes the reference's
+    assignment raise, and the galaxy is flagged (extraction.py:36-41).  No GPU involved on this path."""
+    from debvader_amd.deblend.field_deblender import DeblendField
+
+    rng = np.random.default_rng(5)
+    field = rng.normal(size=(1, 200, 140, 6))                    # rectangular: field_size is shape[1] = 200
+    db = DeblendField(_PlainNet(), field)
+    dists = [[0, 0], [-60, -40], [40, 20], [90, 0]]              # third: fits 200 rows, leaves the 140 columns; fourth: leaves both
+    res = db.deblend_field(dists)
+    assert "too close from the border" in capsys.readouterr().out
+    assert list(res["list_idx"]) == [0, 1] and len(res) == 2
+    for row, (dx, dy) in zip(res, dists[:2]):
+        xs, ys = 100 + dx - 29, 100 + dy - 29
+        want = field[0, xs:xs + 59, ys:ys + 59]
+        np.testing.assert_array_equal(row["cutout_images"], want)
+        np.testing.assert_allclose(row["output_images_mean"], 0.5 * want.astype(np.float32), rtol=0, atol=0)
+        assert row["output_images_stddev"].dtype == np.float32 and row["cutout_images"].dtype == np.float64
+    assert db.nb_of_detected_objects == [4] and db.nb_of_deblended_galaxies == [2]
+    # a square field with the same plain net: every window that fits goes through
+    sq = DeblendField(_PlainNet(), rng.normal(size=(1, 200, 200, 6)))
+    assert list(sq.deblend_field(dists)["list_idx"]) == [0, 1, 2]

@@ -160,6 +160,22 @@ def run_drop_in(ctx=None, n_cutouts=131072, chunk=8192, dtype=0, field=None, til
         n_pass += int(np.sum(res["passed_cuts"]))
         del res
     total = time.perf_counter() - t0
+    # ... and ONE call of the same size with the result-array pool switched off (what DV_HOST_POOL_GB=0 gives: every
+    # result array fresh from np.empty, page-faulted while the copy threads fill it, unmapped when it is dropped)
+    pool_cap, E._host_pool.cap = E._host_pool.cap, 0
+    E.host_pool_clear()
+    try:
+        res = db.deblend_field(dist[:per_call])
+        del res
+        db.res_deblend = None
+        t2 = time.perf_counter()
+        res = db.deblend_field(dist[:per_call])
+        checksum += float(res["output_images_mean"][0][29, 29, 2])
+        del res
+        db.res_deblend = None
+        t_nopool = time.perf_counter() - t2
+    finally:
+        E._host_pool.cap = pool_cap
     # the same forward with the stamps resident in HBM (no host copies)
     nres = min(chunk, n_cutouts)
     x32 = ctx.scene_extract(scene, starts[:nres], cs).astype(np.float32)
@@ -181,8 +197,15 @@ def run_drop_in(ctx=None, n_cutouts=131072, chunk=8192, dtype=0, field=None, til
         "value": n / total, "unit": "stamps/s", "dtype": "bf16" if dtype else "f32", "n_cutouts": n, "chunk": chunk,
         "per_call": per_call,
         "includes": "per call: field H2D, cutout gather + float32 cast on the GPU, forward, D2H of mean and stddev through the "
-                    "pinned ring into fresh arrays, the float64 cutout_images assembled on the host from the field beside the "
-                    "forward passes (dv_infer_cutouts_keep), the centre-MSE quality cut and the pandas recarray of the reference",
+                    "pinned ring into result arrays RECYCLED from the previous call (engine._HostPool: the loop drops each "
+                    "recarray before the next call, so its blocks are handed out again), the float64 cutout_images assembled "
+                    "on the host from the field beside the forward passes (dv_infer_cutouts_keep), the centre-MSE quality cut "
+                    "and the pandas recarray of the reference",
+        "definition_changed_in": "r05: until r04 this entry timed extract_cutouts -> deblend (tools/field_cutouts.py::cutouts_run, "
+                                 "43.7 k stamps/s there); since r05 it times DeblendField.deblend_field per 32768 galaxies - "
+                                 "not like for like",
+        "value_without_result_pool": min(per_call, n) / t_nopool,
+        "value_without_result_pool_note": "one call of the same size with DV_HOST_POOL_GB=0 semantics: fresh np.empty result arrays",
         "engine_call_stamps_per_s": n / t_eng[0] if t_eng[0] > 0 else None,
         "python_side_s": total - t_eng[0],
         "host_bytes_per_stamp": cs * cs * 6 * (8 + 4 + 4), "link_bytes_per_stamp": cs * cs * 6 * 8,
