@@ -1259,7 +1259,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   {   // DV_EXP_SKIP_WGRAD=2 (MEASUREMENT, wrong gradients): no conv weight-gradient work at all (all three families and their
       // slab sums; the fused first layer and the dense layers stay) - what the whole weight-gradient stream costs the step
     static const int exp_all = DV_EXP_SWITCH("DV_EXP_SKIP_WGRAD");
-    if (exp_all >= 2 && !single_tap && !fz) return OK;
+    if (exp_all == 2 && !single_tap && !fz) return OK;
     if (single_tap && exp_skip_dense()) return OK;
   }
   // slab region and the stream that sums the slabs: with the weight gradients on the aux stream the reduction goes to
@@ -1339,7 +1339,8 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
         const double exec = 2.0 * (double)NB * nbh * nbh * 16.0 * 16.0 * (double)Cx * (double)Cy;
         const double bytes = 4.0 * ((double)NB * Hy * Hy * (Cx + Cy) + (double)S * 16.0 * Cx * Cy);
         ProfScope ps(m, 1, ws, PF_WINOW, wflops, exec, bytes);
-        st = launch_wino_wgrad(wp, out, ws);
+        static const bool exp_skip_winow = DV_EXP_SWITCH("DV_EXP_SKIP_WGRAD") == 3;   // (3: the Winograd-domain launches only)
+        st = exp_skip_winow ? OK : launch_wino_wgrad(wp, out, ws);
         if (st > 0) prof_uncount(m, 1, PF_WINOW, wflops, exec, bytes);
       }
       if (st < 0) return st;
@@ -1394,7 +1395,13 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
     }
     {
       ProfScope ps(m, 1, ws, PF_WSTRIP, wflops);
-      st = launch_wgrad_strip(sp, Cx, Cy, sx, ws, &ns);
+      static const bool exp_skip_strip = DV_EXP_SWITCH("DV_EXP_SKIP_WGRAD") == 4;     // (4: the strip launches only, not the fused first layer)
+      if (exp_skip_strip && !fz) {
+        st = OK;
+        ns = (int)std::min<size_t>(256, part_cap / ((size_t)9 * Cx * Cy));             // (the slabs it would have written)
+      } else {
+        st = launch_wgrad_strip(sp, Cx, Cy, sx, ws, &ns);
+      }
       if (st > 0) prof_uncount(m, 1, PF_WSTRIP, wflops);
     }
     if (st < 0) return st;
@@ -1469,7 +1476,7 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   p.pchunk = pchunk;
   // DV_EXP_SKIP_WGRAD=1 (a MEASUREMENT switch, gradients are wrong): the tiled weight-gradient launches of the conv layers
   // are left out, slab sums and stream hand-overs kept - the upper bound of what a faster wgrad_kernel can give the step
-  static const bool exp_skip = DV_EXP_SWITCH("DV_EXP_SKIP_WGRAD") >= 1;
+  static const bool exp_skip = DV_EXP_SWITCH("DV_EXP_SKIP_WGRAD") == 1 || DV_EXP_SWITCH("DV_EXP_SKIP_WGRAD") == 2;
   if (!(exp_skip && !single_tap)) {
     ProfScope ps(m, 1, ws, PF_WGRAD, wflops);
     DV_TRY(launch_wgrad(p, ws));

@@ -1028,6 +1028,13 @@ size_t wino_wgrad_part_floats(int NB, int H, int Cx, int Cy, int* splits_out) {
   // and with 128 workgroups the overlapped step takes 4.68 ms against 4.75 with 256 (192: 4.70, 96: 4.87, 64: 5.13; same
   // box, alternating runs).
   long S = std::max(1, cus / 2 / tiles);
+#ifdef DV_DEBUG_EXPORTS
+  {   // development build: DV_EXP_WINOW_WGS=n workgroups per launch instead of half the CUs (a tuning sweep, same results up
+      // to the order of the slab sums)
+    static const int wgs = DV_EXP_SWITCH("DV_EXP_WINOW_WGS");
+    if (wgs > 0) S = std::max(1, wgs / tiles);
+  }
+#endif
   S = std::min(S, nblocks);
   if (splits_out) *splits_out = (int)S;
   return (size_t)(S + (S >= 64 ? 16 : 0)) * 16 * Cx * Cy;    // + the 16 group sums of the two-stage reduction

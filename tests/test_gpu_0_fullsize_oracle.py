@@ -27,19 +27,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("sigma_bias", [0.0, 0.3])
 def test_full_arch_stage1_step_at_batch_256_against_the_oracle(sigma_bias):
-    from debvader_amd.data import synthetic_stamps
-
-    x, y = synthetic_stamps(256, seed=5)
-    worst = _run_parity(vo.Arch(), B=256, seed=2, data=(x, y), sigma_bias=sigma_bias, f32_floor=True)
+    worst = _run_parity(vo.Arch(), B=256, seed=2, data_seed=5, sigma_bias=sigma_bias, f32_floor=True)
     print(f"\n59 px, 256 stamps, sigma bias {sigma_bias}: largest gradient error {worst[1]:.2e} * max ({worst[0]})")
 
 
 def test_full_arch_stage2_frozen_decoder_at_batch_256():
     # stage 2 of train_deblender (train.py:175-183): decoder frozen, gradients still flow through it
-    from debvader_amd.data import synthetic_stamps
-
-    x, y = synthetic_stamps(256, seed=6)
-    _run_parity(vo.Arch(), B=256, seed=3, data=(x, y), train_decoder=False, sigma_bias=0.3, f32_floor=True)
+    _run_parity(vo.Arch(), B=256, seed=3, data_seed=6, train_decoder=False, sigma_bias=0.3, f32_floor=True)
 
 
 def test_128px_six_level_arch_at_its_per_gpu_batch_of_64():

@@ -63,7 +63,11 @@ def toy_arch():
 
 
 def _run(arch, B, seed, data=None, train_decoder=True, tol_out=1e-2, tol_grad_b=5e-3, check_fp64_grads=True,
-         min_cos=0.97, tol_grad_64=0.25, tol_scal_64=5e-3):
+         min_cos=0.97, tol_grad_64=0.25, tol_scal_64=5e-3, data_seed=None):
+    from tests import oracle_jobs, oracle_pool
+
+    if data_seed is not None:
+        data = oracle_jobs.stamps(B, data_seed)
     p, x, y, eps = _case(arch, B, seed, data)
     eng = _engine(arch, B)
     eng.set_params(p)
@@ -72,13 +76,13 @@ def _run(arch, B, seed, data=None, train_decoder=True, tol_out=1e-2, tol_grad_b=
     eng.upload(0, x, y)
     eng.keep_outputs(True)
     x64, y64, e64 = x.astype(np.float64), y.astype(np.float64), eps.astype(np.float64)
-    fused = ((B + 15) // 16 * 16) % 64 == 0
-    cb = vb.forward(arch, p, x64, e64, training=True)
-    rb = vo.losses(arch, cb, y64)
-    gb = vb.backward(arch, p, cb, y64, train_decoder=train_decoder, fused=fused)
-    c = vo.forward(arch, p, x64, e64, training=True)
-    r = vo.losses(arch, c, y64)
-    g = vo.backward(arch, p, c, y64, train_decoder=train_decoder)
+    # both oracles (bf16-rounding and float64); seed-built cases may come from a worker process (tests/oracle_pool.py)
+    if (data is None or data_seed is not None) and arch == oracle_jobs.make_arch(oracle_jobs.arch_kw(arch)):
+        ev = oracle_pool.fetch("bf16_case", arch_kw=oracle_jobs.arch_kw(arch), B=B, seed=seed, data_seed=data_seed,
+                               train_decoder=train_decoder)
+    else:
+        ev = oracle_jobs.bf16_eval(arch, p, x, y, eps, train_decoder)
+    cb, rb, gb, c, r, g = ev["cb"], ev["rb"], ev["gb"], ev["c"], ev["r"], ev["g"]
 
     out = eng.grad_step(0, first=0, B=B, eps=eps)
     H, W, C = arch.input_shape
@@ -192,8 +196,7 @@ def test_full_arch_dc2_stamps():
 def test_full_arch_64_stamps():
     from debvader_amd.data import synthetic_stamps
 
-    x, y = synthetic_stamps(64, seed=6)
-    _run(vo.Arch(), B=64, seed=3, data=(x, y), tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25)
+    _run(vo.Arch(), B=64, seed=3, data_seed=6, tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25)
 
 
 def test_full_arch_at_the_quoted_batch_of_256_stamps():
@@ -204,10 +207,7 @@ def test_full_arch_at_the_quoted_batch_of_256_stamps():
     bf16 oracle and against float64, cosine >= 0.97 - the bounds of the 64-stamp case; every flipped bf16 rounding of an
     activation seeds a difference that 17 layers carry on, and the two bf16 evaluations sit as far from each other as
     each sits from float64 (the measured numbers per tensor: profiles/r05_parity_margins.txt)."""
-    from debvader_amd.data import synthetic_stamps
-
-    x, y = synthetic_stamps(256, seed=9)
-    _run(vo.Arch(), B=256, seed=5, data=(x, y), tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25)
+    _run(vo.Arch(), B=256, seed=5, data_seed=9, tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25)
 
 
 def test_inference_matches_the_bf16_oracle_and_other_entry_points():

@@ -58,17 +58,7 @@ def _grad_tol(name):
     return 2e-3 if name in ("enc/bn/gamma", "enc/bn/beta") else 1e-3
 
 
-def _f32_floor(arch, p, x, y, eps, g, train_decoder):
-    """What float32 itself costs on this case: the SAME step evaluated by the numpy oracle in float32 (float32 parameters,
-    activations, BLAS accumulation), per gradient tensor as |g32 - g64| / max|g64|.  An independent fp32 evaluation, not
-    the engine: tests/test_gpu_0_fullsize_oracle.py uses it to tell float32's noise at 256 stamps from a kernel error."""
-    p32 = {k: v.astype(np.float32) for k, v in p.items()}
-    c32 = vo.forward(arch, p32, x.astype(np.float32), eps.astype(np.float32), training=True)
-    g32 = vo.backward(arch, p32, c32, y.astype(np.float32), train_decoder=train_decoder)
-    return {k: _relmax(g32[k], g[k]) for k in g}
-
-
-def _run_parity(arch, B, seed, data=None, train_decoder=True, sigma_bias=0.0, f32_floor=False):
+def _run_parity(arch, B, seed, data=None, train_decoder=True, sigma_bias=0.0, f32_floor=False, data_seed=None):
     """f32_floor: gradient tolerance per tensor = max(_grad_tol, min(1.5 x the error of a numpy float32 evaluation of the
     same step against the float64 oracle, 1e-2)) - at the quoted batch sizes a gradient is a sum over ~10^6 signed pixel
     terms that went through 25 (59 px) or 37 (128 px) layers, and a plain float32 evaluation misses float64 by up to
@@ -77,6 +67,10 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True, sigma_bias=0.0, f3
     3.63e-3 - the same conditioning, two implementations).  So: within 1e-3, or no worse than an independent float32
     evaluation of the same formulas (1.5 x: two float32 orders scatter around each other), and never beyond 1e-2.  The
     tight per-layer bound (<= 2e-5 of every tensor, nothing cascades) is tests/test_gpu_0_layers_f32.py's."""
+    from tests import oracle_jobs, oracle_pool
+
+    if data_seed is not None:
+        data = oracle_jobs.stamps(B, data_seed)
     p, x, y, eps = _case(arch, B, seed, data, sigma_bias)
     eng = _engine(arch, max_batch=B)
     eng.set_params(p)
@@ -84,11 +78,14 @@ def _run_parity(arch, B, seed, data=None, train_decoder=True, sigma_bias=0.0, f3
     eng.optimizer_reset(1e-4)
     eng.upload(0, x, y)
 
-    x64, y64, e64 = x.astype(np.float64), y.astype(np.float64), eps.astype(np.float64)
-    c = vo.forward(arch, p, x64, e64, training=True)
-    ref = vo.losses(arch, c, y64)
-    g = vo.backward(arch, p, c, y64, train_decoder=train_decoder)
-    floor = _f32_floor(arch, p, x, y, eps, g, train_decoder) if f32_floor else {}
+    # the oracle: float64 forward / losses / backward (and the numpy-float32 evaluation of the same step for f32_floor).
+    # Cases built from seeds alone may have been evaluated ahead by a worker process (tests/oracle_pool.py)
+    if (data is None or data_seed is not None) and arch == oracle_jobs.make_arch(oracle_jobs.arch_kw(arch)):
+        ev = oracle_pool.fetch("f32_case", arch_kw=oracle_jobs.arch_kw(arch), B=B, seed=seed, data_seed=data_seed,
+                               sigma_bias=sigma_bias, train_decoder=train_decoder, f32_floor=f32_floor)
+    else:
+        ev = oracle_jobs.f32_eval(arch, p, x, y, eps, train_decoder, f32_floor)
+    c, ref, g, floor = dict(ev["acts"], **ev["bn"]), ev["ref"], ev["g"], ev["floor"]
 
     def tol(name):
         return max(_grad_tol(name), min(1.5 * floor.get(name, 0.0), 1e-2))
