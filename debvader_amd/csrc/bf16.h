@@ -60,6 +60,61 @@ struct BWgradParams {
 };
 int launch_bwgrad(const BWgradParams& p, hipStream_t s, int* nsplit_out);
 
+// ---- dense trunk on the bf16 matrix cores (btrunk.hip) ----------------------------------------------------------
+// C[m][n] = sum_k A[m][k] * B[n][k], m = stamp: Flatten -> PReLU -> Dense (model.py:94-98), Dense -> PReLU -> Reshape
+// (model.py:116-119) and their data gradients, with the layout changes and PReLU passes of the two seams between the
+// conv stacks and the sampler folded into the operand loads and the epilogues.
+enum { BGA_ROWS_F32 = 0, BGA_STAMP = 1, BGA_STAMP_PRELU = 2 };
+enum { BGE_SLAB = 0, BGE_STAMP_BIAS_PRELU = 1, BGE_STAMP_GATE2 = 2 };
+struct BGemmParams {
+  const void* A;         // ROWS_F32: fp32 [Mreal][lda] (rounded to bf16 on load; rows >= Mreal and columns >= Kreal read as 0)
+                         // STAMP / STAMP_PRELU: bf16 stamp-inner [P][NBp][C], k = p * C + c (C a multiple of 64)
+  const void* B;         // bf16 [N][ldb], k contiguous; rows past the real n count and columns past the real k count are zero
+  int amode, epi;
+  int M, Mreal;          // M = NBp rows are computed, Mreal = NB exist (pad stamps come out as zeros)
+  int N, K, Kreal;       // N a multiple of 32, K of 64
+  int lda, ldb;
+  int NBp, C;            // stamp-inner geometry of A
+  const float* a_alpha;  // STAMP_PRELU: [K] slopes applied on load
+  // SLAB: fp32 slab[s][M][ldc], s < nslab: the K range in nslab * wg_ksplit runs, the wg_ksplit runs of one workgroup
+  // summed through LDS in wave order; the consumer adds the slabs in order
+  float* slab;
+  long slab_stride;
+  int ldc, nslab, wg_ksplit;
+  // STAMP_*: column n = p * Co + c of row m goes to bf16 [(p * NBp + m) * Co + c]
+  int Co;
+  const float* bias;     // BIAS_PRELU: [N]
+  const float* alpha;    // BIAS_PRELU: [N]
+  void* U;               // BIAS_PRELU: pre-activation (may be null)
+  void* Aout;            // BIAS_PRELU: PReLU output
+  // GATE2 (C = d(flatten PReLU output)): du = C * (a7 > 0 ? 1 : alpha_flat) * (u7 > 0 ? 1 : alpha7)
+  const void* a7;        // bf16 stamp-inner: activation of the last encoder conv (input of the flatten PReLU)
+  const void* u7;        // its pre-activation
+  const float* alpha_flat;
+  const float* alpha7;
+  void* dU;              // bf16 stamp-inner d(pre-activation)
+  float* part_dal_flat;  // [ceil(M / 32)][N] partial column sums of C * min(a7, 0) (all three null: no gradients wanted)
+  float* part_dal7;      // ... of C * gate_flat * min(u7, 0)
+  float* part_db;        // ... of du
+};
+int launch_bgemm(const BGemmParams& p, hipStream_t s);
+// G[i][j] = sum_m X[m][i] * Y[m][j] (dense kernel gradients, train.py:27-37's backward): fp32, written once, no slabs
+struct BGemmTnParams {
+  const void* X;         // xmode ROWS_F32: fp32 [Mreal][ldx]; STAMP / STAMP_PRELU: bf16 [P][NBp][Cx], i = p * Cx + c
+  const void* Y;
+  int xmode, ymode;
+  int NBp, Mreal;
+  int I, Ireal, J, Jreal;   // I, J multiples of 32; rows i >= Ireal / columns j >= Jreal are neither read nor written
+  int ldx, ldy, Cx, Cy;
+  const float* x_alpha;  // STAMP_PRELU: [I]
+  float* G;              // [Ireal][ldg]
+  int ldg;
+};
+int launch_bgemm_tn(const BGemmTnParams& p, hipStream_t s);
+// out[b][i] = (bias ? bias[i] : 0) + sum_s slab[s][b][i] for i < n, 0 for n <= i < ldo
+int launch_bt_finish_rows(const float* slab, int nslab, long slab_stride, int lds, const float* bias, float* out, int NB,
+                          int n, int ldo, hipStream_t s);
+
 // ---- pointwise kernels of the family (bf16_point.hip) -------------------------------------------------------
 // dataset rows (fp32 [*, HW, C], row = idx ? idx[b] : first + b) -> normalised input, bf16 [HW][NBp][16]:
 // channels 0..C-1 = (x - mean) * inv_std (bnstate[2C..4C)), channel C = 1, rest 0; stamps >= NB are zero

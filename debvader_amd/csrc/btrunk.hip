@@ -269,7 +269,7 @@ __device__ __forceinline__ bt_bf16x8 bt_load_t(const void* base, int ld, int NBp
     if constexpr (MODE == BGA_STAMP_PRELU) al = alpha[e];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      bt_bf16 x = src[(size_t)q * C];
+      bt_bf16 x = m + q < NBp ? src[(size_t)q * C] : (bt_bf16)0.f;     // (a last block of 16 stamps: NBp % 32 == 16)
       if constexpr (MODE == BGA_STAMP_PRELU) {
         const float f = (float)x;
         x = (bt_bf16)(f > 0.f ? f : al * f);

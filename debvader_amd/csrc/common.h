@@ -379,6 +379,14 @@ struct SamplerParams {
   unsigned row0;
   int rep_nb;          // > 0: row r is Monte-Carlo sample r / rep_nb of stamp r % rep_nb (seed + sample, t row of the stamp)
   const unsigned long long* seed_ptr;   // non-null: the seed is read from device memory (replayed hipGraphs)
+  // nslab > 0 (bf16 engine, btrunk.hip): the encoder Dense arrives as K-split partial sums; the row is
+  // t[b][i] = tbias[i] + sum_s slab[s][b][i] (added in order), formed here and also written to `t_out` (same strides as
+  // t, pad columns zero) for the backward pass and the API - the finish launch of the split product is this kernel
+  const float* slab;   // [nslab][*][lds]
+  const float* tbias;  // [d + d(d+1)/2]
+  float* t_out;
+  long slab_stride;
+  int nslab, lds;
 };
 int launch_sampler_fwd(const SamplerParams& p, hipStream_t s);
 // ldt: row stride of t and dt, ldz: of eps, z and dz (pad columns of dt are written as zeros)

@@ -385,11 +385,12 @@ struct ProfRec {
 // kernel families of the MFMA work, by the name rocprofv3 prints for them (per-kernel roofline rows of bench.py)
 enum {
   PF_NONE = -1, PF_GCONV2 = 0, PF_GCONV_S2, PF_GSTRIP, PF_GSTRIP8, PF_GCONV, PF_WGRAD, PF_WSTRIP, PF_BCONV, PF_BWGRAD,
-  PF_WINO, PF_WINOW, PF_COUNT
+  PF_WINO, PF_WINOW, PF_BTRUNK, PF_COUNT
 };
 static const char* const kProfFamName[PF_COUNT] = {
     "gconv2_kernel", "gconv_s2_kernel", "gconv_strip_kernel", "gconv_strip8_kernel", "gconv_kernel", "wgrad_kernel",
-    "wgrad_strip_kernel / wgrad_strip8_kernel", "bconv_kernel", "bwgrad_kernel", "wino_conv4_kernel / wino_conv_kernel", "wino_wgrad_kernel"};
+    "wgrad_strip_kernel / wgrad_strip8_kernel", "bconv_kernel", "bwgrad_kernel", "wino_conv4_kernel / wino_conv_kernel", "wino_wgrad_kernel",
+    "bgemm_kernel / bgemm_tn_kernel"};
 
 struct DataSlot {
   float* x = nullptr;
@@ -435,6 +436,17 @@ struct BfState {
   void* zero = nullptr;          // 1 KiB of zeros
   float* trunk[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // fp32 gradient rows of the dense trunk, one buffer per
                                  // stage of a backward pass (its weight gradients read them from the aux stream)
+  // ---- dense trunk on the bf16 matrix cores (btrunk.hip, round 6): the two large Dense layers (flatten -> params_size,
+  // 560 -> w*w*f) and their data / kernel gradients as bf16-MFMA products that read and write the stamp-inner tensors of
+  // the conv stacks directly.  On when the last encoder level has a multiple of 64 filters (the 59-px and 128-px nets);
+  // other geometries keep the fp32 trunk between two layout conversions (DV_BF_TRUNK=0 forces that form for an A/B).
+  bool trunk_mfma = false;
+  int FL = 0, TWn = 0, TWk = 0, HIDn = 0, HIDk = 0;   // flat; params_size padded to 32 (as N) / 64 (as K); 560 likewise
+  void *wenc_f = nullptr, *wenc_d = nullptr;          // encoder Dense kernel: [TWn][FL] (forward), [FL][TWk] (data gradient)
+  void *w1_f = nullptr, *w1_d = nullptr;              // decoder Dense 560 -> flat: [FL][HIDk] (forward), [HIDn][FL] (data gradient)
+  float* tslab = nullptr;                             // K-split partial sums [<= 8][Bp][max(TWn, HIDn)]
+  int t_nslab = 0;                                    // > 0: m->t is still these slabs + bias (the sampler, or bf_finish_t, adds them)
+  void* dec_ur = nullptr;                             // bf16 stamp-inner pre-activation of the decoder trunk's output
 };
 
 // Winograd-domain weights of one stride-1 3x3 layer in one form (forward or data gradient), see wino.hip
@@ -1699,7 +1711,7 @@ static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first,
   return OK;
 }
 
-static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u);
+static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u, bool defer_t);
 static int bf_decoder_forward(dv_model* m, int NB, bool keep_u);
 static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
                         bool want_out, int part_block0, int* nblk);
@@ -1720,8 +1732,9 @@ static int exp_epi(bool keep_u, int hout) {
   return (min_h > 0 && keep_u && hout >= min_h) ? 1 : 2;
 }
 
-static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u) {
-  if (m->bf.on) return bf_encoder_forward(m, xsrc, idx, first, NB, keep_u);
+// defer_t: the caller runs sampler_forward right behind this call, which may then finish a K-split encoder Dense itself
+static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u, bool defer_t = false) {
+  if (m->bf.on) return bf_encoder_forward(m, xsrc, idx, first, NB, keep_u, defer_t);
   const Arch& A = m->A;
   hipStream_t s = fwd_stream(m);
   const int HW = A.H * A.H;
@@ -1809,6 +1822,15 @@ static int sampler_forward(dv_model* m, int NB, bool gen, uint64_t seed, unsigne
   sp.row0 = row0 + (unsigned)m->b0;
   sp.rep_nb = rep_nb;
   sp.seed_ptr = m->use_seed_dev ? m->seed_dev : nullptr;
+  if (m->bf.on && m->bf.t_nslab > 0) {           // the encoder Dense left K-split slabs: this launch is their finish
+    sp.slab = m->bf.tslab;
+    sp.nslab = m->bf.t_nslab;
+    sp.slab_stride = (long)m->bf.NBp * m->bf.TWn;
+    sp.lds = m->bf.TWn;
+    sp.tbias = m->P + A.specs[A.enc_db()].off;
+    sp.t_out = LANE(m->t, A.twp);
+    m->bf.t_nslab = 0;
+  }
   ProfScope ps(m, 2);
   return launch_sampler_fwd(sp, fwd_stream(m));
 }
@@ -1911,7 +1933,7 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
     const int nb = std::min(per, NB - m->b0);
     if (nb <= 0) break;
     int nblk = 0;
-    if (run_encoder) st = encoder_forward(m, xsrc, idx, first, nb, keep_u);
+    if (run_encoder) st = encoder_forward(m, xsrc, idx, first, nb, keep_u, /*defer_t=*/true);
     if (st == OK && run_encoder) st = sampler_forward(m, nb, eps_host == nullptr, seed, stream_id, row0, want_std);
     if (st == OK) st = decoder_forward(m, nb, keep_u);
     if (st == OK) st = head_lane(m, ysrc, idx, first, nb, Bg, want_grad, want_out, blk_done, &nblk);
@@ -4047,6 +4069,10 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
     return DV_OK;
   }
   else if (n == "kl") { src = m->kl; elems = B; }
+  else if (n == "dec_ah") { src = m->dec_ah; elems = B * A.dec_hidden; }       // PReLU output of the decoder's hidden Dense
+  else if (n == "dec_uh") { src = m->dec_uh; elems = B * A.dec_hidden; }       // ... and its pre-activation
+  else if (n == "d_t" && m->bf.on) { src = m->bf.trunk[3]; elems = B * A.twp; } // d(t) rows of the last backward pass (stride twp)
+  else if (n == "d_dec_ah" && m->bf.on) { src = m->bf.trunk[1]; elems = B * A.dec_hidden; }   // d(hidden PReLU output) -> d(pre-activation), in place
   else if (n == "loc") { src = m->loc; elems = B * A.H * A.H * A.C; }
   else if (n == "scale") { src = m->scale; elems = B * A.H * A.H * A.C; }
   else if (n == "head_pre") {
@@ -4078,6 +4104,15 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
     if (n == "xn") { bsrc = m->bf.xh; Pn = (size_t)A.H * A.H; Cn = 16; }
     else if (n == "dec_in") { bsrc = m->bf.dec_in; Pn = (size_t)A.w0 * A.w0; Cn = A.cfg.filters[A.L - 1]; }
     else if (n == "d_dec_in") { bsrc = m->bf.d_dec_in; Pn = (size_t)A.w0 * A.w0; Cn = A.cfg.filters[A.L - 1]; }
+    else if (n == "dec_ur") {
+      // pre-activation of the decoder trunk's output: stamp-inner only when the trunk runs on the bf16 matrix cores
+      // (btrunk.hip); "d_dec_in" is then d(that pre-activation), else the raw d(trunk output)
+      if (!m->bf.trunk_mfma) {
+        set_error("activation dec_ur: the dense trunk of this configuration runs on the fp32 kernels");
+        return DV_E_STATE;
+      }
+      bsrc = m->bf.dec_ur; Pn = (size_t)A.w0 * A.w0; Cn = A.cfg.filters[A.L - 1];
+    }
     else if (n == "d_head_pre") { bsrc = m->bf.dt; Pn = (size_t)A.dec_out * A.dec_out; Cn = 16; }
     else if (n.size() > 6 && (n.rfind("enc_du", 0) == 0 || n.rfind("dec_du", 0) == 0)) {
       // d(pre-activation) of conv layer j as the last backward pass left it (bf16; tests/test_gpu_bf16_layers.py)

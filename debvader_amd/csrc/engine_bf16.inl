@@ -120,6 +120,30 @@ static int bf_alloc(dv_model* m) {
     DV_TRY(add(kh, f0, 2 * A.C, 0, f0, 16, 3, &bf.head_w.d, &bf.head_w.Kd));
   }
   {
+    // dense trunk on the bf16 matrix cores (btrunk.hip): two forms of each large Dense kernel, the K-split slabs, the
+    // trunk output's pre-activation in the stamp-inner layout
+    static const bool trunk_off = getenv("DV_BF_TRUNK") != nullptr && atoi(getenv("DV_BF_TRUNK")) == 0;
+    const int fl = A.cfg.filters[A.L - 1];
+    bf.FL = A.flat;
+    bf.TWn = bf_pad32(A.tw);
+    bf.TWk = (A.tw + 63) & ~63;
+    bf.HIDn = bf_pad32(A.dec_hidden);
+    bf.HIDk = (A.dec_hidden + 63) & ~63;
+    bf.trunk_mfma = !trunk_off && fl % 64 == 0 && A.flat == A.w0 * A.w0 * fl && A.enc_sizes[A.L] == A.w0 &&
+                    A.dec_hidden % 4 == 0 && A.twp % 4 == 0;
+    if (bf.trunk_mfma) {
+      const float* wenc = P + A.specs[A.enc_dk()].off;         // [flat][tw]
+      const float* w1 = P + A.specs[A.D0 + 4].off;              // [560][flat]
+      int kk = 0;
+      DV_TRY(add(wenc, A.flat, A.tw, 1, bf.TWn, A.flat, 1, &bf.wenc_f, &kk));     // [n = tw][k = flat]
+      DV_TRY(add(wenc, A.flat, A.tw, 0, A.flat, bf.TWk, 1, &bf.wenc_d, &kk));     // [n = flat][k = tw]
+      DV_TRY(add(w1, A.dec_hidden, A.flat, 1, A.flat, bf.HIDk, 1, &bf.w1_f, &kk));    // [n = flat][k = 560]
+      DV_TRY(add(w1, A.dec_hidden, A.flat, 0, bf.HIDn, A.flat, 1, &bf.w1_d, &kk));    // [n = 560][k = flat]
+      DV_TRY(balloc((void**)&bf.tslab, (size_t)8 * Bp * std::max(bf.TWn, bf.HIDn) * 4));
+      DV_TRY(balloc(&bf.dec_ur, r * Bp * 2));
+    }
+  }
+  {
     bool any = false;
     for (int i = 0; i < A.L; ++i) any = any || A.cfg.kernels[i] != 3 || !(A.cfg.filters[i] == 16 || A.cfg.filters[i] % 32 == 0);
     if (any) {                     // operands of the fp32 weight-gradient kernels (bf_wgrad_f32)
@@ -166,7 +190,27 @@ static int bf_conv(dv_model* m, const void* X, const void* W, int Kpad, int form
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------------
-static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u) {
+// K split of a trunk product with `tiles` 32 x 32 wave tiles: enough waves to fill the chip (>= 1024), at most eight runs
+static void bf_trunk_ksplit(int tiles, int K, int* wg_ksplit, int* nslab) {
+  int total = 1;
+  while (total < 8 && tiles * total < 1024 && (K >> 6) >= 2 * total) total *= 2;
+  *wg_ksplit = std::min(total, 4);
+  *nslab = total / *wg_ksplit;
+}
+
+// t = bias + sum of the slabs the encoder Dense left behind, for consumers of m->t that do not run the sampler
+static int bf_finish_t(dv_model* m, int NB, hipStream_t s) {
+  BfState& bf = m->bf;
+  if (bf.t_nslab <= 0) return OK;
+  const Arch& A = m->A;
+  ProfScope ps(m, 2, s);
+  DV_TRY(launch_bt_finish_rows(bf.tslab, bf.t_nslab, (long)bf.NBp * bf.TWn, bf.TWn, m->P + A.specs[A.enc_db()].off, m->t, NB,
+                               A.tw, A.twp, s));
+  bf.t_nslab = 0;
+  return OK;
+}
+
+static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, int first, int NB, bool keep_u, bool defer_t) {
   const Arch& A = m->A;
   BfState& bf = m->bf;
   hipStream_t s = fwd_stream(m);
@@ -189,6 +233,24 @@ static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, in
     in = bf.enc_a[j];
   }
   const int sl = A.enc_sizes[A.L], fl = A.cfg.filters[A.L - 1];
+  if (bf.trunk_mfma) {
+    // Flatten -> PReLU -> Dense (model.py:94-98) as ONE product over the stamp-inner activation of the last conv: the
+    // flatten PReLU is applied where the A fragments are loaded, K = flat is split, and the slabs + bias are added by
+    // the sampler launch that follows (defer_t) or by bf_finish_t
+    BGemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = in; g.B = bf.wenc_f; g.amode = BGA_STAMP_PRELU; g.epi = BGE_SLAB;
+    g.M = bf.NBp; g.Mreal = NB; g.N = bf.TWn; g.K = bf.FL; g.Kreal = bf.FL; g.ldb = bf.FL;
+    g.NBp = bf.NBp; g.C = fl; g.a_alpha = P + A.specs[A.enc_flat_al()].off;
+    g.slab = bf.tslab; g.slab_stride = (long)bf.NBp * bf.TWn; g.ldc = bf.TWn;
+    bf_trunk_ksplit(((bf.NBp + 31) / 32) * (bf.TWn / 32), bf.FL, &g.wg_ksplit, &g.nslab);
+    {
+      ProfScope ps(m, 0, nullptr, PF_BTRUNK, 2.0 * bf.NBp * (double)A.flat * A.tw);
+      DV_TRY(launch_bgemm(g, s));
+    }
+    bf.t_nslab = g.nslab;
+    return defer_t ? OK : bf_finish_t(m, NB, s);
+  }
   {
     ProfScope ps(m, 2);
     if (!exp_skip_small()) DV_TRY(launch_bf_to_rows(in, bf.flat_in, NB, bf.NBp, sl * sl, fl, s));
@@ -214,10 +276,23 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
                      1, 0, true));
   const int fl = A.cfg.filters[A.L - 1];
   const int r = A.w0 * A.w0 * fl;
-  DV_TRY(gconv_fprop(m, m->dec_ah, P + A.specs[A.D0 + 4].off, false, P + A.specs[A.D0 + 5].off,
-                     P + A.specs[A.D0 + 6].off, keep_u ? m->dec_ur : nullptr, m->dec_ar, 2, NB, 1, A.dec_hidden, 1, r, 1,
-                     0, true));
-  {
+  if (bf.trunk_mfma) {
+    // Dense(560 -> w*w*f) -> PReLU -> Reshape (model.py:116-119): the fp32 rows of the hidden layer are rounded to bf16
+    // where they are loaded, bias and PReLU run in the epilogue, which writes the stamp-inner tensors the first
+    // Conv2DTranspose reads (and, in training, the pre-activation its PReLU backward needs)
+    BGemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = m->dec_ah; g.B = bf.w1_f; g.amode = BGA_ROWS_F32; g.epi = BGE_STAMP_BIAS_PRELU;
+    g.M = bf.NBp; g.Mreal = NB; g.N = bf.FL; g.K = bf.HIDk; g.Kreal = A.dec_hidden; g.lda = A.dec_hidden; g.ldb = bf.HIDk;
+    g.NBp = bf.NBp; g.nslab = 1; g.wg_ksplit = 1; g.Co = fl;
+    g.bias = P + A.specs[A.D0 + 5].off; g.alpha = P + A.specs[A.D0 + 6].off;
+    g.U = keep_u ? bf.dec_ur : nullptr; g.Aout = bf.dec_in;
+    ProfScope ps(m, 0, nullptr, PF_BTRUNK, 2.0 * bf.NBp * (double)A.dec_hidden * r);
+    DV_TRY(launch_bgemm(g, s));
+  } else {
+    DV_TRY(gconv_fprop(m, m->dec_ah, P + A.specs[A.D0 + 4].off, false, P + A.specs[A.D0 + 5].off,
+                       P + A.specs[A.D0 + 6].off, keep_u ? m->dec_ur : nullptr, m->dec_ar, 2, NB, 1, A.dec_hidden, 1, r, 1,
+                       0, true));
     ProfScope ps(m, 2);
     if (!exp_skip_small()) DV_TRY(launch_bf_from_rows(m->dec_ar, bf.dec_in, NB, bf.NBp, A.w0 * A.w0, fl, s));
   }
@@ -378,9 +453,11 @@ static int bf_wgrad_f32(dv_model* m, const void* X, int Hx, int Cx, const void* 
 
 // data gradient into `out` with the PReLU backward of the target layer (pre-activation u, slopes / bias specs) applied:
 // fused into the epilogue when the stamp padding allows it, else a separate pass
+// dense_bias: the bias of the target layer has one entry per (pixel, channel) - the decoder trunk's Dense -> Reshape
+// (model.py:116-119) - instead of one per channel: its gradient is the stamp sum itself, not summed over the pixels
 static int bf_dgrad_prelu(dv_model* m, const void* X, const void* W, int Kpad, int form, int Hin, int Cin, int Hout,
                           int Cout, int s, int pb, void* out, const void* u, int alpha_spec, int bias_spec,
-                          bool want_grads, int ksz = 3) {
+                          bool want_grads, int ksz = 3, bool dense_bias = false) {
   const Arch& A = m->A;
   BfState& bf = m->bf;
   hipStream_t st = m->ctx->stream;
@@ -410,7 +487,9 @@ static int bf_dgrad_prelu(dv_model* m, const void* X, const void* W, int Kpad, i
       BRedEntry& a = bf.red.e[bf.red.count++];
       a.src = dal; a.out = m->G + A.specs[alpha_spec].off; a.final_out = nullptr; a.nparts = nparts; a.n = (int)E; a.cols = 0;
       BRedEntry& b = bf.red.e[bf.red.count++];
-      b.src = db; b.out = dbimg; b.final_out = m->G + A.specs[bias_spec].off; b.nparts = nparts; b.n = (int)E; b.cols = Cout;
+      b.src = db; b.nparts = nparts; b.n = (int)E;
+      if (dense_bias) { b.out = m->G + A.specs[bias_spec].off; b.final_out = nullptr; b.cols = 0; }
+      else { b.out = dbimg; b.final_out = m->G + A.specs[bias_spec].off; b.cols = Cout; }
     }
     return bf_conv(m, X, W, Kpad, form, Hin, Cin, Hout, Cout, s, pb, BEPI_BWD, out, nullptr, nullptr, nullptr, alpha, u, dal,
                    db, ksz);
@@ -429,8 +508,23 @@ static int bf_dgrad_prelu(dv_model* m, const void* X, const void* W, int Kpad, i
   ProfScope ps(m, 2, st);
   DV_TRY(launch_bf_prelu_bwd(out, u, alpha, out, want_grads ? m->G + A.specs[alpha_spec].off : nullptr, dbr, bf.NBp,
                              (int)P, Cout, st));
-  if (want_grads) DV_TRY(launch_reduce_rows_f64(dbr, (int)P, Cout, m->G + A.specs[bias_spec].off, 1.0f, st));
+  if (want_grads) {
+    if (dense_bias) DV_TRY(launch_reduce_rows_f64(dbr, 1, (int)E, m->G + A.specs[bias_spec].off, 1.0f, st));
+    else DV_TRY(launch_reduce_rows_f64(dbr, (int)P, Cout, m->G + A.specs[bias_spec].off, 1.0f, st));
+  }
   return OK;
+}
+
+// a dense kernel gradient on the weight-gradient stream (btrunk.hip): ordered behind the main stream's product of its
+// operands, written once, no slabs - the bucket boundaries that follow join the weight-gradient stream
+static int bf_trunk_wgrad(dv_model* m, const BGemmTnParams& t, double flops) {
+  hipStream_t st = bf_wstream(m);
+  if (st != m->ctx->stream) {
+    DV_HIP(hipEventRecord(m->ctx->ev_ready, m->ctx->stream));
+    DV_HIP(hipStreamWaitEvent(st, m->ctx->ev_ready, 0));
+  }
+  ProfScope ps(m, 1, st, PF_BTRUNK, flops);
+  return launch_bgemm_tn(t, st);
 }
 
 static int bf_backward(dv_model* m, int NB, int Bg) {
@@ -486,6 +580,12 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     if (j > 0) {
       DV_TRY(bf_dgrad_prelu(m, cur, bf.dec_w[j].d, bf.dec_w[j].Kd, 0, hout, cout, hin, cin, st, pb, oth, bf.dec_u[j - 1],
                             A.dec_al(j - 1), A.dec_b(j - 1), dg, ksz));
+    } else if (bf.trunk_mfma) {
+      // the PReLU behind the decoder trunk's Dense (model.py:117-118) is the "layer below" of the first transposed conv:
+      // its pre-activation sits in the stamp-inner layout (bf_decoder_forward), so its backward runs in this epilogue
+      // like every other layer's, and d(pre-activation) arrives where the two dense products below read it
+      DV_TRY(bf_dgrad_prelu(m, cur, bf.dec_w[j].d, bf.dec_w[j].Kd, 0, hout, cout, hin, cin, st, pb, oth, bf.dec_ur,
+                            A.D0 + 6, A.D0 + 5, dg, ksz, /*dense_bias=*/true));
     } else {
       DV_TRY(bf_conv(m, cur, bf.dec_w[j].d, bf.dec_w[j].Kd, 0, hout, cout, hin, cin, st, pb, BEPI_RAWBF, oth, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ksz));
@@ -505,14 +605,40 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   float* const tr3 = bf.trunk[3];   // d(t)                      [NB, tw]
   float* const tr4 = bf.trunk[4];   // d(flatten)                [NB, flat]
   m->wstream = ws;
-  {
+  if (bf.trunk_mfma) {
+    // cur = d(pre-activation of the trunk's output), bf16 stamp-inner (the epilogue above).  Its two consumers read it
+    // as it lies: the kernel gradient of Dense(560 -> flat) on the weight-gradient stream, and the data gradient - K =
+    // flat, split, slabs added by one small launch - on the main stream
+    if (dg) {
+      BGemmTnParams t;
+      memset(&t, 0, sizeof t);
+      t.X = m->dec_ah; t.xmode = BGA_ROWS_F32; t.ldx = A.dec_hidden; t.I = bf.HIDn; t.Ireal = A.dec_hidden;
+      t.Y = cur; t.ymode = BGA_STAMP; t.Cy = fl; t.J = bf.FL; t.Jreal = bf.FL;
+      t.NBp = bf.NBp; t.Mreal = NB; t.G = G + A.specs[A.D0 + 4].off; t.ldg = r;
+      DV_TRY(bf_trunk_wgrad(m, t, 2.0 * bf.NBp * (double)A.dec_hidden * r));
+    }
+    BGemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = cur; g.B = bf.w1_d; g.amode = BGA_STAMP; g.epi = BGE_SLAB;
+    g.M = bf.NBp; g.Mreal = NB; g.N = bf.HIDn; g.K = bf.FL; g.Kreal = bf.FL; g.ldb = bf.FL; g.NBp = bf.NBp; g.C = fl;
+    g.slab = bf.tslab; g.slab_stride = (long)bf.NBp * bf.HIDn; g.ldc = bf.HIDn;
+    bf_trunk_ksplit(((bf.NBp + 31) / 32) * (bf.HIDn / 32), bf.FL, &g.wg_ksplit, &g.nslab);
+    {
+      ProfScope ps(m, 0, s, PF_BTRUNK, 2.0 * bf.NBp * (double)A.dec_hidden * r);
+      DV_TRY(launch_bgemm(g, s));
+    }
     ProfScope ps(m, 2, s);
-    if (!exp_skip_small()) DV_TRY(launch_bf_to_rows(cur, tr0, NB, bf.NBp, A.w0 * A.w0, fl, s));
+    DV_TRY(launch_bt_finish_rows(bf.tslab, g.nslab, g.slab_stride, bf.HIDn, nullptr, tr1, NB, A.dec_hidden, A.dec_hidden, s));
+  } else {
+    {
+      ProfScope ps(m, 2, s);
+      if (!exp_skip_small()) DV_TRY(launch_bf_to_rows(cur, tr0, NB, bf.NBp, A.w0 * A.w0, fl, s));
+    }
+    DV_TRY(prelu_bwd(m, tr0, m->dec_ur, A.D0 + 6, A.D0 + 5, NB, r, r, dg));
+    if (dg) DV_TRY(wgrad(m, m->dec_ah, 1, A.dec_hidden, tr0, 1, r, NB, 1, 0, true, G + A.specs[A.D0 + 4].off, 1, 1));
+    DV_TRY(gconv_fprop(m, tr0, P + A.specs[A.D0 + 4].off, true, nullptr, nullptr, tr1, nullptr, 0, NB, 1, r, 1,
+                       A.dec_hidden, 1, 0, true));
   }
-  DV_TRY(prelu_bwd(m, tr0, m->dec_ur, A.D0 + 6, A.D0 + 5, NB, r, r, dg));
-  if (dg) DV_TRY(wgrad(m, m->dec_ah, 1, A.dec_hidden, tr0, 1, r, NB, 1, 0, true, G + A.specs[A.D0 + 4].off, 1, 1));
-  DV_TRY(gconv_fprop(m, tr0, P + A.specs[A.D0 + 4].off, true, nullptr, nullptr, tr1, nullptr, 0, NB, 1, r, 1,
-                     A.dec_hidden, 1, 0, true));
   DV_TRY(prelu_bwd(m, tr1, m->dec_uh, A.D0 + 3, A.D0 + 2, NB, A.dec_hidden, A.dec_hidden, dg));
   if (dg) {
     DV_TRY(wgrad(m, m->dec_ain, 1, A.dp, tr1, 1, A.dec_hidden, NB, 1, 0, true, dec_dense0_g(m), 1, 1));
@@ -570,6 +696,60 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   }
   m->main_marked = false;   // (the record prelu_bwd left behind predates the sampler: the dense weight gradient below needs its own)
   DV_TRY(bias_grad_colsum(m, tr3, NB, A.twp, A.tw, A.enc_db()));
+  if (bf.trunk_mfma) {
+    const int jl = 2 * A.L - 1;
+    // kernel gradient of the encoder Dense on the weight-gradient stream: X = PReLU(flatten(activation of the last conv)),
+    // read from the stamp-inner tensor with the slope applied on load, Y = d(t) rows
+    {
+      BGemmTnParams t;
+      memset(&t, 0, sizeof t);
+      t.X = bf.enc_a[jl]; t.xmode = BGA_STAMP_PRELU; t.Cx = fl; t.I = bf.FL; t.Ireal = bf.FL;
+      t.x_alpha = P + A.specs[A.enc_flat_al()].off;
+      t.Y = tr3; t.ymode = BGA_ROWS_F32; t.ldy = A.twp; t.J = bf.TWn; t.Jreal = A.tw;
+      t.NBp = bf.NBp; t.Mreal = NB; t.G = G + A.specs[A.enc_dk()].off; t.ldg = A.tw;
+      DV_TRY(bf_trunk_wgrad(m, t, 2.0 * bf.NBp * (double)A.flat * A.tw));
+    }
+    // data gradient of the encoder Dense with BOTH PReLU backward passes of the seam in its epilogue (the flatten PReLU,
+    // model.py:95, and the last conv's, :92): d(pre-activation) of that conv leaves in the stamp-inner layout, the
+    // column sums of d(alpha) of either and of d(bias) as one partial row per 32 stamps (summed with the other fused
+    // epilogues' partials at the next bucket boundary)
+    const int MT = (bf.NBp + 31) / 32;
+    const size_t E = (size_t)bf.FL;
+    if (bf.red.count + 3 > DV_BF_MAX_RED) {
+      ProfScope ps(m, 2, s);
+      DV_TRY(launch_bf_reduce_batch(bf.red, s));
+      bf.red.count = 0;
+    }
+    if (m->arena_off + (size_t)3 * MT * E + std::max<size_t>(E, (size_t)64 * fl) > m->arena_elems) {
+      set_error("gradient-partial arena exhausted");
+      return E_STATE;
+    }
+    float* pflat = m->arena + m->arena_off;
+    float* p7 = pflat + (size_t)MT * E;
+    float* pdb = p7 + (size_t)MT * E;
+    float* dbimg = pdb + (size_t)MT * E;
+    m->arena_off += (size_t)3 * MT * E + std::max<size_t>(E, (size_t)64 * fl);
+    {
+      BRedEntry& e0 = bf.red.e[bf.red.count++];
+      e0.src = pflat; e0.out = G + A.specs[A.enc_flat_al()].off; e0.final_out = nullptr; e0.nparts = MT; e0.n = (int)E; e0.cols = 0;
+      BRedEntry& e1 = bf.red.e[bf.red.count++];
+      e1.src = p7; e1.out = G + A.specs[A.enc_al(jl)].off; e1.final_out = nullptr; e1.nparts = MT; e1.n = (int)E; e1.cols = 0;
+      BRedEntry& e2 = bf.red.e[bf.red.count++];
+      e2.src = pdb; e2.out = dbimg; e2.final_out = G + A.specs[A.enc_b(jl)].off; e2.nparts = MT; e2.n = (int)E; e2.cols = fl;
+    }
+    cur = next_buf();
+    BGemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = tr3; g.B = bf.wenc_d; g.amode = BGA_ROWS_F32; g.epi = BGE_STAMP_GATE2;
+    g.M = bf.NBp; g.Mreal = NB; g.N = bf.FL; g.K = bf.TWk; g.Kreal = A.twp; g.lda = A.twp; g.ldb = bf.TWk;
+    g.NBp = bf.NBp; g.nslab = 1; g.wg_ksplit = 1; g.Co = fl;
+    g.a7 = bf.enc_a[jl]; g.u7 = bf.enc_u[jl];
+    g.alpha_flat = P + A.specs[A.enc_flat_al()].off; g.alpha7 = P + A.specs[A.enc_al(jl)].off;
+    g.dU = cur; g.part_dal_flat = pflat; g.part_dal7 = p7; g.part_db = pdb;
+    ProfScope ps(m, 0, s, PF_BTRUNK, 2.0 * bf.NBp * (double)A.flat * A.tw);
+    DV_TRY(launch_bgemm(g, s));
+    m->wstream = s;
+  } else {
   DV_TRY(wgrad(m, m->flat_a, 1, A.flat, tr3, 1, A.twp, NB, 1, 0, true, enc_dense_g(m), 1, 1));
   if (m->Gdp) DV_TRY(take_padded_grad(m, m->Gdp, G + A.specs[A.enc_dk()].off, A.flat, A.twp, A.tw));
   DV_TRY(gconv_fprop(m, tr3, enc_dense_w(m), true, nullptr, nullptr, tr4, nullptr, 0, NB, 1, A.twp, 1, A.flat,
@@ -594,6 +774,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     DV_TRY(launch_bf_prelu_bwd(cur, bf.enc_u[jl], P + A.specs[A.enc_al(jl)].off, cur, G + A.specs[A.enc_al(jl)].off, dbr,
                                bf.NBp, (int)Pn, fl, s));
     DV_TRY(launch_reduce_rows_f64(dbr, (int)Pn, fl, G + A.specs[A.enc_b(jl)].off, 1.0f, s));
+  }
   }
   // ---- encoder conv stack: cur = d(pre-activation) of layer j ----
   // The tail of a pass is the weight-gradient stream's backlog: when the main stream has queued its last data gradient

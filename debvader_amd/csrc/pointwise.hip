@@ -637,7 +637,20 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
   // d dependent, divergent global loads per stamp (31 us per step at d = 32)
   __shared__ float st_all[4][64 + 64 * 65 / 2];
   float* st = st_all[threadIdx.x >> 6];
-  for (int i = lane; i < tw; i += 64) st[i] = t[i];
+  if (p.nslab > 0) {
+    float* to = p.t_out + (size_t)bs * p.ldt;
+    for (int i = lane; i < p.ldt; i += 64) {
+      float v = 0.f;
+      if (i < tw) {
+        v = p.tbias[i];
+        for (int sl = 0; sl < p.nslab; ++sl) v += p.slab[(size_t)sl * p.slab_stride + (size_t)bs * p.lds + i];
+        st[i] = v;
+      }
+      if (p.rep_nb == 0 || b < p.rep_nb) to[i] = v;
+    }
+  } else {
+    for (int i = lane; i < tw; i += 64) st[i] = t[i];
+  }
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
   float e = 0.f;

