@@ -111,6 +111,42 @@ struct BGemmTnParams {
   int ldg;
 };
 int launch_bgemm_tn(const BGemmTnParams& p, hipStream_t s);
+// Backward of the sampler side of the trunk in ONE launch (one workgroup per stamp), model.py:112-115 and :43-58 in reverse:
+//   d(hidden activation) = sum of the K-split slabs of the data gradient of Dense(560 -> flat)   [bgemm SLAB]
+//   d(hidden pre-activation) = that * PReLU gate(u_h)                  -> duh   (+ rows of d(alpha_h) terms -> dalh)
+//   d(z') = d(hidden pre-activation) . W0^T                             (560 -> latent_dim, wave butterflies)
+//   d(z)  = d(z') * PReLU gate(z)                                       -> dz    (+ rows of d(alpha_in) terms -> dalin)
+//   d(t)  = backward of z = mu + L eps and of the KL regulariser        -> dt    (sampler_bwd_kernel's arithmetic)
+// until round 6: split-K finish, PReLU backward, narrow Dense, PReLU backward, sampler backward - five launches of the
+// main stream's chain.  The batch sums (d(bias), d(alpha)) are column sums of the row outputs: launch_bt_colsums.
+struct BMidBwdParams {
+  const float* slab;     // [nslab][*][lds]
+  long slab_stride;
+  int nslab, lds;
+  const float* uh;       // [NB][hid] pre-activation of the hidden Dense
+  const float* alpha_h;  // [hid]
+  const float* W0;       // [>= d][hid] kernel of Dense(latent -> hid), row = latent index
+  const float* z;        // [NB][ldz]
+  const float* alpha_in; // [d]
+  const float* eps;      // [NB][ldz]
+  const float* t;        // [NB][ldt]
+  float* duh;            // [NB][hid]
+  float* dalh;           // [NB][hid] or null
+  float* dz;             // [NB][ldz]
+  float* dalin;          // [NB][ldz] or null
+  float* dt;             // [NB][ldt] (pad columns zero)
+  int NB, hid, d, ldt, ldz;
+  float diag_shift, kls;
+};
+int launch_bt_mid_bwd(const BMidBwdParams& p, hipStream_t s);
+// up to four column sums in one launch: out[c] = sum_b x[b * ld + c], c < n (fp64 accumulation, fixed order)
+struct BColsums {
+  const float* x[4];
+  float* out[4];
+  int ld[4], n[4];
+  int count, NB;
+};
+int launch_bt_colsums(const BColsums& c, hipStream_t s);
 // out[b][i] = (bias ? bias[i] : 0) + sum_s slab[s][b][i] for i < n, 0 for n <= i < ldo
 int launch_bt_finish_rows(const float* slab, int nslab, long slab_stride, int lds, const float* bias, float* out, int NB,
                           int n, int ldo, hipStream_t s);

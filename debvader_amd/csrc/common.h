@@ -387,6 +387,10 @@ struct SamplerParams {
   float* t_out;
   long slab_stride;
   int nslab, lds;
+  // non-null: the PReLU in front of the decoder's first Dense (model.py:113) is applied here as well,
+  // ain[b][i] = z > 0 ? z : alpha_in[i] * z (row stride ldz, pad columns zero) - one launch less on the forward chain
+  const float* alpha_in;
+  float* ain;
 };
 int launch_sampler_fwd(const SamplerParams& p, hipStream_t s);
 // ldt: row stride of t and dt, ldz: of eps, z and dz (pad columns of dt are written as zeros)

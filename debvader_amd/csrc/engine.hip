@@ -407,7 +407,11 @@ struct BfW {
 };
 struct BfState {
   bool on = false;
-  bool dirty = true;             // master weights changed since the bf16 matrices were cast
+  // master weights changed since the bf16 matrices were cast, per gradient bucket (bit 0: shallow half of the encoder, 1: deep
+  // half - conv L .. dense -, 2: decoder; the descriptors are sorted by bucket).  A bucket that early Adam updates on the
+  // comm stream is re-cast right there (bf_cast_bucket), off the main stream; the next forward casts what is left
+  unsigned dirty_mask = 7, early_cast = 0;
+  int desc_off[4] = {0, 0, 0, 0};
   int NBp = 0;                   // stamps of the current pass padded to 16
   void* xh = nullptr;            // normalised input [HW][NBp][16]
   std::vector<void*> enc_u, enc_a, dec_u, dec_a;
@@ -489,6 +493,7 @@ struct dv_model {
   float* da_enc0 = nullptr;
   float *flat_a = nullptr, *t = nullptr, *eps = nullptr, *z = nullptr, *zstd = nullptr, *kl = nullptr;
   float *dec_ain = nullptr, *dec_uh = nullptr, *dec_ah = nullptr, *dec_ur = nullptr, *dec_ar = nullptr;
+  bool ain_done = false;   // the sampler launch of this pass has already written dec_ain = PReLU(z) (model.py:113)
   float *tpre = nullptr, *loc = nullptr, *scale = nullptr;
   float *gA = nullptr, *gB = nullptr, *gC = nullptr;
   float* ws4 = nullptr;  // split-K slabs of the dense layers (ws1 belongs to the weight-gradient stream)
@@ -1645,7 +1650,7 @@ static int copy_rows(float* dst, size_t dst_ld, const float* src, size_t src_ld,
 
 static int refresh_head_pad(dv_model* m, hipStream_t st = nullptr) {
   const Arch& A = m->A;
-  m->bf.dirty = true;
+  m->bf.dirty_mask = 7;
   m->param_epoch++;
   if (!st) st = m->ctx->stream;
   if (m->W0p)      // decoder Dense 0 [d, hidden] -> [dp, hidden]: as one row of d * hidden floats padded to dp * hidden
@@ -1656,7 +1661,7 @@ static int refresh_head_pad(dv_model* m, hipStream_t st = nullptr) {
 
 static int refresh_w1p(dv_model* m) {
   const Arch& A = m->A;
-  m->bf.dirty = true;
+  m->bf.dirty_mask = 7;
   m->param_epoch++;
   if (m->Wdp) {
     DV_TRY(launch_pad_cols(m->P + A.specs[A.enc_dk()].off, m->Wdp, A.flat, A.tw, A.twp, m->ctx->stream));
@@ -1774,7 +1779,9 @@ static int decoder_forward(dv_model* m, int NB, bool keep_u) {
   {
     ProfScope ps(m, 2);
     // (dp > d: the slopes' 16-byte aligned slot is read past its d values; z's pad columns are zero, so are theirs)
-    if (!exp_skip_small()) DV_TRY(launch_prelu_fwd(LANE(m->z, A.dp), P + A.specs[A.D0].off, LANE(m->dec_ain, A.dp), NB, A.dp, s));
+    if (!exp_skip_small() && !m->ain_done)
+      DV_TRY(launch_prelu_fwd(LANE(m->z, A.dp), P + A.specs[A.D0].off, LANE(m->dec_ain, A.dp), NB, A.dp, s));
+    m->ain_done = false;
   }
   DV_TRY(gconv_fprop(m, LANE(m->dec_ain, A.dp), dec_dense0_w(m), false, P + A.specs[A.D0 + 2].off,
                      P + A.specs[A.D0 + 3].off, keep_u ? LANE(m->dec_uh, A.dec_hidden) : nullptr,
@@ -1831,6 +1838,10 @@ static int sampler_forward(dv_model* m, int NB, bool gen, uint64_t seed, unsigne
     sp.t_out = LANE(m->t, A.twp);
     m->bf.t_nslab = 0;
   }
+  // the PReLU in front of the decoder's first Dense rides along (same formula, same bits as prelu_fwd_kernel)
+  sp.alpha_in = m->P + A.specs[A.D0].off;
+  sp.ain = LANE(m->dec_ain, A.dp);
+  m->ain_done = true;
   ProfScope ps(m, 2);
   return launch_sampler_fwd(sp, fwd_stream(m));
 }
@@ -2250,10 +2261,11 @@ static void begin_update(dv_model* m) {     // step counter and bias-corrected s
 static int optimizer_step(dv_model* m) {
   const Arch& A = m->A;
   DV_TRY(adam_range(m, 0, std::min(m->adam_done_from, A.n_train), m->ctx->stream));
-  m->bf.dirty = true;
   m->param_epoch++;
   if (m->opt_enc) DV_TRY(refresh_w1p(m));
   if (m->opt_dec && m->adam_done_from > A.n_enc_train) DV_TRY(refresh_head_pad(m));
+  m->bf.dirty_mask = 7 & ~m->bf.early_cast;     // (the buckets updated on the comm stream were re-cast there)
+  m->bf.early_cast = 0;
   return OK;
 }
 
@@ -3501,7 +3513,7 @@ int dv_model_get_param(dv_model* m, int32_t i, float* host, size_t nbytes) {
 }
 int dv_model_set_param(dv_model* m, int32_t i, const float* host, size_t nbytes) {
   DV_TRY(tensor_io(m, m ? m->P : nullptr, i, const_cast<float*>(host), nbytes, false));
-  m->bf.dirty = true;
+  m->bf.dirty_mask = 7;
   m->param_epoch++;
   if (i == m->A.head_k() || i == m->A.head_b()) {
     DV_TRY(refresh_head_pad(m));

@@ -152,21 +152,54 @@ static int bf_alloc(dv_model* m) {
       DV_TRY(balloc((void**)&bf.wy32, max_e * (size_t)m->Bc * 4));
     }
   }
+  {   // descriptors sorted by gradient bucket (see BfState::dirty_mask)
+    const size_t split = enc_bucket_split(A);
+    auto bucket = [&](const BCastDesc& d) { const size_t off = (size_t)(d.src - P); return off < split ? 0 : off < A.n_enc_train ? 1 : 2; };
+    std::stable_sort(bf.descs.begin(), bf.descs.end(), [&](const BCastDesc& a, const BCastDesc& b) { return bucket(a) < bucket(b); });
+    int n = 0;
+    for (int b = 0; b < 3; ++b) {
+      bf.desc_off[b] = n;
+      while (n < (int)bf.descs.size() && bucket(bf.descs[n]) == b) ++n;
+    }
+    bf.desc_off[3] = n;
+  }
   DV_TRY(balloc((void**)&bf.descs_dev, bf.descs.size() * sizeof(BCastDesc)));
   DV_HIP(hipMemcpyAsync(bf.descs_dev, bf.descs.data(), bf.descs.size() * sizeof(BCastDesc), hipMemcpyHostToDevice,
                         m->ctx->stream));
   DV_HIP(hipStreamSynchronize(m->ctx->stream));
   bf.on = true;
-  bf.dirty = true;
+  bf.dirty_mask = 7;
+  return OK;
+}
+
+static int bf_cast_buckets(dv_model* m, unsigned mask, hipStream_t s) {
+  BfState& bf = m->bf;
+  ProfScope ps(m, 2, s);
+  for (int b = 0; b < 3; ++b) {
+    if (!(mask & (1u << b))) continue;
+    int b1 = b;
+    while (b1 + 1 < 3 && (mask & (1u << (b1 + 1)))) ++b1;          // neighbouring buckets in one launch
+    const int lo = bf.desc_off[b], hi = bf.desc_off[b1 + 1];
+    if (hi > lo) DV_TRY(launch_bf_cast_weights(bf.descs_dev + lo, bf.descs.data() + lo, hi - lo, s));
+    b = b1;
+  }
   return OK;
 }
 
 static int bf_refresh_weights(dv_model* m, hipStream_t s) {
   BfState& bf = m->bf;
-  if (!bf.dirty) return OK;
-  ProfScope ps(m, 2, s);
-  DV_TRY(launch_bf_cast_weights(bf.descs_dev, bf.descs.data(), (int)bf.descs.size(), s));
-  bf.dirty = false;
+  if (!bf.dirty_mask) return OK;
+  DV_TRY(bf_cast_buckets(m, bf.dirty_mask, s));
+  bf.dirty_mask = 0;
+  return OK;
+}
+
+// the bf16 matrices of a bucket that early Adam has just updated on `st` (the comm stream), re-cast behind the update:
+// no kernel of this step reads them any more (the same argument that lets Adam run there), and the next step's forward
+// is ordered behind the comm stream
+static int bf_cast_bucket_early(dv_model* m, int b, hipStream_t st) {
+  DV_TRY(bf_cast_buckets(m, 1u << b, st));
+  m->bf.early_cast |= 1u << b;
   return OK;
 }
 
@@ -190,10 +223,13 @@ static int bf_conv(dv_model* m, const void* X, const void* W, int Kpad, int form
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------------
-// K split of a trunk product with `tiles` 32 x 32 wave tiles: enough waves to fill the chip (>= 1024), at most eight runs
+// K split of a trunk product: the products are latency-bound (a wave keeps three 64-wide K steps in flight), so K is cut
+// until a wave has about three steps - sixteen runs for K = 4096: four per workgroup (summed through LDS), four slabs
 static void bf_trunk_ksplit(int tiles, int K, int* wg_ksplit, int* nslab) {
+  (void)tiles;
+  const int ksteps = K >> 6;
   int total = 1;
-  while (total < 8 && tiles * total < 1024 && (K >> 6) >= 2 * total) total *= 2;
+  while (total < 16 && ksteps > 3 * total) total *= 2;
   *wg_ksplit = std::min(total, 4);
   *nslab = total / *wg_ksplit;
 }
@@ -269,7 +305,8 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
   DV_TRY(bf_refresh_weights(m, s));
   {
     ProfScope ps(m, 2);
-    if (!exp_skip_small()) DV_TRY(launch_prelu_fwd(m->z, P + A.specs[A.D0].off, m->dec_ain, NB, A.dp, s));
+    if (!exp_skip_small() && !m->ain_done) DV_TRY(launch_prelu_fwd(m->z, P + A.specs[A.D0].off, m->dec_ain, NB, A.dp, s));
+    m->ain_done = false;
   }
   DV_TRY(gconv_fprop(m, m->dec_ain, dec_dense0_w(m), false, P + A.specs[A.D0 + 2].off,
                      P + A.specs[A.D0 + 3].off, keep_u ? m->dec_uh : nullptr, m->dec_ah, 2, NB, 1, A.dp, 1, A.dec_hidden,
@@ -284,7 +321,7 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
     memset(&g, 0, sizeof g);
     g.A = m->dec_ah; g.B = bf.w1_f; g.amode = BGA_ROWS_F32; g.epi = BGE_STAMP_BIAS_PRELU;
     g.M = bf.NBp; g.Mreal = NB; g.N = bf.FL; g.K = bf.HIDk; g.Kreal = A.dec_hidden; g.lda = A.dec_hidden; g.ldb = bf.HIDk;
-    g.NBp = bf.NBp; g.nslab = 1; g.wg_ksplit = 1; g.Co = fl;
+    g.NBp = bf.NBp; g.nslab = 1; g.wg_ksplit = 4; g.Co = fl;      // (K = 576: three steps per wave, summed through LDS)
     g.bias = P + A.specs[A.D0 + 5].off; g.alpha = P + A.specs[A.D0 + 6].off;
     g.U = keep_u ? bf.dec_ur : nullptr; g.Aout = bf.dec_in;
     ProfScope ps(m, 0, nullptr, PF_BTRUNK, 2.0 * bf.NBp * (double)A.dec_hidden * r);
@@ -627,8 +664,61 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       ProfScope ps(m, 0, s, PF_BTRUNK, 2.0 * bf.NBp * (double)A.dec_hidden * r);
       DV_TRY(launch_bgemm(g, s));
     }
-    ProfScope ps(m, 2, s);
-    DV_TRY(launch_bt_finish_rows(bf.tslab, g.nslab, g.slab_stride, bf.HIDn, nullptr, tr1, NB, A.dec_hidden, A.dec_hidden, s));
+    // ... and everything between that product and d(t) in one launch: slab sum, PReLU backward of the hidden layer,
+    // Dense(latent -> 560) data gradient, PReLU backward of z, sampler backward (bt_mid_bwd_kernel).  The four batch sums
+    // it leaves as rows (d(bias) / d(alpha) of the hidden layer, d(alpha) of z's PReLU, d(bias) of the encoder Dense) are
+    // column sums on the reduction stream, off the chain
+    hipStream_t rs = (m->arena_reduce && ws != s) ? m->ctx->red_stream : s;
+    float *dalh = nullptr, *dalin = nullptr;
+    if (dg) {
+      const size_t need = (size_t)NB * A.dec_hidden + (size_t)NB * A.dp;
+      if (m->arena_off + need > m->arena_elems) {
+        set_error("gradient-partial arena exhausted");
+        return E_STATE;
+      }
+      dalh = m->arena + m->arena_off;
+      dalin = dalh + (size_t)NB * A.dec_hidden;
+      m->arena_off += (need + 3) & ~(size_t)3;
+    }
+    const float kls_mid = (float)((double)A.cfg.kl_multiplicity * A.cfg.kl_weight / ((double)Bg * (double)Bg));
+    {
+      BMidBwdParams q;
+      memset(&q, 0, sizeof q);
+      q.slab = bf.tslab; q.slab_stride = g.slab_stride; q.nslab = g.nslab; q.lds = bf.HIDn;
+      q.uh = m->dec_uh; q.alpha_h = P + A.specs[A.D0 + 3].off; q.W0 = dec_dense0_w(m);
+      q.z = m->z; q.alpha_in = P + A.specs[A.D0].off; q.eps = m->eps; q.t = m->t;
+      q.duh = tr1; q.dalh = dalh; q.dz = tr2; q.dalin = dalin; q.dt = tr3;
+      q.NB = NB; q.hid = A.dec_hidden; q.d = A.d; q.ldt = A.twp; q.ldz = A.dp;
+      q.diag_shift = A.cfg.diag_shift; q.kls = kls_mid;
+      ProfScope ps(m, 2, s);
+      DV_TRY(launch_bt_mid_bwd(q, s));
+    }
+    m->main_marked = false;
+    if (rs != s) {
+      DV_HIP(hipEventRecord(m->ctx->ev_ready, s));
+      DV_HIP(hipStreamWaitEvent(rs, m->ctx->ev_ready, 0));
+      m->main_marked = true;             // the weight gradient of Dense(latent -> 560) below waits on the same record
+    }
+    {
+      BColsums c;
+      memset(&c, 0, sizeof c);
+      c.NB = NB;
+      auto add = [&](const float* x, int ld, int n, int spec) {
+        c.x[c.count] = x; c.ld[c.count] = ld; c.n[c.count] = n; c.out[c.count] = G + A.specs[spec].off; ++c.count;
+      };
+      add(tr3, A.twp, A.tw, A.enc_db());
+      if (dg) {
+        add(tr1, A.dec_hidden, A.dec_hidden, A.D0 + 2);
+        add(dalh, A.dec_hidden, A.dec_hidden, A.D0 + 3);
+        add(dalin, A.dp, A.d, A.D0);
+      }
+      ProfScope ps(m, 2, rs);
+      DV_TRY(launch_bt_colsums(c, rs));
+    }
+    if (dg) {
+      DV_TRY(wgrad(m, m->dec_ain, 1, A.dp, tr1, 1, A.dec_hidden, NB, 1, 0, true, dec_dense0_g(m), 1, 1));
+      if (m->G0p) DV_TRY(take_padded_grad(m, m->G0p, G + A.specs[A.D0 + 1].off, 1, A.dp * A.dec_hidden, A.d * A.dec_hidden));
+    }
   } else {
     {
       ProfScope ps(m, 2, s);
@@ -639,14 +729,16 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     DV_TRY(gconv_fprop(m, tr0, P + A.specs[A.D0 + 4].off, true, nullptr, nullptr, tr1, nullptr, 0, NB, 1, r, 1,
                        A.dec_hidden, 1, 0, true));
   }
-  DV_TRY(prelu_bwd(m, tr1, m->dec_uh, A.D0 + 3, A.D0 + 2, NB, A.dec_hidden, A.dec_hidden, dg));
-  if (dg) {
-    DV_TRY(wgrad(m, m->dec_ain, 1, A.dp, tr1, 1, A.dec_hidden, NB, 1, 0, true, dec_dense0_g(m), 1, 1));
-    if (m->G0p) DV_TRY(take_padded_grad(m, m->G0p, G + A.specs[A.D0 + 1].off, 1, A.dp * A.dec_hidden, A.d * A.dec_hidden));
+  if (!bf.trunk_mfma) {
+    DV_TRY(prelu_bwd(m, tr1, m->dec_uh, A.D0 + 3, A.D0 + 2, NB, A.dec_hidden, A.dec_hidden, dg));
+    if (dg) {
+      DV_TRY(wgrad(m, m->dec_ain, 1, A.dp, tr1, 1, A.dec_hidden, NB, 1, 0, true, dec_dense0_g(m), 1, 1));
+      if (m->G0p) DV_TRY(take_padded_grad(m, m->G0p, G + A.specs[A.D0 + 1].off, 1, A.dp * A.dec_hidden, A.d * A.dec_hidden));
+    }
+    DV_TRY(gconv_fprop(m, tr1, dec_dense0_w(m), true, nullptr, nullptr, tr2, nullptr, 0, NB, 1, A.dec_hidden, 1,
+                       A.dp, 1, 0, true));
+    DV_TRY(prelu_bwd(m, tr2, m->z, A.D0, -1, NB, A.dp, A.dp, dg));
   }
-  DV_TRY(gconv_fprop(m, tr1, dec_dense0_w(m), true, nullptr, nullptr, tr2, nullptr, 0, NB, 1, A.dec_hidden, 1,
-                     A.dp, 1, 0, true));
-  DV_TRY(prelu_bwd(m, tr2, m->z, A.D0, -1, NB, A.dp, A.dp, dg));
   const bool trunk_red = ws != s && m->arena_reduce && m->ctx->red_stream != nullptr;   // sums on the reduction stream
   // Every decoder gradient has been queued and no later kernel of the step reads a decoder parameter: finish the
   // decoder's reductions now (slab sums and d(alpha) / d(bias) partials, one launch each, on the weight-gradient
@@ -684,18 +776,21 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       if (early && m->opt_dec) {
         DV_TRY(adam_range(m, A.n_enc_train, A.n_train, cx->comm_stream));
         DV_TRY(refresh_head_pad(m, cx->comm_stream));
+        DV_TRY(bf_cast_bucket_early(m, 2, cx->comm_stream));
         m->adam_done_from = A.n_enc_train;
       }
       dec_bucket_done = true;
     }
   }
   const float kls = (float)((double)A.cfg.kl_multiplicity * A.cfg.kl_weight / ((double)Bg * (double)Bg));
-  {
-    ProfScope ps(m, 2);
-    DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, tr2, tr3, NB, A.d, A.twp, A.dp, A.cfg.diag_shift, kls, s));
+  if (!bf.trunk_mfma) {
+    {
+      ProfScope ps(m, 2);
+      DV_TRY(launch_sampler_bwd(m->t, m->eps, m->z, tr2, tr3, NB, A.d, A.twp, A.dp, A.cfg.diag_shift, kls, s));
+    }
+    m->main_marked = false;   // (the record prelu_bwd left behind predates the sampler: the dense weight gradient below needs its own)
+    DV_TRY(bias_grad_colsum(m, tr3, NB, A.twp, A.tw, A.enc_db()));
   }
-  m->main_marked = false;   // (the record prelu_bwd left behind predates the sampler: the dense weight gradient below needs its own)
-  DV_TRY(bias_grad_colsum(m, tr3, NB, A.twp, A.tw, A.enc_db()));
   if (bf.trunk_mfma) {
     const int jl = 2 * A.L - 1;
     // kernel gradient of the encoder Dense on the weight-gradient stream: X = PReLU(flatten(activation of the last conv)),
@@ -742,7 +837,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     memset(&g, 0, sizeof g);
     g.A = tr3; g.B = bf.wenc_d; g.amode = BGA_ROWS_F32; g.epi = BGE_STAMP_GATE2;
     g.M = bf.NBp; g.Mreal = NB; g.N = bf.FL; g.K = bf.TWk; g.Kreal = A.twp; g.lda = A.twp; g.ldb = bf.TWk;
-    g.NBp = bf.NBp; g.nslab = 1; g.wg_ksplit = 1; g.Co = fl;
+    g.NBp = bf.NBp; g.nslab = 1; g.wg_ksplit = 4; g.Co = fl;
     g.a7 = bf.enc_a[jl]; g.u7 = bf.enc_u[jl];
     g.alpha_flat = P + A.specs[A.enc_flat_al()].off; g.alpha7 = P + A.specs[A.enc_al(jl)].off;
     g.dU = cur; g.part_dal_flat = pflat; g.part_dal7 = p7; g.part_db = pdb;
@@ -864,6 +959,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
         }
         if (early && m->opt_enc) {
           DV_TRY(adam_range(m, split, A.n_enc_train, cx->comm_stream));
+          DV_TRY(bf_cast_bucket_early(m, 1, cx->comm_stream));
           m->adam_done_from = std::min(m->adam_done_from, split);
         }
       }

@@ -638,15 +638,23 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
   __shared__ float st_all[4][64 + 64 * 65 / 2];
   float* st = st_all[threadIdx.x >> 6];
   if (p.nslab > 0) {
-    float* to = p.t_out + (size_t)bs * p.ldt;
-    for (int i = lane; i < p.ldt; i += 64) {
-      float v = 0.f;
-      if (i < tw) {
-        v = p.tbias[i];
-        for (int sl = 0; sl < p.nslab; ++sl) v += p.slab[(size_t)sl * p.slab_stride + (size_t)bs * p.lds + i];
-        st[i] = v;
-      }
-      if (p.rep_nb == 0 || b < p.rep_nb) to[i] = v;
+    // (two passes: the sums go to LDS first, so that no global store sits between the loads of consecutive elements -
+    // the compiler cannot tell that t_out does not alias the slabs - and all of a lane's slab loads are in flight together)
+    const float* __restrict__ sb = p.slab + (size_t)bs * p.lds;
+    const size_t ss = (size_t)p.slab_stride;
+    const int ns = p.nslab;
+#pragma unroll 3
+    for (int i = lane; i < tw; i += 64) {
+      // (up to four slabs as four independent loads - a run-time slab loop is a chain of dependent round trips: 18 us
+      // per launch instead of 8 - added in slab order)
+      const float v0 = sb[i], v1 = ns > 1 ? sb[ss + i] : 0.f, v2 = ns > 2 ? sb[2 * ss + i] : 0.f, v3 = ns > 3 ? sb[3 * ss + i] : 0.f;
+      float v = (((p.tbias[i] + v0) + v1) + v2) + v3;
+      for (int sl = 4; sl < ns; ++sl) v += sb[(size_t)sl * ss + i];
+      st[i] = v;
+    }
+    if (p.rep_nb == 0 || b < p.rep_nb) {
+      float* to = p.t_out + (size_t)bs * p.ldt;
+      for (int i = lane; i < p.ldt; i += 64) to[i] = i < tw ? st[i] : 0.f;
     }
   } else {
     for (int i = lane; i < tw; i += 64) st[i] = t[i];
@@ -693,6 +701,7 @@ __global__ __launch_bounds__(256) void sampler_fwd_kernel(const SamplerParams p)
   k = wave_sum(k);
   if (lane < p.ldz) {                                 // (pad columns d .. ldz - 1: zeros)
     p.z[zo + lane] = lane < d ? z : 0.f;
+    if (p.ain) p.ain[zo + lane] = lane < d ? (z > 0.f ? z : p.alpha_in[lane] * z) : 0.f;
     if (p.stddev) p.stddev[zo + lane] = lane < d ? sqrtf(l2) : 0.f;
   }
   if (lane == 0) p.kl[b] = k;
