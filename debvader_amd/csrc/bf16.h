@@ -168,15 +168,16 @@ int launch_bf_prelu_bwd(const void* da, const void* u, const float* alpha, void*
 int launch_bf_colsum(const void* x, long rows, int C, float* part, int* nrows_out, hipStream_t s);
 
 struct BHeadParams {
-  const float* tpre;   // fp32 [Hd*Hd][NBp][16] head conv output before relu
+  const float* tpre;   // fp32 [Hd*Hd][NBp][cw] head conv output before relu
   const float* y;      // dataset labels [*,H,H,nb] (null: no loss)
   const int* idx;
   int first;
-  void* dt;            // bf16 [Hd*Hd][NBp][16] gradient wrt tpre (null: none); zero outside the crop / pad rows
+  void* dt;            // bf16 [Hd*Hd][NBp][cw] gradient wrt tpre (null: none); zero outside the crop / pad rows
   float* loc;          // fp32 [NB,H,H,nb] or null
   float* scale;
   float* part;         // [nblocks][2]
   int NB, NBp, Hd, H, nb, crop0;
+  int cw;              // columns of tpre / dt: 16 (1 .. 7 bands) or 32 (8 .. 15 bands); 2 * nb <= cw
   float sigma_floor, gscale;
   int mse_sample;      // see HeadParams (common.h)
   unsigned mse_stream;

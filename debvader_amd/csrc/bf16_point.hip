@@ -28,7 +28,7 @@ __device__ __forceinline__ float bp_block_sum(float v, float* sh) {
 // A workgroup moves 32 pixels x 16 stamps through LDS: the dataset side is read in whole stamp rows (32 pixels x C
 // floats, contiguous), the stamp-inner side is written 16 stamps x 32 bytes = 512 contiguous bytes per pixel.
 // (One thread per (pixel, stamp) without the tile read 24-byte pieces 83 KB apart: 92 us instead of ~20 for 256 stamps.)
-constexpr int BI_PX = 32, BI_ST = 16, BI_MAXC = 7;
+constexpr int BI_PX = 32, BI_ST = 16, BI_MAXC = 15;   // 1 .. 15 bands + the constant-one channel fill the 16 (train.py:86,104-107 takes any)
 __global__ __launch_bounds__(256) void bf_input_kernel(const float* __restrict__ x, const int* __restrict__ idx, int first,
                                                        int NB, int NBp, int HW, int C, const float* __restrict__ bn,
                                                        bp_bf16* __restrict__ xh) {
@@ -53,11 +53,12 @@ __global__ __launch_bounds__(256) void bf_input_kernel(const float* __restrict__
     for (int j = 0; j < 8; ++j) lo[j] = hi[j] = (bp_bf16)0.f;
     if (b < NB) {
 #pragma unroll
-      for (int c = 0; c < BI_MAXC; ++c)
-        if (c < C) lo[c] = (bp_bf16)((tile[sr][pp * C + c] - bn[2 * DV_BN_MAXC + c]) * bn[3 * DV_BN_MAXC + c]);   // bnstate rows are DV_BN_MAXC wide
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (c == C) lo[c] = (bp_bf16)1.f;
+      for (int c = 0; c < 16; ++c) {                     // (static register indexing: the band count is a run-time value)
+        bp_bf16 v = (bp_bf16)0.f;
+        if (c < C && c < BI_MAXC) v = (bp_bf16)((tile[sr][pp * C + c] - bn[2 * DV_BN_MAXC + c]) * bn[3 * DV_BN_MAXC + c]);   // bnstate rows are DV_BN_MAXC wide
+        if (c == C) v = (bp_bf16)1.f;
+        if (c < 8) lo[c] = v; else hi[c - 8] = v;
+      }
     }
     if (b < NBp) {
       bp_bf16x8* o = reinterpret_cast<bp_bf16x8*>(xh + ((size_t)(p0 + pp) * NBp + b) * 16);
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void bf_input_kernel(const float* __restrict__
 int launch_bf_input(const float* x, const int* idx, int first, int NB, int NBp, int HW, int C, const float* bnstate,
                     void* xh, hipStream_t s) {
   if (C > BI_MAXC) {
-    set_error("bf_input: at most 7 bands");
+    set_error("bf_input: at most 15 bands");
     return E_INVALID;
   }
   hipLaunchKernelGGL(bf_input_kernel, dim3((unsigned)((HW + BI_PX - 1) / BI_PX), (unsigned)(NBp / BI_ST)), dim3(256), 0, s,
@@ -231,40 +232,41 @@ int launch_bf_prelu_bwd(const void* da, const void* u, const float* alpha, void*
   return OK;
 }
 
-// ---- column sums of a bf16 [rows][C] tensor (C = 16): d(bias) of the head --------------------------------------------
+// ---- column sums of a bf16 [rows][CW] tensor (CW = 16, or 32 for 8 - 15 bands): d(bias) of the head -----------------
+template <int CW>
 __global__ __launch_bounds__(256) void bf_colsum16_kernel(const bp_bf16* __restrict__ x, long rows, float* __restrict__ part) {
-  __shared__ float sh[256 * 16];
+  __shared__ float sh[256 * CW];
   const long per = (rows + gridDim.x - 1) / gridDim.x;
   const long r0 = (long)blockIdx.x * per, r1 = min(rows, r0 + per);
-  float a[16];
+  float a[CW];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) a[j] = 0.f;
+  for (int j = 0; j < CW; ++j) a[j] = 0.f;
   for (long r = r0 + threadIdx.x; r < r1; r += 256) {
-    const bp_bf16x8 v0 = *reinterpret_cast<const bp_bf16x8*>(x + r * 16);
-    const bp_bf16x8 v1 = *reinterpret_cast<const bp_bf16x8*>(x + r * 16 + 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      a[j] += (float)v0[j];
-      a[8 + j] += (float)v1[j];
+    for (int q = 0; q < CW / 8; ++q) {
+      const bp_bf16x8 v = *reinterpret_cast<const bp_bf16x8*>(x + r * CW + 8 * q);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[8 * q + j] += (float)v[j];
     }
   }
 #pragma unroll
-  for (int j = 0; j < 16; ++j) sh[threadIdx.x * 16 + j] = a[j];
+  for (int j = 0; j < CW; ++j) sh[threadIdx.x * CW + j] = a[j];
   __syncthreads();
-  if (threadIdx.x < 16) {
+  if (threadIdx.x < CW) {
     float t = 0.f;
-    for (int i = 0; i < 256; ++i) t += sh[i * 16 + threadIdx.x];
-    part[blockIdx.x * 16 + threadIdx.x] = t;
+    for (int i = 0; i < 256; ++i) t += sh[i * CW + threadIdx.x];
+    part[blockIdx.x * CW + threadIdx.x] = t;
   }
 }
 
 int launch_bf_colsum(const void* x, long rows, int C, float* part, int* nrows_out, hipStream_t s) {
-  if (C != 16) {
-    set_error("bf_colsum: 16 channels only");
+  if (C != 16 && C != 32) {
+    set_error("bf_colsum: 16 or 32 channels only");
     return E_INVALID;
   }
   const int nb = (int)std::min<long>(512, std::max<long>(1, rows / 1024));
-  hipLaunchKernelGGL(bf_colsum16_kernel, dim3(nb), dim3(256), 0, s, reinterpret_cast<const bp_bf16*>(x), rows, part);
+  if (C == 16) hipLaunchKernelGGL(bf_colsum16_kernel<16>, dim3(nb), dim3(256), 0, s, reinterpret_cast<const bp_bf16*>(x), rows, part);
+  else hipLaunchKernelGGL(bf_colsum16_kernel<32>, dim3(nb), dim3(256), 0, s, reinterpret_cast<const bp_bf16*>(x), rows, part);
   if (nrows_out) *nrows_out = nb;
   DV_HIP(hipGetLastError());
   return OK;
@@ -275,9 +277,10 @@ int launch_bf_colsum(const void* x, long rows, int C, float* part, int* nrows_ou
 // pre-activation is stored in bf16 (it feeds bf16 MFMA operands), zero outside the crop and for the pad stamps.
 // A workgroup is 16 consecutive pixels of one row of the 2^L grid x 16 stamps; the labels of the tile (16 stamps x a run of
 // 16 pixels x nb floats each, contiguous per stamp) arrive through LDS.
+template <int CW>   // columns of the head tensors: 16 (1 .. 7 bands) or 32 (8 .. 15)
 __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
   __shared__ float sh[4];
-  __shared__ float ytile[16][16 * 8 + 1];
+  __shared__ float ytile[16][16 * (CW / 2) + 1];
   const int chunks = (p.Hd * p.Hd) >> 4;
   const int pc = blockIdx.x % chunks, sc = blockIdx.x / chunks;
   const int pix0 = pc * 16, b0 = sc * 16;
@@ -309,21 +312,24 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
   float nll = 0.f, se = 0.f;
   {
     const bool in = rowin && (unsigned)w < (unsigned)p.H && b < p.NB;
-    float d[16];
+    float d[CW];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) d[j] = 0.f;
+    for (int j = 0; j < CW; ++j) d[j] = 0.f;
     if (in) {
-      const f32x4* tp = reinterpret_cast<const f32x4*>(p.tpre + e * 16);
-      const f32x4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
-      const float t[16] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3],
-                           t2[0], t2[1], t2[2], t2[3], t3[0], t3[1], t3[2], t3[3]};
+      const f32x4* tp = reinterpret_cast<const f32x4*>(p.tpre + e * CW);
+      float t[CW];
+#pragma unroll
+      for (int q = 0; q < CW / 4; ++q) {
+        const f32x4 tq = tp[q];
+        t[4 * q] = tq[0]; t[4 * q + 1] = tq[1]; t[4 * q + 2] = tq[2]; t[4 * q + 3] = tq[3];
+      }
       const long opix = ((long)b * p.H + h) * p.H + w;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < CW / 2; ++c) {
         if (c >= p.nb) break;
         float tl = 0.f, ts = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {             // static register indexing (runtime index = scratch)
+        for (int j = 0; j < CW; ++j) {             // static register indexing (runtime index = scratch)
           if (j == c) tl = t[j];
           if (j == p.nb + c) ts = t[j];
         }
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
           const float dl = tl > 0.f ? -(r * inv) * p.gscale : 0.f;
           const float ds = ts > 0.f ? (inv - r * r * inv) * p.gscale : 0.f;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
+          for (int j = 0; j < CW; ++j) {
             if (j == c) d[j] = dl;
             if (j == p.nb + c) d[j] = ds;
           }
@@ -355,15 +361,14 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
       }
     }
     if (p.dt) {
-      bp_bf16x8 o0, o1;
+      bp_bf16x8* o = reinterpret_cast<bp_bf16x8*>(reinterpret_cast<bp_bf16*>(p.dt) + e * CW);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        o0[j] = (bp_bf16)d[j];
-        o1[j] = (bp_bf16)d[8 + j];
+      for (int q = 0; q < CW / 8; ++q) {
+        bp_bf16x8 oq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oq[j] = (bp_bf16)d[8 * q + j];
+        o[q] = oq;
       }
-      bp_bf16x8* o = reinterpret_cast<bp_bf16x8*>(reinterpret_cast<bp_bf16*>(p.dt) + e * 16);
-      o[0] = o0;
-      o[1] = o1;
     }
   }
   const float a = bp_block_sum(nll, sh);
@@ -375,14 +380,15 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const BHeadParams p) {
 }
 
 int launch_bf_head(const BHeadParams& p, hipStream_t s, int* nblocks_out) {
-  if (p.nb > 8 || ((p.Hd * p.Hd) & 15) || (p.NBp & 15)) {
-    set_error("bf_head: at most 8 bands, pixel count and stamp padding multiples of 16");
+  if (p.nb > 15 || p.nb < 1 || (p.cw != 16 && p.cw != 32) || 2 * p.nb > p.cw || ((p.Hd * p.Hd) & 15) || (p.NBp & 15)) {
+    set_error("bf_head: 1 .. 15 bands in 16 or 32 columns, pixel count and stamp padding multiples of 16");
     return E_INVALID;
   }
   const int nb = ((p.Hd * p.Hd) >> 4) * (p.NBp >> 4);
   if (nblocks_out) *nblocks_out = nb;
   if (nb == 0) return OK;
-  hipLaunchKernelGGL(bf_head_kernel, dim3(nb), dim3(256), 0, s, p);
+  if (p.cw == 16) hipLaunchKernelGGL(bf_head_kernel<16>, dim3(nb), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(bf_head_kernel<32>, dim3(nb), dim3(256), 0, s, p);
   DV_HIP(hipGetLastError());
   return OK;
 }

@@ -167,10 +167,6 @@ struct Arch {
       set_error("unsupported architecture (levels=%d bands=%d latent=%d size=%d)", L, C, d, H);
       return E_INVALID;
     }
-    if (C > 7 && c->dtype == DV_DTYPE_BF16) {
-      set_error("the bf16 engine takes 1 .. 7 bands (bands=%d): use dtype f32 for 8 .. 15", C);
-      return E_INVALID;
-    }
     for (int i = 0; i < L; ++i) {
       if (c->kernels[i] < 1 || c->kernels[i] > 5) {
         set_error("kernel sizes 1 .. 5 are implemented (kernels[%d]=%d)", i, c->kernels[i]);
@@ -4097,12 +4093,12 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
     DV_HIP(hipStreamSynchronize(m->ctx->stream));
     if (m->bf.on) {
       // stamp-inner fp32 [Hd*Hd][NBp][16] -> [B][Hd][Hd][2C]
-      const size_t Pn = (size_t)A.dec_out * A.dec_out, NBp = (size_t)m->bf.NBp;
-      std::vector<float> tmp(Pn * NBp * 16);
+      const size_t Pn = (size_t)A.dec_out * A.dec_out, NBp = (size_t)m->bf.NBp, HC = (size_t)A.C2p;
+      std::vector<float> tmp(Pn * NBp * HC);
       DV_HIP(hipMemcpy(tmp.data(), m->bf.tpre32, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
       for (size_t b = 0; b < B; ++b)
         for (size_t px = 0; px < Pn; ++px)
-          memcpy(host + (b * Pn + px) * 2 * A.C, tmp.data() + (px * NBp + b) * 16, 2 * A.C * sizeof(float));
+          memcpy(host + (b * Pn + px) * 2 * A.C, tmp.data() + (px * NBp + b) * HC, 2 * A.C * sizeof(float));
       return DV_OK;
     }
     DV_HIP(hipMemcpy2D(host, 2 * A.C * sizeof(float), m->tpre, A.C2p * sizeof(float), 2 * A.C * sizeof(float),
@@ -4125,7 +4121,7 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
       }
       bsrc = m->bf.dec_ur; Pn = (size_t)A.w0 * A.w0; Cn = A.cfg.filters[A.L - 1];
     }
-    else if (n == "d_head_pre") { bsrc = m->bf.dt; Pn = (size_t)A.dec_out * A.dec_out; Cn = 16; }
+    else if (n == "d_head_pre") { bsrc = m->bf.dt; Pn = (size_t)A.dec_out * A.dec_out; Cn = (size_t)A.C2p; }
     else if (n.size() > 6 && (n.rfind("enc_du", 0) == 0 || n.rfind("dec_du", 0) == 0)) {
       // d(pre-activation) of conv layer j as the last backward pass left it (bf16; tests/test_gpu_bf16_layers.py)
       const int j = atoi(n.c_str() + 6);
@@ -4170,6 +4166,7 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
   }
   else if (n == "xn") { src = m->xn; elems = B * A.H * A.H * A.C0p; }
   else if (n == "dec_in") { src = m->dec_ar; elems = B * A.w0 * A.w0 * A.cfg.filters[A.L - 1]; }
+  else if (n == "dec_ur") { src = m->dec_ur; elems = B * A.w0 * A.w0 * A.cfg.filters[A.L - 1]; }   // its pre-activation (fp32 engine: rows)
   else if (n == "d_head_pre" || n == "enc_da0" || n.rfind("enc_du", 0) == 0 || n.rfind("dec_du", 0) == 0) {
     // gradients the last backward pass left in its per-step buffer pool (tests/test_gpu_layers.py)
     if (!m->du_valid) {

@@ -25,10 +25,11 @@ static int bf_alloc(dv_model* m) {
     set_error("bf16 engine: the decoder output (%d x %d pixels) must be a multiple of 16 pixels", A.dec_out, A.dec_out);
     return E_INVALID;
   }
-  if (A.cfg.filters[A.L - 1] & 7 || A.C2p != 16) {
+  if (A.cfg.filters[A.L - 1] & 7 || (A.C2p != 16 && A.C2p != 32) || A.C > 15) {
     set_error("bf16 engine: unsupported head / trunk geometry");
     return E_INVALID;
   }
+  const int HC = A.C2p;            // columns of the head tensors: 16 for 1 .. 7 bands, 32 for 8 .. 15 (train.py:86,104-107)
   auto balloc = [&](void** p, size_t bytes) -> int {
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, std::max<size_t>(bytes, 64));
@@ -45,7 +46,7 @@ static int bf_alloc(dv_model* m) {
   for (int i = 0; i < A.L; ++i) zero_bytes = std::max(zero_bytes, (size_t)Bp * A.cfg.filters[i] * 2);
   DV_TRY(balloc(&bf.zero, zero_bytes));
   DV_HIP(hipMemsetAsync(bf.zero, 0, zero_bytes, m->ctx->stream));
-  size_t max_e = (size_t)A.dec_out * A.dec_out * 16;
+  size_t max_e = (size_t)A.dec_out * A.dec_out * HC;
   bf.enc_u.resize(2 * A.L); bf.enc_a.resize(2 * A.L); bf.dec_u.resize(2 * A.L); bf.dec_a.resize(2 * A.L);
   bf.enc_w.resize(2 * A.L); bf.dec_w.resize(2 * A.L);
   for (int j = 0; j < 2 * A.L; ++j) {
@@ -64,8 +65,8 @@ static int bf_alloc(dv_model* m) {
   }
   const size_t r = (size_t)A.w0 * A.w0 * A.cfg.filters[A.L - 1];
   DV_TRY(balloc(&bf.dec_in, r * Bp * 2));
-  DV_TRY(balloc((void**)&bf.tpre32, (size_t)A.dec_out * A.dec_out * Bp * 16 * 4));
-  DV_TRY(balloc(&bf.dt, (size_t)A.dec_out * A.dec_out * Bp * 16 * 2));
+  DV_TRY(balloc((void**)&bf.tpre32, (size_t)A.dec_out * A.dec_out * Bp * HC * 4));
+  DV_TRY(balloc(&bf.dt, (size_t)A.dec_out * A.dec_out * Bp * HC * 2));
   DV_TRY(balloc((void**)&bf.flat_in, (size_t)m->Bc * A.flat * 4));
   {
     const size_t w[5] = {r, (size_t)A.dec_hidden, (size_t)A.dp, (size_t)A.twp, (size_t)A.flat};
@@ -116,8 +117,8 @@ static int bf_alloc(dv_model* m) {
   {
     const int f0 = A.cfg.filters[0];
     const float* kh = P + A.specs[A.head_k()].off;           // HWIO [9][f0][2C]
-    DV_TRY(add(kh, f0, 2 * A.C, 1, 16, f0, 3, &bf.head_w.f, &bf.head_w.Kf));
-    DV_TRY(add(kh, f0, 2 * A.C, 0, f0, 16, 3, &bf.head_w.d, &bf.head_w.Kd));
+    DV_TRY(add(kh, f0, 2 * A.C, 1, HC, f0, 3, &bf.head_w.f, &bf.head_w.Kf));
+    DV_TRY(add(kh, f0, 2 * A.C, 0, f0, HC, 3, &bf.head_w.d, &bf.head_w.Kd));
   }
   {
     // dense trunk on the bf16 matrix cores (btrunk.hip): two forms of each large Dense kernel, the K-split slabs, the
@@ -344,7 +345,7 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
                    P + A.specs[A.dec_al(j)].off, nullptr, nullptr, nullptr, A.dec_ksz(j)));
     in = bf.dec_a[j];
   }
-  return bf_conv(m, in, bf.head_w.f, bf.head_w.Kf, 0, A.dec_out, A.cfg.filters[0], A.dec_out, 16, 1, 1, BEPI_RAW32,
+  return bf_conv(m, in, bf.head_w.f, bf.head_w.Kf, 0, A.dec_out, A.cfg.filters[0], A.dec_out, A.C2p, 1, 1, BEPI_RAW32,
                  nullptr, nullptr, bf.tpre32, m->bhp, nullptr, nullptr, nullptr, nullptr);
 }
 
@@ -367,6 +368,7 @@ static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int firs
   hp.Hd = A.dec_out;
   hp.H = A.H;
   hp.nb = A.C;
+  hp.cw = A.C2p;
   hp.crop0 = A.crop0;
   hp.sigma_floor = A.cfg.sigma_floor;
   hp.gscale = (float)(1.0 / ((double)Bg * A.H * A.H * A.C));
@@ -590,16 +592,16 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   size_t enc_reduced = A.n_enc_train;                    // [enc_reduced, n_enc_train) all-reduced inside this pass
   // ---- head conv ----
   if (dg) {
-    if (bf_wgrad_takes(f0)) DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, 1, 1, m->Ghs, f0, f0));   // (columns taken at the end)
-    else DV_TRY(bf_wgrad_f32(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, 16, NB, 1, 1, m->Ghs, f0, f0, 3));
+    if (bf_wgrad_takes(f0)) DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, A.C2p, 1, 1, m->Ghs, f0, f0));   // (columns taken at the end)
+    else DV_TRY(bf_wgrad_f32(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, A.C2p, NB, 1, 1, m->Ghs, f0, f0, 3));
     ProfScope ps(m, 2, s);
     int nr = 0;
-    DV_TRY(launch_bf_colsum(bf.dt, (long)Hd * Hd * bf.NBp, 16, m->ws3, &nr, s));
-    DV_TRY(launch_reduce_rows_f64(m->ws3, nr, C2, G + A.specs[A.head_b()].off, 1.0f, s, 16));
+    DV_TRY(launch_bf_colsum(bf.dt, (long)Hd * Hd * bf.NBp, A.C2p, m->ws3, &nr, s));
+    DV_TRY(launch_reduce_rows_f64(m->ws3, nr, C2, G + A.specs[A.head_b()].off, 1.0f, s, A.C2p));
   }
   {
     const int jl = 2 * A.L - 1;
-    DV_TRY(bf_dgrad_prelu(m, bf.dt, bf.head_w.d, bf.head_w.Kd, 1, Hd, 16, Hd, f0, 1, 1, cur, bf.dec_u[jl], A.dec_al(jl),
+    DV_TRY(bf_dgrad_prelu(m, bf.dt, bf.head_w.d, bf.head_w.Kd, 1, Hd, A.C2p, Hd, f0, 1, 1, cur, bf.dec_u[jl], A.dec_al(jl),
                           A.dec_b(jl), dg));
   }
   // ---- decoder conv-transpose stack: cur = d(pre-activation) of layer j ----
@@ -756,7 +758,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       DV_TRY(bf_flush_wred(m));
       {
         ProfScope ps(m, 2, ws);
-        DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, ws));
+        DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, A.C2p, C2, ws));
         DV_TRY(launch_bf_reduce_batch(bf.red, ws));
       }
       bf.red.count = 0;
@@ -891,8 +893,9 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       // last launch of the pass: on the (otherwise idle) main stream, slabs in the pool's tail region
       const bool wg0 = ksz == 3 && bf_wgrad_takes(cout);
       const bool lm = !wg0 || (ws != s && (size_t)((bf.NBp + 63) / 64) * 9 * 16 * cout <= bf.slab_tail / BF_MAIN_SLOTS);
-      if (wg0) DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, 8, lm));
-      else DV_TRY(bf_wgrad_f32(m, bf.xh, hin, 16, cur, hout, cout, NB, st, pb, m->G0s, 16, 8, ksz));
+      // (the folded kernel's gradient has A.C0p input channels: 8 for 1 .. 7 bands, all 16 for 8 .. 15)
+      if (wg0) DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, A.C0p, lm));
+      else DV_TRY(bf_wgrad_f32(m, bf.xh, hin, 16, cur, hout, cout, NB, st, pb, m->G0s, 16, A.C0p, ksz));
       for (int jd = 1; jd < BF_MAIN_SLOTS; ++jd) {       // the launches held back behind the last data gradient
         if (!deferred[jd]) continue;
         int h1, c1, ho1, co1, s1;
@@ -907,9 +910,9 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       // every slab reduction of the pass, then what reads the two scratch gradients (padded head kernel, folded first conv)
       DV_TRY(bf_flush_wred(m));
       ProfScope ps(m, 2, ws);
-      if (dg && !head_cols_taken) DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, 16, C2, ws));
+      if (dg && !head_cols_taken) DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, A.C2p, C2, ws));
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
-                                   G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, ksz * ksz, A.C, 8, cout,
+                                   G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, ksz * ksz, A.C, A.C0p, cout,
                                    ws));
       break;
     }

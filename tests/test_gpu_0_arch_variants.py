@@ -101,8 +101,12 @@ def test_latent_dim_ten_on_the_bf16_engine():
     _run(arch, B=5, seed=75, check_fp64_grads=False)
 
 
-@pytest.mark.parametrize("bands", [5, 3])
+@pytest.mark.parametrize("bands", [5, 3, 8, 10, 15])
 def test_band_counts_on_the_bf16_engine(bands):
+    """train.py:86,104-107 builds (59, 59, nb_of_bands) for any band count.  1 .. 7 bands: 16-column head tensors; 8 .. 15
+    (round 6; the bf16 engine refused them until then): the normalised input still fits the 16-channel stamp-inner form
+    (bands + the constant-one channel that carries beta), the folded first kernel's gradient has 16 input channels and the
+    head tensors 32 columns (bf_head_kernel<32>, bf_colsum<32>, a 32-column head conv and 32-channel head gradient)."""
     from tests.test_gpu_bf16 import _run
 
     arch = vo.Arch(input_shape=(13, 13, bands), latent_dim=8, filters=(16, 32), kernels=(3, 3))
@@ -110,6 +114,17 @@ def test_band_counts_on_the_bf16_engine(bands):
     # cost on gradients is a property of the 4-band toy case of test_gpu_bf16.py, not of the band count)
     _run(arch, B=5, seed=70 + bands, check_fp64_grads=False)
     _run(arch, B=64, seed=80 + bands, tol_grad_b=5e-2, check_fp64_grads=False)
+    if bands >= 8:
+        _run(arch, B=256, seed=90 + bands, tol_grad_b=5e-2, check_fp64_grads=False)       # 256-stamp uniform tiles
+
+
+def test_ten_bands_on_the_reference_architecture_bf16():
+    """(59, 59, 10) on the bf16 engine at 64 stamps: the 32-column head forms at the reference's sizes, the dense trunk on
+    the matrix cores, inference through deblend()'s entry point."""
+    from tests.test_gpu_bf16 import _run
+
+    arch = vo.Arch(input_shape=(59, 59, 10), latent_dim=32, filters=(32, 64, 128, 256), kernels=(3, 3, 3, 3))
+    _run(arch, B=64, seed=97, tol_grad_b=0.25, min_cos=0.97, tol_grad_64=0.25)
 
 
 @pytest.mark.parametrize("filters,kernels,size", [((16, 32), (5, 5), 13), ((16, 32, 64), (3, 5, 3), 20), ((32, 32), (1, 5), 13),
@@ -157,8 +172,8 @@ def test_bf16_engine_refuses_what_it_does_not_implement_with_a_message():
 
     with pytest.raises(DvError, match="filters must be multiples of 16"):
         E.Engine(E.make_config((13, 13, 4), 8, (8, 24), (3, 3), max_batch=4, dtype=1))
-    with pytest.raises(DvError, match="bands"):
-        E.Engine(E.make_config((13, 13, 9), 8, (16, 32), (3, 3), max_batch=4, dtype=1))
+    with pytest.raises(DvError, match="bands"):                      # (1 .. 15 bands on both engines since round 6)
+        E.Engine(E.make_config((13, 13, 16), 8, (16, 32), (3, 3), max_batch=4, dtype=1))
 
 
 def test_train_deblender_with_five_bands_like_the_reference_notebook():
