@@ -17,7 +17,8 @@ def pytest_configure(config):
 # oracle cases (B <= 64 on the toy nets) still run first, so that `-x` reaches an oracle comparison before the HIP-vs-HIP checks.
 _POOLED = ("test_full_arch_stage1_step_at_batch_256_against_the_oracle", "test_full_arch_stage2_frozen_decoder_at_batch_256",
            "test_128px_six_level_arch_at_its_per_gpu_batch_of_64", "test_full_arch_at_the_quoted_batch_of_256_stamps",
-           "test_full_arch_64_stamps", "test_deep_arch_128px_at_its_per_gpu_batch_of_64")
+           "test_full_arch_64_stamps", "test_deep_arch_128px_at_its_per_gpu_batch_of_64",
+           "test_ten_bands_on_the_reference_architecture_bf16")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -131,4 +131,5 @@ HEAVY = [
     ("bf16_case", dict(arch_kw=FULL, B=256, seed=5, data_seed=9, train_decoder=True)),
     ("bf16_case", dict(arch_kw=FULL, B=64, seed=3, data_seed=6, train_decoder=True)),
     ("bf16_case", dict(arch_kw=DEEP, B=64, seed=23, data_seed=None, train_decoder=True)),
+    ("bf16_case", dict(arch_kw=dict(FULL, input_shape=(59, 59, 10)), B=64, seed=97, data_seed=None, train_decoder=True)),
 ]

@@ -21,6 +21,7 @@ import time
 _pool = None
 _pending = {}
 _stats = {"waited_s": 0.0, "fetched": 0, "inline": 0}
+_last_inline = {}
 
 
 def _key(fn, kwargs):
@@ -60,10 +61,15 @@ def start(n_workers=None):
 
 def fetch(fn, **kwargs):
     """The result of tests.oracle_jobs.<fn>(**kwargs): from a worker when the case was queued, else computed here."""
-    res = _pending.pop(_key(fn, kwargs), None)
+    k = _key(fn, kwargs)
+    res = _pending.pop(k, None)
     if res is None:
+        if _last_inline.get("key") == k:                # the same case twice in a row (a test that repeats a case under
+            return _last_inline["out"]                  # another kernel selection): evaluated once
         _stats["inline"] += 1
-        return _call(fn, kwargs)[0]
+        out = _call(fn, kwargs)[0]
+        _last_inline.update(key=k, out=out)
+        return out
     t0 = time.perf_counter()
     out, _ = res.get(timeout=1800)
     _stats["waited_s"] += time.perf_counter() - t0

@@ -172,21 +172,21 @@ def test_wide_channel_arch_all_column_tile_widths():
     import os
 
     arch = vo.Arch(input_shape=(20, 20, 4), latent_dim=8, filters=(32, 64, 128), kernels=(3, 3, 3))
-    for min_tiles in ("1", None):
-        if min_tiles is None:
-            os.environ.pop("DV_BCONV_MIN_TILES", None)
-        else:
-            os.environ["DV_BCONV_MIN_TILES"] = min_tiles
-        try:
-            # (d(gamma) / d(beta) of the input BatchNorm are four numbers each, sums over every pixel with heavy
-            # cancellation: they carry the loosest agreement, 0.1-0.2 of their maximum between any two bf16 evaluations)
-            # (outputs at 1.5e-2 * max, round 6: with the dense trunk on the matrix cores one more chain of bf16 roundings
-            # sits between the two orderings of the same sums - measured 1.07e-2 on `loc` at 256 stamps, one flipped
-            # rounding of the hidden layer; every product of the trunk alone stays within 1e-2: test_gpu_0_layers_bf16.py)
-            _run(arch, B=256, seed=11, tol_out=1.5e-2, tol_grad_b=0.25, min_cos=0.95, tol_grad_64=0.35)
-            _run(arch, B=48, seed=12, tol_out=1.5e-2, tol_grad_b=0.25, min_cos=0.95, tol_grad_64=0.35)
-        finally:
-            os.environ.pop("DV_BCONV_MIN_TILES", None)
+    # (d(gamma) / d(beta) of the input BatchNorm are four numbers each, sums over every pixel with heavy
+    # cancellation: they carry the loosest agreement, 0.1-0.2 of their maximum between any two bf16 evaluations)
+    # (outputs at 1.5e-2 * max, round 6: with the dense trunk on the matrix cores one more chain of bf16 roundings
+    # sits between the two orderings of the same sums - measured 1.07e-2 on `loc` at 256 stamps, one flipped
+    # rounding of the hidden layer; every product of the trunk alone stays within 1e-2: test_gpu_0_layers_bf16.py)
+    for B, seed in ((256, 11), (48, 12)):                # (each case under both tile rules in a row: one oracle evaluation)
+        for min_tiles in ("1", None):
+            if min_tiles is None:
+                os.environ.pop("DV_BCONV_MIN_TILES", None)
+            else:
+                os.environ["DV_BCONV_MIN_TILES"] = min_tiles
+            try:
+                _run(arch, B=B, seed=seed, tol_out=1.5e-2, tol_grad_b=0.25, min_cos=0.95, tol_grad_64=0.35)
+            finally:
+                os.environ.pop("DV_BCONV_MIN_TILES", None)
 
 
 def test_full_arch_dc2_stamps():

@@ -289,7 +289,7 @@ def test_full_arch_parity_b4():
     from debvader_amd.data import synthetic_stamps
 
     x, y = synthetic_stamps(4, seed=5)
-    _run_parity(vo.Arch(), B=4, seed=2, data=(x, y))
+    _run_parity(vo.Arch(), B=4, seed=2, data=(x, y), gate_matched=True)
 
 
 def test_deeper_128px_arch_parity():
