@@ -125,10 +125,11 @@ def test_bad_architectures_are_rejected_with_a_message():
     with pytest.raises(DvError, match="kernel sizes 1 .. 5"):
         E.arch_counts(E.make_config(kernels=(3, 7, 3, 3)))
     assert E.arch_counts(E.make_config(kernels=(3, 5, 3, 3), dtype=1))["tensors"] == 64   # bf16 engine: 1 .. 5 too (round 5)
-    with pytest.raises(DvError, match="bands"):                 # 1 .. 15 bands (fp32), 1 .. 7 (bf16)
+    with pytest.raises(DvError, match="bands"):                 # 1 .. 15 bands on both engines (bf16: since round 6)
         E.arch_counts(E.make_config(input_shape=(59, 59, 16)))
+    assert E.arch_counts(E.make_config(input_shape=(59, 59, 8), dtype=1))["tensors"] == 64
     with pytest.raises(DvError, match="bands"):
-        E.arch_counts(E.make_config(input_shape=(59, 59, 8), dtype=1))
+        E.arch_counts(E.make_config(input_shape=(59, 59, 16), dtype=1))
     ten = E.make_config(input_shape=(59, 59, 10), latent_dim=10)   # 8 .. 15 bands and any latent size: accepted (fp32)
     from oracle import vae_oracle as vo
     assert E.arch_specs(ten) == vo.Arch((59, 59, 10), 10).param_specs() and E.arch_counts(ten)["tensors"] == 64
