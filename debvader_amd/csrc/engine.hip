@@ -362,6 +362,7 @@ struct dv_ctx {
   hipEvent_t ev_ready = nullptr, ev_join = nullptr, ev_buf[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_dec = nullptr, ev_enc = nullptr, ev_comm = nullptr, ev_small = nullptr, ev_small2 = nullptr;
   hipEvent_t ev_mid = nullptr;
+  hipEvent_t ev_wred = nullptr;   // weight-gradient stream -> reduction stream at a bucket boundary of the bf16 backward
   ncclComm_t comm = nullptr;
   // timing of the collectives (dv_comm_prof_*: the multi-rank bench's "comm time vs exposed comm time"): event pairs around
   // every collective on the comm stream, and around the main stream's waits for them
@@ -426,6 +427,8 @@ struct BfState {
   size_t slab_tail = 0;          // extra region behind the pool for the one launch queued on the main stream (never
                                  // touched by the weight-gradient stream, whose reductions may lag behind the main stream)
   dv::WRedBatch wred;            // their reductions, all in one launch at the end of the pass (bf_flush_wred)
+  bool red_pending = false;      // a bucket boundary of this pass queued its slab sums on the REDUCTION stream: the pool must
+                                 // not be rewound under them (bf_wgrad's pool-full path waits for that stream first)
   std::vector<BfW> enc_w, dec_w;
   BfW head_w;
   std::vector<dv::BCastDesc> descs;
@@ -3006,6 +3009,7 @@ static int ctx_build(dv_ctx* c, int world, int rank, const void* unique_id) {
   DV_HIP(hipEventCreateWithFlags(&c->ev_small, comm_gate_event_flags()));
   DV_HIP(hipEventCreateWithFlags(&c->ev_small2, sync_event_flags()));
   DV_HIP(hipEventCreateWithFlags(&c->ev_mid, comm_gate_event_flags()));
+  DV_HIP(hipEventCreateWithFlags(&c->ev_wred, sync_event_flags()));
   DV_HIP(hipMalloc((void**)&c->red_dev, 4096 * sizeof(float)));
   if (world == 1 && getenv("DV_FORCE_COMM")) {
     // test hook: a one-rank communicator, so that the collective code paths (streams, events, in-place all-reduces)
@@ -3101,6 +3105,7 @@ int dv_ctx_destroy(dv_ctx* c) {
   if (c->ev_small) (void)hipEventDestroy(c->ev_small);
   if (c->ev_small2) (void)hipEventDestroy(c->ev_small2);
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
+  if (c->ev_wred) (void)hipEventDestroy(c->ev_wred);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_red) (void)hipEventDestroy(c->ev_red);

@@ -391,16 +391,47 @@ static hipStream_t bf_wstream(dv_model* m) {
   return (m->overlap_wgrad && !m->prof_on && m->ctx->aux_stream) ? m->ctx->aux_stream : m->ctx->stream;
 }
 // queues the reductions registered so far (one launch) on the weight-gradient stream and empties the slab pool
-static int bf_flush_wred(dv_model* m) {
+// rs: the stream the sums run on.  The weight-gradient stream itself (default): the pool is rewound behind them.  The
+// REDUCTION stream (bucket boundaries, round 6): the caller has ordered it behind the launches registered so far; the pool
+// is NOT rewound - the later launches of the pass keep filling it - so that the sums do not sit in the weight-gradient
+// stream's queue, which is the stream the END of a pass waits for (two boundaries x ~45 us of sums per pass)
+static int bf_flush_wred(dv_model* m, hipStream_t rs = nullptr) {
   BfState& bf = m->bf;
+  hipStream_t wst = bf_wstream(m);
+  if (!rs) rs = wst;
+  if (rs == wst && bf.red_pending) {
+    // the pool is about to be rewound: sums that an earlier boundary queued on the reduction stream must have read it
+    DV_HIP(hipEventRecord(m->ctx->ev_red, m->ctx->red_stream));
+    DV_HIP(hipStreamWaitEvent(wst, m->ctx->ev_red, 0));
+    bf.red_pending = false;
+  }
   if (bf.wred.count > 0) {
-    hipStream_t st = bf_wstream(m);
-    ProfScope ps(m, 2, st);
-    DV_TRY(launch_reduce_partials_batch(bf.wred, st));
+    ProfScope ps(m, 2, rs);
+    DV_TRY(launch_reduce_partials_batch(bf.wred, rs));
   }
   bf.wred.count = 0;
-  bf.slab_off = 0;
+  if (rs == wst) bf.slab_off = 0;
+  else bf.red_pending = true;
   return OK;
+}
+
+// the stream a bucket boundary's sums go to: the reduction stream when the pass has one, ordered here behind everything
+// the weight-gradient stream and the main stream have queued (slabs; the fused epilogues' partials); else the
+// weight-gradient stream, which the caller has already ordered behind the main stream
+static bool bf_boundary_on_red(bool trunk_red) {
+  static const bool off = getenv("DV_BF_BOUNDARY_ON_WGRAD_STREAM") != nullptr;      // (A/B: the form until round 5)
+  return trunk_red && !off;
+}
+static hipStream_t bf_boundary_stream(dv_model* m, hipStream_t ws, hipStream_t s, bool trunk_red, int* status) {
+  *status = OK;
+  if (!bf_boundary_on_red(trunk_red)) return ws;
+  dv_ctx* cx = m->ctx;
+  if (hipEventRecord(cx->ev_wred, ws) != hipSuccess || hipStreamWaitEvent(cx->red_stream, cx->ev_wred, 0) != hipSuccess ||
+      hipStreamWaitEvent(cx->red_stream, cx->ev_ready, 0) != hipSuccess) {
+    *status = E_HIP;
+    return ws;
+  }
+  return cx->red_stream;
 }
 
 constexpr int BF_MAIN_SLOTS = 2;   // slab regions behind the pool for the launches queued on the main stream (layers 0, 1)
@@ -578,6 +609,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   bf.red.count = 0;
   bf.wred.count = 0;
   bf.slab_off = 0;
+  bf.red_pending = false;          // (the previous pass ended with the main stream joined to the reduction stream)
   m->ws_count = 0;
   m->main_marked = false;
   const int Hd = A.dec_out, f0 = A.cfg.filters[0], C2 = 2 * A.C;
@@ -753,13 +785,16 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     if ((cx->comm || early) && dg && A.n_train > A.n_enc_train) {
       if (ovl) {                                         // the partials of the fused epilogues come from the main stream
         DV_HIP(hipEventRecord(cx->ev_ready, s));
-        DV_HIP(hipStreamWaitEvent(ws, cx->ev_ready, 0));
+        if (!bf_boundary_on_red(trunk_red)) DV_HIP(hipStreamWaitEvent(ws, cx->ev_ready, 0));   // (else the reduction stream waits)
       }
-      DV_TRY(bf_flush_wred(m));
+      int bst = OK;
+      hipStream_t rs = bf_boundary_stream(m, ws, s, trunk_red, &bst);
+      DV_TRY(bst);
+      DV_TRY(bf_flush_wred(m, rs));
       {
-        ProfScope ps(m, 2, ws);
-        DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, A.C2p, C2, ws));
-        DV_TRY(launch_bf_reduce_batch(bf.red, ws));
+        ProfScope ps(m, 2, rs);
+        DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, A.C2p, C2, rs));
+        DV_TRY(launch_bf_reduce_batch(bf.red, rs));
       }
       bf.red.count = 0;
       head_cols_taken = true;
@@ -940,12 +975,15 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       if ((cx->comm || early) && split < A.n_enc_train) {
         if (ovl) {
           DV_HIP(hipEventRecord(cx->ev_ready, s));
-          DV_HIP(hipStreamWaitEvent(ws, cx->ev_ready, 0));
+          if (!bf_boundary_on_red(trunk_red)) DV_HIP(hipStreamWaitEvent(ws, cx->ev_ready, 0));
         }
-        DV_TRY(bf_flush_wred(m));
+        int bst = OK;
+        hipStream_t rs = bf_boundary_stream(m, ws, s, trunk_red, &bst);
+        DV_TRY(bst);
+        DV_TRY(bf_flush_wred(m, rs));
         {
-          ProfScope ps(m, 2, ws);
-          DV_TRY(launch_bf_reduce_batch(bf.red, ws));
+          ProfScope ps(m, 2, rs);
+          DV_TRY(launch_bf_reduce_batch(bf.red, rs));
         }
         bf.red.count = 0;
         DV_HIP(hipEventRecord(cx->ev_mid, ws));
