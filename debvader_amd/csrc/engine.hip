@@ -411,6 +411,11 @@ struct BfState {
   int desc_off[4] = {0, 0, 0, 0};
   int NBp = 0;                   // stamps of the current pass padded to 16
   void* xh = nullptr;            // normalised input [HW][NBp][16]
+  // Round 6: the input of the NEXT training step is normalised ahead, on the comm stream, into the other of two buffers
+  // (bn_prefetch: batch statistics -> bn_finalize -> bf_input; 26 us that used to open every step on the main stream).
+  // `xh` is the buffer of the step in flight (its first conv and, at the very end, its first-layer weight gradient read it).
+  void* xh_alt = nullptr;
+  bool in_pre = false;           // xh_alt holds the prefetched batch, bnstate / the moving statistics are already its
   std::vector<void*> enc_u, enc_a, dec_u, dec_a;
   void* dec_in = nullptr;        // decoder trunk output as a stamp-inner tensor [w0*w0][NBp][f_last]
   float* tpre32 = nullptr;       // head conv output, fp32 [Hd*Hd][NBp][16]
@@ -525,6 +530,7 @@ struct dv_model {
   float* bn_pre_sums = nullptr;
   size_t bn_pre_part_elems = 0;
   bool bn_pre_valid = false;
+  bool bnpre_go_pending = false;   // bf16 engine: ev_bnpre_go is recorded behind the input kernel of this forward pass
   const float* bn_pre_x = nullptr;
   const int* bn_pre_idx = nullptr;   // device index vector the prefetched sums belong to (null: contiguous rows)
   int* idx_slots = nullptr;          // [4][Bc] device index vectors of queued train steps (filled on the comm stream)
@@ -1690,7 +1696,22 @@ static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first,
       // previous step: no reduction kernels and no latency-bound collective at the head of this step
       DV_TRY(main_waits_for_comm(m->ctx, m->ev_bnpre));
       sums = m->bn_pre_sums;
+      if (m->bf.in_pre) {
+        // bf16 engine: the prefetch also ran bn_finalize (moving statistics included) and the input kernel for this
+        // batch on the comm stream: nothing left to do here
+        if (!upd_moving) {
+          set_error("a prefetched training input met a step that does not update the moving statistics");
+          return E_STATE;
+        }
+        m->bn_pre_valid = false;
+        m->bnpre_go_pending = true;
+        return OK;
+      }
     } else {
+      if (m->bf.in_pre) {
+        set_error("the input prefetched for the next training step does not match the step that follows");
+        return E_STATE;
+      }
       int nblk = 0;
       ProfScope ps(m, 2, s);
       // one 16-float partial row per 1024 pixels (pointwise.hip BN_PIX_PER_BLOCK): checked BEFORE the launch writes them
@@ -1710,8 +1731,13 @@ static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first,
                               P + A.specs[2].off, P + A.specs[3].off, A.cfg.bn_eps, A.cfg.bn_momentum,
                               A.cfg.bn_moving_var_unbiased, training ? 1 : 0, upd_moving ? 1 : 0, m->bnstate, s));
   }
-  // the prefetched sums have been consumed: the comm stream may compute the next batch's into the same buffer
-  if (sums == m->bn_pre_sums) DV_HIP(hipEventRecord(m->ev_bnpre_go, s));
+  // the prefetched sums have been consumed: the comm stream may compute the next batch's into the same buffer (the bf16
+  // engine records this behind its input kernel instead, bf_encoder_forward: bnstate and the input buffers are part of
+  // what the next prefetch overwrites)
+  if (sums == m->bn_pre_sums) {
+    if (m->bf.on) m->bnpre_go_pending = true;
+    else DV_HIP(hipEventRecord(m->ev_bnpre_go, s));
+  }
   return OK;
 }
 
@@ -2302,7 +2328,7 @@ static int check_step_args(dv_model* m, int slot, const int32_t* idx, int64_t fi
 // Batch sums of the input BatchNorm for a batch that is about to be (idx_host != null: the step being queued, whose
 // index vector is copied to idx_dev on the comm stream first) or will next be (contiguous rows from `first`) trained
 // on, computed on the comm stream while the previous step still runs.
-static int bn_prefetch(dv_model* m, const float* x, int64_t first, int NB, int* idx_dev = nullptr,
+static int bn_prefetch(dv_model* m, const float* x, int64_t first, int NB, int Bg, int* idx_dev = nullptr,
                        const int32_t* idx_host = nullptr) {
   const Arch& A = m->A;
   dv_ctx* c = m->ctx;
@@ -2320,6 +2346,17 @@ static int bn_prefetch(dv_model* m, const float* x, int64_t first, int NB, int* 
   DV_TRY(launch_bn_stats(x, idx_dev, (int)first, NB, HW, A.C, m->bn_pre_part, &nblk, c->comm_stream));
   DV_TRY(launch_reduce_rows_f64(m->bn_pre_part, nblk, 2 * DV_BN_MAXC, m->bn_pre_sums, 1.0f, c->comm_stream));
   if (c->comm) DV_TRY(comm_allreduce(c, m->bn_pre_sums, 2 * DV_BN_MAXC));
+  static const bool no_input_ahead = getenv("DV_NO_INPUT_AHEAD") != nullptr;
+  if (m->bf.on && m->bf.xh_alt && !no_input_ahead) {
+    // bf16 engine: the whole head of the step - statistics -> bn_finalize (this is a TRAINING step: batch statistics, moving
+    // statistics updated) -> normalised stamp-inner input - runs here, into the buffer the step in flight does not read
+    float* P = m->P;
+    DV_TRY(launch_bn_finalize(m->bn_pre_sums, (float)((double)Bg * HW), A.C, P + A.specs[0].off, P + A.specs[1].off,
+                              P + A.specs[2].off, P + A.specs[3].off, A.cfg.bn_eps, A.cfg.bn_momentum,
+                              A.cfg.bn_moving_var_unbiased, 1, 1, m->bnstate, c->comm_stream));
+    DV_TRY(launch_bf_input(x, idx_dev, (int)first, NB, (NB + 15) & ~15, HW, A.C, m->bnstate, m->bf.xh_alt, c->comm_stream));
+    m->bf.in_pre = true;
+  }
   DV_HIP(hipEventRecord(m->ev_bnpre, c->comm_stream));
   m->bn_pre_valid = true;
   m->bn_pre_x = x;
@@ -2342,7 +2379,7 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
       // host reaches while the previous step is still running (steps are queued two ahead) - the forward pass below
       // then starts with bn_finalize instead of a statistics pass over the batch
       int* slotp = m->idx_slots + (size_t)(m->idx_slot_next++ & 3) * m->Bc;
-      DV_TRY(bn_prefetch(m, ds.x, first, B, slotp, idx_host));
+      DV_TRY(bn_prefetch(m, ds.x, first, B, Bg, slotp, idx_host));
       idx = slotp;
     } else {
       DV_HIP(hipMemcpyAsync(m->idx_dev, idx_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
@@ -2370,7 +2407,7 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
       DV_HIP(hipEventRecord(m->ctx->ev_small, s));
       DV_HIP(hipStreamWaitEvent(m->ctx->comm_stream, m->ctx->ev_small, 0));
     }
-    DV_TRY(bn_prefetch(m, ds.x, m->hint_next_first, B));
+    DV_TRY(bn_prefetch(m, ds.x, m->hint_next_first, B, Bg));
     m->hint_next_first = -1;
   }
   if (mode == MODE_TRAIN) begin_update(m);
@@ -3597,6 +3634,10 @@ int dv_data_upload(dv_model* m, int32_t slot, const float* x, const float* y, in
   }
   DV_TRY(dv_data_free(m, slot));
   m->bn_pre_valid = false;     // prefetched batch sums refer to the old rows
+  if (m->bf.in_pre) {
+    set_error("data uploaded while the input of a queued training step was prefetched");
+    return DV_E_STATE;
+  }
   size_t bytes = (size_t)n * A.H * A.H * A.C * sizeof(float);
   DataSlot& d = m->slots[slot];
   hipError_t e = hipMalloc((void**)&d.x, bytes);

@@ -40,6 +40,7 @@ static int bf_alloc(dv_model* m) {
   };
   const size_t HW = (size_t)A.H * A.H;
   DV_TRY(balloc(&bf.xh, HW * Bp * 16 * 2));
+  DV_TRY(balloc(&bf.xh_alt, HW * Bp * 16 * 2));
   // zero page: as long as ONE pixel's [Bp][C] block of the widest conv layer, so that the row-strip kernel can read an
   // out-of-image block at its usual lane offsets from a uniform base (bconv_row_kernel); >= 1 KiB for the DMA kernels
   size_t zero_bytes = 1024;
@@ -254,9 +255,16 @@ static int bf_encoder_forward(dv_model* m, const float* xsrc, const int* idx, in
   float* P = m->P;
   bf.NBp = (NB + 15) & ~15;
   DV_TRY(bf_refresh_weights(m, s));
-  {
+  if (bf.in_pre) {
+    std::swap(bf.xh, bf.xh_alt);           // normalised ahead on the comm stream (bn_prefetch); bn_prepare has waited for it
+    bf.in_pre = false;
+  } else {
     ProfScope ps(m, 2);
     DV_TRY(launch_bf_input(xsrc, idx, first, NB, bf.NBp, A.H * A.H, A.C, m->bnstate, bf.xh, s));
+  }
+  if (m->bnpre_go_pending) {               // bnstate, the sums and the other input buffer may be overwritten from here on
+    DV_HIP(hipEventRecord(m->ev_bnpre_go, s));
+    m->bnpre_go_pending = false;
   }
   const void* in = bf.xh;
   for (int j = 0; j < 2 * A.L; ++j) {
