@@ -155,7 +155,7 @@ def _git_head():
 def _pmc_traffic():
     """HBM bytes per step and kernel family from the committed rocprofv3 PMC passes of this round (FETCH_SIZE doubled as
     the micro-architecture guide prescribes for gfx950; tools/pmc_traffic.py spells out the collection)."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as fh:
@@ -217,8 +217,8 @@ def secondary_entries(E, ctx, synthetic_stamps, quick: bool):
     alg_bytes = ACT_ELEMS_PER_STAMP * 2 * TRAIN_PASSES * B + PARAM_STEP_BYTES
     pmc, src = _pmc_traffic()
     out["bf16_train"] = {
-        "workload": "BASELINE configs[2] per GPU: same model, bf16 storage + bf16 MFMA operands, fp32 accumulation / master "
-                    "weights / dense trunk / head, batch 256",
+        "workload": "BASELINE configs[2] per GPU: same model, bf16 storage + bf16 MFMA operands (conv stacks and, since r06, "
+                    "the two large Dense layers of the trunk), fp32 accumulation / master weights / sampler / head, batch 256",
         "value": B * steps / dt, "unit": "stamps/s", "ms_per_step": ms, "dtype": "bf16", "last_loss": scal["loss"],
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

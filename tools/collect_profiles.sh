@@ -5,7 +5,7 @@
 # PMC passes (HBM traffic: FETCH_SIZE and WRITE_SIZE in separate runs; matrix-pipe occupancy) - counters always in runs
 # of their own with --kernel-trace only, the program itself (python3 ...) right behind "--".
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
