@@ -271,6 +271,10 @@ struct WGradParams {
   unsigned div_hw_m, div_hw_s1, div_hw_s2, div_w_m, div_w_s1, div_w_s2;
 };
 int launch_wgrad(const WGradParams& p, hipStream_t s);
+// Dense kernel gradient G[i][j] = sum_b X[b][i] * Y[b][j] (fp32 rows X [NB][ldx], Y [NB][ldy]; Dense layers of the trunk,
+// model.py:96-98,114-117): one pass, written once, no slabs (wgrad.hip, round 6)
+int launch_dense_wgrad_tn(const float* X, int ldx, const float* Y, int ldy, int NB, int I, int J, float* G, int ldg,
+                          hipStream_t s);
 
 // Strip form for the high-resolution few-channel layers (wgrad_strip.hip)
 struct WStripParams {

@@ -1289,6 +1289,24 @@ static int wgrad_impl(dv_model* m, hipStream_t ws, const float* X, int Hx, int C
   dv_ctx* cx = m->ctx;
   const double wflops = 2.0 * NB * Hy * Hy * (single_tap ? 1.0 : (double)(ksz * ksz)) * (double)(X == m->xn ? m->A.C : Cx) *
                         (double)(out == m->Ghs ? 2 * m->A.C : Cy);
+  {
+    // Dense layers (one tap, one pixel: out[cx][cy] = sum over stamps): a stamp-major one-pass kernel that writes the
+    // gradient itself - no slab region, no slab sum - exists (dense_wgrad_tn_kernel, round 6), is parity-green, and is NOT
+    // the default: in the overlapped step it is slower than the tiled kernel + slab sum it would replace (fp32 4.594 ->
+    // 4.630 ms, bf16 1.882 -> 1.910 ms, alternating runs, profiles/r06_exp_dense_wgrad_onepass.txt): 576 - 1152 waves that
+    // each walk all 256 stamps as one dependent chain hold their CUs longer than 160 short-K tiles do.  Opt-in for the A/B.
+    static const bool onepass = getenv("DV_DENSE_WGRAD_ONEPASS") != nullptr;
+    if (single_tap && Hx == 1 && Hy == 1 && sx == 1 && cpad == creal && !fz && !g_force_v1 && !g_no_special && onepass &&
+        !(Cx & 1) && !(Cy & 3)) {
+      {
+        ProfScope ps(m, 1, ws, PF_WGRAD, wflops);
+        DV_TRY(launch_dense_wgrad_tn(X, Cx, Y, Cy, NB, Cx, Cy, out, Cy, ws));
+      }
+      m->ws_last_rs = ws;
+      m->ws_last = -1;
+      return OK;
+    }
+  }
   // the regions rotate whenever weight-gradient work may be in flight on the aux stream, also for a launch that is
   // itself queued on the main stream (which then reduces its own slabs: no stream hop)
   const bool rot = m->wstream && m->wstream != cx->stream && m->arena_reduce && cx->red_stream && m->ev_wk[0];

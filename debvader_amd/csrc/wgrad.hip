@@ -414,4 +414,85 @@ int launch_reduce_partials(const float* part, float* out, int nsplit, long slab_
   return OK;
 }
 
+// ---- dense kernel gradients -----------------------------------------------------------------------------------------
+// G[i][j] = sum_b X[b][i] * Y[b][j]: the contraction index is the stamp and both operands are stamp-major, which is exactly
+// what v_mfma_f32_16x16x4_f32 wants - its A operand is one value per lane, A[row = lane % 16][k = lane / 16], so the lanes
+// of a 16-lane group read CONSECUTIVE columns of one stamp row.  A lane loads a float2 of X and a float4 of Y per four
+// stamps (columns i0 + 2 (lane % 16) + {0, 1} and j0 + 4 (lane % 16) + {0 .. 3}); component q of such a load is the
+// operand of a "virtual" 16-row block made of every second / fourth column, so one pair of loads feeds 2 x 4 MFMAs and the
+// four accumulators that share a row block are four consecutive output columns: one 16-byte store per lane.  A wave owns
+// 32 x 64 outputs and walks all stamps, four steps in flight; no LDS, no slabs, one fixed summation order.  The tiled
+// wgrad_kernel took 28 us for each of the two 4096 x 560 layers of the 59-px net at 256 stamps (+ a slab-sum launch).
+constexpr int DW_PF = 4;
+__global__ __launch_bounds__(256) void dense_wgrad_tn_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ Y,
+                                                             int ldy, int NB, int I, int J, float* __restrict__ G, int ldg) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int JT = (J + 63) >> 6, IT = (I + 31) >> 5;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= IT * JT) return;
+  const int it = tile / JT, jt = tile - it * JT;
+  const int lr = lane & 15, kq = lane >> 4;
+  const int ic = it * 32 + 2 * lr, jc = jt * 64 + 4 * lr;        // first column of this lane's X pair / Y quad
+  const bool xin = ic + 1 < I, xhalf = ic < I, yin = jc + 3 < J;  // (I even, J a multiple of 4: a quad is in or out)
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load = [&](int m0, f32x2& x, f32x4& y) {
+    const int m = m0 + kq;
+    x = f32x2{0.f, 0.f};
+    y = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m < NB) {
+      if (xin) x = *reinterpret_cast<const f32x2*>(X + (size_t)m * ldx + ic);
+      else if (xhalf) x[0] = X[(size_t)m * ldx + ic];
+      if (yin) y = *reinterpret_cast<const f32x4*>(Y + (size_t)m * ldy + jc);
+    }
+  };
+  f32x2 rx[DW_PF];
+  f32x4 ry[DW_PF];
+#pragma unroll
+  for (int q = 0; q < DW_PF; ++q) load(4 * q, rx[q], ry[q]);
+  for (int m0 = 0; m0 < NB; m0 += 4 * DW_PF) {
+#pragma unroll
+    for (int q = 0; q < DW_PF; ++q) {
+      if (m0 + 4 * q < NB) {
+        const f32x2 x = rx[q];
+        const f32x4 y = ry[q];
+        load(m0 + 4 * (q + DW_PF), rx[q], ry[q]);                 // (past the last stamp: zeros, never used)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[a], y[b], acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+  // accumulator (a, b), register t: row 4 (lane / 16) + t of virtual block a = column i0 + 2 (4 (lane / 16) + t) + a of G's
+  // rows, column lane % 16 of virtual block b = output column j0 + 4 (lane % 16) + b
+  if (!yin) return;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = it * 32 + 2 * (4 * kq + t) + a;
+      if (i < I)
+        *reinterpret_cast<f32x4*>(G + (size_t)i * ldg + jc) = f32x4{acc[a][0][t], acc[a][1][t], acc[a][2][t], acc[a][3][t]};
+    }
+}
+
+int launch_dense_wgrad_tn(const float* X, int ldx, const float* Y, int ldy, int NB, int I, int J, float* G, int ldg,
+                          hipStream_t s) {
+  if (NB < 1 || I < 1 || J < 4 || (I & 1) || (J & 3) || (ldx & 1) || (ldy & 3) || (ldg & 3)) {
+    set_error("dense_wgrad_tn: widths must be even (X) / multiples of 4 (Y, G) (I %d, J %d, strides %d / %d / %d)", I, J, ldx,
+              ldy, ldg);
+    return E_INVALID;
+  }
+  const int tiles = ((I + 31) / 32) * ((J + 63) / 64);
+  hipLaunchKernelGGL(dense_wgrad_tn_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, X, ldx, Y, ldy, NB, I, J, G,
+                     ldg);
+  DV_HIP(hipGetLastError());
+  return OK;
+}
+
 }  // namespace dv

@@ -148,8 +148,12 @@ def run_drop_in(ctx=None, n_cutouts=131072, chunk=8192, dtype=0, field=None, til
         return r
 
     eng.infer_cutouts_keep = timed
-    res = db.deblend_field(dist[:min(2 * chunk, n_cutouts)])     # warm-up: kernel attributes, the pinned transfer ring
-    assert len(res) == min(2 * chunk, n_cutouts)
+    # warm-up with a call of the size that is timed: kernel attributes, the pinned transfer ring, and the result arrays'
+    # blocks (engine._HostPool) - a smaller warm-up leaves smaller blocks behind whose ageing out of the pool (an munmap of
+    # 2.7 GB, ~0.1 s) then falls into the timed calls (tools/probes/drop_in_calls.py: 258, 258, 258, 383, 258, 258 ms per call)
+    nw = min(per_call, n_cutouts)
+    res = db.deblend_field(dist[:nw])
+    assert len(res) == nw
     del res
     t_eng[0] = 0.0
     checksum, n_pass = 0.0, 0
@@ -204,6 +208,7 @@ def run_drop_in(ctx=None, n_cutouts=131072, chunk=8192, dtype=0, field=None, til
         "definition_changed_in": "r05: until r04 this entry timed extract_cutouts -> deblend (tools/field_cutouts.py::cutouts_run, "
                                  "43.7 k stamps/s there); since r05 it times DeblendField.deblend_field per 32768 galaxies - "
                                  "not like for like",
+        "steady_state": "one untimed call of the same size first: every timed call reuses the previous call's result blocks",
         "value_without_result_pool": min(per_call, n) / t_nopool,
         "value_without_result_pool_note": "one call of the same size with DV_HOST_POOL_GB=0 semantics: fresh np.empty result arrays",
         "engine_call_stamps_per_s": n / t_eng[0] if t_eng[0] > 0 else None,
