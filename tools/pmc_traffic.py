@@ -12,6 +12,7 @@ import csv, glob, json, sys
 
 FAMILIES = (("bconv_kernel / bconv_uni_kernel", ("bconv_",)),
             ("bwgrad_kernel", ("bwgrad_kernel",)),
+            ("bgemm_kernel / bgemm_tn_kernel (dense trunk)", ("bgemm_",)),
             ("wino_wgrad family (wino_wgrad, presum, finish)", ("wino_wgrad",)),
             ("wino_conv_kernel (+ wino_weights_kernel)", ("wino_conv", "wino_weights")),
             ("gconv family (gconv2, gconv_s2, gconv_strip, gconv_strip8, gconv, splitk_finish)", ("gconv", "splitk_finish")),
