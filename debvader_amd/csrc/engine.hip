@@ -23,6 +23,9 @@
 #include <mutex>
 #include <set>
 #include <vector>
+#ifdef DV_DEBUG_EXPORTS
+#include <functional>
+#endif
 
 #include "../../include/debvader_hip.h"
 #ifdef DV_DEBUG_EXPORTS
@@ -65,6 +68,15 @@ struct Spec {
   size_t count;
   size_t off;  // offset in the flat parameter buffer (floats)
 };
+
+// DV_EXP_SKIP_TAIL=<bits> (MEASUREMENT switch, wrong results): what the serial seams of a train step cost.  1: the tail of
+// the shallow gradient bucket (slab / partial sums behind the last weight gradient, first-conv gradients, Adam of the last
+// range, BN fold, bf16 cast / Winograd transform).  2: the loss sums and the head's bias column sums on the main stream
+// between the forward and the backward pass.  4 (fp32): bn_finalize + bn_apply at the head of the step.
+static int exp_skip_tail() {
+  static const int v = DV_EXP_SWITCH("DV_EXP_SKIP_TAIL");
+  return v;
+}
 
 // DV_EXP_SKIP_SMALL=1 (a MEASUREMENT switch, results are wrong): the elementwise neighbours of the dense trunk that a fused
 // trunk would absorb (split-K finish, the two PReLU forwards, the narrow dense data gradient, the bias column sums, the
@@ -415,6 +427,7 @@ struct BfState {
   // (bn_prefetch: batch statistics -> bn_finalize -> bf_input; 26 us that used to open every step on the main stream).
   // `xh` is the buffer of the step in flight (its first conv and, at the very end, its first-layer weight gradient read it).
   void* xh_alt = nullptr;
+  bool head_marked = false;      // bf_backward recorded the main stream behind the head kernel: the head's weight gradient waits for that record
   bool in_pre = false;           // xh_alt holds the prefetched batch, bnstate / the moving statistics are already its
   std::vector<void*> enc_u, enc_a, dec_u, dec_a;
   void* dec_in = nullptr;        // decoder trunk output as a stamp-inner tensor [w0*w0][NBp][f_last]
@@ -554,6 +567,14 @@ struct dv_model {
   int ws_nreg = 3;               // slab regions: 3 (rotating, with waits) or one per launch of a step
   size_t ws_region_cap = 0;
   int ws_count = 0;              // weight-gradient launches of this step so far
+  // bf16 train / gradient steps with a reduction stream: the loss sums (and the head's bias column sums) are queued there
+  // at the start of the backward pass instead of on the main stream between the two passes (bf_backward)
+  float* ws_head = nullptr;      // head partials of such a step (ws3 stays the main stream's)
+  bool defer_loss_sums = false, loss_pending = false;
+  int loss_blocks = 0, loss_NB = 0;
+#ifdef DV_DEBUG_EXPORTS
+  std::vector<std::function<int()>> exp_deferred;   // DV_EXP_DEFER_WGRAD (MEASUREMENT only): launches held back for the next forward pass
+#endif
   hipStream_t ws_last_rs = nullptr;
   bool step_pool_tried = false;
   size_t max_act_elems = 0;      // Bc * largest per-stamp activation
@@ -1743,7 +1764,8 @@ static int bn_prepare(dv_model* m, const float* xsrc, const int* idx, int first,
     }
     m->bn_pre_valid = false;
   }
-  {
+  static int exp_calls = 0;
+  if (!((exp_skip_tail() & 4) && ++exp_calls > 3)) {
     ProfScope ps(m, 2, s);
     DV_TRY(launch_bn_finalize(sums, (float)((double)Bg * HW), A.C, P + A.specs[0].off, P + A.specs[1].off,
                               P + A.specs[2].off, P + A.specs[3].off, A.cfg.bn_eps, A.cfg.bn_momentum,
@@ -1788,7 +1810,8 @@ static int encoder_forward(dv_model* m, const float* xsrc, const int* idx, int f
   const int HW = A.H * A.H;
   float* P = m->P;
   float* xn = LANE(m->xn, (size_t)HW * A.C0p);
-  {
+  static int exp_calls = 0;
+  if (!((exp_skip_tail() & 4) && ++exp_calls > 3)) {
     ProfScope ps(m, 2);
     DV_TRY(launch_bn_apply(xsrc, idx ? idx + m->b0 : nullptr, first + m->b0, NB, HW, A.C, A.C0p, m->bnstate, xn, s));
   }
@@ -1938,6 +1961,17 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
   hipStream_t s = cx->stream;
   m->cur_seed = seed;
   if (!m->bf.on) DV_TRY(wino_refresh_all(m, s));   // before the lanes split: both read the same transformed weights
+#ifdef DV_DEBUG_EXPORTS
+  if (!m->exp_deferred.empty()) {                  // DV_EXP_DEFER_WGRAD: see backward()
+    if (ysrc && want_grad && cx->aux_stream) {
+      m->wstream = cx->aux_stream;
+      m->main_marked = false;
+      for (auto& f : m->exp_deferred) DV_TRY(f());
+      m->wstream = s;
+    }
+    m->exp_deferred.clear();
+  }
+#endif
   if (run_encoder) DV_TRY(bn_prepare(m, xsrc, idx, first, NB, Bg, training, upd_moving));
   if (eps_host) DV_TRY(copy_rows(m->eps, A.dp, eps_host, A.d, A.d, NB, hipMemcpyHostToDevice, s));
   const long head_blocks_total = ((long)NB * A.dec_out * A.dec_out + 255) / 256 + 2;
@@ -2003,7 +2037,11 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
   m->cs = nullptr;
   if (st != OK) return st;
   const int blk0 = blk_done, blk1 = 0;
-  if (ysrc) {
+  if (ysrc && m->defer_loss_sums) {
+    m->loss_blocks = blk0 + blk1;
+    m->loss_NB = NB;
+    m->loss_pending = true;
+  } else if (ysrc && !(exp_skip_tail() & 2)) {
     ProfScope ps(m, 2, s);
     DV_TRY(launch_reduce_rows_f64(m->ws3, blk0 + blk1, 2, m->scal, 1.0f, s));
     DV_TRY(launch_reduce_rows_f64(m->kl, NB, 1, m->scal + 2, 1.0f, s));
@@ -2091,16 +2129,31 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
   } while (0)
   const int Hd = A.dec_out, f0 = A.cfg.filters[0], C2 = 2 * A.C, C2p = A.C2p;
   // head conv (stored with C2p output channels; the pad channels carry zeros)
+#ifdef DV_DEBUG_EXPORTS
+  // DV_EXP_DEFER_WGRAD=n (MEASUREMENT only: the optimizer runs before these gradients exist): the kernel gradients of the
+  // head conv and of the last n transposed convs are held back and queued on the weight-gradient stream at the start of the
+  // NEXT forward pass, whose encoder has no second stream beside it - what a cross-step pipeline of the decoder's late
+  // layers could gain
+  static const int exp_defer = DV_EXP_SWITCH("DV_EXP_DEFER_WGRAD");
+#else
+  [[maybe_unused]] constexpr int exp_defer = 0;
+#endif
   if (dg) {
     hipStream_t ws = m->wstream ? m->wstream : s;
-    DV_TRY(wgrad(m, m->dec_a[2 * A.L - 1], Hd, f0, cur, Hd, C2p, NB, 1, 1, false, m->Ghs, f0, f0));
-    DV_TRY(wgrad_result_ready(m, ws));
-    {
+    auto head_wg = [=]() -> int {
+      DV_TRY(wgrad(m, m->dec_a[2 * A.L - 1], Hd, f0, cur, Hd, C2p, NB, 1, 1, false, m->Ghs, f0, f0));
+      DV_TRY(wgrad_result_ready(m, ws));
       ProfScope ps(m, 2, ws);
       DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, C2p, C2, ws));
-    }
+      return OK;
+    };
+#ifdef DV_DEBUG_EXPORTS
+    if (exp_defer > 0 && no_reuse && ovl) m->exp_deferred.push_back(head_wg);
+    else
+#endif
+      DV_TRY(head_wg());
     DV_TRY(wgrad_read());
-    DV_TRY(bias_grad_colsum(m, cur, (long)NB * Hd * Hd, C2p, C2, A.head_b()));
+    if (!(exp_skip_tail() & 2)) DV_TRY(bias_grad_colsum(m, cur, (long)NB * Hd * Hd, C2p, C2, A.head_b()));
   }
   bool cur_is_du = false;   // true when the data-gradient launch already applied the PReLU backward of `cur`'s layer
   {
@@ -2121,8 +2174,16 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
     m->du_dec[j] = cur;
     const float* xin = j == 0 ? m->dec_ar : m->dec_a[j - 1];
     if (dg) {
-      DV_TRY(wgrad(m, cur, hout, cout, xin, hin, cin, NB, st, pb, false, G + A.specs[A.dec_k(j)].off, cout, cout, nullptr,
-                   false, ksz));
+      float* const gk = G + A.specs[A.dec_k(j)].off;
+      const float* const dy = cur;
+      auto layer_wg = [=]() -> int {
+        return wgrad(m, dy, hout, cout, xin, hin, cin, NB, st, pb, false, gk, cout, cout, nullptr, false, ksz);
+      };
+#ifdef DV_DEBUG_EXPORTS
+      if (exp_defer > 0 && j >= 2 * A.L - exp_defer && no_reuse && ovl) m->exp_deferred.push_back(layer_wg);
+      else
+#endif
+        DV_TRY(layer_wg());
       DV_TRY(wgrad_read());
     }
     // d(input) = strided conv of d(pre-activation) with K[kh,kw,co,ci] (rows (tap,co), cols ci: k-major)
@@ -2224,6 +2285,7 @@ static int backward(dv_model* m, int NB, int Bg, const float* xsrc, const int* i
       FuseBwd f0{m->enc_u[0], A.enc_al(0), A.enc_b(0), true};
       DV_TRY(wgrad(m, xin, hin, A.C0p, cur, hout, cout, NB, st, pb, false, m->G0s, A.C0p, A.C0p, fuse0 ? &f0 : nullptr,
                    last_on_main, ksz));
+      if (exp_skip_tail() & 1) break;
       DV_TRY(wgrad_result_ready(m, ws));
       ProfScope ps(m, 2, ws);
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
@@ -2303,6 +2365,11 @@ static void begin_update(dv_model* m) {     // step counter and bias-corrected s
 // what is left of the update at the end of the step: the ranges below adam_done_from, then the derived tensors
 static int optimizer_step(dv_model* m) {
   const Arch& A = m->A;
+  if (exp_skip_tail() & 1) {
+    m->bf.dirty_mask = 0;
+    m->bf.early_cast = 0;
+    return OK;
+  }
   DV_TRY(adam_range(m, 0, std::min(m->adam_done_from, A.n_train), m->ctx->stream));
   m->param_epoch++;
   if (m->opt_enc) DV_TRY(refresh_w1p(m));
@@ -2410,11 +2477,18 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   // Philox stream: one counter row per (rank-local) stamp; ranks are separated through the stream id
   // loc / scale of a gradient or train step are only written on request (dv_model_set_keep_outputs: the parity
   // tests read them back) - 42 MB of stores per 256-stamp step that training has no reader for
-  DV_TRY(forward_all(m, ds.x, ds.y, idx, (int)first, B, Bg, training, mode == MODE_TRAIN, bwd, eps_host, seed,
-                     (unsigned)m->ctx->rank, 0u, false, bwd, !bwd || m->keep_outputs));
+  static const bool sums_on_main = getenv("DV_BF_SUMS_ON_MAIN") != nullptr;     // (A/B: the form until round 6)
+  m->defer_loss_sums = bwd && m->bf.on && bf_wstream(m) != s && m->arena_reduce && m->ctx->red_stream != nullptr && m->ws_head &&
+                       !sums_on_main;
+  const int fst = forward_all(m, ds.x, ds.y, idx, (int)first, B, Bg, training, mode == MODE_TRAIN, bwd, eps_host, seed,
+                              (unsigned)m->ctx->rank, 0u, false, bwd, !bwd || m->keep_outputs);
+  const bool sums_deferred = m->defer_loss_sums;
+  m->defer_loss_sums = false;
+  DV_TRY(fst);
   // the loss sums are only read after the step: with a backward pass the main stream joins the comm stream behind
   // the last gradient bucket anyway, so it does not stop here for this latency-bound collective
-  DV_TRY(allreduce_small(m->ctx, m->scal, 4, !bwd));
+  // (sums_deferred: sums and collective are queued by bf_backward, on the reduction and the comm stream)
+  if (!sums_deferred) DV_TRY(allreduce_small(m->ctx, m->scal, 4, !bwd));
   if (mode == MODE_TRAIN && m->hint_next_first >= 0 && !m->prof_on) {
     // fp32 engine: the statistics pass of the NEXT batch (35 us, HBM-bound, comm stream) is held until this forward pass
     // has drained: beside the forward's persistent one-workgroup-per-CU Winograd kernels it takes CU slots one of their
@@ -3410,6 +3484,7 @@ int dv_model_create(dv_ctx* ctx, const dv_config* cfg, dv_model** out) {
   // be derived from other users of the buffer and overran silently above ~19k stamps of 59 px)
   m->ws3_elems = std::max(m->ws3_elems, ((Bc * (size_t)A.H * A.H + 1023) / 1024 + 1) * (2 * DV_BN_MAXC));
   ALLOC(m->ws3, m->ws3_elems);
+  if (bf16) ALLOC(m->ws_head, m->ws3_elems);
   ALLOC(m->scal, 16);
   ALLOC(m->zero_page, 64);
   ALLOC(m->bnstate, 4 * DV_BN_MAXC);

@@ -370,7 +370,7 @@ static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int firs
   hp.dt = want_grad ? bf.dt : nullptr;
   hp.loc = want_out ? m->loc : nullptr;
   hp.scale = want_out ? m->scale : nullptr;
-  hp.part = m->ws3 + (size_t)part_block0 * 2;
+  hp.part = (m->defer_loss_sums ? m->ws_head : m->ws3) + (size_t)part_block0 * 2;
   hp.NB = NB;
   hp.NBp = bf.NBp;
   hp.Hd = A.dec_out;
@@ -474,9 +474,10 @@ static int bf_wgrad(dv_model* m, const void* X, int Hx, int Cx, const void* Y, i
   hipStream_t st = on_main ? m->ctx->stream : bf_wstream(m);
   static const bool exp_no_events = DV_EXP_SWITCH("DV_EXP_NO_WGRAD_EVENTS") != 0;   // MEASUREMENT only (races: use with DV_EXP_SKIP_WGRAD)
   if (st != m->ctx->stream && !exp_no_events) {
-    DV_HIP(hipEventRecord(m->ctx->ev_ready, m->ctx->stream));
+    if (!bf.head_marked) DV_HIP(hipEventRecord(m->ctx->ev_ready, m->ctx->stream));   // (else recorded at the head of the pass)
     DV_HIP(hipStreamWaitEvent(st, m->ctx->ev_ready, 0));
   }
+  bf.head_marked = false;
   {
     const double cx_alg = X == bf.xh ? m->A.C : Cx, cy_alg = out == m->Ghs ? 2 * m->A.C : Cy;
     ProfScope ps(m, 1, st, PF_BWGRAD, 2.0 * bf.NBp * (double)Hy * Hy * 9.0 * cx_alg * cy_alg);
@@ -630,15 +631,47 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   hipStream_t ws = bf_wstream(m);
   bool head_cols_taken = false, dec_bucket_done = false;
   size_t enc_reduced = A.n_enc_train;                    // [enc_reduced, n_enc_train) all-reduced inside this pass
+  const bool trunk_red = ws != s && m->arena_reduce && m->ctx->red_stream != nullptr;   // sums on the reduction stream
+  // ---- what the forward pass left for the reduction stream: the loss sums, and with them the head's bias column sums ----
+  // (both used to sit on the main stream between the head kernel and the first data gradient: four launches of 5 - 10 us
+  // in front of the chain the whole pass hangs on, and in front of the record the first weight gradient waits for)
+  const bool sums_on_red = m->loss_pending;
+  if (sums_on_red) {
+    if (!trunk_red) {
+      set_error("deferred loss sums without a reduction stream");
+      return E_STATE;
+    }
+    dv_ctx* cx = m->ctx;
+    hipStream_t rs = cx->red_stream;
+    DV_HIP(hipEventRecord(cx->ev_ready, s));               // behind the head kernel; the head's weight gradient shares it
+    DV_HIP(hipStreamWaitEvent(rs, cx->ev_ready, 0));
+    bf.head_marked = true;
+    {
+      ProfScope ps(m, 2, rs);
+      DV_TRY(launch_reduce_rows_f64(m->ws_head, m->loss_blocks, 2, m->scal, 1.0f, rs));
+      DV_TRY(launch_reduce_rows_f64(m->kl, m->loss_NB, 1, m->scal + 2, 1.0f, rs));
+    }
+    if (cx->comm) {                                        // (allreduce_small's place in enqueue_step, one stream over)
+      DV_HIP(hipEventRecord(cx->ev_small, rs));
+      DV_HIP(hipStreamWaitEvent(cx->comm_stream, cx->ev_small, 0));
+      DV_TRY(comm_allreduce(cx, m->scal, 4));
+    }
+    m->loss_pending = false;
+  }
   // ---- head conv ----
   if (dg) {
     if (bf_wgrad_takes(f0)) DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, A.C2p, 1, 1, m->Ghs, f0, f0));   // (columns taken at the end)
     else DV_TRY(bf_wgrad_f32(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, A.C2p, NB, 1, 1, m->Ghs, f0, f0, 3));
-    ProfScope ps(m, 2, s);
+    hipStream_t bs = sums_on_red ? m->ctx->red_stream : s;
+    float* part = sums_on_red ? m->ws_head : m->ws3;       // (same stream as the loss sums above: ordered behind their reads)
+    ProfScope ps(m, 2, bs);
     int nr = 0;
-    DV_TRY(launch_bf_colsum(bf.dt, (long)Hd * Hd * bf.NBp, A.C2p, m->ws3, &nr, s));
-    DV_TRY(launch_reduce_rows_f64(m->ws3, nr, C2, G + A.specs[A.head_b()].off, 1.0f, s, A.C2p));
+    if (!(exp_skip_tail() & 2)) {
+      DV_TRY(launch_bf_colsum(bf.dt, (long)Hd * Hd * bf.NBp, A.C2p, part, &nr, bs));
+      DV_TRY(launch_reduce_rows_f64(part, nr, C2, G + A.specs[A.head_b()].off, 1.0f, bs, A.C2p));
+    }
   }
+  bf.head_marked = false;
   {
     const int jl = 2 * A.L - 1;
     DV_TRY(bf_dgrad_prelu(m, bf.dt, bf.head_w.d, bf.head_w.Kd, 1, Hd, A.C2p, Hd, f0, 1, 1, cur, bf.dec_u[jl], A.dec_al(jl),
@@ -781,7 +814,6 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
                        A.dp, 1, 0, true));
     DV_TRY(prelu_bwd(m, tr2, m->z, A.D0, -1, NB, A.dp, A.dp, dg));
   }
-  const bool trunk_red = ws != s && m->arena_reduce && m->ctx->red_stream != nullptr;   // sums on the reduction stream
   // Every decoder gradient has been queued and no later kernel of the step reads a decoder parameter: finish the
   // decoder's reductions now (slab sums and d(alpha) / d(bias) partials, one launch each, on the weight-gradient
   // stream), all-reduce the bucket on the comm stream while the encoder backward runs and - early_adam - update it there
@@ -923,7 +955,7 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
   // no further gain, four alternating same-box runs each).
   const int want_defer = 1;
   bool deferred[BF_MAIN_SLOTS] = {false, false};
-  bool any_deferred = false;
+  bool any_deferred = false, tail_on_main = false;
   for (int j = 2 * A.L - 1; j >= 0; --j) {
     int hin, cin, hout, cout, st;
     A.enc_layer(j, &hin, &cin, &hout, &cout, &st);
@@ -936,6 +968,21 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       // last launch of the pass: on the (otherwise idle) main stream, slabs in the pool's tail region
       const bool wg0 = ksz == 3 && bf_wgrad_takes(cout);
       const bool lm = !wg0 || (ws != s && (size_t)((bf.NBp + 63) / 64) * 9 * 16 * cout <= bf.slab_tail / BF_MAIN_SLOTS);
+      // The tail of the pass (round 6).  The d(alpha) / d(bias) partials of the shallow layers are complete once the last
+      // data gradient has been queued: their sums go to the reduction stream NOW, beside the last weight gradients, instead
+      // of behind them.  And what follows the last weight gradients - slab sums, the first conv's gradients - runs on the
+      // MAIN stream behind its join with the weight-gradient stream, where the optimizer continues, instead of on the
+      // weight-gradient stream with a second hand-over behind it.  DV_BF_TAIL_ON_WGRAD_STREAM=1: the form until round 6.
+      static const bool old_tail = getenv("DV_BF_TAIL_ON_WGRAD_STREAM") != nullptr;
+      tail_on_main = trunk_red && lm && wg0 && !old_tail;
+      if (tail_on_main && bf.red.count > 0) {
+        dv_ctx* cx = m->ctx;
+        DV_HIP(hipEventRecord(cx->ev_ready, s));
+        DV_HIP(hipStreamWaitEvent(cx->red_stream, cx->ev_ready, 0));
+        ProfScope ps(m, 2, cx->red_stream);
+        DV_TRY(launch_bf_reduce_batch(bf.red, cx->red_stream));
+        bf.red.count = 0;
+      }
       // (the folded kernel's gradient has A.C0p input channels: 8 for 1 .. 7 bands, all 16 for 8 .. 15)
       if (wg0) DV_TRY(bf_wgrad(m, bf.xh, hin, 16, cur, hout, cout, st, pb, m->G0s, 16, A.C0p, lm));
       else DV_TRY(bf_wgrad_f32(m, bf.xh, hin, 16, cur, hout, cout, NB, st, pb, m->G0s, 16, A.C0p, ksz));
@@ -946,17 +993,23 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
         DV_TRY(bf_wgrad(m, bf.enc_a[jd - 1], h1, c1, bf.du_enc[jd], ho1, co1, s1, same_pad_before(h1, 3, s1, nullptr),
                         G + A.specs[A.enc_k(jd)].off, c1, c1, true, jd));     // (only 3 x 3 layers are deferred)
       }
-      if (lm || any_deferred) {                          // their slabs are summed on the weight-gradient stream
+      hipStream_t ts = ws;                               // the stream the tail runs on
+      if (tail_on_main) {                                // the main stream joins the weight-gradient stream here
+        DV_HIP(hipEventRecord(m->ctx->ev_join, ws));
+        DV_HIP(hipStreamWaitEvent(s, m->ctx->ev_join, 0));
+        ts = s;
+      } else if (lm || any_deferred) {                   // their slabs are summed on the weight-gradient stream
         DV_HIP(hipEventRecord(m->ctx->ev_ready, s));
         DV_HIP(hipStreamWaitEvent(ws, m->ctx->ev_ready, 0));
       }
       // every slab reduction of the pass, then what reads the two scratch gradients (padded head kernel, folded first conv)
-      DV_TRY(bf_flush_wred(m));
-      ProfScope ps(m, 2, ws);
-      if (dg && !head_cols_taken) DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, A.C2p, C2, ws));
+      if (exp_skip_tail() & 1) break;
+      DV_TRY(bf_flush_wred(m, ts));
+      ProfScope ps(m, 2, ts);
+      if (dg && !head_cols_taken) DV_TRY(launch_take_cols(m->Ghs, G + A.specs[A.head_k()].off, 9 * f0, A.C2p, C2, ts));
       DV_TRY(launch_bn_conv0_grads(m->G0s, P + A.specs[A.enc_k(0)].off, P + A.specs[0].off, P + A.specs[1].off,
                                    G + A.specs[A.enc_k(0)].off, G + A.specs[0].off, G + A.specs[1].off, ksz * ksz, A.C, A.C0p, cout,
-                                   ws));
+                                   ts));
       break;
     }
     if (ksz != 3 || !bf_wgrad_takes(cin) || !bf_wgrad_takes(cout)) {
@@ -1014,11 +1067,11 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
       }
     }
   }
-  {
+  if (!(exp_skip_tail() & 1)) {
     ProfScope ps(m, 2, s);
     DV_TRY(launch_bf_reduce_batch(bf.red, s));           // d(alpha) / d(bias) of every fused epilogue of this pass
   }
-  if (ws != s) {                                         // join: every parameter gradient is final past this point
+  if (ws != s && !tail_on_main) {                        // join: every parameter gradient is final past this point
     DV_HIP(hipEventRecord(m->ctx->ev_join, ws));
     DV_HIP(hipStreamWaitEvent(s, m->ctx->ev_join, 0));
   }

@@ -22,7 +22,9 @@ def _exported_symbols(path):
     import subprocess
 
     out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
-    return sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
+    # EVERY defined dynamic symbol, whatever its type: kernel handles (D / V), weak template instantiations and implicit
+    # members of the handle types (W) are exports too, and interposable ones (csrc/exports.map keeps them out)
+    return sorted(ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3)
 
 
 def test_library_exports_every_declared_symbol():
@@ -52,6 +54,8 @@ def test_the_product_library_exports_the_boundary_and_nothing_else():
     assert not [n for n in exported if "debug" in n]
     dbg = _declared_symbols("debvader_hip_debug.h")
     assert len(dbg) >= 8 and sorted(debug_lib.DEBUG_SIGNATURES) == dbg
+    # the development build: the same surface plus its own header, again nothing else (a test process holds BOTH builds:
+    # any other exported symbol of one would be bound into the other)
     exported_dbg = _exported_symbols(debug_lib.DEBUG_LIB_PATH)
     assert sorted(set(exported) | set(dbg)) == exported_dbg
     for d, _, files in os.walk(os.path.join(ROOT, "debvader_amd")):
