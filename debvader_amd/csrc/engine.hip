@@ -1786,6 +1786,7 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u);
 static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
                         bool want_out, int part_block0, int* nblk);
 static int bf_backward(dv_model* m, int NB, int Bg);
+static int bf_flush_wred(dv_model* m, hipStream_t rs);
 
 // encoder: dataset rows (idx / first) of the lane -> t
 struct TinyCall {          // scope of one public inference call of at most 16 stamps
@@ -1967,6 +1968,7 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
       m->wstream = cx->aux_stream;
       m->main_marked = false;
       for (auto& f : m->exp_deferred) DV_TRY(f());
+      if (m->bf.on) DV_TRY(bf_flush_wred(m, nullptr));
       m->wstream = s;
     }
     m->exp_deferred.clear();

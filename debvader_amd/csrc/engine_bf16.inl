@@ -659,9 +659,23 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     m->loss_pending = false;
   }
   // ---- head conv ----
+#ifdef DV_DEBUG_EXPORTS
+  static const int exp_defer = DV_EXP_SWITCH("DV_EXP_DEFER_WGRAD");     // MEASUREMENT only, see backward() in engine.hip
+#else
+  [[maybe_unused]] constexpr int exp_defer = 0;
+#endif
   if (dg) {
-    if (bf_wgrad_takes(f0)) DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, A.C2p, 1, 1, m->Ghs, f0, f0));   // (columns taken at the end)
-    else DV_TRY(bf_wgrad_f32(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, A.C2p, NB, 1, 1, m->Ghs, f0, f0, 3));
+    if (bf_wgrad_takes(f0)) {
+#ifdef DV_DEBUG_EXPORTS
+      if (exp_defer > 0 && ws != s) {
+        const void* xa = bf.dec_a[2 * A.L - 1];
+        const void* ya = bf.dt;
+        const int c2p = A.C2p;
+        m->exp_deferred.push_back([=]() -> int { return bf_wgrad(m, xa, Hd, f0, ya, Hd, c2p, 1, 1, m->Ghs, f0, f0); });
+      } else
+#endif
+        DV_TRY(bf_wgrad(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, A.C2p, 1, 1, m->Ghs, f0, f0));   // (columns taken at the end)
+    } else DV_TRY(bf_wgrad_f32(m, bf.dec_a[2 * A.L - 1], Hd, f0, bf.dt, Hd, A.C2p, NB, 1, 1, m->Ghs, f0, f0, 3));
     hipStream_t bs = sums_on_red ? m->ctx->red_stream : s;
     float* part = sums_on_red ? m->ws_head : m->ws3;       // (same stream as the loss sums above: ordered behind their reads)
     ProfScope ps(m, 2, bs);
@@ -686,6 +700,13 @@ static int bf_backward(dv_model* m, int NB, int Bg) {
     const void* xin = j == 0 ? bf.dec_in : bf.dec_a[j - 1];
     bf.du_dec[j] = cur;
     const bool wg_bf = ksz == 3 && bf_wgrad_takes(cout) && bf_wgrad_takes(cin);
+#ifdef DV_DEBUG_EXPORTS
+    if (dg && wg_bf && exp_defer > 0 && j >= 2 * A.L - exp_defer && ws != s) {
+      const void* dy = cur;
+      float* gk = G + A.specs[A.dec_k(j)].off;
+      m->exp_deferred.push_back([=]() -> int { return bf_wgrad(m, dy, hout, cout, xin, hin, cin, st, pb, gk, cout, cout); });
+    } else
+#endif
     if (dg && wg_bf) DV_TRY(bf_wgrad(m, cur, hout, cout, xin, hin, cin, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout));
     if (dg && !wg_bf) DV_TRY(bf_wgrad_f32(m, cur, hout, cout, xin, hin, cin, NB, st, pb, G + A.specs[A.dec_k(j)].off, cout, cout, ksz));
     oth = next_buf();
