@@ -437,15 +437,23 @@ eng.close()
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for extra in ({}, {}, {}, {"DV_NO_OVERLAP": "1"}):
+    # ... and in the stream orders the product's A/B switches restore: the forms of the step's seams until round 6 (loss /
+    # head-bias sums on the main stream, the tail of the pass on the weight-gradient stream), bucket-boundary sums on the
+    # weight-gradient stream, the input normalised at the head of the step, a one-rank communicator
+    orders = ({}, {}, {}, {"DV_NO_OVERLAP": "1"}, {"DV_BF_SUMS_ON_MAIN": "1"}, {"DV_BF_TAIL_ON_WGRAD_STREAM": "1"},
+              {"DV_BF_SUMS_ON_MAIN": "1", "DV_BF_TAIL_ON_WGRAD_STREAM": "1", "DV_BF_BOUNDARY_ON_WGRAD_STREAM": "1",
+               "DV_NO_INPUT_AHEAD": "1"}, {"DV_FORCE_COMM": "1"})
+    switches = ("DV_FORCE_COMM", "DV_NO_EARLY_ADAM", "DV_NO_OVERLAP", "DV_BF_SUMS_ON_MAIN", "DV_BF_TAIL_ON_WGRAD_STREAM",
+                "DV_BF_BOUNDARY_ON_WGRAD_STREAM", "DV_NO_INPUT_AHEAD")
+    for extra in orders:
         env = dict(os.environ)
-        for k in ("DV_FORCE_COMM", "DV_NO_EARLY_ADAM", "DV_NO_OVERLAP"):
+        for k in switches:
             env.pop(k, None)
         env.update(extra)
         r = subprocess.run([sys.executable, "-c", code % root], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
-    assert outs[0] == outs[1] == outs[2] == outs[3], outs
+    assert len(set(outs)) == 1, list(zip(orders, outs))
 
 
 def test_python_surface_with_the_bf16_engine(tmp_path):
