@@ -2480,6 +2480,7 @@ static int enqueue_step(dv_model* m, StepMode mode, int slot, const int32_t* idx
   // loc / scale of a gradient or train step are only written on request (dv_model_set_keep_outputs: the parity
   // tests read them back) - 42 MB of stores per 256-stamp step that training has no reader for
   static const bool sums_on_main = getenv("DV_BF_SUMS_ON_MAIN") != nullptr;     // (A/B: the form until round 6)
+  m->loss_pending = false;       // (a step that failed between its two passes leaves nothing behind for this one)
   m->defer_loss_sums = bwd && m->bf.on && bf_wstream(m) != s && m->arena_reduce && m->ctx->red_stream != nullptr && m->ws_head &&
                        !sums_on_main;
   const int fst = forward_all(m, ds.x, ds.y, idx, (int)first, B, Bg, training, mode == MODE_TRAIN, bwd, eps_host, seed,
