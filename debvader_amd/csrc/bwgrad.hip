@@ -375,11 +375,6 @@ __global__ __launch_bounds__(256, 1) void bwgrad2_kernel(const BWgradParams p, c
   const unsigned xoff_l = XC16 ? ((lane & 31) >> 1) * 32 + (lane & 1) * 16 : (lane >> 2) * p.Cx * 2 + (lane & 3) * 16;
   const unsigned yoff_l = YC16 ? ((lane & 31) >> 1) * 32 + (lane & 1) * 16 : (lane >> 2) * p.Cy * 2 + (lane & 3) * 16;
   const bw_u64 xps = (bw_u64)p.NBp * p.Cx * 2, yps = (bw_u64)p.NBp * p.Cy * 2;   // bytes per pixel
-  auto dma = [&](bw_u64 base, bw_u64 pixoff, bool ok, unsigned off_l, unsigned char* dst) {
-    const bw_u64 m = (bw_u64)0 - (bw_u64)ok;
-    const bw_u64 ub = zu + (m & (base - zu + pixoff));
-    __builtin_amdgcn_global_load_lds((bw_gptr_t)(ub + off_l), (bw_lptr_t)dst, 16, 0, 0);
-  };
 
   const int g = lane >> 4, li = lane & 15;
   const int chalf = g & 1, khalf = g >> 1;
@@ -407,34 +402,59 @@ __global__ __launch_bounds__(256, 1) void bwgrad2_kernel(const BWgradParams p, c
     const int ncols = c1 - c0;
     const int T = ((r1 - r0 + 1) >> 1) * ncols;
     int l_t = 0, l_r = r0, l_w = c0, l_base = 0;        // loader: next column, its upper row / column, its first slot
-    auto load_col = [&](int j, bool real) {            // window column j (0..2) of the loader's column: four X rows
-      const int xc = l_w - p.pb + j;
-      unsigned char* dst = xwin + ((l_base + j) & (B2_NCS - 1)) * 1024;
+    // Addresses of the loader, kept incrementally (the first version multiplied a 64-bit pixel offset out for each of a
+    // column's six blocks: ~15 scalar instructions per DMA in a loop whose one wave per SIMD has nobody to hide them behind):
+    // per row pair the zero-page-relative origin of each of its four X rows and two Y rows and whether the row exists, per
+    // column one offset that advances by a pixel.  A block outside the image - or a whole pair past the end of the segment,
+    // or the lower Y row of a last, odd pair - is the zero page: `ok` masks the offset away, no branch.
+    bw_u64 xrow[4], yrow[2], xco = 0, yco = 0;          // xco: offset of window column 2 of the loader's column
+    bool xrok[4], yrok[2];
+    auto set_pair = [&]() {
 #pragma unroll
       for (int kh = 0; kh < 4; ++kh) {
         const int xr = l_r - p.pb + kh;
-        const bool ok = real & ((unsigned)xr < (unsigned)p.Hx) & ((unsigned)xc < (unsigned)p.Hx);
-        dma(xu, (bw_u64)(unsigned)(xr * p.Hx + xc) * xps, ok, xoff_l, dst + kh * XROW);
+        xrok[kh] = (l_r < r1) & ((unsigned)xr < (unsigned)p.Hx);
+        xrow[kh] = (xu - zu) + (bw_u64)(unsigned)(xr * p.Hx) * xps;
+      }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        yrok[rr] = l_r + rr < r1;
+        yrow[rr] = (yu - zu) + (bw_u64)(unsigned)((l_r + rr) * p.Hy) * yps;
+      }
+      xco = (bw_u64)((long long)(c0 - p.pb + 2) * (long long)xps);
+      yco = (bw_u64)(unsigned)c0 * yps;
+    };
+    set_pair();
+    auto load_col = [&](int j) {                       // window column j (0..2) of the loader's column: four X rows
+      const bool cok = (unsigned)(l_w - p.pb + j) < (unsigned)p.Hx;
+      const bw_u64 co = xco - (bw_u64)(2 - j) * xps;
+      unsigned char* dst = xwin + ((l_base + j) & (B2_NCS - 1)) * 1024;
+#pragma unroll
+      for (int kh = 0; kh < 4; ++kh) {
+        const bw_u64 m = (bw_u64)0 - (bw_u64)(xrok[kh] & cok);
+        __builtin_amdgcn_global_load_lds((bw_gptr_t)(zu + (m & (xrow[kh] + co)) + xoff_l), (bw_lptr_t)(dst + kh * XROW), 16, 0, 0);
       }
     };
     auto load_column = [&]() {
-      const bool real = l_t < T;                        // past the end: the same instructions from the zero page
-      if (l_w == c0) {                                  // (the counted waits rely on their number)
-        load_col(0, real);
-        load_col(1, real);
+      if (l_w == c0) {                                  // (the counted waits rely on the number of these instructions)
+        load_col(0);
+        load_col(1);
       }
-      load_col(2, real);
+      load_col(2);
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
-        const bool ok = real & (l_r + rr < r1);
-        dma(yu, (bw_u64)(unsigned)((l_r + rr) * p.Hy + l_w) * yps, ok, yoff_l,
-            ywin + (rr * B2_NYS + (l_t & (B2_NYS - 1))) * 1024);
+        const bw_u64 m = (bw_u64)0 - (bw_u64)yrok[rr];
+        __builtin_amdgcn_global_load_lds((bw_gptr_t)(zu + (m & (yrow[rr] + yco)) + yoff_l),
+                                         (bw_lptr_t)(ywin + (rr * B2_NYS + (l_t & (B2_NYS - 1))) * 1024), 16, 0, 0);
       }
       ++l_t;
+      xco += xps;
+      yco += yps;
       if (++l_w == c1) {
         l_w = c0;
         l_r += 2;
         l_base = (l_base + 3) & (B2_NCS - 1);
+        set_pair();
       } else {
         l_base = (l_base + 1) & (B2_NCS - 1);
       }
