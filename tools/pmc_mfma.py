@@ -9,7 +9,7 @@ mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel
 (MI355X_MICROARCH.md, DVFS section); v_mfma_f32_16x16x4_f32 holds the pipe for 32 cycles."""
 import csv, glob, json, sys
 
-FAMILIES = (("bconv_uni_kernel / bconv_kernel (bf16)", ("bconv_",)), ("bwgrad_kernel (bf16)", ("bwgrad_kernel",)),
+FAMILIES = (("bconv_uni_kernel / bconv_kernel (bf16)", ("bconv_",)), ("bwgrad_kernel / bwgrad2_kernel (bf16)", ("bwgrad_kernel", "bwgrad2_kernel")),
             ("bgemm_kernel / bgemm_tn_kernel (bf16 dense trunk, round 6)", ("bgemm_",)),
             ("wino_conv4_kernel (Winograd F(2x2,3x3) forward / data gradient, four-wave form)", ("wino_conv4_kernel",)),
             ("wino_conv_kernel (same, eight-wave form: the 32-input-channel launches)", ("wino_conv_kernel",)),

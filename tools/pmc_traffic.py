@@ -11,7 +11,7 @@ coalesced reads, MI355X_MICROARCH.md HBM section); both counters are in KB."""
 import csv, glob, json, sys
 
 FAMILIES = (("bconv_kernel / bconv_uni_kernel", ("bconv_",)),
-            ("bwgrad_kernel", ("bwgrad_kernel",)),
+            ("bwgrad_kernel / bwgrad2_kernel", ("bwgrad_kernel", "bwgrad2_kernel")),
             ("bgemm_kernel / bgemm_tn_kernel (dense trunk)", ("bgemm_",)),
             ("wino_wgrad family (wino_wgrad, presum, finish)", ("wino_wgrad",)),
             ("wino_conv_kernel (+ wino_weights_kernel)", ("wino_conv", "wino_weights")),
