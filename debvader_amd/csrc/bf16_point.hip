@@ -483,27 +483,36 @@ __global__ __launch_bounds__(256) void bf_cast_kernel(const BCastDesc* __restric
   if (!d.src) return;
   bp_bf16* dst = reinterpret_cast<bp_bf16*>(d.dst);
   const long total = (long)d.N * d.Kpad;
-  if (d.taps == 1 && d.n_is_b && !d.gamma) {
-    // a TRANSPOSED dense kernel (dst[n][k] = src[k][n]; the 4096 x 560 matrices of the trunk, btrunk.hip): 64 x 64 tiles
-    // through LDS, so that the fp32 reads run along n and the bf16 writes along k (the element-per-thread loop below reads
-    // such a matrix with a stride of B floats per thread: 50 us for the two of the 59-px net, 8 this way)
+  if (d.n_is_b && !d.gamma) {
+    // TRANSPOSED kernels (dst[n][tap * Cin + c] = src[tap][c][n]: the forward forms of the Conv2D layers, the data-gradient
+    // forms of the transposed ones, the 4096 x 560 matrices of the trunk): 64 x 64 tiles through LDS, tap by tap, so that the
+    // fp32 reads run along n and the bf16 writes along c.  The element-per-thread loop below reads such a tensor with a
+    // stride of B floats per thread (50 us for the trunk's two alone; a whole decoder bucket: 44 us for 66 MB).
     __shared__ float tile[64][65];
-    const int kt = (d.Kpad + 63) >> 6, nt = (d.N + 63) >> 6;
+    const int taps = d.taps ? d.taps : 9;
+    const int kt = (d.Cin + 63) >> 6, nt = (d.N + 63) >> 6, per = kt * nt;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int t = blockIdx.x; t < kt * nt; t += gridDim.x) {
-      const int k0 = (t % kt) * 64, n0 = (t / kt) * 64;
+    for (int t = blockIdx.x; t < taps * per; t += gridDim.x) {
+      const int tap = t / per, r0 = t - tap * per;
+      const int c0 = (r0 % kt) * 64, n0 = (r0 / kt) * 64;
+      const float* src = d.src + (size_t)tap * d.A * d.B;
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int k = k0 + r * 4 + ty, n = n0 + tx;
-        tile[r * 4 + ty][tx] = (k < d.A && n < d.B) ? d.src[(size_t)k * d.B + n] : 0.f;
+        const int c = c0 + r * 4 + ty, n = n0 + tx;
+        tile[r * 4 + ty][tx] = (c < d.A && n < d.B) ? src[(size_t)c * d.B + n] : 0.f;
       }
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + r * 4 + ty, k = k0 + tx;
-        if (n < d.N && k < d.Kpad) dst[(size_t)n * d.Kpad + k] = (bp_bf16)tile[tx][r * 4 + ty];
+        const int n = n0 + r * 4 + ty, c = c0 + tx;
+        if (n < d.N && c < d.Cin) dst[(size_t)n * d.Kpad + tap * d.Cin + c] = (bp_bf16)tile[tx][r * 4 + ty];
       }
+    }
+    const int tail = d.Kpad - taps * d.Cin;              // K padding behind the last tap: zeros
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)d.N * tail; e += (long)gridDim.x * 256) {
+      const int n = (int)(e / tail), j = (int)(e - (long)n * tail);
+      dst[(size_t)n * d.Kpad + taps * d.Cin + j] = (bp_bf16)0.f;
     }
     return;
   }
