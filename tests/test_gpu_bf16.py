@@ -540,3 +540,56 @@ def test_channel_counts_that_are_not_powers_of_two():
     # (the KL regulariser of this tiny net is ~1e-3: its bf16 cost is 0.55 % of itself, the stated 1 % here)
     _run(arch, B=5, seed=21, tol_grad_b=5e-2, tol_scal_64=1e-2)
     _run(arch, B=64, seed=22, tol_grad_b=0.1, min_cos=0.95, tol_grad_64=0.35, tol_scal_64=1e-2)
+
+
+def test_two_row_weight_gradient_against_the_one_row_form_on_odd_shapes():
+    """bwgrad2_kernel (stride-1 layers: two Y rows per wave, row pairs and - for wide rows - column segments per workgroup)
+    against bwgrad_kernel (DV_BWGRAD_ONE_ROW=1, read once per process: two child processes) on shapes the BASELINE nets do not
+    have: odd and small row counts (21, 11, 6 / 37, 19, 10, 5), a last pair with one row, 48 and 20 stamps (three and two
+    16-stamp chunks, a workgroup with idle waves), 16-channel operands on both sides.  The two forms add the same bf16
+    products in different orders into fp32: every kernel gradient agrees to 2e-5 of the tensor's largest entry, everything
+    that is not a stride-1 kernel gradient bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from debvader_amd import engine as E
+from debvader_amd.data import synthetic_stamps
+out = {}
+for size, filters, B in ((21, (32, 64, 128), 48), (37, (32, 32, 64, 64), 20), (64, (32, 64), 16)):
+    x, y = synthetic_stamps(B, seed=5, size=size, nb=6)
+    eng = E.Engine(E.make_config((size, size, 6), 16, filters, (3,) * len(filters), max_batch=B, dtype=1))
+    eng.init(seed=9); eng.upload(0, x, y)
+    eng.grad_step(0, first=0, B=B, seed=3)
+    for name, _, tr in eng.specs:
+        if tr and name.endswith("/kernel"):
+            out["%%d/%%s" %% (size, name)] = eng.get_grad(name)
+    eng.close()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for form in ("two", "one"):
+            env = dict(os.environ)
+            env.pop("DV_BWGRAD_ONE_ROW", None)
+            if form == "one":
+                env["DV_BWGRAD_ONE_ROW"] = "1"
+            path = os.path.join(td, form + ".npz")
+            r = subprocess.run([sys.executable, "-c", code % root, path], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res.append(dict(np.load(path)))
+    two, one = res
+    assert sorted(two) == sorted(one) and len(two) >= 20
+    differing = 0
+    for k in two:
+        scale = float(np.abs(one[k]).max())
+        err = float(np.abs(two[k].astype(np.float64) - one[k]).max())
+        assert scale > 0 and err <= 2e-5 * scale, (k, err, scale)
+        differing += int(err > 0)
+    assert differing >= 6          # (the stride-1 layers really took the other kernel)
