@@ -866,11 +866,19 @@ __global__ __launch_bounds__(256) void bn_conv0_grads_kernel(const float* __rest
 #pragma unroll
     for (int c = 0; c < BN_MAXC; ++c) sg[c][threadIdx.x] = round ? ab[c] : ag[c];
     __syncthreads();
+    // fixed-order sum of a band's 256 partials in two levels of 16 (one thread walking all 256 with a dependent LDS read and
+    // a double add per term made this one-block kernel 13 us of the serial tail of every train step)
+    const int c = threadIdx.x >> 4, j = threadIdx.x & 15;          // 16 bands x 16 runs
+    double part = 0.0;
+    if (c < cin)
+      for (int k = 0; k < 16; ++k) part += sg[c][j * 16 + k];
+    __syncthreads();
+    if (c < cin) sg[c][j] = part;
+    __syncthreads();
     if ((int)threadIdx.x < cin) {
-      const int c = threadIdx.x;
       double acc = 0.0;
-      for (int k = 0; k < 256; ++k) acc += sg[c][k];
-      (round ? dbeta : dgamma)[c] = (float)acc;
+      for (int k = 0; k < 16; ++k) acc += sg[threadIdx.x][k];
+      (round ? dbeta : dgamma)[threadIdx.x] = (float)acc;
     }
     __syncthreads();
   }
