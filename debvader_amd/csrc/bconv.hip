@@ -939,6 +939,30 @@ __global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) 
   // source = out + k - 1; form 1 (Conv2DTranspose forward / Conv2D data gradient): source = out + 1 - k
   const int sgn = p.form == 0 ? 1 : -1;
 
+  // BEPI_HEAD: the labels this lane's share of the head needs (lane = stamp l >> 2, bands (l & 3) and (l & 3) + 4; eight
+  // pixels) are requested here, ahead of the whole K loop, so that the epilogue finds them in registers
+  float hy[P][2];
+#pragma unroll
+  for (int px = 0; px < P; ++px) hy[px][0] = hy[px][1] = 0.f;
+  if constexpr (NBLK == 1) {
+    if (p.epi == BEPI_HEAD) {
+      const int hs = lane >> 2, hq = lane & 3;
+      const int b = st0 + hs, h = oh - p.hd.crop0;
+      if ((unsigned)h < (unsigned)p.hd.H && b < p.hd.NB) {
+        const long row = p.hd.idx ? (long)p.hd.idx[b] : (long)p.hd.first + b;
+        const float* yrow = p.hd.y + (row * p.hd.H + h) * p.hd.H * p.hd.nb;
+#pragma unroll
+        for (int px = 0; px < P; ++px) {
+          const int w = ow0 + px - p.hd.crop0;
+          if ((unsigned)w < (unsigned)p.hd.H && px < npx) {
+            if (hq < p.hd.nb) hy[px][0] = yrow[w * p.hd.nb + hq];
+            if (hq + 4 < p.hd.nb) hy[px][1] = yrow[w * p.hd.nb + hq + 4];
+          }
+        }
+      }
+    }
+  }
+
   // weights of chunk cc -> stage buffer: 9 * NBLK pieces, dealt round-robin over the four waves
   auto issue_b = [&](int cc, int buf) {
     unsigned char* dst = sB + buf * BSTAGE;
@@ -958,7 +982,7 @@ __global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) 
     float bias[NBLK];
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) bias[j] = 0.f;
-    if (p.bias && (p.epi == BEPI_FWD || p.epi == BEPI_RAW32)) load_f32<NBLK>(p.bias + ch0, bias);
+    if (p.bias && (p.epi == BEPI_FWD || p.epi == BEPI_RAW32 || p.epi == BEPI_HEAD)) load_f32<NBLK>(p.bias + ch0, bias);
 #pragma unroll
     for (int px = 0; px < P; ++px)
 #pragma unroll
@@ -1073,11 +1097,60 @@ __global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) 
     }
   };
   constexpr int NPC = 16 * BN / 512;                      // 16-byte pieces per lane of a [16][BN] bf16 tile (NBLK >= 2)
+  float h_nll = 0.f, h_se = 0.f;                          // BEPI_HEAD: this lane's share of the two loss sums
 #pragma unroll
   for (int px = 0; px < P; ++px) {
     if (px >= npx) break;                                 // (uniform)
     const int pix = oh * p.Hout + ow0 + px;
     const size_t rb0 = (size_t)pix * p.NBp + st0;
+    if (p.epi == BEPI_HEAD) {
+      if constexpr (NBLK == 1) {
+        // the wave's [16 stamps][16 columns] fp32 tile of this pixel, then bf_head_kernel's arithmetic on it: lane (stamp
+        // l >> 2, q = l & 3) takes the bands q and q + 4 (column c = loc, column nb + c = scale pre-activation)
+        float* tile = reinterpret_cast<float*>(wreg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(4 * g4 + r) * 16 + c] = acc[px][0][r];
+        bc_bf16* dtile = reinterpret_cast<bc_bf16*>(pbuf) + wave * 256;     // [16][16] bf16
+        const int hs = lane >> 2, hq = lane & 3;
+        const int b = st0 + hs;
+        const int h = oh - p.hd.crop0, w = ow0 + px - p.hd.crop0;
+        const bool in = (unsigned)h < (unsigned)p.hd.H && (unsigned)w < (unsigned)p.hd.H && b < p.hd.NB;
+        {
+          bc_bf16x4 z;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) z[k] = (bc_bf16)0.f;
+          *reinterpret_cast<bc_bf16x4*>(dtile + hs * 16 + 4 * hq) = z;
+        }
+        if (in) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int cb = hq + 4 * k;
+            if (cb < p.hd.nb) {
+              const float tl = tile[hs * 16 + cb], ts = tile[hs * 16 + p.hd.nb + cb];
+              const float loc = fmaxf(tl, 0.f);
+              const float sig = p.hd.sigma_floor + fmaxf(ts, 0.f);
+              const float inv = 1.0f / sig;
+              const float df = hy[px][k] - loc;
+              const float rr = df * inv;
+              h_nll += 0.5f * rr * rr + logf(sig) + 0.91893853320467274178f;
+              if (p.hd.mse_sample) {
+                const float dsm = df - sig * dv_philox_normal((unsigned)b, (unsigned)((h * p.hd.H + w) * p.hd.nb + cb),
+                                                              p.hd.mse_stream, p.hd.mse_seed);
+                h_se += dsm * dsm;
+              } else {
+                h_se += df * df;
+              }
+              dtile[hs * 16 + cb] = (bc_bf16)(tl > 0.f ? -(rr * inv) * p.hd.gscale : 0.f);
+              dtile[hs * 16 + p.hd.nb + cb] = (bc_bf16)(ts > 0.f ? (inv - rr * rr * inv) * p.hd.gscale : 0.f);
+            }
+          }
+        }
+        if (lane < 32)                                     // the wave's 512 B of this pixel: 16 rows x 32 B
+          *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.hd.dt) + (rb0 + (lane >> 1)) * 32 + (lane & 1) * 16) =
+              *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(dtile) + lane * 16);
+      }
+      continue;
+    }
     if (p.epi == BEPI_RAW32) {
       if constexpr (NBLK == 1) {
 #pragma unroll
@@ -1161,6 +1234,25 @@ __global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) 
       }
     }
   }
+  if constexpr (NBLK == 1) {
+    if (p.epi == BEPI_HEAD) {                             // (uniform) one row of partial sums per workgroup, waves in order
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        h_nll += __shfl_xor(h_nll, o);
+        h_se += __shfl_xor(h_se, o);
+      }
+      __syncthreads();                                    // every wave is done with pbuf's tiles
+      if (lane == 0) {
+        pbuf[wave * 2] = h_nll;
+        pbuf[wave * 2 + 1] = h_se;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        p.hd.part[blockIdx.x * 2] = ((pbuf[0] + pbuf[2]) + pbuf[4]) + pbuf[6];
+        p.hd.part[blockIdx.x * 2 + 1] = ((pbuf[1] + pbuf[3]) + pbuf[5]) + pbuf[7];
+      }
+    }
+  }
   if constexpr (NBLK >= 2) {
     if (p.epi == BEPI_BWD && p.dal_part) {
       // ... then over the four waves = 64 stamps, in wave order: one partial row per 64-stamp quad, as bconv_uni_kernel
@@ -1180,6 +1272,13 @@ __global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) 
       }
     }
   }
+}
+
+long bconv_head_tiles(const BConvParams& p) {
+  static const int row_mode = getenv("DV_BCONV_ROW") ? atoi(getenv("DV_BCONV_ROW")) : 1;
+  const int ksz = p.ksz == 0 ? 3 : p.ksz;
+  if (!row_mode || p.Cin % 32 || ksz != 3 || p.s != 1 || p.pb != 1 || p.Hin != p.Hout || (p.NBp & 63) || p.Cout != 16) return 0;
+  return (long)p.Hout * ((p.Hout + 7) / 8) * (p.NBp >> 6);
 }
 
 int launch_bconv(const BConvParams& p_in, hipStream_t s) {
@@ -1252,7 +1351,8 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
     auto rtiles = [&](int b) { return strips * (p.NBp >> 6) * (p.Cout / (16 * b)); };
     // at least one workgroup per CU before the column tile stays wide
     while (nb > 1 && rtiles(nb) < 256) nb >>= 1;
-    if (nb == 1 && p.epi != BEPI_RAW32) nb = 0;            // the bf16 epilogues want >= 32 columns (1-KiB row pieces)
+    if (nb == 1 && p.epi != BEPI_RAW32 && p.epi != BEPI_HEAD) nb = 0;   // the bf16 epilogues want >= 32 columns (1-KiB row pieces)
+    if (p.epi == BEPI_HEAD && (nb != 1 || p.Cout != 16)) nb = 0;
     if (nb == 1 && p.Cout % 16) nb = 0;
     if (nb > 1 && row_mode < 2) nb = 0;
     if (nb) {
@@ -1274,6 +1374,10 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
       DV_HIP(hipGetLastError());
       return OK;
     }
+  }
+  if (p.epi == BEPI_HEAD) {
+    set_error("bconv: the fused head needs the row-strip form (ask bconv_head_tiles first)");
+    return E_INVALID;
   }
   // TWO ring stages instead of three (round 4): half of a launch's time is prologue and epilogue (HBM-bound stores on
   // the 64 x 64 layers; launch, tap table and tile sums on the deep ones), which only ANOTHER resident workgroup can

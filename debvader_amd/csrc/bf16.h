@@ -15,7 +15,22 @@
 
 namespace dv {
 
-enum { BEPI_RAW32 = 0, BEPI_FWD = 1, BEPI_RAWBF = 2, BEPI_BWD = 3 };
+enum { BEPI_RAW32 = 0, BEPI_FWD = 1, BEPI_RAWBF = 2, BEPI_BWD = 3, BEPI_HEAD = 4 };
+// BEPI_HEAD (row-strip form of the 16-column head conv only): the head of the network - relu / crop / sigma floor / Normal NLL
+// and its gradient, bf_head_kernel's arithmetic - runs in the conv's epilogue on the fp32 tile the wave has just produced:
+// the fp32 head tensor (67 MB at 256 stamps) is neither written nor read back, one launch less at the end of every forward
+struct BHeadFuse {
+  const float* y;      // dataset labels [*,H,H,nb]
+  const int* idx;
+  int first;
+  void* dt;            // bf16 [Hd*Hd][NBp][16] gradient wrt the head conv's output (zero outside the crop / pad stamps)
+  float* part;         // [workgroups][2] partial sums (NLL, squared error)
+  int NB, H, nb, crop0;
+  float sigma_floor, gscale;
+  int mse_sample;
+  unsigned mse_stream;
+  unsigned long long mse_seed;
+};
 
 // Gather-GEMM over stamp-inner tensors: out[pix][b][n] = sum_{tap,c} X[src(pix,tap)][b][c] * W[n][tap*Cin + c]
 //   form 0 (Conv2D forward, Conv2DTranspose data gradient): source pixel = out*s + k - pb
@@ -37,12 +52,16 @@ struct BConvParams {
   int Kpad;
   int epi;
   int ksz;             // kernel size 1 .. 5 (0: 3); taps t = kh * ksz + kw, k = t * Cin + c
+  BHeadFuse hd;        // BEPI_HEAD only
 #ifdef DV_DEBUG_EXPORTS   // (development library only: every translation unit that sees this struct is built both ways)
   int exp;             // measurement switch (DV_EXP_BCONV; results are wrong): 1 = the K loop stops after one step,
                        // 2 = launch_bconv returns without launching, 3 = K loop as usual but no epilogue stores
 #endif
 };
 int launch_bconv(const BConvParams& p, hipStream_t s);
+// > 0: a launch with these parameters takes the row-strip form that carries BEPI_HEAD, with that many workgroups (= rows of
+// hd.part); 0: it would not (another tile form, another stamp padding) and the head has to run as a kernel of its own
+long bconv_head_tiles(const BConvParams& p);
 // BWD epilogue is usable (a wave's four 16-stamp groups share one pixel)
 static inline bool bconv_bwd_fusable(int NBp) { return (NBp & 63) == 0; }
 

@@ -427,6 +427,11 @@ struct BfState {
   // (bn_prefetch: batch statistics -> bn_finalize -> bf_input; 26 us that used to open every step on the main stream).
   // `xh` is the buffer of the step in flight (its first conv and, at the very end, its first-layer weight gradient read it).
   void* xh_alt = nullptr;
+  // head fused into the head conv's epilogue (BEPI_HEAD): forward_all leaves the request before the decoder runs, the head conv
+  // takes it when its launch has the row-strip form, head_lane then only reports the number of partial rows
+  dv::BHeadFuse hfuse;
+  bool hfuse_req = false;
+  long hfuse_tiles = 0;
   bool head_marked = false;      // bf_backward recorded the main stream behind the head kernel: the head's weight gradient waits for that record
   bool in_pre = false;           // xh_alt holds the prefetched batch, bnstate / the moving statistics are already its
   std::vector<void*> enc_u, enc_a, dec_u, dec_a;
@@ -1787,6 +1792,8 @@ static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int firs
                         bool want_out, int part_block0, int* nblk);
 static int bf_backward(dv_model* m, int NB, int Bg);
 static int bf_flush_wred(dv_model* m, hipStream_t rs);
+static void bf_head_fuse_request(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
+                                 bool want_out, int part_block0);
 
 // encoder: dataset rows (idx / first) of the lane -> t
 struct TinyCall {          // scope of one public inference call of at most 16 stamps
@@ -2025,6 +2032,7 @@ static int forward_all(dv_model* m, const float* xsrc, const float* ysrc, const 
     int nblk = 0;
     if (run_encoder) st = encoder_forward(m, xsrc, idx, first, nb, keep_u, /*defer_t=*/true);
     if (st == OK && run_encoder) st = sampler_forward(m, nb, eps_host == nullptr, seed, stream_id, row0, want_std);
+    if (st == OK && m->bf.on) bf_head_fuse_request(m, ysrc, idx, first, nb, Bg, want_grad, want_out, blk_done);
     if (st == OK) st = decoder_forward(m, nb, keep_u);
     if (st == OK) st = head_lane(m, ysrc, idx, first, nb, Bg, want_grad, want_out, blk_done, &nblk);
     blk_done += nblk;

@@ -214,6 +214,7 @@ static int bf_conv(dv_model* m, const void* X, const void* W, int Kpad, int form
   p.dal_part = dalp; p.db_part = dbp;
   p.Hin = Hin; p.Hout = Hout; p.Cin = Cin; p.Cout = Cout; p.NBp = m->bf.NBp;
   p.form = form; p.s = s; p.pb = pb; p.Kpad = Kpad; p.epi = epi; p.ksz = ksz;
+  if (epi == BEPI_HEAD) p.hd = m->bf.hfuse;
   // algorithmic FLOPs: form 0 meets nine taps per output pixel, form 1 nine per source pixel; the folded
   // first conv and the padded head count their real channels
   const BfState& bf = m->bf;
@@ -353,14 +354,55 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
                    P + A.specs[A.dec_al(j)].off, nullptr, nullptr, nullptr, A.dec_ksz(j)));
     in = bf.dec_a[j];
   }
+  bf.hfuse_tiles = 0;
+  if (bf.hfuse_req) {
+    bf.hfuse_req = false;
+    BConvParams q;
+    memset(&q, 0, sizeof q);
+    q.Hin = q.Hout = A.dec_out; q.Cin = A.cfg.filters[0]; q.Cout = A.C2p; q.NBp = bf.NBp; q.s = 1; q.pb = 1; q.ksz = 3;
+    const long tiles = bconv_head_tiles(q);
+    if (tiles > 0 && (size_t)tiles * 2 + 64 <= m->ws3_elems) {
+      bf.hfuse_tiles = tiles;
+      return bf_conv(m, in, bf.head_w.f, bf.head_w.Kf, 0, A.dec_out, A.cfg.filters[0], A.dec_out, A.C2p, 1, 1, BEPI_HEAD,
+                     nullptr, nullptr, nullptr, m->bhp, nullptr, nullptr, nullptr, nullptr);
+    }
+  }
   return bf_conv(m, in, bf.head_w.f, bf.head_w.Kf, 0, A.dec_out, A.cfg.filters[0], A.dec_out, A.C2p, 1, 1, BEPI_RAW32,
                  nullptr, nullptr, bf.tpre32, m->bhp, nullptr, nullptr, nullptr, nullptr);
+}
+
+// The head in the head conv's epilogue: a training / gradient step that keeps no outputs (loc / scale are only stored on
+// request) on a batch padded to 64 stamps with a 16-column head (1 .. 7 bands), whole batch in one lane.  Everything else -
+// inference, kept outputs, 8 .. 15 bands, odd paddings - takes bf_head_kernel as before.  DV_BF_HEAD_FUSED=0: never.
+static void bf_head_fuse_request(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
+                                 bool want_out, int part_block0) {
+  static const bool off = getenv("DV_BF_HEAD_FUSED") != nullptr && atoi(getenv("DV_BF_HEAD_FUSED")) == 0;
+  const Arch& A = m->A;
+  BfState& bf = m->bf;
+  bf.hfuse_req = false;
+  if (off || !ysrc || !want_grad || want_out || part_block0 != 0 || A.C2p != 16 || m->prof_on || exp_skip_tail()) return;
+  BHeadFuse& h = bf.hfuse;
+  memset(&h, 0, sizeof h);
+  h.y = ysrc; h.idx = idx; h.first = first; h.dt = bf.dt;
+  h.part = m->defer_loss_sums ? m->ws_head : m->ws3;
+  h.NB = NB; h.H = A.H; h.nb = A.C; h.crop0 = A.crop0;
+  h.sigma_floor = A.cfg.sigma_floor;
+  h.gscale = (float)(1.0 / ((double)Bg * A.H * A.H * A.C));
+  h.mse_sample = m->mse_sample ? 1 : 0;
+  h.mse_stream = DV_MSE_STREAM + (unsigned)m->ctx->rank;
+  h.mse_seed = m->cur_seed;
+  bf.hfuse_req = true;
 }
 
 static int bf_head_lane(dv_model* m, const float* ysrc, const int* idx, int first, int NB, int Bg, bool want_grad,
                         bool want_out, int part_block0, int* nblk) {
   const Arch& A = m->A;
   BfState& bf = m->bf;
+  if (bf.hfuse_tiles > 0) {                  // the head conv's epilogue has done it (bf_decoder_forward)
+    if (nblk) *nblk = (int)bf.hfuse_tiles;
+    bf.hfuse_tiles = 0;
+    return OK;
+  }
   BHeadParams hp;
   memset(&hp, 0, sizeof hp);
   hp.tpre = bf.tpre32;

@@ -593,3 +593,33 @@ np.savez(sys.argv[1], **out)
         assert scale > 0 and err <= 2e-5 * scale, (k, err, scale)
         differing += int(err > 0)
     assert differing >= 6          # (the stride-1 layers really took the other kernel)
+
+
+def test_head_in_the_head_convs_epilogue_against_the_head_kernel():
+    """A bf16 train / gradient step that keeps no outputs runs the head (relu, crop, sigma floor, Normal NLL and its gradient;
+    model.py:139-161, train.py:27-37) in the epilogue of the head conv (BEPI_HEAD); with kept outputs - or DV_BF_HEAD_FUSED=0 -
+    the head conv writes its fp32 tensor and bf_head_kernel reads it.  Same arithmetic per element: every parameter gradient
+    must be bit-identical between the two, the loss sums (other partial sums) to 1e-6; also with the Keras sample-MSE metric
+    (Philox draws per element) and on a batch with pad stamps (200 of 256)."""
+    from debvader_amd import engine as E
+    from debvader_amd.data import synthetic_stamps
+
+    for B, sample in ((256, False), (200, True), (64, False)):
+        x, y = synthetic_stamps(B, seed=21)
+        eng = E.Engine(E.make_config(max_batch=B, dtype=1))
+        eng.init(seed=2)
+        hb = eng.get_param("dec/head/bias")                 # (zero at initialisation: a head without its bias would pass)
+        hb += np.linspace(-0.2, 0.4, hb.size).astype(np.float32)
+        eng.set_param("dec/head/bias", hb)
+        eng.upload(0, x, y)
+        eng.set_mse_sample(sample)
+        eng.keep_outputs(True)
+        ref = eng.grad_step(0, first=0, B=B, seed=13)
+        gref = {n: eng.get_grad(n).copy() for n, _, tr in eng.specs if tr}
+        eng.keep_outputs(False)
+        out = eng.grad_step(0, first=0, B=B, seed=13)
+        for k in ("loss", "nll_mean", "mse"):
+            assert abs(out[k] - ref[k]) <= 1e-6 * abs(ref[k]), (B, k, out[k], ref[k])
+        for n, g in gref.items():
+            assert np.array_equal(eng.get_grad(n), g), (B, n)
+        eng.close()
