@@ -430,6 +430,7 @@ struct BfState {
   // head fused into the head conv's epilogue (BEPI_HEAD): forward_all leaves the request before the decoder runs, the head conv
   // takes it when its launch has the row-strip form, head_lane then only reports the number of partial rows
   dv::BHeadFuse hfuse;
+  bool tpre_stale = false;       // the last forward pass ran the head in the conv's epilogue: tpre32 was not written
   bool hfuse_req = false;
   long hfuse_tiles = 0;
   bool head_marked = false;      // bf_backward recorded the main stream behind the head kernel: the head's weight gradient waits for that record
@@ -4241,6 +4242,11 @@ int dv_model_get_activation(dv_model* m, const char* name, float* host, size_t n
     }
     DV_HIP(hipSetDevice(m->ctx->device));
     DV_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (m->bf.on && m->bf.tpre_stale) {
+      set_error("head_pre is not stored by a step that runs the head in the head conv's epilogue: keep the outputs "
+                "(dv_model_set_keep_outputs) or set DV_BF_HEAD_FUSED=0");
+      return DV_E_STATE;
+    }
     if (m->bf.on) {
       // stamp-inner fp32 [Hd*Hd][NBp][16] -> [B][Hd][Hd][2C]
       const size_t Pn = (size_t)A.dec_out * A.dec_out, NBp = (size_t)m->bf.NBp, HC = (size_t)A.C2p;

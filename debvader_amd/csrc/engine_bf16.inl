@@ -363,10 +363,12 @@ static int bf_decoder_forward(dv_model* m, int NB, bool keep_u) {
     const long tiles = bconv_head_tiles(q);
     if (tiles > 0 && (size_t)tiles * 2 + 64 <= m->ws3_elems) {
       bf.hfuse_tiles = tiles;
+      bf.tpre_stale = true;
       return bf_conv(m, in, bf.head_w.f, bf.head_w.Kf, 0, A.dec_out, A.cfg.filters[0], A.dec_out, A.C2p, 1, 1, BEPI_HEAD,
                      nullptr, nullptr, nullptr, m->bhp, nullptr, nullptr, nullptr, nullptr);
     }
   }
+  bf.tpre_stale = false;
   return bf_conv(m, in, bf.head_w.f, bf.head_w.Kf, 0, A.dec_out, A.cfg.filters[0], A.dec_out, A.C2p, 1, 1, BEPI_RAW32,
                  nullptr, nullptr, bf.tpre32, m->bhp, nullptr, nullptr, nullptr, nullptr);
 }

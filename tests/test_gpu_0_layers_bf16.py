@@ -75,6 +75,7 @@ def test_every_conv_layer_alone_against_the_oracle_primitives(arch_name, B, stag
     eng.set_params(p)
     eng.optimizer_reset(1e-4)
     eng.upload(0, x, y)
+    eng.keep_outputs(True)          # (head_pre is read below: a step that keeps nothing runs the head inside the head conv)
     eng.grad_step(0, first=0, B=B, eps=eps)
     fused = ((B + 15) // 16 * 16) % 64 == 0      # PReLU backward inside the data-gradient epilogue (bconv_bwd_fusable)
     H, C = arch.input_shape[0], arch.nb
