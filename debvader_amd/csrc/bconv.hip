@@ -890,9 +890,8 @@ __global__ __launch_bounds__(256, bconv_uni_occupancy(NBLK, GT, CH, NS)) void bc
 // barrier per CHUNK (not per K step), and are read as fragments per input row (3 NBLK ds_read_b128).  Input rows /
 // columns outside the image are read from a zero page, so the instruction stream - and with it the counted vmcnt at the
 // chunk boundary - is the same for every strip.
-template <int NBLK>
+template <int NBLK, int P = 8>                          // P: output pixels per strip
 __global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) {
-  constexpr int P = 8;                                    // output pixels per strip
   constexpr int BN = 16 * NBLK;
   constexpr int BSTAGE = 9 * NBLK * 1024;                 // weights of one chunk: [tap][column block][1 KiB fragment image]
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -1274,11 +1273,16 @@ __global__ __launch_bounds__(256, 1) void bconv_row_kernel(const BConvParams p) 
   }
 }
 
+static int bconv_head_strip() {     // pixels per strip of the head-carrying row launch
+  static const int v = getenv("DV_BF_HEAD_STRIP") ? atoi(getenv("DV_BF_HEAD_STRIP")) : 4;
+  return v == 8 ? 8 : (v == 2 ? 2 : 4);
+}
 long bconv_head_tiles(const BConvParams& p) {
   static const int row_mode = getenv("DV_BCONV_ROW") ? atoi(getenv("DV_BCONV_ROW")) : 1;
   const int ksz = p.ksz == 0 ? 3 : p.ksz;
   if (!row_mode || p.Cin % 32 || ksz != 3 || p.s != 1 || p.pb != 1 || p.Hin != p.Hout || (p.NBp & 63) || p.Cout != 16) return 0;
-  return (long)p.Hout * ((p.Hout + 7) / 8) * (p.NBp >> 6);
+  const int P = bconv_head_strip();
+  return (long)p.Hout * ((p.Hout + P - 1) / P) * (p.NBp >> 6);
 }
 
 int launch_bconv(const BConvParams& p_in, hipStream_t s) {
@@ -1355,6 +1359,27 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
     if (p.epi == BEPI_HEAD && (nb != 1 || p.Cout != 16)) nb = 0;
     if (nb == 1 && p.Cout % 16) nb = 0;
     if (nb > 1 && row_mode < 2) nb = 0;
+    // the head-carrying launch (BEPI_HEAD) takes FOUR-pixel strips: 57 us against 68 with eight (half the registers of input
+    // fragments, twice the workgroups; alone the 8-pixel strip is the better head conv).  DV_BF_HEAD_STRIP=8 | 2: A/B
+    const int head_p = bconv_head_strip();
+    if (nb == 1 && p.epi == BEPI_HEAD && head_p != 8) {
+      const long rtp = (long)p.Hout * ((p.Hout + head_p - 1) / head_p) * (p.NBp >> 6);
+      const size_t rlp = (size_t)2 * 9 * 1024 + 4 * 16 * 16 * 4 + (size_t)8 * 4 * 2 * 16 * 4 + 1024;
+#define BROW_HEAD(P_)                                                                                      \
+      do {                                                                                                 \
+        static bool attr = false;                                                                          \
+        if (!attr) {                                                                                       \
+          DV_HIP(hipFuncSetAttribute((const void*)bconv_row_kernel<1, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlp)); \
+          attr = true;                                                                                     \
+        }                                                                                                  \
+        hipLaunchKernelGGL((bconv_row_kernel<1, P_>), dim3((unsigned)rtp), dim3(256), rlp, s, p);          \
+      } while (0)
+      if (head_p == 4) BROW_HEAD(4);
+      else BROW_HEAD(2);
+#undef BROW_HEAD
+      DV_HIP(hipGetLastError());
+      return OK;
+    }
     if (nb) {
       const long rt = rtiles(nb);
       const size_t rl = (size_t)2 * 9 * nb * 1024 + 4 * 16 * 16 * nb * (nb == 1 ? 4 : 2) + (size_t)8 * 4 * 2 * 16 * nb * 4 + 1024;
