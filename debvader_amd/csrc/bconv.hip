@@ -1360,7 +1360,7 @@ int launch_bconv(const BConvParams& p_in, hipStream_t s) {
     if (nb == 1 && p.Cout % 16) nb = 0;
     if (nb > 1 && row_mode < 2) nb = 0;
     // the head-carrying launch (BEPI_HEAD) takes FOUR-pixel strips: 57 us against 68 with eight (half the registers of input
-    // fragments, twice the workgroups; alone the 8-pixel strip is the better head conv).  DV_BF_HEAD_STRIP=8 | 2: A/B
+    // fragments, twice the workgroups; the plain head conv keeps eight, not re-measured).  DV_BF_HEAD_STRIP=8 | 2: A/B
     const int head_p = bconv_head_strip();
     if (nb == 1 && p.epi == BEPI_HEAD && head_p != 8) {
       const long rtp = (long)p.Hout * ((p.Hout + head_p - 1) / head_p) * (p.NBp >> 6);
